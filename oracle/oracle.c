@@ -1,0 +1,712 @@
+/* oracle/oracle.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * CPU restatement of the `regtools junctions extract` hot path, from SURVEY.md section 9.
+ * All file:line citations are relative to /root/reference.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "oracle.h"
+
+#include <ctype.h>
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+/* ------------------------------------------------------------------------------------------------
+ * small helpers
+ * ---------------------------------------------------------------------------------------------- */
+static uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | p[1] << 8); }
+static uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+static uint64_t rd64(const uint8_t *p) { return (uint64_t)rd32(p) | (uint64_t)rd32(p + 4) << 32; }
+
+static int fail(char *err, size_t errlen, const char *msg) {
+    if (err && errlen) { strncpy(err, msg, errlen - 1); err[errlen - 1] = 0; }
+    return 1;
+}
+
+static uint8_t *slurp(const char *path, size_t *len) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return NULL;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (n < 0) { fclose(f); return NULL; }
+    uint8_t *buf = (uint8_t *)malloc((size_t)n + 1);
+    if (!buf) { fclose(f); return NULL; }
+    if (n && fread(buf, 1, (size_t)n, f) != (size_t)n) { free(buf); fclose(f); return NULL; }
+    fclose(f);
+    *len = (size_t)n;
+    return buf;
+}
+
+void orc_default_params(orc_params *p) {
+    /* junctions_extractor.h:185-198 default ctor */
+    memset(p, 0, sizeof *p);
+    p->region = ".";
+    p->strandness = -1;
+    p->strand_tag[0] = 'X'; p->strand_tag[1] = 'S';
+    p->min_anchor = 8; p->min_intron = 70; p->max_intron = 500000;
+    p->fasta = NULL;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * BGZF: block walk + inflate  (src/utils/htslib/bgzf.c:348-355 check_header, :421-546 read_block,
+ * :292-316 inflate_block -- raw DEFLATE at +18, zlib windowBits -15, CRC/ISIZE never checked)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t coff;   /* compressed offset of the member */
+    uint64_t uoff;   /* offset of its first inflated byte in the concatenated stream */
+    uint32_t ulen;   /* inflated length */
+} bgzf_blk;
+
+typedef struct {
+    uint8_t  *data;  /* concatenated inflated stream */
+    uint64_t  len;
+    bgzf_blk *blk;
+    size_t    nblk;
+    int       stop_reason; /* 0 = clean EOF, 1 = empty block, 2 = corrupt block */
+} bgzf_stream;
+
+static int bgzf_header_ok(const uint8_t *h) {
+    if (h[0] != 31 || h[1] != 139 || h[2] != 8) return 0;
+    return (h[3] & 4) && rd16(h + 10) == 6 && h[12] == 'B' && h[13] == 'C' && rd16(h + 14) == 2;
+}
+
+/* Inflate every member from file offset 0.  The stream handed to the record reader ends at the first
+ * member that inflates to zero bytes *after* `first_coff` (bgzf.c:548-578: bgzf_read breaks out when a
+ * freshly loaded block has no data, so bam_read1 sees a short read == EOF), at a corrupt member, or at
+ * end of file. Members before first_coff that are empty are kept as zero-length entries. */
+static int bgzf_inflate_all(const uint8_t *file, size_t flen, bgzf_stream *s) {
+    memset(s, 0, sizeof *s);
+    size_t cap_blk = 1024, cap_data = 1 << 20;
+    s->blk = (bgzf_blk *)malloc(cap_blk * sizeof(bgzf_blk));
+    s->data = (uint8_t *)malloc(cap_data);
+    size_t off = 0;
+    while (off < flen) {
+        if (flen - off < 18 || !bgzf_header_ok(file + off)) { s->stop_reason = 2; break; }
+        size_t blen = (size_t)rd16(file + off + 16) + 1;
+        if (off + blen > flen || blen < 26) { s->stop_reason = 2; break; }
+        if (s->len + 65536 > cap_data) {
+            while (s->len + 65536 > cap_data) cap_data *= 2;
+            s->data = (uint8_t *)realloc(s->data, cap_data);
+        }
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        zs.next_in = (Bytef *)(file + off + 18);
+        zs.avail_in = (uInt)(blen - 16 <= flen - off - 18 ? blen - 16 : flen - off - 18);
+        zs.next_out = s->data + s->len;
+        zs.avail_out = 65536;
+        if (inflateInit2(&zs, -15) != Z_OK) { s->stop_reason = 2; break; }
+        int zr = inflate(&zs, Z_FINISH);
+        uint32_t ulen = (uint32_t)zs.total_out;
+        inflateEnd(&zs);
+        if (zr != Z_STREAM_END) { s->stop_reason = 2; break; }
+        if (s->nblk == cap_blk) { cap_blk *= 2; s->blk = (bgzf_blk *)realloc(s->blk, cap_blk * sizeof(bgzf_blk)); }
+        s->blk[s->nblk].coff = off; s->blk[s->nblk].uoff = s->len; s->blk[s->nblk].ulen = ulen;
+        s->nblk++;
+        s->len += ulen;
+        off += blen;
+    }
+    return 0;
+}
+
+static void bgzf_stream_free(bgzf_stream *s) { free(s->data); free(s->blk); }
+
+/* virtual offset -> stream offset; returns -1 if the compressed offset is not a member start */
+static int64_t voff_to_stream(const bgzf_stream *s, uint64_t voff) {
+    uint64_t c = voff >> 16, u = voff & 0xffff;
+    size_t lo = 0, hi = s->nblk;
+    while (lo < hi) { size_t m = (lo + hi) / 2; if (s->blk[m].coff < c) lo = m + 1; else hi = m; }
+    if (lo == s->nblk || s->blk[lo].coff != c) return -1;
+    return (int64_t)(s->blk[lo].uoff + u);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * BAI (hts.c:1517-1567 load_core, :1607-1613, :1092 META_BIN, :1721-1731 HTS_IDX_START,
+ * :2009-2042 file-name resolution)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t  n_ref;
+    int      have_start;    /* some reference has the pseudo-bin */
+    uint64_t start_voff;    /* smallest pseudo-bin chunk[0].beg */
+    uint64_t n_no_coor;
+} bai_info;
+
+static int file_readable(const char *p) { FILE *f = fopen(p, "rb"); if (!f) return 0; fclose(f); return 1; }
+
+/* hts_idx_getfn: "<fn><ext>" else replace the last ".xxx" (search i = len-1 .. 1) by ext */
+static char *idx_name(const char *fn, const char *ext) {
+    size_t l = strlen(fn), e = strlen(ext);
+    char *buf = (char *)calloc(l + e + 1, 1);
+    strcpy(buf, fn); strcpy(buf + l, ext);
+    if (file_readable(buf)) return buf;
+    long i;
+    for (i = (long)l - 1; i > 0; --i) if (buf[i] == '.') break;
+    strcpy(buf + i, ext);
+    if (file_readable(buf)) return buf;
+    free(buf);
+    return NULL;
+}
+
+static int bai_load(const char *bam, bai_info *bi) {
+    memset(bi, 0, sizeof *bi);
+    char *fn = idx_name(bam, ".csi");
+    if (fn) { free(fn); return -2; } /* CSI not restated (out of scope) */
+    fn = idx_name(bam, ".bai");
+    if (!fn) return -1;
+    size_t len; uint8_t *d = slurp(fn, &len); free(fn);
+    if (!d) return -1;
+    if (len < 8 || memcmp(d, "BAI\1", 4)) { free(d); return -1; }
+    size_t p = 4;
+    bi->n_ref = (int32_t)rd32(d + p); p += 4;
+    const uint32_t meta_bin = 37450; /* ((1<<18)-1)/7 + 1 for min_shift 14, 5 levels */
+    bi->start_voff = UINT64_MAX;
+    for (int32_t r = 0; r < bi->n_ref; ++r) {
+        if (p + 4 > len) { free(d); return -1; }
+        int32_t n_bin = (int32_t)rd32(d + p); p += 4;
+        for (int32_t b = 0; b < n_bin; ++b) {
+            if (p + 8 > len) { free(d); return -1; }
+            uint32_t bin = rd32(d + p); int32_t n_chunk = (int32_t)rd32(d + p + 4); p += 8;
+            if (p + (size_t)n_chunk * 16 > len) { free(d); return -1; }
+            if (bin == meta_bin && n_chunk > 0) {
+                uint64_t u = rd64(d + p);
+                bi->have_start = 1;
+                if (u < bi->start_voff) bi->start_voff = u;
+            }
+            p += (size_t)n_chunk * 16;
+        }
+        if (p + 4 > len) { free(d); return -1; }
+        int32_t n_intv = (int32_t)rd32(d + p); p += 4;
+        if (p + (size_t)n_intv * 8 > len) { free(d); return -1; }
+        p += (size_t)n_intv * 8;
+    }
+    bi->n_no_coor = (p + 8 <= len) ? rd64(d + p) : 0;
+    free(d);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * region string (hts.c:1834-1895 hts_parse_decimal / hts_parse_reg, :1897-1922 hts_itr_querys,
+ * sam.c:262-277 bam_name2id: duplicate names -> the last one wins)
+ * ---------------------------------------------------------------------------------------------- */
+static long long parse_decimal(const char *str, const char **end) {
+    long long n = 0; int decimals = 0, e = 0; char sign = '+', esign = '+';
+    while (isspace((unsigned char)*str)) str++;
+    const char *s = str;
+    if (*s == '+' || *s == '-') sign = *s++;
+    while (*s) {
+        if (isdigit((unsigned char)*s)) n = 10 * n + (*s++ - '0');
+        else if (*s == ',') s++;
+        else break;
+    }
+    if (*s == '.') { s++; while (isdigit((unsigned char)*s)) { decimals++; n = 10 * n + (*s++ - '0'); } }
+    if (*s == 'E' || *s == 'e') {
+        s++;
+        if (*s == '+' || *s == '-') esign = *s++;
+        while (isdigit((unsigned char)*s)) e = 10 * e + (*s++ - '0');
+        if (esign == '-') e = -e;
+    }
+    e -= decimals;
+    while (e > 0) { n *= 10; e--; }
+    while (e < 0) { n /= 10; e++; }
+    if (end) *end = s;
+    return sign == '+' ? n : -n;
+}
+
+static int name2id(const orc_table *t, const char *name) {
+    int id = -1;
+    for (int32_t i = 0; i < t->n_ref; ++i) if (!strcmp(t->ref_name[i], name)) id = i;
+    return id;
+}
+
+/* returns 0 ok (tid/beg/end set), 1 = iterator would be NULL */
+static int parse_region(const orc_table *hdr, const char *reg, int *tid, int *beg, int *end) {
+    const char *colon = strrchr(reg, ':');
+    int parsed = 0;
+    if (!colon) { *beg = 0; *end = INT_MAX; parsed = 1; colon = reg + strlen(reg); }
+    else {
+        const char *hy;
+        *beg = (int)(parse_decimal(colon + 1, &hy) - 1);
+        if (*beg < 0) *beg = 0;
+        if (*hy == '\0') { *end = INT_MAX; parsed = 1; }
+        else if (*hy == '-') { *end = (int)parse_decimal(hy + 1, NULL); parsed = 1; }
+        if (parsed && *beg >= *end) parsed = 0;
+    }
+    if (parsed) {
+        size_t l = (size_t)(colon - reg);
+        char *tmp = (char *)malloc(l + 1);
+        memcpy(tmp, reg, l); tmp[l] = 0;
+        *tid = name2id(hdr, tmp);
+        free(tmp);
+    } else {
+        *tid = name2id(hdr, reg);
+        *beg = 0; *end = INT_MAX;
+    }
+    return *tid < 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * FASTA access for the intron-motif rule (faidx.c:288-339 fai_load, :341-413 fai_fetch;
+ * junctions_extractor.cc:547-584).  Bytes are used raw; isgraph() filter as the reference does.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { char *name; int64_t len, offset; int line_blen, line_len; } fa_seq;
+typedef struct { uint8_t *data; size_t dlen; fa_seq *seq; int n; } fasta;
+
+static void fasta_free(fasta *fa) {
+    if (!fa) return;
+    for (int i = 0; i < fa->n; ++i) free(fa->seq[i].name);
+    free(fa->seq); free(fa->data); free(fa);
+}
+
+static fasta *fasta_load(const char *path) {
+    fasta *fa = (fasta *)calloc(1, sizeof *fa);
+    fa->data = slurp(path, &fa->dlen);
+    if (!fa->data) { free(fa); return NULL; }
+    char *fai = (char *)malloc(strlen(path) + 5);
+    sprintf(fai, "%s.fai", path);
+    FILE *f = fopen(fai, "r");
+    free(fai);
+    int cap = 0;
+    if (f) {
+        char line[4096];
+        while (fgets(line, sizeof line, f)) {
+            char name[2048]; long long len, off; int lb, ll;
+            char *tab = strchr(line, '\t');
+            if (!tab) continue;
+            size_t nl = (size_t)(tab - line); if (nl >= sizeof name) nl = sizeof name - 1;
+            memcpy(name, line, nl); name[nl] = 0;
+            if (sscanf(tab + 1, "%lld\t%lld\t%d\t%d", &len, &off, &lb, &ll) != 4) continue;
+            if (fa->n == cap) { cap = cap ? cap * 2 : 64; fa->seq = (fa_seq *)realloc(fa->seq, (size_t)cap * sizeof(fa_seq)); }
+            fa_seq *s = &fa->seq[fa->n++];
+            s->name = strdup(name); s->len = len; s->offset = off; s->line_blen = lb; s->line_len = ll;
+        }
+        fclose(f);
+    } else {
+        /* build the index in memory (faidx.c fai_build_core): name = up to first whitespace */
+        size_t i = 0, n = fa->dlen;
+        while (i < n) {
+            if (fa->data[i] != '>') { while (i < n && fa->data[i] != '\n') ++i; ++i; continue; }
+            size_t j = i + 1; while (j < n && !isspace(fa->data[j])) ++j;
+            if (fa->n == cap) { cap = cap ? cap * 2 : 64; fa->seq = (fa_seq *)realloc(fa->seq, (size_t)cap * sizeof(fa_seq)); }
+            fa_seq *s = &fa->seq[fa->n++];
+            s->name = (char *)malloc(j - i); memcpy(s->name, fa->data + i + 1, j - i - 1); s->name[j - i - 1] = 0;
+            while (j < n && fa->data[j] != '\n') ++j;
+            ++j;
+            s->offset = (int64_t)j; s->len = 0; s->line_blen = 0; s->line_len = 0;
+            while (j < n && fa->data[j] != '>') {
+                size_t k = j, bases = 0;
+                while (k < n && fa->data[k] != '\n') { if (isgraph(fa->data[k])) ++bases; ++k; }
+                size_t ll = k - j + (k < n ? 1 : 0);
+                if (!s->line_len) { s->line_len = (int)ll; s->line_blen = (int)bases; }
+                s->len += (int64_t)bases;
+                j = k + 1;
+            }
+            i = j;
+        }
+    }
+    return fa;
+}
+
+/* fetch 0-based [beg,end) of contig `name`, clipped; returns number of bytes placed in out (<= cap).
+ * returns -1 when the contig is missing (fai_fetch NULL -> runtime_error upstream). */
+static int fasta_fetch(const fasta *fa, const char *name, int64_t beg1, int64_t end1, char *out, int cap) {
+    /* region string semantics of fai_fetch for "name:beg1-end1": beg = beg1>0 ? beg1-1 : beg1 */
+    const fa_seq *s = NULL;
+    for (int i = 0; i < fa->n; ++i) if (!strcmp(fa->seq[i].name, name)) { s = &fa->seq[i]; }
+    if (!s) return -1;
+    int64_t beg = beg1, end = end1;
+    if (beg > 0) --beg;
+    if (beg >= s->len) beg = s->len;
+    if (end >= s->len) end = s->len;
+    if (beg > end) beg = end;
+    if (s->line_blen <= 0) return 0;
+    size_t p = (size_t)(s->offset + beg / s->line_blen * s->line_len + beg % s->line_blen);
+    int l = 0;
+    while (p < fa->dlen && l < end - beg && l < cap) {
+        int c = fa->data[p++];
+        if (isgraph(c)) out[l++] = (char)c;
+    }
+    return l;
+}
+
+/* common.h:59-83 rev_comp: reverse + complement, anything but ACGT -> N (upper-case only table) */
+static void rev_comp(char *s, int n) {
+    for (int i = 0; i < n / 2; ++i) { char t = s[i]; s[i] = s[n - 1 - i]; s[n - 1 - i] = t; }
+    for (int i = 0; i < n; ++i) {
+        switch (s[i]) { case 'A': s[i] = 'T'; break; case 'C': s[i] = 'G'; break;
+                        case 'G': s[i] = 'C'; break; case 'T': s[i] = 'A'; break; default: s[i] = 'N'; }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * strand rules
+ * ---------------------------------------------------------------------------------------------- */
+/* junctions_extractor.cc:297-322 set_junction_strand_flag */
+char orc_strand_from_flag(uint32_t flag, int strandness) {
+    int rev = (flag >> 4) & 1, mrev = (flag >> 5) & 1, r1 = (flag >> 6) & 1, r2 = (flag >> 7) & 1;
+    int b = strandness - 1;
+    int f = (!b) ^ r1 ^ rev;
+    int s = (!b) ^ r2 ^ mrev;
+    if (f != s) return '?';
+    return f ? '+' : '-';
+}
+
+/* junctions_extractor.cc:283-294 + sam.c:1254-1266 bam_aux_get, :1233-1252 skip_aux, :1301-1307 bam_aux2A */
+static char strand_from_tag(const uint8_t *aux, const uint8_t *end, const char tag[2]) {
+    const uint8_t *s = aux;
+    while (s + 3 <= end) {                 /* two tag bytes + one type byte must be present */
+        int hit = (s[0] == (uint8_t)tag[0] && s[1] == (uint8_t)tag[1]);
+        s += 2;
+        if (hit) {
+            if (s[0] == 'A' && s + 2 <= end && s[1] != 0) return (char)s[1];
+            return '?';
+        }
+        uint8_t t = *s++;
+        switch (t) {
+            case 'A': case 'c': case 'C': s += 1; break;
+            case 's': case 'S': s += 2; break;
+            case 'i': case 'I': case 'f': s += 4; break;
+            case 'd': s += 8; break;
+            case 'Z': case 'H': while (s < end && *s) ++s; ++s; break;
+            case 'B': {
+                if (s + 5 > end) return '?';
+                uint8_t st = *s++; uint32_t n = rd32(s); s += 4;
+                int sz = (st == 'c' || st == 'C' || st == 'A') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : (st == 'd') ? 8 : 0;
+                if ((uint64_t)sz * n > (uint64_t)(end - s)) return '?';
+                s += (size_t)sz * n;
+                break;
+            }
+            default: return '?'; /* the reference abort()s here; treated as "tag not found" */
+        }
+    }
+    return '?';
+}
+
+/* junctions_extractor.cc:325-342 */
+static char strand_from_motif(const char *m) {
+    if (!strcmp(m, "GT-AG") || !strcmp(m, "GC-AG") || !strcmp(m, "AT-AC")) return '+';
+    if (!strcmp(m, "CT-AC") || !strcmp(m, "CT-GC") || !strcmp(m, "GT-AT")) return '-';
+    return '?';
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * CIGAR state machine (junctions_extractor.cc:377-497), SURVEY.md 9.3
+ * ---------------------------------------------------------------------------------------------- */
+typedef void (*emit_fn)(void *ctx, uint32_t start, uint32_t end, uint32_t ts, uint32_t te);
+
+static void cigar_walk(int32_t pos, const uint8_t *cigar, int n_cigar, emit_fn emit, void *ctx) {
+    uint32_t start = (uint32_t)pos, ts = (uint32_t)pos, end = 0, te = 0;
+    int started = 0;
+    for (int i = 0; i < n_cigar; ++i) {
+        uint32_t c = rd32(cigar + 4 * (size_t)i);
+        uint32_t op = c & 0xf, len = c >> 4;
+        switch (op) {
+            case 3: /* N */
+                if (!started) { end = start + len; te = end; started = 1; }
+                else { emit(ctx, start, end, ts, te); ts = end; start = te; end = start + len; te = end; }
+                break;
+            case 0: case 7: /* M = */
+                if (!started) start += len; else te += len;
+                break;
+            case 2: case 8: /* D X */
+                if (!started) { start += len; ts = start; }
+                else { emit(ctx, start, end, ts, te); start = te + len; ts = start; }
+                started = 0;
+                break;
+            case 1: case 4: /* I S */
+                if (!started) ts = start;
+                else { emit(ctx, start, end, ts, te); start = te; ts = start; }
+                started = 0;
+                break;
+            default: /* H: nothing; P, B and 10..15: "Unknown cigar" on stderr, nothing else */
+                break;
+        }
+    }
+    if (started) emit(ctx, start, end, ts, te);
+}
+
+typedef struct { orc_candidate *out; int n, max; } cand_ctx;
+static void cand_emit(void *c, uint32_t s, uint32_t e, uint32_t ts, uint32_t te) {
+    cand_ctx *x = (cand_ctx *)c;
+    if (x->n < x->max) { x->out[x->n].start = s; x->out[x->n].end = e; x->out[x->n].thick_start = ts; x->out[x->n].thick_end = te; }
+    x->n++;
+}
+int orc_cigar_walk(int32_t pos, const uint32_t *cigar, int n_cigar, orc_candidate *out, int max_out) {
+    cand_ctx c = { out, 0, max_out };
+    uint8_t *le = (uint8_t *)malloc((size_t)n_cigar * 4 + 4);
+    for (int i = 0; i < n_cigar; ++i) { le[4*i] = cigar[i] & 0xff; le[4*i+1] = (cigar[i] >> 8) & 0xff; le[4*i+2] = (cigar[i] >> 16) & 0xff; le[4*i+3] = cigar[i] >> 24; }
+    cigar_walk(pos, le, n_cigar, cand_emit, &c);
+    free(le);
+    return c.n;
+}
+
+/* bedFile.h:339-354 getBin, offsets bedFile.h:59 */
+uint32_t orc_get_bin(uint32_t start, uint32_t end) {
+    static const uint32_t off[7] = { 32678 + 4096 + 512 + 64 + 8 + 1, 4096 + 512 + 64 + 8 + 1, 512 + 64 + 8 + 1, 64 + 8 + 1, 8 + 1, 1, 0 };
+    --end; start >>= 14; end >>= 14;
+    for (int i = 0; i < 7; ++i) { if (start == end) return off[i] + start; start >>= 3; end >>= 3; }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * group-by (junctions_extractor.cc:160-235): open-addressing hash on (tid,start,end,class)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    orc_junction *rows; size_t n, cap;
+    int64_t *slot; size_t nslot;           /* row index or -1 */
+} jmap;
+
+static uint64_t jhash(int32_t tid, uint32_t s, uint32_t e, int cls) {
+    uint64_t h = (uint64_t)(uint32_t)tid * 0x9E3779B97F4A7C15ull;
+    h ^= ((uint64_t)s << 32 | e) * 0xC2B2AE3D27D4EB4Full; h ^= h >> 29; h *= 0x165667B19E3779F9ull; h ^= (uint64_t)cls << 7; h ^= h >> 32;
+    return h;
+}
+static int sclass(char c) { return c == '+' ? 0 : c == '-' ? 1 : 2; }
+
+static void jmap_init(jmap *m) {
+    m->cap = 1024; m->n = 0; m->rows = (orc_junction *)malloc(m->cap * sizeof(orc_junction));
+    m->nslot = 4096; m->slot = (int64_t *)malloc(m->nslot * sizeof(int64_t));
+    for (size_t i = 0; i < m->nslot; ++i) m->slot[i] = -1;
+}
+static void jmap_grow(jmap *m) {
+    size_t ns = m->nslot * 2; int64_t *sl = (int64_t *)malloc(ns * sizeof(int64_t));
+    for (size_t i = 0; i < ns; ++i) sl[i] = -1;
+    for (size_t r = 0; r < m->n; ++r) {
+        orc_junction *j = &m->rows[r];
+        size_t h = (size_t)jhash(j->tid, j->start, j->end, sclass(j->strand)) & (ns - 1);
+        while (sl[h] >= 0) h = (h + 1) & (ns - 1);
+        sl[h] = (int64_t)r;
+    }
+    free(m->slot); m->slot = sl; m->nslot = ns;
+}
+
+typedef struct {
+    const orc_params *p; jmap *m; int32_t tid; uint64_t *n_events;
+    char xs_or_flag_strand;       /* strand from the tag / flag rule for this read */
+    const fasta *fa; const char *chrom; char carried; /* motif mode: strand carried over within the read */
+    int fa_error;
+} emit_ctx;
+
+/* EMIT = strand (9.5) then add_junction (9.4) */
+static void junction_emit(void *vc, uint32_t start, uint32_t end, uint32_t ts, uint32_t te) {
+    emit_ctx *c = (emit_ctx *)vc;
+    const orc_params *p = c->p;
+    char strand;
+    if (c->fa) {
+        /* junctions_extractor.cc:564-584 get_splice_site (uint32 arithmetic) then :345-359 */
+        char s1[8], s2[8], motif[24];
+        uint32_t a1 = start + 1, a2 = start + 2, b1 = end + 1 - 2, b2 = end + 1 - 1;
+        int l1 = fasta_fetch(c->fa, c->chrom, a1, a2, s1, 4);
+        int l2 = fasta_fetch(c->fa, c->chrom, b1, b2, s2, 4);
+        if (l1 < 0 || l2 < 0) { c->fa_error = 1; return; }
+        s1[l1] = 0; s2[l2] = 0;
+        if (c->carried == '-') { rev_comp(s1, l1); rev_comp(s2, l2); snprintf(motif, sizeof motif, "%s-%s", s2, s1); }
+        else snprintf(motif, sizeof motif, "%s-%s", s1, s2);
+        strand = strand_from_motif(motif);
+        if (strand == '?') strand = c->xs_or_flag_strand;
+        c->carried = strand;
+    } else strand = c->xs_or_flag_strand;
+
+    /* junction_qc :160-170 (unsigned) */
+    uint32_t ilen = end - start;
+    if (ilen < p->min_intron || ilen > p->max_intron) return;
+    uint8_t l_ok = (uint32_t)(start - ts) >= p->min_anchor, r_ok = (uint32_t)(te - end) >= p->min_anchor;
+    (*c->n_events)++;
+
+    jmap *m = c->m;
+    int cls = sclass(strand);
+    size_t h = (size_t)jhash(c->tid, start, end, cls) & (m->nslot - 1);
+    while (m->slot[h] >= 0) {
+        orc_junction *j = &m->rows[m->slot[h]];
+        if (j->tid == c->tid && j->start == start && j->end == end && sclass(j->strand) == cls) {
+            j->read_count++;
+            if (ts < j->thick_start) j->thick_start = ts;
+            if (te > j->thick_end) j->thick_end = te;
+            j->left_ok |= l_ok; j->right_ok |= r_ok;
+            j->strand = strand;           /* newest read overwrites (cc:233) */
+            return;
+        }
+        h = (h + 1) & (m->nslot - 1);
+    }
+    if (m->n == m->cap) { m->cap *= 2; m->rows = (orc_junction *)realloc(m->rows, m->cap * sizeof(orc_junction)); }
+    orc_junction *j = &m->rows[m->n];
+    j->tid = c->tid; j->start = start; j->end = end; j->thick_start = ts; j->thick_end = te;
+    j->read_count = 1; j->name_index = (uint64_t)m->n + 1; j->strand = strand; j->left_ok = l_ok; j->right_ok = r_ok;
+    m->slot[h] = (int64_t)m->n;
+    m->n++;
+    if (m->n * 2 > m->nslot) jmap_grow(m);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * output order (junctions_extractor.h:117-140): chrom string, thick_start, thick_end, name string
+ * ---------------------------------------------------------------------------------------------- */
+static const orc_table *g_sort_tab;
+static int cmp_rows(const void *a, const void *b) {
+    const orc_junction *x = (const orc_junction *)a, *y = (const orc_junction *)b;
+    if (x->tid != y->tid) {
+        int c = strcmp(g_sort_tab->ref_name[x->tid], g_sort_tab->ref_name[y->tid]);
+        if (c) return c;
+    }
+    if (x->thick_start != y->thick_start) return x->thick_start < y->thick_start ? -1 : 1;
+    if (x->thick_end != y->thick_end) return x->thick_end < y->thick_end ? -1 : 1;
+    char nx[32], ny[32];
+    snprintf(nx, sizeof nx, "JUNC%08llu", (unsigned long long)x->name_index);
+    snprintf(ny, sizeof ny, "JUNC%08llu", (unsigned long long)y->name_index);
+    return strcmp(nx, ny);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * the driver (junctions_extractor.cc:500-535)
+ * ---------------------------------------------------------------------------------------------- */
+int orc_extract(const orc_params *p, orc_table **out, char *err, size_t errlen) {
+    *out = NULL;
+    size_t flen = 0;
+    uint8_t *file = p->bam ? slurp(p->bam, &flen) : NULL;
+    if (!file) return fail(err, errlen, "Unable to open BAM/SAM file.\n\n");
+    if (flen < 18 || !bgzf_header_ok(file)) { free(file); return fail(err, errlen, "Unable to open BAM/SAM file.\n\n"); }
+    bai_info bi;
+    if (bai_load(p->bam, &bi) != 0) { free(file); return fail(err, errlen, "Unable to open BAM/SAM index. Make sure alignments are indexed\n\n"); }
+
+    bgzf_stream st;
+    bgzf_inflate_all(file, flen, &st);
+    free(file);
+
+    orc_table *t = (orc_table *)calloc(1, sizeof *t);
+    t->inflated_bytes = st.len;
+    /* header (sam.c:114-223 bam_hdr_read) */
+    int hdr_ok = 0;
+    uint64_t q = 0;
+    const uint8_t *d = st.data;
+    if (st.len >= 12 && !memcmp(d, "BAM\1", 4)) {
+        uint32_t l_text = rd32(d + 4);
+        q = 8 + (uint64_t)l_text;
+        if (q + 4 <= st.len) {
+            t->n_ref = (int32_t)rd32(d + q); q += 4;
+            t->ref_name = (char **)calloc((size_t)(t->n_ref > 0 ? t->n_ref : 1), sizeof(char *));
+            t->ref_len = (uint32_t *)calloc((size_t)(t->n_ref > 0 ? t->n_ref : 1), sizeof(uint32_t));
+            hdr_ok = 1;
+            for (int32_t i = 0; i < t->n_ref; ++i) {
+                if (q + 4 > st.len) { hdr_ok = 0; break; }
+                uint32_t ln = rd32(d + q); q += 4;
+                if (q + ln + 4 > st.len) { hdr_ok = 0; break; }
+                t->ref_name[i] = (char *)malloc(ln + 1); memcpy(t->ref_name[i], d + q, ln); t->ref_name[i][ln] = 0; q += ln;
+                t->ref_len[i] = rd32(d + q); q += 4;
+            }
+        }
+    }
+    const char *itr_err = "Unable to iterate to region within BAM.\n\n";
+    if (!hdr_ok) { bgzf_stream_free(&st); orc_table_free(t); return fail(err, errlen, itr_err); }
+
+    /* iterator set-up */
+    int whole = !strcmp(p->region, ".");
+    int r_tid = -1, r_beg = 0, r_end = 0;
+    uint64_t pos0;
+    if (whole) {
+        uint64_t v;
+        if (bi.have_start) v = bi.start_voff;
+        else if (bi.n_no_coor) v = 0;
+        else { bgzf_stream_free(&st); orc_table_free(t); return fail(err, errlen, itr_err); }
+        /* curr_off == 0 means "do not seek": continue right after the header */
+        if (v == 0) pos0 = q;
+        else {
+            int64_t so = voff_to_stream(&st, v);
+            if (so < 0) so = (int64_t)st.len;
+            pos0 = (uint64_t)so;
+        }
+    } else {
+        if (!strcmp(p->region, "*")) { bgzf_stream_free(&st); orc_table_free(t); return fail(err, errlen, itr_err); } /* not restated */
+        if (parse_region(t, p->region, &r_tid, &r_beg, &r_end) || r_tid >= bi.n_ref || r_end < r_beg) {
+            bgzf_stream_free(&st); orc_table_free(t); return fail(err, errlen, itr_err);
+        }
+        pos0 = q; /* sorted+indexed input: index-driven iteration == predicate filter in file order */
+    }
+
+    /* the record stream ends at the first empty member at/after the start position (bgzf.c:548-578) */
+    uint64_t lim = st.len;
+    for (size_t b = 0; b < st.nblk; ++b)
+        if (st.blk[b].ulen == 0 && st.blk[b].uoff >= pos0) { lim = st.blk[b].uoff; break; }
+
+    fasta *fa = NULL;
+    if (p->fasta) {
+        fa = fasta_load(p->fasta);
+        if (!fa) { bgzf_stream_free(&st); orc_table_free(t); return fail(err, errlen, "Unable to open FASTA file.\n\n"); }
+    }
+
+    jmap m; jmap_init(&m);
+    emit_ctx ec; memset(&ec, 0, sizeof ec);
+    ec.p = p; ec.m = &m; ec.n_events = &t->n_events; ec.fa = fa;
+
+    uint64_t o = pos0;
+    int rc = 0;
+    while (o + 4 <= lim) {
+        /* bam_read1 sam.c:399-433 */
+        int32_t block_len = (int32_t)rd32(d + o);
+        if (o + 36 > lim) break;
+        const uint8_t *x = d + o + 4;
+        int32_t tid = (int32_t)rd32(x), pos = (int32_t)rd32(x + 4);
+        uint32_t x2 = rd32(x + 8), x3 = rd32(x + 12);
+        int32_t l_qseq = (int32_t)rd32(x + 16);
+        uint32_t l_qname = x2 & 0xff, n_cigar = x3 & 0xffff, flag = x3 >> 16;
+        int64_t l_data = (int64_t)block_len - 32;
+        if (l_data < 0 || l_qseq < 0 || l_qname < 1) break;
+        int64_t aux_off = (int64_t)l_qname + 4 * (int64_t)n_cigar + (((int64_t)l_qseq + 1) >> 1) + l_qseq;
+        if (aux_off > l_data) break;
+        if (o + 36 + (uint64_t)l_data > lim) break;
+        const uint8_t *data = d + o + 36;
+        const uint8_t *cig = data + l_qname;
+        o += 4 + (uint64_t)block_len;
+        t->n_records_total++;
+
+        if (!whole) {
+            /* hts_itr_next hts.c:1946-1957 with bam_endpos sam.c:336-342 */
+            if (tid != r_tid || pos >= r_end) continue; /* sorted input: == the reference's early stop */
+            int32_t endpos;
+            if (!(flag & 4) && n_cigar > 0) {
+                int32_t l = 0;
+                for (uint32_t k = 0; k < n_cigar; ++k) {
+                    uint32_t c = rd32(cig + 4 * k), op = c & 0xf;
+                    if ((0x3C1A7 >> (op << 1)) & 2) l += (int32_t)(c >> 4);
+                }
+                endpos = pos + l;
+            } else endpos = pos + 1;
+            if (!(endpos > r_beg && r_end > pos)) continue;
+        }
+        t->n_records++;
+        if (n_cigar <= 1) continue;             /* junctions_extractor.cc:378-380 */
+        if (tid < 0 || tid >= t->n_ref) continue; /* UB upstream; skipped */
+        ec.tid = tid; ec.chrom = t->ref_name[tid]; ec.carried = 0;
+        if (p->strandness == 0) ec.xs_or_flag_strand = strand_from_tag(data + aux_off, data + l_data, p->strand_tag);
+        else ec.xs_or_flag_strand = orc_strand_from_flag(flag, p->strandness);
+        cigar_walk(pos, cig, (int)n_cigar, junction_emit, &ec);
+        if (ec.fa_error) { rc = fail(err, errlen, "Unable to extract FASTA sequence for position\n\n"); break; }
+    }
+    bgzf_stream_free(&st);
+    fasta_free(fa);
+    free(m.slot);
+    if (rc) { free(m.rows); orc_table_free(t); return rc; }
+
+    t->rows = m.rows; t->n = m.n;
+    g_sort_tab = t;
+    qsort(t->rows, t->n, sizeof(orc_junction), cmp_rows);
+    *out = t;
+    return 0;
+}
+
+void orc_table_free(orc_table *t) {
+    if (!t) return;
+    if (t->ref_name) for (int32_t i = 0; i < t->n_ref; ++i) free(t->ref_name[i]);
+    free(t->ref_name); free(t->ref_len); free(t->rows); free(t);
+}
+
+/* junctions_extractor.h:90-98 */
+void orc_print_bed12(const orc_table *t, FILE *out, int only_anchored) {
+    for (size_t i = 0; i < t->n; ++i) {
+        const orc_junction *j = &t->rows[i];
+        if (only_anchored && !(j->left_ok && j->right_ok)) continue;
+        fprintf(out, "%s\t%u\t%u\tJUNC%08llu\t%u\t%c\t%u\t%u\t255,0,0\t2\t%u,%u\t0,%u\n",
+                t->ref_name[j->tid], j->thick_start, j->thick_end, (unsigned long long)j->name_index,
+                j->read_count, j->strand, j->thick_start, j->thick_end,
+                (uint32_t)(j->start - j->thick_start), (uint32_t)(j->thick_end - j->end),
+                (uint32_t)(j->end - j->thick_start));
+    }
+}

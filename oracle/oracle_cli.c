@@ -1,0 +1,62 @@
+/* oracle/oracle_cli.c -- TEST INFRASTRUCTURE ONLY.
+ * Command-line face of the CPU restatement, flag-compatible with `regtools junctions extract`
+ * (junctions_extractor.cc:42-122), plus `time` used by bench.py's cpu_baseline leg. */
+#define _POSIX_C_SOURCE 200809L
+#include "oracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+static double now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+int main(int argc, char **argv) {
+    if (argc < 2 || (strcmp(argv[1], "extract") && strcmp(argv[1], "time"))) {
+        fprintf(stderr, "usage: oracle_cli {extract|time} [-a N -m N -M N -o FILE -r REGION -t TAG -s XS|RF|FR|intron-motif] in.bam [ref.fa]\n");
+        return 1;
+    }
+    int timing = !strcmp(argv[1], "time");
+    orc_params p; orc_default_params(&p);
+    const char *outfile = NULL;
+    int c;
+    optind = 2;
+    while ((c = getopt(argc, argv, "a:m:M:o:r:t:s:")) != -1) {
+        switch (c) {
+            case 'a': p.min_anchor = (uint32_t)atoi(optarg); break;
+            case 'm': p.min_intron = (uint32_t)atoi(optarg); break;
+            case 'M': p.max_intron = (uint32_t)atoi(optarg); break;
+            case 'o': outfile = optarg; break;
+            case 'r': p.region = optarg; break;
+            case 't': p.strand_tag[0] = optarg[0]; p.strand_tag[1] = optarg[0] ? optarg[1] : 0; break;
+            case 's':
+                if (!strcmp(optarg, "XS")) p.strandness = 0; else if (!strcmp(optarg, "RF")) p.strandness = 1;
+                else if (!strcmp(optarg, "FR")) p.strandness = 2; else if (!strcmp(optarg, "intron-motif")) p.strandness = 3;
+                else { fprintf(stderr, "Unrecognized strandness argument!\n\n"); return 1; }
+                break;
+            default: fprintf(stderr, "Error parsing inputs!(1)\n\n"); return 1;
+        }
+    }
+    if (argc - optind >= 1) p.bam = argv[optind++];
+    if (argc - optind >= 1) p.fasta = argv[optind++];
+    if (optind < argc || !p.bam) { fprintf(stderr, "Error parsing inputs!(2)\n\n"); return 1; }
+    if (p.strandness == -1) { fprintf(stderr, "Please supply strandness mode with '-s' option!\n\n"); return 1; }
+    if (p.strandness == 3 && !p.fasta) { fprintf(stderr, "Strandness mode 'intron-motif' requires a fasta file!\n\n"); return 1; }
+
+    char err[256]; orc_table *t = NULL;
+    double t0 = now();
+    if (orc_extract(&p, &t, err, sizeof err)) { fputs(err, stderr); return 1; }
+    double t1 = now();
+    if (timing) {
+        printf("{\"records\": %llu, \"events\": %llu, \"junctions\": %zu, \"inflated_bytes\": %llu, \"seconds\": %.6f}\n",
+               (unsigned long long)t->n_records_total, (unsigned long long)t->n_events, t->n,
+               (unsigned long long)t->inflated_bytes, t1 - t0);
+    } else {
+        FILE *out = outfile ? fopen(outfile, "w") : stdout;
+        if (!out) { perror("open output"); return 1; }
+        orc_print_bed12(t, out, 1);
+        if (outfile) fclose(out);
+    }
+    orc_table_free(t);
+    return 0;
+}
