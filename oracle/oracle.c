@@ -53,72 +53,64 @@ void orc_default_params(orc_params *p) {
  * BGZF: block walk + inflate  (src/utils/htslib/bgzf.c:348-355 check_header, :421-546 read_block,
  * :292-316 inflate_block -- raw DEFLATE at +18, zlib windowBits -15, CRC/ISIZE never checked)
  * ---------------------------------------------------------------------------------------------- */
-typedef struct {
-    uint64_t coff;   /* compressed offset of the member */
-    uint64_t uoff;   /* offset of its first inflated byte in the concatenated stream */
-    uint32_t ulen;   /* inflated length */
-} bgzf_blk;
-
-typedef struct {
-    uint8_t  *data;  /* concatenated inflated stream */
-    uint64_t  len;
-    bgzf_blk *blk;
-    size_t    nblk;
-    int       stop_reason; /* 0 = clean EOF, 1 = empty block, 2 = corrupt block */
-} bgzf_stream;
-
 static int bgzf_header_ok(const uint8_t *h) {
     if (h[0] != 31 || h[1] != 139 || h[2] != 8) return 0;
     return (h[3] & 4) && rd16(h + 10) == 6 && h[12] == 'B' && h[13] == 'C' && rd16(h + 14) == 2;
 }
 
-/* Inflate every member from file offset 0.  The stream handed to the record reader ends at the first
- * member that inflates to zero bytes *after* `first_coff` (bgzf.c:548-578: bgzf_read breaks out when a
- * freshly loaded block has no data, so bam_read1 sees a short read == EOF), at a corrupt member, or at
- * end of file. Members before first_coff that are empty are kept as zero-length entries. */
-static int bgzf_inflate_all(const uint8_t *file, size_t flen, bgzf_stream *s) {
-    memset(s, 0, sizeof *s);
-    size_t cap_blk = 1024, cap_data = 1 << 20;
-    s->blk = (bgzf_blk *)malloc(cap_blk * sizeof(bgzf_blk));
-    s->data = (uint8_t *)malloc(cap_data);
-    size_t off = 0;
-    while (off < flen) {
-        if (flen - off < 18 || !bgzf_header_ok(file + off)) { s->stop_reason = 2; break; }
-        size_t blen = (size_t)rd16(file + off + 16) + 1;
-        if (off + blen > flen || blen < 26) { s->stop_reason = 2; break; }
-        if (s->len + 65536 > cap_data) {
-            while (s->len + 65536 > cap_data) cap_data *= 2;
-            s->data = (uint8_t *)realloc(s->data, cap_data);
-        }
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        zs.next_in = (Bytef *)(file + off + 18);
-        zs.avail_in = (uInt)(blen - 16 <= flen - off - 18 ? blen - 16 : flen - off - 18);
-        zs.next_out = s->data + s->len;
-        zs.avail_out = 65536;
-        if (inflateInit2(&zs, -15) != Z_OK) { s->stop_reason = 2; break; }
-        int zr = inflate(&zs, Z_FINISH);
-        uint32_t ulen = (uint32_t)zs.total_out;
-        inflateEnd(&zs);
-        if (zr != Z_STREAM_END) { s->stop_reason = 2; break; }
-        if (s->nblk == cap_blk) { cap_blk *= 2; s->blk = (bgzf_blk *)realloc(s->blk, cap_blk * sizeof(bgzf_blk)); }
-        s->blk[s->nblk].coff = off; s->blk[s->nblk].uoff = s->len; s->blk[s->nblk].ulen = ulen;
-        s->nblk++;
-        s->len += ulen;
-        off += blen;
-    }
-    return 0;
+/* Sequential reader over the inflated stream, one member at a time (bgzf.c:548-578 bgzf_read):
+ * a member that inflates to zero bytes, a corrupt member or end of file all end the stream
+ * (bgzf_read breaks out on an empty block, so bam_read1 sees a short read == EOF). */
+typedef struct {
+    const uint8_t *file; size_t flen;
+    size_t   coff;          /* compressed offset of the next member to load */
+    uint8_t *buf; size_t cap, beg, end;   /* unconsumed inflated bytes are buf[beg,end) */
+    int      eof;
+    uint64_t inflated;      /* total bytes inflated (statistics) */
+} bgzf_reader;
+
+static void rdr_init(bgzf_reader *r, const uint8_t *file, size_t flen) {
+    memset(r, 0, sizeof *r);
+    r->file = file; r->flen = flen; r->cap = 1 << 18; r->buf = (uint8_t *)malloc(r->cap);
 }
 
-static void bgzf_stream_free(bgzf_stream *s) { free(s->data); free(s->blk); }
+static int rdr_load(bgzf_reader *r) {   /* returns 1 if a non-empty member was appended */
+    if (r->eof) return 0;
+    size_t off = r->coff;
+    if (off >= r->flen) { r->eof = 1; return 0; }
+    if (r->flen - off < 18 || !bgzf_header_ok(r->file + off)) { r->eof = 1; return 0; }
+    size_t blen = (size_t)rd16(r->file + off + 16) + 1;
+    if (off + blen > r->flen || blen < 26) { r->eof = 1; return 0; }
+    if (r->beg && r->beg == r->end) r->beg = r->end = 0;
+    if (r->end + 65536 > r->cap) {
+        if (r->beg) { memmove(r->buf, r->buf + r->beg, r->end - r->beg); r->end -= r->beg; r->beg = 0; }
+        if (r->end + 65536 > r->cap) { while (r->end + 65536 > r->cap) r->cap *= 2; r->buf = (uint8_t *)realloc(r->buf, r->cap); }
+    }
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    zs.next_in = (Bytef *)(r->file + off + 18);
+    zs.avail_in = (uInt)(blen - 16 <= r->flen - off - 18 ? blen - 16 : r->flen - off - 18);
+    zs.next_out = r->buf + r->end; zs.avail_out = 65536;
+    if (inflateInit2(&zs, -15) != Z_OK) { r->eof = 1; return 0; }
+    int zr = inflate(&zs, Z_FINISH);
+    size_t ulen = zs.total_out;
+    inflateEnd(&zs);
+    if (zr != Z_STREAM_END) { r->eof = 1; return 0; }
+    r->coff = off + blen;
+    if (ulen == 0) { r->eof = 1; return 0; }
+    r->end += ulen; r->inflated += ulen;
+    return 1;
+}
 
-/* virtual offset -> stream offset; returns -1 if the compressed offset is not a member start */
-static int64_t voff_to_stream(const bgzf_stream *s, uint64_t voff) {
-    uint64_t c = voff >> 16, u = voff & 0xffff;
-    size_t lo = 0, hi = s->nblk;
-    while (lo < hi) { size_t m = (lo + hi) / 2; if (s->blk[m].coff < c) lo = m + 1; else hi = m; }
-    if (lo == s->nblk || s->blk[lo].coff != c) return -1;
-    return (int64_t)(s->blk[lo].uoff + u);
+/* make n bytes available at buf+beg; returns 0 if the stream ends first */
+static int rdr_need(bgzf_reader *r, size_t n) {
+    while (r->end - r->beg < n) if (!rdr_load(r)) return 0;
+    return 1;
+}
+
+/* bgzf_seek to a virtual offset: load that member, position inside it */
+static void rdr_seek(bgzf_reader *r, uint64_t voff) {
+    r->coff = (size_t)(voff >> 16); r->beg = r->end = 0; r->eof = 0;
+    if (rdr_load(r)) { size_t u = (size_t)(voff & 0xffff); r->beg = u <= r->end ? u : r->end; }
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -566,83 +558,64 @@ int orc_extract(const orc_params *p, orc_table **out, char *err, size_t errlen) 
     if (flen < 18 || !bgzf_header_ok(file)) { free(file); return fail(err, errlen, "Unable to open BAM/SAM file.\n\n"); }
     bai_info bi;
     if (bai_load(p->bam, &bi) != 0) { free(file); return fail(err, errlen, "Unable to open BAM/SAM index. Make sure alignments are indexed\n\n"); }
-
-    bgzf_stream st;
-    bgzf_inflate_all(file, flen, &st);
-    free(file);
-
+    bgzf_reader rd; rdr_init(&rd, file, flen);
     orc_table *t = (orc_table *)calloc(1, sizeof *t);
-    t->inflated_bytes = st.len;
     /* header (sam.c:114-223 bam_hdr_read) */
     int hdr_ok = 0;
-    uint64_t q = 0;
-    const uint8_t *d = st.data;
-    if (st.len >= 12 && !memcmp(d, "BAM\1", 4)) {
-        uint32_t l_text = rd32(d + 4);
-        q = 8 + (uint64_t)l_text;
-        if (q + 4 <= st.len) {
-            t->n_ref = (int32_t)rd32(d + q); q += 4;
+    if (rdr_need(&rd, 12) && !memcmp(rd.buf + rd.beg, "BAM\1", 4)) {
+        uint32_t l_text = rd32(rd.buf + rd.beg + 4);
+        if (rdr_need(&rd, 8 + (size_t)l_text + 4)) {
+            rd.beg += 8 + (size_t)l_text;
+            t->n_ref = (int32_t)rd32(rd.buf + rd.beg); rd.beg += 4;
             t->ref_name = (char **)calloc((size_t)(t->n_ref > 0 ? t->n_ref : 1), sizeof(char *));
             t->ref_len = (uint32_t *)calloc((size_t)(t->n_ref > 0 ? t->n_ref : 1), sizeof(uint32_t));
             hdr_ok = 1;
             for (int32_t i = 0; i < t->n_ref; ++i) {
-                if (q + 4 > st.len) { hdr_ok = 0; break; }
-                uint32_t ln = rd32(d + q); q += 4;
-                if (q + ln + 4 > st.len) { hdr_ok = 0; break; }
-                t->ref_name[i] = (char *)malloc(ln + 1); memcpy(t->ref_name[i], d + q, ln); t->ref_name[i][ln] = 0; q += ln;
-                t->ref_len[i] = rd32(d + q); q += 4;
+                if (!rdr_need(&rd, 4)) { hdr_ok = 0; break; }
+                uint32_t ln = rd32(rd.buf + rd.beg);
+                if (!rdr_need(&rd, 4 + (size_t)ln + 4)) { hdr_ok = 0; break; }
+                t->ref_name[i] = (char *)malloc(ln + 1); memcpy(t->ref_name[i], rd.buf + rd.beg + 4, ln); t->ref_name[i][ln] = 0;
+                t->ref_len[i] = rd32(rd.buf + rd.beg + 4 + ln);
+                rd.beg += 4 + (size_t)ln + 4;
             }
         }
     }
     const char *itr_err = "Unable to iterate to region within BAM.\n\n";
-    if (!hdr_ok) { bgzf_stream_free(&st); orc_table_free(t); return fail(err, errlen, itr_err); }
+#define BAIL(msg) do { free(rd.buf); free(file); orc_table_free(t); return fail(err, errlen, msg); } while (0)
+    if (!hdr_ok) BAIL(itr_err);
 
     /* iterator set-up */
     int whole = !strcmp(p->region, ".");
     int r_tid = -1, r_beg = 0, r_end = 0;
-    uint64_t pos0;
     if (whole) {
         uint64_t v;
         if (bi.have_start) v = bi.start_voff;
         else if (bi.n_no_coor) v = 0;
-        else { bgzf_stream_free(&st); orc_table_free(t); return fail(err, errlen, itr_err); }
-        /* curr_off == 0 means "do not seek": continue right after the header */
-        if (v == 0) pos0 = q;
-        else {
-            int64_t so = voff_to_stream(&st, v);
-            if (so < 0) so = (int64_t)st.len;
-            pos0 = (uint64_t)so;
-        }
+        else BAIL(itr_err);
+        if (v != 0) rdr_seek(&rd, v);   /* curr_off == 0 means "do not seek": continue right after the header */
     } else {
-        if (!strcmp(p->region, "*")) { bgzf_stream_free(&st); orc_table_free(t); return fail(err, errlen, itr_err); } /* not restated */
-        if (parse_region(t, p->region, &r_tid, &r_beg, &r_end) || r_tid >= bi.n_ref || r_end < r_beg) {
-            bgzf_stream_free(&st); orc_table_free(t); return fail(err, errlen, itr_err);
-        }
-        pos0 = q; /* sorted+indexed input: index-driven iteration == predicate filter in file order */
+        if (!strcmp(p->region, "*")) BAIL(itr_err); /* not restated */
+        if (parse_region(t, p->region, &r_tid, &r_beg, &r_end) || r_tid >= bi.n_ref || r_end < r_beg) BAIL(itr_err);
+        /* sorted+indexed input: index-driven iteration == predicate filter in file order */
     }
-
-    /* the record stream ends at the first empty member at/after the start position (bgzf.c:548-578) */
-    uint64_t lim = st.len;
-    for (size_t b = 0; b < st.nblk; ++b)
-        if (st.blk[b].ulen == 0 && st.blk[b].uoff >= pos0) { lim = st.blk[b].uoff; break; }
 
     fasta *fa = NULL;
     if (p->fasta) {
         fa = fasta_load(p->fasta);
-        if (!fa) { bgzf_stream_free(&st); orc_table_free(t); return fail(err, errlen, "Unable to open FASTA file.\n\n"); }
+        if (!fa) BAIL("Unable to open FASTA file.\n\n");
     }
 
     jmap m; jmap_init(&m);
     emit_ctx ec; memset(&ec, 0, sizeof ec);
     ec.p = p; ec.m = &m; ec.n_events = &t->n_events; ec.fa = fa;
 
-    uint64_t o = pos0;
     int rc = 0;
-    while (o + 4 <= lim) {
+    for (;;) {
         /* bam_read1 sam.c:399-433 */
-        int32_t block_len = (int32_t)rd32(d + o);
-        if (o + 36 > lim) break;
-        const uint8_t *x = d + o + 4;
+        if (!rdr_need(&rd, 4)) break;
+        int32_t block_len = (int32_t)rd32(rd.buf + rd.beg);
+        if (!rdr_need(&rd, 36)) break;
+        const uint8_t *x = rd.buf + rd.beg + 4;
         int32_t tid = (int32_t)rd32(x), pos = (int32_t)rd32(x + 4);
         uint32_t x2 = rd32(x + 8), x3 = rd32(x + 12);
         int32_t l_qseq = (int32_t)rd32(x + 16);
@@ -651,10 +624,10 @@ int orc_extract(const orc_params *p, orc_table **out, char *err, size_t errlen) 
         if (l_data < 0 || l_qseq < 0 || l_qname < 1) break;
         int64_t aux_off = (int64_t)l_qname + 4 * (int64_t)n_cigar + (((int64_t)l_qseq + 1) >> 1) + l_qseq;
         if (aux_off > l_data) break;
-        if (o + 36 + (uint64_t)l_data > lim) break;
-        const uint8_t *data = d + o + 36;
+        if (!rdr_need(&rd, 36 + (size_t)l_data)) break;
+        const uint8_t *data = rd.buf + rd.beg + 36;
         const uint8_t *cig = data + l_qname;
-        o += 4 + (uint64_t)block_len;
+        rd.beg += 4 + (size_t)block_len;
         t->n_records_total++;
 
         if (!whole) {
@@ -680,10 +653,12 @@ int orc_extract(const orc_params *p, orc_table **out, char *err, size_t errlen) 
         cigar_walk(pos, cig, (int)n_cigar, junction_emit, &ec);
         if (ec.fa_error) { rc = fail(err, errlen, "Unable to extract FASTA sequence for position\n\n"); break; }
     }
-    bgzf_stream_free(&st);
+    t->inflated_bytes = rd.inflated;
+    free(rd.buf); free(file);
     fasta_free(fa);
     free(m.slot);
     if (rc) { free(m.rows); orc_table_free(t); return rc; }
+#undef BAIL
 
     t->rows = m.rows; t->n = m.n;
     g_sort_tab = t;
