@@ -1,0 +1,133 @@
+/* include/regtools_amd.h -- C ABI of libregtools_amd.so, the MI355X (gfx950) drop-in for the
+ * `regtools junctions extract` hot path.
+ *
+ * The reference has no FFI layer; its seam is the public interface of class JunctionsExtractor
+ * (/root/reference/src/junctions/junctions_extractor.h:183-247).  Each entry point below names the
+ * reference interface it replaces.  Pure C: plain pointers and sizes, no C++ or torch types.
+ * INTEGRATION.md shows the binding a regtools maintainer would add.
+ *
+ * Error model (replaces `throw std::runtime_error(msg)` caught in junctions_main.cc:51-57): every call
+ * returns 0 on success; otherwise nonzero with the reference's own message text in `err`.
+ * There is NO CPU fallback: without a HIP device (or if the gfx950 code object cannot be loaded)
+ * rgx_ctx_create fails loudly with RGX_ERR_NO_DEVICE.
+ */
+#ifndef REGTOOLS_AMD_H
+#define REGTOOLS_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGX_OK             0
+#define RGX_ERR_OPEN       1  /* "Unable to open BAM/SAM file.\n\n"                      junctions_extractor.cc:505 */
+#define RGX_ERR_INDEX      2  /* "Unable to open BAM/SAM index. Make sure ...\n\n"       junctions_extractor.cc:510 */
+#define RGX_ERR_REGION     3  /* "Unable to iterate to region within BAM.\n\n"           junctions_extractor.cc:521 */
+#define RGX_ERR_NO_DEVICE  4  /* no usable HIP device / code object: the product never falls back to a CPU */
+#define RGX_ERR_DEVICE     5  /* HIP runtime error */
+#define RGX_ERR_FORMAT     6  /* malformed BGZF/BAM beyond what the reference tolerates silently */
+#define RGX_ERR_ARG        7
+#define RGX_ERR_FASTA      8  /* "Unable to extract FASTA sequence for position ...\n\n" junctions_extractor.cc:553 */
+
+typedef struct rgx_ctx rgx_ctx;   /* one per process+device: HIP stream(s) and a reusable HBM workspace */
+
+/* Parameters of one extraction.
+ * Replaces the JunctionsExtractor constructors (junctions_extractor.h:185-205) and the option parser
+ * (junctions_extractor.cc:42-122).  rgx_extract_params_default fills the default-ctor values. */
+typedef struct {
+    const char *region;        /* "." = whole file (h:196); "chr:beg-end" as sam_itr_querys parses it */
+    int32_t     strandness;    /* 0 XS tag, 1 RF, 2 FR, 3 intron-motif (cc:71-84) */
+    char        strand_tag[2]; /* "XS" (h:192) */
+    uint32_t    min_anchor;    /* 8   (h:186)  -a */
+    uint32_t    min_intron;    /* 70  (h:187)  -m */
+    uint32_t    max_intron;    /* 500000 (h:188) -M */
+    const char *fasta_path;    /* NULL = "NA"; required by strandness 3 (cc:105-110) */
+    /* shard of the BGZF member list handled by this call (multi-GPU): members are cut into
+     * n_shards contiguous ranges balanced by compressed bytes; records belong to the shard their first
+     * byte is in.  0/1 = everything. */
+    int32_t     shard;
+    int32_t     n_shards;
+} rgx_extract_params;
+
+void rgx_extract_params_default(rgx_extract_params *p);
+
+/* Result table, structure-of-arrays, rows in the reference's output order
+ * (compare_junctions, junctions_extractor.h:117-140).  Replaces vector<Junction> from
+ * JunctionsExtractor::get_all_junctions (cc:238-246); `left_ok && right_ok` is the filter
+ * print_all_junctions applies (cc:267).  Owned by the library; release with rgx_table_free. */
+typedef struct {
+    int32_t    n_ref;
+    char     **ref_name;        /* header->target_name */
+    uint32_t  *ref_len;
+    uint64_t   n;               /* rows */
+    int32_t   *tid;
+    uint32_t  *start, *end;     /* Junction::start/end (BED::start/end) */
+    uint32_t  *thick_start, *thick_end;
+    uint32_t  *read_count;
+    uint64_t  *name_index;      /* k of "JUNC%08d" (get_new_junction_name, cc:152-157) */
+    char      *strand;
+    uint8_t   *left_ok, *right_ok;
+    /* statistics (not part of the reference interface) */
+    uint64_t   n_records;       /* alignments iterated in this shard */
+    uint64_t   n_events;        /* junction events that passed junction_qc */
+    uint64_t   inflated_bytes, compressed_bytes, n_members;
+    double     ms_total, ms_inflate, ms_records, ms_scan, ms_reduce; /* wall + HIP-event stage times */
+    /* partial (per-shard) tables also carry what a cross-shard merge needs */
+    uint64_t  *first_seen;      /* event order of the first read of each row (shard-local) */
+    uint64_t  *last_seen;       /* event order of the last read (its strand is the row's strand) */
+} rgx_junction_table;
+
+int  rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errlen);
+void rgx_ctx_destroy(rgx_ctx *ctx);
+
+/* Replaces JunctionsExtractor::identify_junctions_from_BAM + get_all_junctions (cc:500-535, 238-246):
+ * reads <bam_path> and its .bai from disk, uploads, runs the device pipeline, returns the table. */
+int  rgx_extract(rgx_ctx *ctx, const char *bam_path, const rgx_extract_params *p,
+                 rgx_junction_table **out, char *err, size_t errlen);
+
+/* Same, input already in host memory (file bytes of the .bam and of its .bai). */
+int  rgx_extract_mem(rgx_ctx *ctx, const void *bam, size_t bam_len, const void *bai, size_t bai_len,
+                     const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen);
+
+/* Same, with the .bam bytes ALREADY RESIDENT IN HBM at d_bam (the measured configuration: bench.py and a
+ * pipeline that DMA'd the file straight to the device).  h_bam must hold the same bytes on the host: the
+ * BGZF member chain (BSIZE at +16 of every member, bgzf.c:525) is walked there while the GPU already
+ * inflates the members found so far.  d_bam must be readable up to bam_len + 8 bytes. */
+int  rgx_extract_device(rgx_ctx *ctx, const void *d_bam, const void *h_bam, size_t bam_len,
+                        const void *bai, size_t bai_len, const rgx_extract_params *p,
+                        rgx_junction_table **out, char *err, size_t errlen);
+
+void rgx_table_free(rgx_junction_table *t);
+
+/* Merge per-shard tables (shard order = file order) into the final table: sum counts, min/max thick
+ * bounds, earliest first_seen names the row, latest last_seen gives the strand; rows are renamed and
+ * re-sorted.  This is the host-side half of the multi-GPU path; the device-side exchange is an
+ * all-gather of the packed rows (see rgx_table_pack / rgx_table_unpack). */
+int  rgx_table_merge(const rgx_junction_table *const *parts, int n_parts, uint32_t min_anchor,
+                     rgx_junction_table **out, char *err, size_t errlen);
+
+/* Fixed-width row packing for the RCCL all-gather: 48 bytes per row. */
+#define RGX_PACKED_ROW_BYTES 48
+size_t rgx_table_pack(const rgx_junction_table *t, void *dst, size_t dst_cap); /* returns bytes needed */
+int    rgx_table_unpack(const void *src, size_t n_rows, const rgx_junction_table *names_from,
+                        rgx_junction_table **out);
+
+/* Replaces Junction::print / print_all_junctions (junctions_extractor.h:90-98, cc:249-280): BED12 text.
+ * only_anchored != 0 keeps rows with both anchors (the `junctions extract` output).  Returns the number
+ * of bytes written, or the size needed when buf is NULL. */
+size_t rgx_table_format_bed12(const rgx_junction_table *t, int only_anchored, char *buf, size_t cap);
+
+/* Library/build identification: "regtools_amd <version> gfx950". */
+const char *rgx_version(void);
+
+/* Stage-level kernel entry points on caller-provided DEVICE buffers (used by tests/bench to measure the
+ * dominant kernel in isolation; all asynchronous on `stream`, a hipStream_t passed as void*). */
+typedef struct { uint64_t cpos, upos; uint32_t clen, isize; } rgx_member;   /* == rgx::Member */
+int  rgx_k_inflate(const void *d_comp, const rgx_member *d_members, uint32_t n_members,
+                   void *d_arena, uint32_t *d_status, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,104 @@
+"""ctypes bindings of the C ABI declared in include/regtools_amd.h (libregtools_amd.so, HIP/gfx950)
+and of the tooling library libregtools_synth.so (synthetic BAM writer).
+
+The product library is loaded lazily and loading failures are NEVER swallowed: there is no Python or CPU
+fallback for the hot path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libregtools_amd.so")
+SYNTH_PATH = os.path.join(_HERE, "libregtools_synth.so")
+
+
+class ExtractParams(C.Structure):
+    _fields_ = [("region", C.c_char_p), ("strandness", C.c_int32), ("strand_tag", C.c_char * 2),
+                ("min_anchor", C.c_uint32), ("min_intron", C.c_uint32), ("max_intron", C.c_uint32),
+                ("fasta_path", C.c_char_p), ("shard", C.c_int32), ("n_shards", C.c_int32)]
+
+
+class JunctionTable(C.Structure):
+    _fields_ = [("n_ref", C.c_int32), ("ref_name", C.POINTER(C.c_char_p)), ("ref_len", C.POINTER(C.c_uint32)),
+                ("n", C.c_uint64), ("tid", C.POINTER(C.c_int32)), ("start", C.POINTER(C.c_uint32)),
+                ("end", C.POINTER(C.c_uint32)), ("thick_start", C.POINTER(C.c_uint32)),
+                ("thick_end", C.POINTER(C.c_uint32)), ("read_count", C.POINTER(C.c_uint32)),
+                ("name_index", C.POINTER(C.c_uint64)), ("strand", C.POINTER(C.c_char)),
+                ("left_ok", C.POINTER(C.c_uint8)), ("right_ok", C.POINTER(C.c_uint8)),
+                ("n_records", C.c_uint64), ("n_events", C.c_uint64), ("inflated_bytes", C.c_uint64),
+                ("compressed_bytes", C.c_uint64), ("n_members", C.c_uint64),
+                ("ms_total", C.c_double), ("ms_inflate", C.c_double), ("ms_records", C.c_double),
+                ("ms_scan", C.c_double), ("ms_reduce", C.c_double),
+                ("first_seen", C.POINTER(C.c_uint64)), ("last_seen", C.POINTER(C.c_uint64))]
+
+
+class Member(C.Structure):
+    _fields_ = [("cpos", C.c_uint64), ("upos", C.c_uint64), ("clen", C.c_uint32), ("isize", C.c_uint32)]
+
+
+# every symbol include/regtools_amd.h declares (tests check the library exports all of them)
+EXPORTS = ["rgx_extract_params_default", "rgx_ctx_create", "rgx_ctx_destroy", "rgx_extract", "rgx_extract_mem",
+           "rgx_extract_device", "rgx_table_free", "rgx_table_merge", "rgx_table_pack", "rgx_table_unpack",
+           "rgx_table_format_bed12", "rgx_version", "rgx_k_inflate"]
+
+_lib = None
+
+
+def lib():
+    """Load libregtools_amd.so (raises if it was not built: no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("regtools_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        P = C.POINTER
+        L.rgx_version.restype = C.c_char_p
+        L.rgx_extract_params_default.argtypes = [P(ExtractParams)]
+        L.rgx_ctx_create.argtypes = [C.c_int, P(C.c_void_p), C.c_char_p, C.c_size_t]
+        L.rgx_ctx_destroy.argtypes = [C.c_void_p]
+        L.rgx_extract.argtypes = [C.c_void_p, C.c_char_p, P(ExtractParams), P(P(JunctionTable)), C.c_char_p, C.c_size_t]
+        L.rgx_extract_mem.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, P(ExtractParams),
+                                      P(P(JunctionTable)), C.c_char_p, C.c_size_t]
+        L.rgx_extract_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                         P(ExtractParams), P(P(JunctionTable)), C.c_char_p, C.c_size_t]
+        L.rgx_table_free.argtypes = [P(JunctionTable)]
+        L.rgx_table_merge.argtypes = [P(P(JunctionTable)), C.c_int, C.c_uint32, P(P(JunctionTable)), C.c_char_p, C.c_size_t]
+        L.rgx_table_pack.argtypes = [P(JunctionTable), C.c_void_p, C.c_size_t]
+        L.rgx_table_pack.restype = C.c_size_t
+        L.rgx_table_unpack.argtypes = [C.c_void_p, C.c_size_t, P(JunctionTable), P(P(JunctionTable))]
+        L.rgx_table_format_bed12.argtypes = [P(JunctionTable), C.c_int, C.c_char_p, C.c_size_t]
+        L.rgx_table_format_bed12.restype = C.c_size_t
+        L.rgx_k_inflate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("shape", C.c_int), ("n_reads", C.c_uint64), ("seed", C.c_uint64), ("level", C.c_int),
+                ("threads", C.c_int), ("n_introns", C.c_uint32), ("spliced_frac", C.c_double),
+                ("realistic_payload", C.c_int)]
+
+
+class SynthResult(C.Structure):
+    _fields_ = [("bam", C.c_void_p), ("bam_len", C.c_size_t), ("bai", C.c_void_p), ("bai_len", C.c_size_t),
+                ("n_reads", C.c_uint64), ("n_spliced", C.c_uint64), ("n_blocks", C.c_uint64),
+                ("inflated_bytes", C.c_uint64), ("cigar_ops", C.c_uint64)]
+
+
+_synth = None
+
+
+def synth():
+    global _synth
+    if _synth is None:
+        if not os.path.exists(SYNTH_PATH):
+            raise RuntimeError("regtools_amd: %s is missing -- run __graft_entry__.build()" % SYNTH_PATH)
+        L = C.CDLL(SYNTH_PATH)
+        P = C.POINTER
+        L.rgx_synth_generate.argtypes = [P(SynthParams), P(SynthResult)]
+        L.rgx_synth_free.argtypes = [P(SynthResult)]
+        L.rgx_synth_write.argtypes = [P(SynthParams), C.c_char_p, P(SynthResult)]
+        L.rgx_synth_index.argtypes = [C.c_char_p]
+        _synth = L
+    return _synth

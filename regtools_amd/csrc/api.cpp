@@ -1,0 +1,627 @@
+// api.cpp -- C ABI (include/regtools_amd.h) and the host orchestration of the device pipeline.
+//
+//   members (host BSIZE walk) -> [K] inflate -> header/BAI -> [K] segment chains + verify -> [K] fill offsets
+//   -> [K] decode SoA + count -> scan -> [K] emit events -> 8 radix passes -> [K] heads/reduce/name -> 12 radix
+//   passes (output order) -> D2H of the unique rows.
+// There is no CPU fallback anywhere in this file: every byte of BAM payload is touched on the device only.
+#include "../../include/regtools_amd.h"
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "host_io.h"
+#include "kernels.h"
+
+using namespace rgx;
+
+namespace {
+
+int fail(char *err, size_t errlen, int code, const char *fmt, ...) {
+    if (err && errlen) { va_list ap; va_start(ap, fmt); vsnprintf(err, errlen, fmt, ap); va_end(ap); }
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return fail(err, errlen, RGX_ERR_DEVICE, "HIP error %s at %s:%d (%s)\n", hipGetErrorString(e_), __FILE__, __LINE__, #expr); \
+    } while (0)
+
+const char *kMsgOpen = "Unable to open BAM/SAM file.\n\n";
+const char *kMsgIndex = "Unable to open BAM/SAM index. Make sure alignments are indexed\n\n";
+const char *kMsgRegion = "Unable to iterate to region within BAM.\n\n";
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+uint32_t bitlen(uint32_t v) { uint32_t b = 0; while (v) { ++b; v >>= 1; } return b; }
+
+// growable device buffer that survives across calls (workspace reuse: no hipMalloc in steady state)
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+}  // namespace
+
+struct rgx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    std::map<std::string, DevBuf> bufs;
+    void *pinned = nullptr; size_t pinned_cap = 0;     // small pinned staging for scalar readbacks
+    DevBuf &buf(const char *name) { return bufs[name]; }
+};
+
+extern "C" const char *rgx_version(void) { return "regtools_amd 0.1 gfx950"; }
+
+extern "C" void rgx_extract_params_default(rgx_extract_params *p) {
+    memset(p, 0, sizeof *p);
+    p->region = "."; p->strandness = -1; p->strand_tag[0] = 'X'; p->strand_tag[1] = 'S';
+    p->min_anchor = 8; p->min_intron = 70; p->max_intron = 500000; p->fasta_path = nullptr; p->shard = 0; p->n_shards = 1;
+}
+
+extern "C" int rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errlen) {
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(err, errlen, RGX_ERR_NO_DEVICE, "regtools_amd: no HIP device visible; this library has no CPU fallback\n");
+    if (device < 0 || device >= n) return fail(err, errlen, RGX_ERR_NO_DEVICE, "regtools_amd: device %d out of range (%d visible)\n", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (!strstr(prop.gcnArchName, "gfx950"))
+        return fail(err, errlen, RGX_ERR_NO_DEVICE, "regtools_amd: device %d is %s; the kernels are built for gfx950 only\n", device, prop.gcnArchName);
+    rgx_ctx *c = new rgx_ctx();
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
+    c->pinned_cap = 4096;
+    *out = c;
+    return RGX_OK;
+}
+
+extern "C" void rgx_ctx_destroy(rgx_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (auto &kv : c->bufs) kv.second.release();
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ---- table plumbing --------------------------------------------------------------------------------------
+static rgx_junction_table *table_alloc(const BamHeader &h, uint64_t n) {
+    rgx_junction_table *t = (rgx_junction_table *)calloc(1, sizeof *t);
+    t->n_ref = (int32_t)h.names.size();
+    t->ref_name = (char **)calloc(h.names.size() + 1, sizeof(char *));
+    t->ref_len = (uint32_t *)calloc(h.names.size() + 1, sizeof(uint32_t));
+    for (size_t i = 0; i < h.names.size(); ++i) { t->ref_name[i] = strdup(h.names[i].c_str()); t->ref_len[i] = h.lens[i]; }
+    t->n = n;
+    size_t m = (size_t)n + 1;
+    t->tid = (int32_t *)calloc(m, 4); t->start = (uint32_t *)calloc(m, 4); t->end = (uint32_t *)calloc(m, 4);
+    t->thick_start = (uint32_t *)calloc(m, 4); t->thick_end = (uint32_t *)calloc(m, 4); t->read_count = (uint32_t *)calloc(m, 4);
+    t->name_index = (uint64_t *)calloc(m, 8); t->strand = (char *)calloc(m, 1);
+    t->left_ok = (uint8_t *)calloc(m, 1); t->right_ok = (uint8_t *)calloc(m, 1);
+    t->first_seen = (uint64_t *)calloc(m, 8); t->last_seen = (uint64_t *)calloc(m, 8);
+    return t;
+}
+
+extern "C" void rgx_table_free(rgx_junction_table *t) {
+    if (!t) return;
+    if (t->ref_name) for (int32_t i = 0; i < t->n_ref; ++i) free(t->ref_name[i]);
+    free(t->ref_name); free(t->ref_len);
+    free(t->tid); free(t->start); free(t->end); free(t->thick_start); free(t->thick_end); free(t->read_count);
+    free(t->name_index); free(t->strand); free(t->left_ok); free(t->right_ok); free(t->first_seen); free(t->last_seen);
+    free(t);
+}
+
+// compare_junctions (junctions_extractor.h:117-140): chrom string, thick_start, thick_end, name string
+static void host_sort_rows(rgx_junction_table *t) {
+    std::vector<uint64_t> idx(t->n);
+    for (uint64_t i = 0; i < t->n; ++i) idx[i] = i;
+    auto name_of = [&](uint64_t i, char *buf) { snprintf(buf, 32, "JUNC%08llu", (unsigned long long)t->name_index[i]); };
+    std::sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) {
+        if (t->tid[a] != t->tid[b]) { int c = strcmp(t->ref_name[t->tid[a]], t->ref_name[t->tid[b]]); if (c) return c < 0; }
+        if (t->thick_start[a] != t->thick_start[b]) return t->thick_start[a] < t->thick_start[b];
+        if (t->thick_end[a] != t->thick_end[b]) return t->thick_end[a] < t->thick_end[b];
+        char na[32], nb[32]; name_of(a, na); name_of(b, nb);
+        return strcmp(na, nb) < 0;
+    });
+    auto permute = [&](auto *col) {
+        typedef typename std::remove_reference<decltype(col[0])>::type T;
+        std::vector<T> tmp(t->n);
+        for (uint64_t i = 0; i < t->n; ++i) tmp[i] = col[idx[i]];
+        memcpy(col, tmp.data(), sizeof(T) * t->n);
+    };
+    permute(t->tid); permute(t->start); permute(t->end); permute(t->thick_start); permute(t->thick_end); permute(t->read_count);
+    permute(t->name_index); permute(t->strand); permute(t->left_ok); permute(t->right_ok); permute(t->first_seen); permute(t->last_seen);
+}
+
+extern "C" size_t rgx_table_format_bed12(const rgx_junction_table *t, int only_anchored, char *buf, size_t cap) {
+    size_t need = 0;
+    char line[512];
+    for (uint64_t i = 0; i < t->n; ++i) {
+        if (only_anchored && !(t->left_ok[i] && t->right_ok[i])) continue;
+        // Junction::print (junctions_extractor.h:90-98)
+        int n = snprintf(line, sizeof line, "%s\t%u\t%u\tJUNC%08llu\t%u\t%c\t%u\t%u\t255,0,0\t2\t%u,%u\t0,%u\n", t->ref_name[t->tid[i]],
+                         t->thick_start[i], t->thick_end[i], (unsigned long long)t->name_index[i], t->read_count[i], t->strand[i],
+                         t->thick_start[i], t->thick_end[i], (uint32_t)(t->start[i] - t->thick_start[i]),
+                         (uint32_t)(t->thick_end[i] - t->end[i]), (uint32_t)(t->end[i] - t->thick_start[i]));
+        if (buf && need + (size_t)n <= cap) memcpy(buf + need, line, (size_t)n);
+        need += (size_t)n;
+    }
+    return need;
+}
+
+// ---- the pipeline ------------------------------------------------------------------------------------------------
+static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_bam, size_t bam_len, const uint8_t *bai, size_t bai_len,
+                        const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen) {
+    *out = nullptr;
+    if (!p || p->strandness < 0 || p->strandness > 3) return fail(err, errlen, RGX_ERR_ARG, "Please supply strandness mode with '-s' option!\n\n");
+    if (p->fasta_path || p->strandness == 3)
+        return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: intron-motif / FASTA strand mode is not implemented on the device path yet\n");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const double t_begin = now_ms();
+
+    // -- container structure (host: locating bytes only) ------------------------------------------------------
+    if (bam_len < 18) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
+    std::vector<HostMember> hm;
+    walk_members(h_bam, bam_len, hm);
+    if (hm.empty()) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
+    BaiInfo bi;
+    if (!bai || !parse_bai(bai, bai_len, bi)) return fail(err, errlen, RGX_ERR_INDEX, "%s", kMsgIndex);
+
+    const bool whole = !strcmp(p->region ? p->region : ".", ".");
+    // where the record stream starts (hts.c:1721-1731 for ".")
+    bool seek = false; uint64_t seek_voff = 0;
+    if (whole) {
+        if (bi.have_start) { seek_voff = bi.start_voff; seek = seek_voff != 0; }
+        else if (!bi.n_no_coor) return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion);
+    }
+    auto member_of = [&](uint64_t coff) -> size_t {       // index of the member starting at coff, or hm.size()
+        auto it = std::lower_bound(hm.begin(), hm.end(), coff, [](const HostMember &m, uint64_t v) { return m.coff < v; });
+        return (it != hm.end() && it->coff == coff) ? (size_t)(it - hm.begin()) : hm.size();
+    };
+    const size_t first_member = seek ? member_of(seek_voff >> 16) : 0;
+    // the stream ends at the first empty (or oversized = corrupt) member at/after the first one read (bgzf.c:548-578)
+    size_t stop = hm.size();
+    for (size_t k = first_member; k < hm.size(); ++k) if (hm[k].isize == 0 || hm[k].isize > kBgzfMaxBlock) { stop = k; break; }
+
+    // -- member range of this call: everything, or one shard cut at record starts taken from the index --
+    // A record belongs to the shard in which its first byte lies; cut points are virtual offsets the BAI lists
+    // (every chunk begin and linear-index entry is a record start), so no shard ever guesses its first record.
+    uint64_t cut_lo = seek ? seek_voff : 0, cut_hi = UINT64_MAX;          // virtual offsets; 0 = "right after the header"
+    if (p->n_shards > 1) {
+        auto cut = [&](int g) -> uint64_t {
+            if (g <= 0) return seek ? seek_voff : 0;
+            if (g >= p->n_shards) return UINT64_MAX;
+            const uint64_t target = (uint64_t)((double)bam_len * g / p->n_shards) << 16;
+            auto it = std::lower_bound(bi.anchors.begin(), bi.anchors.end(), std::max<uint64_t>(target, seek ? seek_voff : 1));
+            return it == bi.anchors.end() ? UINT64_MAX : *it;
+        };
+        if (p->shard < 0 || p->shard >= p->n_shards) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: shard %d of %d\n", p->shard, p->n_shards);
+        cut_lo = cut(p->shard); cut_hi = cut(p->shard + 1);
+        if (cut_hi < cut_lo) cut_hi = cut_lo;
+    }
+    size_t m_lo = cut_lo ? member_of(cut_lo >> 16) : 0;
+    size_t m_hi = stop;                                                  // exclusive
+    if (cut_hi != UINT64_MAX) {
+        const size_t mh = member_of(cut_hi >> 16);
+        m_hi = std::min(stop, (cut_hi & 0xffff) ? mh + 1 : mh);
+    }
+    if (m_lo > m_hi) m_lo = m_hi;
+
+    // header members: enough of the file head to hold the BAM header (grown on demand below)
+    const uint8_t *d_bam = d_bam_in;
+    if (!d_bam) {
+        DevBuf &b = c->buf("bam");
+        HIP_TRY(b.ensure(bam_len + 64));
+        HIP_TRY(hipMemcpyAsync(b.p, h_bam, bam_len, hipMemcpyHostToDevice, st));
+        d_bam = b.as<uint8_t>();
+    }
+    DevBuf &b_arena = c->buf("arena"), &b_members = c->buf("members"), &b_scalars = c->buf("scalars"), &b_hdr = c->buf("hdr_arena");
+    HIP_TRY(b_scalars.ensure(256));
+    uint32_t *d_sc = b_scalars.as<uint32_t>();   // [0]=first bad member [1]=its status [2]=changed [3]=n_rec [4]=n_events [5]=n_long [6]=n_unique [8..9]=n_iterated(u64) [12..13]=header inflate status
+    uint32_t *h_sc = (uint32_t *)c->pinned;
+    HIP_TRY(hipMemsetAsync(d_sc, 0, 256, st));
+    HIP_TRY(hipMemsetAsync(d_sc, 0xff, 4, st));
+    HIP_TRY(hipMemsetAsync(d_sc + 12, 0xff, 4, st));
+
+    std::vector<Member> members(m_hi - m_lo);
+    uint64_t total = 0;
+    for (size_t k = m_lo; k < m_hi; ++k) {
+        Member &m = members[k - m_lo];
+        m.cpos = hm[k].coff + 18; m.clen = hm[k].blen - 26; m.upos = total; m.isize = hm[k].isize;
+        total += hm[k].isize;
+    }
+    HIP_TRY(b_arena.ensure(total + 256));
+    HIP_TRY(b_members.ensure((members.size() + 1) * sizeof(Member)));
+    if (!members.empty()) HIP_TRY(hipMemcpyAsync(b_members.p, members.data(), members.size() * sizeof(Member), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(c->ev[0], st));
+    launch_inflate(d_bam, b_members.as<Member>(), (uint32_t)members.size(), b_arena.as<uint8_t>(), d_sc, st);
+    HIP_TRY(hipEventRecord(c->ev[1], st));
+
+    // -- header (sam.c:114-223): inflate the head of the file into its own small arena until it parses ------------------
+    BamHeader hdr;
+    {
+        size_t n_h = std::min<size_t>(hm.size(), 4);
+        for (;;) {
+            std::vector<Member> hmem(n_h);
+            uint64_t htot = 0;
+            size_t used = 0;
+            for (size_t k = 0; k < n_h; ++k) {
+                if (hm[k].isize == 0 || hm[k].isize > kBgzfMaxBlock) break;      // the header read stops at an empty/corrupt member
+                hmem[k].cpos = hm[k].coff + 18; hmem[k].clen = hm[k].blen - 26; hmem[k].upos = htot; hmem[k].isize = hm[k].isize;
+                htot += hm[k].isize; ++used;
+            }
+            if (!used) return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion);
+            DevBuf &b_hm = c->buf("hdr_members");
+            HIP_TRY(b_hm.ensure(used * sizeof(Member)));
+            HIP_TRY(b_hdr.ensure(htot + 256));
+            HIP_TRY(hipMemcpyAsync(b_hm.p, hmem.data(), used * sizeof(Member), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemsetAsync(d_sc + 12, 0xff, 4, st));
+            launch_inflate(d_bam, b_hm.as<Member>(), (uint32_t)used, b_hdr.as<uint8_t>(), d_sc + 12, st);
+            std::vector<uint8_t> hbuf(htot);
+            HIP_TRY(hipMemcpyAsync(hbuf.data(), b_hdr.p, htot, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 64, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            uint64_t have = htot;
+            if (h_sc[12] != 0xffffffffu) have = hmem[h_sc[12]].upos;             // a corrupt member ends the header read
+            uint64_t need = 0;
+            int r = parse_bam_header(hbuf.data(), have, hdr, need);
+            if (r == 0) break;
+            if (r == 2 || used < n_h || n_h == hm.size() || have < htot) return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion);  // sam_hdr_read == NULL (cc:519-522)
+            n_h = std::min(hm.size(), n_h * 4);
+        }
+    }
+    const int32_t n_ref = (int32_t)hdr.names.size();
+
+    // -- stream bounds inside the arena -------------------------------------------------------------------------------------
+    auto arena_of = [&](uint64_t voff) -> uint64_t {     // arena offset of a virtual offset inside [m_lo, m_hi)
+        const size_t k = member_of(voff >> 16);
+        if (k < m_lo || k >= m_hi) return total;
+        return std::min<uint64_t>(total, members[k - m_lo].upos + (voff & 0xffff));
+    };
+    uint64_t lim = total;
+    if (h_sc[0] != 0xffffffffu) lim = members[h_sc[0]].upos;    // a member failed to inflate: the stream ends where it starts
+    uint64_t pos0;
+    if (cut_lo) pos0 = arena_of(cut_lo);
+    else {
+        // no seek: records start right after the header, which lies inside member range starting at 0
+        pos0 = hdr.end;
+    }
+    if (cut_hi != UINT64_MAX) lim = std::min(lim, arena_of(cut_hi));
+    if (pos0 > lim) pos0 = lim;
+
+    ExtractCfg cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.n_ref = n_ref; cfg.strandness = p->strandness; cfg.tag0 = (uint8_t)p->strand_tag[0]; cfg.tag1 = (uint8_t)p->strand_tag[1];
+    cfg.min_anchor = p->min_anchor; cfg.min_intron = p->min_intron; cfg.max_intron = p->max_intron;
+    cfg.region_tid = -2; cfg.long_threshold = 16;
+    if (!whole) {
+        int32_t tid, beg, end;
+        if (!strcmp(p->region, "*") || !parse_region(hdr, p->region, tid, beg, end) || tid >= bi.n_ref || end < beg)
+            return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion);
+        cfg.region_tid = tid; cfg.region_beg = beg; cfg.region_end = end;
+    }
+
+    // -- record framing ------------------------------------------------------------------------------------------------
+    const uint8_t *arena = b_arena.as<uint8_t>();
+    const uint64_t span = lim - pos0;
+    const uint32_t n_seg = (uint32_t)((span + kSegBytes - 1) / kSegBytes);
+    uint32_t n_rec = 0;
+    DevBuf &b_seg = c->buf("seg"), &b_tmp = c->buf("tmp");
+    HIP_TRY(hipEventRecord(c->ev[2], st));
+    uint64_t *seg_start[2] = {nullptr, nullptr}, *seg_exit[2] = {nullptr, nullptr};
+    uint32_t *seg_cnt[2] = {nullptr, nullptr}, *seg_base = nullptr;
+    int cur = 0;
+    if (n_seg) {
+        const size_t per = (size_t)n_seg;
+        HIP_TRY(b_seg.ensure(per * (8 + 8 + 4) * 2 + per * 4 + 64));
+        uint8_t *q = b_seg.as<uint8_t>();
+        for (int k = 0; k < 2; ++k) { seg_start[k] = (uint64_t *)q; q += per * 8; seg_exit[k] = (uint64_t *)q; q += per * 8; }
+        for (int k = 0; k < 2; ++k) { seg_cnt[k] = (uint32_t *)q; q += per * 4; }
+        seg_base = (uint32_t *)q;
+        HIP_TRY(b_tmp.ensure(scan_tmp_words(n_seg) * 4 + 64));
+        launch_seg_walk(arena, pos0, lim, n_seg, n_ref, seg_start[0], seg_exit[0], seg_cnt[0], st);
+        for (int iter = 0;; ++iter) {
+            HIP_TRY(hipMemsetAsync(d_sc + 2, 0, 4, st));
+            launch_seg_verify(arena, pos0, lim, n_seg, seg_start[cur], seg_exit[cur], seg_cnt[cur], seg_start[cur ^ 1], seg_exit[cur ^ 1],
+                              seg_cnt[cur ^ 1], d_sc + 2, st);
+            cur ^= 1;
+            launch_scan_u32(seg_cnt[cur], seg_base, n_seg, d_sc + 3, b_tmp.as<uint32_t>(), st);
+            HIP_TRY(hipMemcpyAsync(h_sc + 2, d_sc + 2, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (h_sc[2] == 0) break;
+            if (iter > 1 << 20) return fail(err, errlen, RGX_ERR_FORMAT, "regtools_amd: record framing did not converge\n");
+        }
+        n_rec = h_sc[3];
+    }
+    HIP_TRY(hipEventRecord(c->ev[3], st));
+
+    // -- decode + count -----------------------------------------------------------------------------------------------------
+    DevBuf &b_rec = c->buf("rec"), &b_soa = c->buf("soa");
+    ReadSoA soa; memset(&soa, 0, sizeof soa);
+    uint32_t *ev_base = nullptr, *long_list = nullptr;
+    uint32_t n_events = 0, n_long = 0;
+    uint64_t n_iterated = 0;
+    if (n_rec) {
+        const size_t R = n_rec;
+        HIP_TRY(b_rec.ensure(R * 8 + 64));
+        launch_seg_fill(arena, pos0, lim, n_seg, seg_start[cur], seg_base, b_rec.as<uint64_t>(), st);
+        HIP_TRY(b_soa.ensure(R * (4 + 4 + 4 + 8 + 1 + 4 + 4 + 4) + 256));
+        uint8_t *q = b_soa.as<uint8_t>();
+        soa.cig_off = (uint64_t *)q; q += R * 8;
+        soa.tid = (int32_t *)q; q += R * 4; soa.pos = (int32_t *)q; q += R * 4; soa.flag_nc = (uint32_t *)q; q += R * 4;
+        soa.n_ev = (uint32_t *)q; q += R * 4; ev_base = (uint32_t *)q; q += R * 4; long_list = (uint32_t *)q; q += R * 4;
+        soa.strand = q;
+        HIP_TRY(b_tmp.ensure(scan_tmp_words(n_rec) * 4 + 64));
+        launch_decode(arena, b_rec.as<uint64_t>(), n_rec, cfg, soa, long_list, d_sc + 5, (unsigned long long *)(d_sc + 8), st);
+        launch_scan_u32(soa.n_ev, ev_base, n_rec, d_sc + 4, b_tmp.as<uint32_t>(), st);
+        HIP_TRY(hipMemcpyAsync(h_sc + 4, d_sc + 4, 24, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n_events = h_sc[4]; n_long = h_sc[5];
+        memcpy(&n_iterated, h_sc + 8, 8);
+    }
+    HIP_TRY(hipEventRecord(c->ev[4], st));
+
+    // -- emit -----------------------------------------------------------------------------------------------------------------
+    DevBuf &b_ev = c->buf("events"), &b_sort = c->buf("sort"), &b_uni = c->buf("unique");
+    EventSoA ev; memset(&ev, 0, sizeof ev);
+    uint32_t n_unique = 0;
+    UniqueSoA u; memset(&u, 0, sizeof u);
+    uint32_t *perm[2] = {nullptr, nullptr};
+    uint32_t *final_perm = nullptr;
+    uint32_t *chrom_rank_rows = nullptr;
+    if (n_events) {
+        const size_t E = n_events;
+        HIP_TRY(b_ev.ensure(E * (4 * 5 + 1) + 256));
+        uint8_t *q = b_ev.as<uint8_t>();
+        ev.tid = (uint32_t *)q; q += E * 4; ev.start = (uint32_t *)q; q += E * 4; ev.ilen_cls = (uint32_t *)q; q += E * 4;
+        ev.ts = (uint32_t *)q; q += E * 4; ev.te = (uint32_t *)q; q += E * 4; ev.strand = q;
+        launch_emit_short(arena, n_rec, cfg, soa, ev_base, ev, st);
+        launch_emit_long(arena, long_list, d_sc + 5, n_long, cfg, soa, ev_base, ev, st);
+    }
+    HIP_TRY(hipEventRecord(c->ev[5], st));
+
+    // -- group-by: radix sort on (tid, start, ilen|class), then segmented reduce ---------------------------------------------
+    if (n_events) {
+        const size_t E = n_events;
+        const size_t rtmp = radix_tmp_words(n_events) + scan_tmp_words(n_events) + 64;
+        HIP_TRY(b_sort.ensure(E * 4 * 4 + rtmp * 4 + 256));
+        uint32_t *q = b_sort.as<uint32_t>();
+        perm[0] = q; q += E; perm[1] = q; q += E;
+        uint32_t *head = q; q += E; uint32_t *seg_excl = q; q += E;
+        uint32_t *tmp = q;
+        int pc = -1;  // current permutation buffer (-1 = identity)
+        auto sort_word = [&](const uint32_t *word, uint32_t nbits) {
+            for (uint32_t sh = 0; sh < nbits; sh += 8) {
+                const uint32_t bits = std::min<uint32_t>(8, nbits - sh);
+                const int nxt = pc < 0 ? 0 : pc ^ 1;
+                launch_radix_pass(word, sh, bits, pc < 0 ? nullptr : perm[pc], perm[nxt], n_events, tmp, st);
+                pc = nxt;
+            }
+        };
+        sort_word(ev.ilen_cls, std::min<uint32_t>(32, bitlen(p->max_intron) + 2));
+        sort_word(ev.start, 32);
+        sort_word(ev.tid, std::max<uint32_t>(1, bitlen((uint32_t)std::max(n_ref - 1, 0))));
+        const uint32_t *sorted = perm[pc];
+        launch_heads(ev, sorted, n_events, head, st);
+        launch_scan_u32(head, seg_excl, n_events, d_sc + 6, tmp, st);
+        HIP_TRY(hipMemcpyAsync(h_sc + 6, d_sc + 6, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n_unique = h_sc[6];
+
+        const size_t U = n_unique;
+        const size_t utmp = radix_tmp_words(n_unique) + 64;
+        HIP_TRY(b_uni.ensure(U * 4 * 13 + U + utmp * 4 + 256));
+        uint32_t *w = b_uni.as<uint32_t>();
+        u.tid = w; w += U; u.start = w; w += U; u.end = w; w += U; u.ts_min = w; w += U; u.te_max = w; w += U; u.count = w; w += U;
+        u.first_seen = w; w += U; u.last_seen = w; w += U; u.name_rank = w; w += U;
+        uint32_t *head_pos = w; w += U; chrom_rank_rows = w; w += U;
+        uint32_t *uperm[2]; uperm[0] = w; w += U; uperm[1] = w; w += U;
+        uint32_t *utmp_p = w; w += utmp;
+        u.strand = (uint8_t *)w;
+        launch_fill_u32(u.ts_min, 0xffffffffu, U, st);
+        launch_fill_u32(u.te_max, 0u, U, st);
+        launch_reduce(ev, sorted, head, seg_excl, n_events, u, head_pos, st);
+        // first-seen naming (junctions_extractor.cc:152-157): rank of the key's first event among all keys
+        uint32_t *first_flag = head;       // reuse: head/seg_excl are dead after launch_reduce
+        HIP_TRY(hipMemsetAsync(first_flag, 0, E * 4, st));
+        launch_reduce_finish(ev, sorted, n_events, n_unique, head_pos, u, first_flag, st);
+        launch_scan_u32(first_flag, seg_excl, n_events, nullptr, tmp, st);
+        launch_name_rank(n_unique, seg_excl, u, st);
+
+        // output order (junctions_extractor.h:117-140): chrom string rank, thick_start, thick_end, name
+        std::vector<uint32_t> order((size_t)n_ref), rank_of_tid((size_t)n_ref);
+        for (int32_t i = 0; i < n_ref; ++i) order[(size_t)i] = (uint32_t)i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hdr.names[a] < hdr.names[b]; });
+        uint32_t rk = 0;
+        for (int32_t i = 0; i < n_ref; ++i) {
+            if (i > 0 && hdr.names[order[(size_t)i]] != hdr.names[order[(size_t)i - 1]]) ++rk;
+            rank_of_tid[order[(size_t)i]] = rk;
+        }
+        DevBuf &b_rank = c->buf("rank");
+        HIP_TRY(b_rank.ensure((size_t)n_ref * 4 + 64));
+        HIP_TRY(hipMemcpyAsync(b_rank.p, rank_of_tid.data(), (size_t)n_ref * 4, hipMemcpyHostToDevice, st));
+        launch_gather_u32(n_unique, b_rank.as<uint32_t>(), u.tid, chrom_rank_rows, st);
+        int upc = -1;
+        auto usort = [&](const uint32_t *word, uint32_t nbits) {
+            for (uint32_t sh = 0; sh < nbits; sh += 8) {
+                const uint32_t bits = std::min<uint32_t>(8, nbits - sh);
+                const int nxt = upc < 0 ? 0 : upc ^ 1;
+                launch_radix_pass(word, sh, bits, upc < 0 ? nullptr : uperm[upc], uperm[nxt], n_unique, utmp_p, st);
+                upc = nxt;
+            }
+        };
+        usort(u.name_rank, std::max<uint32_t>(1, bitlen(n_unique)));
+        usort(u.te_max, 32);
+        usort(u.ts_min, 32);
+        usort(chrom_rank_rows, std::max<uint32_t>(1, bitlen(rk)));
+        final_perm = uperm[upc];
+        HIP_TRY(hipStreamSynchronize(st));   // rank_of_tid (host vector) must outlive the async copy
+    }
+    HIP_TRY(hipEventRecord(c->ev[6], st));
+
+    // -- rows to the host ------------------------------------------------------------------------------------------------------
+    rgx_junction_table *t = table_alloc(hdr, n_unique);
+    if (n_unique) {
+        const size_t U = n_unique;
+        std::vector<uint32_t> col(U), fp(U);
+        std::vector<uint8_t> sc(U);
+        HIP_TRY(hipMemcpy(fp.data(), final_perm, U * 4, hipMemcpyDeviceToHost));
+        auto fetch32 = [&](const uint32_t *d, auto *dst) -> hipError_t {
+            hipError_t e = hipMemcpy(col.data(), d, U * 4, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return e;
+            for (size_t i = 0; i < U; ++i) dst[i] = (typename std::remove_reference<decltype(dst[0])>::type)col[fp[i]];
+            return hipSuccess;
+        };
+        HIP_TRY(fetch32(u.tid, t->tid)); HIP_TRY(fetch32(u.start, t->start)); HIP_TRY(fetch32(u.end, t->end));
+        HIP_TRY(fetch32(u.ts_min, t->thick_start)); HIP_TRY(fetch32(u.te_max, t->thick_end)); HIP_TRY(fetch32(u.count, t->read_count));
+        HIP_TRY(fetch32(u.name_rank, t->name_index)); HIP_TRY(fetch32(u.first_seen, t->first_seen)); HIP_TRY(fetch32(u.last_seen, t->last_seen));
+        HIP_TRY(hipMemcpy(sc.data(), u.strand, U, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < U; ++i) {
+            t->strand[i] = (char)sc[fp[i]];
+            // OR over reads of (start - thick_start >= a) == test on the minimum
+            t->left_ok[i] = (uint32_t)(t->start[i] - t->thick_start[i]) >= p->min_anchor;
+            t->right_ok[i] = (uint32_t)(t->thick_end[i] - t->end[i]) >= p->min_anchor;
+        }
+        if (n_unique >= 100000000u) host_sort_rows(t);   // names wider than 8 digits compare as strings upstream
+    }
+    t->n_records = n_iterated;
+    t->n_events = n_events; t->inflated_bytes = total; t->compressed_bytes = bam_len; t->n_members = members.size();
+    float ms = 0;
+    HIP_TRY(hipEventSynchronize(c->ev[6]));
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); t->ms_inflate = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[4]); t->ms_records = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); t->ms_scan = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); t->ms_reduce = ms;
+    t->ms_total = now_ms() - t_begin;
+    *out = t;
+    return RGX_OK;
+}
+
+extern "C" int rgx_extract_device(rgx_ctx *ctx, const void *d_bam, const void *h_bam, size_t bam_len, const void *bai, size_t bai_len,
+                                  const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen) {
+    if (!ctx || !h_bam || !out) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
+    return run_pipeline(ctx, (const uint8_t *)d_bam, (const uint8_t *)h_bam, bam_len, (const uint8_t *)bai, bai_len, p, out, err, errlen);
+}
+
+extern "C" int rgx_extract_mem(rgx_ctx *ctx, const void *bam, size_t bam_len, const void *bai, size_t bai_len, const rgx_extract_params *p,
+                               rgx_junction_table **out, char *err, size_t errlen) {
+    if (!ctx || !bam || !out) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
+    return run_pipeline(ctx, nullptr, (const uint8_t *)bam, bam_len, (const uint8_t *)bai, bai_len, p, out, err, errlen);
+}
+
+extern "C" int rgx_extract(rgx_ctx *ctx, const char *bam_path, const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen) {
+    if (!ctx || !bam_path || !out) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
+    std::vector<uint8_t> bam, bai;
+    if (!read_file(bam_path, bam)) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
+    std::string idx;
+    int r = find_index(bam_path, idx);
+    if (r != 0 || !read_file(idx, bai)) return fail(err, errlen, RGX_ERR_INDEX, "%s", kMsgIndex);
+    return run_pipeline(ctx, nullptr, bam.data(), bam.size(), bai.data(), bai.size(), p, out, err, errlen);
+}
+
+extern "C" int rgx_k_inflate(const void *d_comp, const rgx_member *d_members, uint32_t n_members, void *d_arena, uint32_t *d_status, void *stream) {
+    static_assert(sizeof(rgx_member) == sizeof(Member), "rgx_member layout");
+    launch_inflate((const uint8_t *)d_comp, (const Member *)d_members, n_members, (uint8_t *)d_arena, d_status, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? RGX_OK : RGX_ERR_DEVICE;
+}
+
+// ---- multi-shard merge (host half of SURVEY 8e) -----------------------------------------------------------------------------------
+extern "C" size_t rgx_table_pack(const rgx_junction_table *t, void *dst, size_t dst_cap) {
+    const size_t need = (size_t)t->n * RGX_PACKED_ROW_BYTES;
+    if (!dst || dst_cap < need) return need;
+    uint8_t *q = (uint8_t *)dst;
+    for (uint64_t i = 0; i < t->n; ++i, q += RGX_PACKED_ROW_BYTES) {
+        uint32_t w[12] = {(uint32_t)t->tid[i], t->start[i], t->end[i], t->thick_start[i], t->thick_end[i], t->read_count[i],
+                          (uint32_t)t->first_seen[i], (uint32_t)(t->first_seen[i] >> 32), (uint32_t)t->last_seen[i], (uint32_t)(t->last_seen[i] >> 32),
+                          (uint32_t)(uint8_t)t->strand[i], 0};
+        memcpy(q, w, sizeof w);
+    }
+    return need;
+}
+
+extern "C" int rgx_table_unpack(const void *src, size_t n_rows, const rgx_junction_table *names_from, rgx_junction_table **out) {
+    BamHeader h;
+    for (int32_t i = 0; i < names_from->n_ref; ++i) { h.names.push_back(names_from->ref_name[i]); h.lens.push_back(names_from->ref_len[i]); }
+    rgx_junction_table *t = table_alloc(h, n_rows);
+    const uint8_t *q = (const uint8_t *)src;
+    for (size_t i = 0; i < n_rows; ++i, q += RGX_PACKED_ROW_BYTES) {
+        uint32_t w[12]; memcpy(w, q, sizeof w);
+        t->tid[i] = (int32_t)w[0]; t->start[i] = w[1]; t->end[i] = w[2]; t->thick_start[i] = w[3]; t->thick_end[i] = w[4]; t->read_count[i] = w[5];
+        t->first_seen[i] = (uint64_t)w[6] | (uint64_t)w[7] << 32; t->last_seen[i] = (uint64_t)w[8] | (uint64_t)w[9] << 32; t->strand[i] = (char)w[10];
+    }
+    *out = t;
+    return RGX_OK;
+}
+
+extern "C" int rgx_table_merge(const rgx_junction_table *const *parts, int n_parts, uint32_t min_anchor, rgx_junction_table **out, char *err, size_t errlen) {
+    if (n_parts <= 0 || !parts || !parts[0]) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: nothing to merge\n");
+    struct Row { int32_t tid; uint32_t start, end, ts, te, cnt; uint64_t first, last; char strand; };
+    auto cls = [](char c) { return c == '+' ? 0 : c == '-' ? 1 : 2; };
+    std::vector<Row> rows;
+    for (int g = 0; g < n_parts; ++g) {
+        const rgx_junction_table *t = parts[g];
+        for (uint64_t i = 0; i < t->n; ++i)
+            rows.push_back({t->tid[i], t->start[i], t->end[i], t->thick_start[i], t->thick_end[i], t->read_count[i],
+                            (uint64_t)g << 40 | t->first_seen[i], (uint64_t)g << 40 | t->last_seen[i], t->strand[i]});
+    }
+    std::stable_sort(rows.begin(), rows.end(), [&](const Row &a, const Row &b) {
+        if (a.tid != b.tid) return a.tid < b.tid;
+        if (a.start != b.start) return a.start < b.start;
+        if (a.end != b.end) return a.end < b.end;
+        return cls(a.strand) < cls(b.strand);
+    });
+    std::vector<Row> uq;
+    for (const Row &r : rows) {
+        if (!uq.empty() && uq.back().tid == r.tid && uq.back().start == r.start && uq.back().end == r.end && cls(uq.back().strand) == cls(r.strand)) {
+            Row &m = uq.back();
+            m.cnt += r.cnt; m.ts = std::min(m.ts, r.ts); m.te = std::max(m.te, r.te);
+            if (r.first < m.first) m.first = r.first;
+            if (r.last > m.last) { m.last = r.last; m.strand = r.strand; }
+        } else uq.push_back(r);
+    }
+    std::vector<size_t> by_first(uq.size());
+    for (size_t i = 0; i < uq.size(); ++i) by_first[i] = i;
+    std::sort(by_first.begin(), by_first.end(), [&](size_t a, size_t b) { return uq[a].first < uq[b].first; });
+    BamHeader h;
+    for (int32_t i = 0; i < parts[0]->n_ref; ++i) { h.names.push_back(parts[0]->ref_name[i]); h.lens.push_back(parts[0]->ref_len[i]); }
+    rgx_junction_table *t = table_alloc(h, uq.size());
+    for (size_t k = 0; k < by_first.size(); ++k) {
+        const Row &r = uq[by_first[k]];
+        const size_t i = by_first[k];
+        t->tid[i] = r.tid; t->start[i] = r.start; t->end[i] = r.end; t->thick_start[i] = r.ts; t->thick_end[i] = r.te; t->read_count[i] = r.cnt;
+        t->name_index[i] = k + 1; t->strand[i] = r.strand; t->first_seen[i] = r.first; t->last_seen[i] = r.last;
+        t->left_ok[i] = (uint32_t)(r.start - r.ts) >= min_anchor; t->right_ok[i] = (uint32_t)(r.te - r.end) >= min_anchor;
+    }
+    host_sort_rows(t);
+    for (int g = 0; g < n_parts; ++g) {
+        t->n_records += parts[g]->n_records; t->n_events += parts[g]->n_events; t->inflated_bytes += parts[g]->inflated_bytes;
+        t->compressed_bytes = parts[g]->compressed_bytes; t->n_members += parts[g]->n_members;
+    }
+    *out = t;
+    return RGX_OK;
+}

@@ -1,0 +1,149 @@
+// regtools_main.cpp -- host CLI in front of libregtools_amd.so: `regtools-amd junctions extract ...`.
+//
+// Keeps the reference's sub-command surface for the accelerated path: same flags, defaults, stderr echo and exit
+// codes as /root/reference/src/junctions/junctions_extractor.cc:42-143 (parse_options/usage),
+// src/junctions/junctions_main.cc:45-107 (dispatch, exception -> exit code) and src/regtools.cc:36-74
+// (banner, top-level usage).  Everything data-parallel happens behind the C ABI (include/regtools_amd.h).
+#include <getopt.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "regtools_amd.h"
+
+namespace {
+
+struct HelpRequested { std::string text; };
+
+struct ExtractOptions {
+    std::string bam = "NA", ref = "NA", output = "NA", barcodes = "NA", region = ".", tag = "XS";
+    uint32_t min_anchor = 8, min_intron = 70, max_intron = 500000;
+    int strandness = -1;
+    int device = 0;
+};
+
+void extract_usage(std::ostream &out) {
+    out << "Usage:\t\tregtools junctions extract [options] indexed_alignments.bam\n"
+        << "Options:\n"
+        << "\t\t-a INT\tMinimum anchor length. Junctions which satisfy a minimum \n\t\t\t anchor length on both sides are reported. [8]\n"
+        << "\t\t-m INT\tMinimum intron length. [70]\n"
+        << "\t\t-M INT\tMaximum intron length. [500000]\n"
+        << "\t\t-o FILE\tThe file to write output to. [STDOUT]\n"
+        << "\t\t-r STR\tThe region to identify junctions \n\t\t\t in \"chr:start-end\" format. Entire BAM by default.\n"
+        << "\t\t-s INT\tStrandness mode \n\t\t\t XS, use XS tags provided by aligner; RF, first-strand; FR, second-strand. REQUIRED\n"
+        << "\t\t-t STR\tTag used in bam to label strand. [XS]\n"
+        << "\t\t-b STR\tThe file containing the barcodes of interest for single cell data.\n\n";
+}
+
+// junctions_extractor.cc:42-122
+ExtractOptions parse_extract(int argc, char **argv) {
+    ExtractOptions o;
+    optind = 1;
+    int c;
+    while ((c = getopt(argc, argv, "ha:m:M:o:r:t:s:b:")) != -1) {
+        switch (c) {
+            case 'h': { std::ostringstream ss; extract_usage(ss); throw HelpRequested{ss.str()}; }
+            case 'a': o.min_anchor = (uint32_t)atoi(optarg); break;
+            case 'm': o.min_intron = (uint32_t)atoi(optarg); break;
+            case 'M': o.max_intron = (uint32_t)atoi(optarg); break;
+            case 'o': o.output = optarg; break;
+            case 'r': o.region = optarg; break;
+            case 't': o.tag = optarg; break;
+            case 's': {
+                std::string s = optarg;
+                if (s == "XS") o.strandness = 0; else if (s == "RF") o.strandness = 1; else if (s == "FR") o.strandness = 2;
+                else if (s == "intron-motif") o.strandness = 3;
+                else throw std::runtime_error("Unrecognized strandness argument!\n\n");
+                break;
+            }
+            case 'b': o.barcodes = optarg; break;
+            default: extract_usage(std::cerr); throw std::runtime_error("Error parsing inputs!(1)\n\n");
+        }
+    }
+    if (argc - optind >= 1) o.bam = argv[optind++];
+    if (argc - optind >= 1) o.ref = argv[optind++];
+    if (optind < argc || o.bam == "NA") { extract_usage(std::cerr); throw std::runtime_error("Error parsing inputs!(2)\n\n"); }
+    if (o.strandness == -1) { extract_usage(std::cerr); throw std::runtime_error("Please supply strandness mode with '-s' option!\n\n"); }
+    if (o.strandness == 3 && o.ref == "NA") { extract_usage(std::cerr); throw std::runtime_error("Strandness mode 'intron-motif' requires a fasta file!\n\n"); }
+    std::cerr << "Minimum junction anchor length: " << o.min_anchor << "\nMinimum intron length: " << o.min_intron
+              << "\nMaximum intron length: " << o.max_intron << "\nAlignment: " << o.bam << "\nOutput file: " << o.output << "\n";
+    if (o.barcodes != "NA") std::cerr << "Barcode file: " << o.barcodes << "\n";
+    std::cerr << std::endl;
+    return o;
+}
+
+// junctions_main.cc:45-59
+int junctions_extract(int argc, char **argv) {
+    try {
+        ExtractOptions o = parse_extract(argc, argv);
+        if (o.barcodes != "NA") throw std::runtime_error("regtools_amd: -b (single-cell barcodes) is outside the accelerated path\n\n");
+        char err[512] = {0};
+        rgx_ctx *ctx = nullptr;
+        if (const char *d = getenv("REGTOOLS_AMD_DEVICE")) o.device = atoi(d);
+        if (rgx_ctx_create(o.device, &ctx, err, sizeof err) != RGX_OK) throw std::runtime_error(err);
+        rgx_extract_params p;
+        rgx_extract_params_default(&p);
+        p.region = o.region.c_str(); p.strandness = o.strandness;
+        p.strand_tag[0] = o.tag.size() > 0 ? o.tag[0] : 0; p.strand_tag[1] = o.tag.size() > 1 ? o.tag[1] : 0;
+        p.min_anchor = o.min_anchor; p.min_intron = o.min_intron; p.max_intron = o.max_intron;
+        p.fasta_path = o.ref == "NA" ? nullptr : o.ref.c_str();
+        rgx_junction_table *t = nullptr;
+        int rc = rgx_extract(ctx, o.bam.c_str(), &p, &t, err, sizeof err);
+        if (rc != RGX_OK) { rgx_ctx_destroy(ctx); throw std::runtime_error(err); }
+        size_t n = rgx_table_format_bed12(t, 1, nullptr, 0);
+        std::vector<char> text(n + 1);
+        rgx_table_format_bed12(t, 1, text.data(), n);
+        FILE *f = o.output == "NA" ? stdout : fopen(o.output.c_str(), "w");
+        if (f) { fwrite(text.data(), 1, n, f); if (f != stdout) fclose(f); }
+        if (getenv("REGTOOLS_AMD_STATS"))
+            fprintf(stderr, "[regtools_amd] records=%llu events=%llu junctions=%llu inflate=%.3fms records=%.3fms scan=%.3fms reduce=%.3fms total=%.3fms\n",
+                    (unsigned long long)t->n_records, (unsigned long long)t->n_events, (unsigned long long)t->n, t->ms_inflate, t->ms_records,
+                    t->ms_scan, t->ms_reduce, t->ms_total);
+        rgx_table_free(t);
+        rgx_ctx_destroy(ctx);
+    } catch (const HelpRequested &h) {
+        std::cerr << h.text;
+        return 0;
+    } catch (const std::runtime_error &e) {
+        std::cerr << e.what();
+        return 1;
+    }
+    return 0;
+}
+
+int junctions_usage(std::ostream &out) {
+    out << "\nUsage:\t\tregtools junctions <command> [options]\n"
+        << "Command:\textract\t\tIdentify exon-exon junctions from alignments.\n"
+        << "\t\tannotate\tAnnotate the junctions. (not part of the accelerated path)\n\n";
+    return 0;
+}
+
+// junctions_main.cc:96-107
+int junctions_main(int argc, char **argv) {
+    if (argc > 1) {
+        std::string sub = argv[1];
+        if (sub == "extract") return junctions_extract(argc - 1, argv + 1);
+        if (sub == "annotate") { std::cerr << "regtools_amd: `junctions annotate` is outside the accelerated path\n"; return 1; }
+    }
+    return junctions_usage(std::cerr);
+}
+
+}  // namespace
+
+// regtools.cc:36-74
+int main(int argc, char **argv) {
+    std::cerr << "\nProgram:\tregtools (MI355X build)\nVersion:\t" << rgx_version() << std::endl;
+    if (argc > 1) {
+        std::string sub = argv[1];
+        if (sub == "junctions") return junctions_main(argc - 1, argv + 1);
+    }
+    std::cerr << "Usage:\t\tregtools <command> [options]\n"
+              << "Command:\tjunctions\t\tTools that operate on feature junctions (e.g. exon-exon junctions from RNA-seq).\n\n";
+    return 0;
+}

@@ -1,0 +1,166 @@
+// host_io.cpp -- see host_io.h.
+#include "host_io.h"
+
+#include <ctype.h>
+#include <limits.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace rgx {
+
+static inline uint16_t h16(const uint8_t *p) { return (uint16_t)(p[0] | p[1] << 8); }
+static inline uint32_t h32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+static inline uint64_t h64(const uint8_t *p) { return (uint64_t)h32(p) | (uint64_t)h32(p + 4) << 32; }
+
+void walk_members(const uint8_t *bam, size_t len, std::vector<HostMember> &out) {
+    out.clear();
+    size_t off = 0;
+    while (off < len) {
+        if (len - off < 18) break;
+        const uint8_t *h = bam + off;
+        bool ok = h[0] == 31 && h[1] == 139 && h[2] == 8 && (h[3] & 4) && h16(h + 10) == 6 && h[12] == 'B' && h[13] == 'C' && h16(h + 14) == 2;
+        if (!ok) break;
+        size_t blen = (size_t)h16(h + 16) + 1;
+        if (blen < 26 || off + blen > len) break;
+        out.push_back({(uint64_t)off, (uint32_t)blen, h32(h + blen - 4)});
+        off += blen;
+    }
+}
+
+bool parse_bai(const uint8_t *d, size_t len, BaiInfo &bi) {
+    bi = BaiInfo();
+    if (len < 8 || memcmp(d, "BAI\1", 4)) return false;
+    size_t p = 4;
+    bi.n_ref = (int32_t)h32(d + p); p += 4;
+    bi.start_voff = UINT64_MAX;
+    for (int32_t r = 0; r < bi.n_ref; ++r) {
+        if (p + 4 > len) return false;
+        int32_t n_bin = (int32_t)h32(d + p); p += 4;
+        for (int32_t b = 0; b < n_bin; ++b) {
+            if (p + 8 > len) return false;
+            uint32_t bin = h32(d + p); int32_t n_chunk = (int32_t)h32(d + p + 4); p += 8;
+            if (n_chunk < 0 || p + (size_t)n_chunk * 16 > len) return false;
+            if (bin == 37450) {                                  // pseudo-bin: chunk 0 = (first offset, last offset)
+                if (n_chunk > 0) { uint64_t u = h64(d + p); bi.have_start = true; if (u < bi.start_voff) bi.start_voff = u; }
+            } else {
+                for (int32_t c = 0; c < n_chunk; ++c) bi.anchors.push_back(h64(d + p + (size_t)c * 16));
+            }
+            p += (size_t)n_chunk * 16;
+        }
+        if (p + 4 > len) return false;
+        int32_t n_intv = (int32_t)h32(d + p); p += 4;
+        if (n_intv < 0 || p + (size_t)n_intv * 8 > len) return false;
+        for (int32_t i = 0; i < n_intv; ++i) { uint64_t v = h64(d + p + (size_t)i * 8); if (v) bi.anchors.push_back(v); }
+        p += (size_t)n_intv * 8;
+    }
+    bi.n_no_coor = (p + 8 <= len) ? h64(d + p) : 0;
+    std::sort(bi.anchors.begin(), bi.anchors.end());
+    bi.anchors.erase(std::unique(bi.anchors.begin(), bi.anchors.end()), bi.anchors.end());
+    return true;
+}
+
+static bool readable(const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (!f) return false; fclose(f); return true; }
+
+static bool idx_name(const std::string &fn, const char *ext, std::string &out) {
+    std::string a = fn + ext;
+    if (readable(a)) { out = a; return true; }
+    size_t i = fn.size();
+    for (i = fn.size(); i-- > 1;) if (fn[i] == '.') break;     // i in [1, len-1]; falls to 0 when no '.'
+    if (fn.size() < 2) i = 0;
+    std::string b = fn.substr(0, i) + ext;
+    if (readable(b)) { out = b; return true; }
+    return false;
+}
+
+int find_index(const std::string &bam_path, std::string &out) {
+    std::string tmp;
+    if (idx_name(bam_path, ".csi", tmp)) return 2;
+    if (idx_name(bam_path, ".bai", out)) return 0;
+    return 1;
+}
+
+bool read_file(const std::string &path, std::vector<uint8_t> &out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (n < 0) { fclose(f); return false; }
+    out.resize((size_t)n);
+    bool ok = n == 0 || fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+    fclose(f);
+    return ok;
+}
+
+int parse_bam_header(const uint8_t *d, uint64_t have, BamHeader &h, uint64_t &need) {
+    h = BamHeader();
+    if (have < 12) { need = 12; return 1; }
+    if (memcmp(d, "BAM\1", 4)) return 2;
+    uint64_t q = 8 + (uint64_t)h32(d + 4);
+    if (q + 4 > have) { need = q + 4; return 1; }
+    int32_t n_ref = (int32_t)h32(d + q); q += 4;
+    for (int32_t i = 0; i < n_ref; ++i) {
+        if (q + 4 > have) { need = q + 4 + 64; return 1; }
+        uint32_t ln = h32(d + q);
+        if (q + 4 + (uint64_t)ln + 4 > have) { need = q + 8 + ln + 64; return 1; }
+        // target names are NUL-terminated C strings upstream
+        std::string name((const char *)d + q + 4, ln);
+        size_t z = name.find('\0'); if (z != std::string::npos) name.resize(z);
+        h.names.push_back(name);
+        h.lens.push_back(h32(d + q + 4 + ln));
+        q += 4 + (uint64_t)ln + 4;
+    }
+    h.end = q;
+    return 0;
+}
+
+static long long parse_decimal(const char *str, const char **end) {
+    long long n = 0; int decimals = 0, e = 0; char sign = '+', esign = '+';
+    while (isspace((unsigned char)*str)) str++;
+    const char *s = str;
+    if (*s == '+' || *s == '-') sign = *s++;
+    while (*s) {
+        if (isdigit((unsigned char)*s)) n = 10 * n + (*s++ - '0');
+        else if (*s == ',') s++;
+        else break;
+    }
+    if (*s == '.') { s++; while (isdigit((unsigned char)*s)) { decimals++; n = 10 * n + (*s++ - '0'); } }
+    if (*s == 'E' || *s == 'e') {
+        s++;
+        if (*s == '+' || *s == '-') esign = *s++;
+        while (isdigit((unsigned char)*s)) e = 10 * e + (*s++ - '0');
+        if (esign == '-') e = -e;
+    }
+    e -= decimals;
+    while (e > 0) { n *= 10; e--; }
+    while (e < 0) { n /= 10; e++; }
+    if (end) *end = s;
+    return sign == '+' ? n : -n;
+}
+
+static int name2id(const BamHeader &h, const std::string &name) {
+    int id = -1;
+    for (size_t i = 0; i < h.names.size(); ++i) if (h.names[i] == name) id = (int)i;
+    return id;
+}
+
+bool parse_region(const BamHeader &h, const char *reg, int32_t &tid, int32_t &beg, int32_t &end) {
+    const char *colon = strrchr(reg, ':');
+    bool parsed = false;
+    if (!colon) { beg = 0; end = INT_MAX; parsed = true; colon = reg + strlen(reg); }
+    else {
+        const char *hy;
+        beg = (int32_t)(parse_decimal(colon + 1, &hy) - 1);
+        if (beg < 0) beg = 0;
+        if (*hy == '\0') { end = INT_MAX; parsed = true; }
+        else if (*hy == '-') { end = (int32_t)parse_decimal(hy + 1, nullptr); parsed = true; }
+        if (parsed && beg >= end) parsed = false;
+    }
+    if (parsed) tid = name2id(h, std::string(reg, (size_t)(colon - reg)));
+    else { tid = name2id(h, reg); beg = 0; end = INT_MAX; }
+    return tid >= 0;
+}
+
+}  // namespace rgx

@@ -1,0 +1,45 @@
+// host_io.h -- host-side container parsing around the device pipeline: BGZF member chain, BAI, BAM header,
+// region strings.  No zlib anywhere: bytes are only *located* here, never inflated.
+// file:line citations are relative to /root/reference/src/utils/htslib.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace rgx {
+
+struct HostMember { uint64_t coff; uint32_t blen; uint32_t isize; };
+
+// bgzf.c:348-355 check_header + :525 block_length. Walks the BSIZE chain from offset 0 and stops at the first
+// malformed member (the reference would fail to read that block, ending iteration).
+void walk_members(const uint8_t *bam, size_t len, std::vector<HostMember> &out);
+
+// hts.c:1517-1567 (BAI loader), :1092 META_BIN, :1721-1731 HTS_IDX_START
+struct BaiInfo {
+    int32_t  n_ref = 0;
+    bool     have_start = false;
+    uint64_t start_voff = 0;
+    uint64_t n_no_coor = 0;
+    std::vector<uint64_t> anchors;   // sorted unique virtual offsets that are record starts (linear index + chunk begins)
+};
+bool parse_bai(const uint8_t *bai, size_t len, BaiInfo &out);
+
+// hts.c:2009-2042 index file name resolution ("<fn>.bai" then "<fn minus extension>.bai"); csi is detected, not read.
+// returns 0 found, 1 none, 2 only a .csi exists
+int find_index(const std::string &bam_path, std::string &out);
+
+bool read_file(const std::string &path, std::vector<uint8_t> &out);
+
+// sam.c:114-223 bam_hdr_read on the first bytes of the inflated stream.
+// returns 0 ok, 1 need more bytes (need set), 2 bad magic
+struct BamHeader { std::vector<std::string> names; std::vector<uint32_t> lens; uint64_t end = 0; };
+int parse_bam_header(const uint8_t *d, uint64_t have, BamHeader &h, uint64_t &need);
+
+// hts.c:1834-1922 hts_parse_decimal / hts_parse_reg / hts_itr_querys (+ sam.c:262-277 bam_name2id, last duplicate wins).
+// returns false when the reference's iterator would be NULL.
+bool parse_region(const BamHeader &h, const char *reg, int32_t &tid, int32_t &beg, int32_t &end);
+
+}  // namespace rgx

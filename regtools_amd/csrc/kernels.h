@@ -1,0 +1,90 @@
+// kernels.h -- launchers of the gfx950 kernels (definitions in kernels.hip). All asynchronous on `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace rgx {
+
+constexpr uint32_t kSegBytes = 16384;   // arena segment walked by one lane during record-boundary discovery
+constexpr uint64_t kChainEnd = ~0ull;   // "the record chain ended before this point" (truncated/corrupt stream)
+
+// ---- a1: BGZF inflate (one lane per member) -----------------------------------------------------------
+void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena,
+                    uint32_t *status /* [0]=first bad member (min), [1]=its status */, hipStream_t stream);
+
+// ---- a2: record framing ---------------------------------------------------------------------------------
+// Segment s covers arena [pos0 + s*kSegBytes, +kSegBytes) clipped to lim. seg_start[s] = guessed (s>0) or exact
+// (s==0) first record start >= segment begin; seg_exit[s] = first record start >= segment end reached by the
+// chain from seg_start[s]; seg_cnt[s] = records that start inside the segment.
+void launch_seg_walk(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, int32_t n_ref,
+                     uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, hipStream_t stream);
+// One verification sweep: segment s re-walks from seg_exit_in[s-1] when that differs from seg_start_in[s].
+// *changed is incremented when anything changed. Reads *_in, writes *_out (all segments).
+void launch_seg_verify(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg,
+                       const uint64_t *seg_start_in, const uint64_t *seg_exit_in, const uint32_t *seg_cnt_in,
+                       uint64_t *seg_start_out, uint64_t *seg_exit_out, uint32_t *seg_cnt_out,
+                       uint32_t *changed, hipStream_t stream);
+void launch_seg_fill(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, const uint64_t *seg_start,
+                     const uint32_t *seg_base, uint64_t *rec_off, hipStream_t stream);
+
+// ---- a2/a3/a5/a6: SoA decode + per-read event count ---------------------------------------------------------
+struct ReadSoA {
+    int32_t  *tid, *pos;
+    uint32_t *flag_nc;     // flag << 16 | n_cigar
+    uint64_t *cig_off;     // arena offset of the CIGAR array
+    uint8_t  *strand;      // per-read strand char from the tag (XS mode) or the flag rule (RF/FR)
+    uint32_t *n_ev;        // junction events this read contributes (after region filter and junction_qc)
+};
+struct ExtractCfg {
+    int32_t  n_ref;
+    int32_t  strandness;           // 0 tag, 1 RF, 2 FR, 3 intron-motif
+    uint8_t  tag0, tag1;
+    uint32_t min_anchor, min_intron, max_intron;
+    int32_t  region_tid;           // -2 = whole file
+    int32_t  region_beg, region_end;
+    uint32_t long_threshold;       // reads with more CIGAR ops than this go to the wave-per-read kernel
+};
+void launch_decode(const uint8_t *arena, const uint64_t *rec_off, uint32_t n_rec, ExtractCfg cfg, ReadSoA soa,
+                   uint32_t *long_list, uint32_t *long_count, unsigned long long *n_iterated, hipStream_t stream);
+
+// ---- a4: CIGAR scan + junction emit ---------------------------------------------------------------------------
+struct EventSoA {
+    uint32_t *tid, *start, *ilen_cls;   // key words: tid | start | (end-start) << 2 | strand class
+    uint32_t *ts, *te;                  // thick_start / thick_end of this read's instance
+    uint8_t  *strand;
+};
+void launch_emit_short(const uint8_t *arena, uint32_t n_rec, ExtractCfg cfg, ReadSoA soa, const uint32_t *ev_base,
+                       EventSoA ev, hipStream_t stream);
+void launch_emit_long(const uint8_t *arena, const uint32_t *long_list, const uint32_t *long_count, uint32_t max_long,
+                      ExtractCfg cfg, ReadSoA soa, const uint32_t *ev_base, EventSoA ev, hipStream_t stream);
+
+// ---- primitives --------------------------------------------------------------------------------------------------
+// exclusive scan of n uint32 (out may alias in); *total (device) receives the sum. tmp needs scan_tmp_words(n) words.
+size_t scan_tmp_words(uint32_t n);
+void launch_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, uint32_t *tmp, hipStream_t stream);
+
+// One stable LSD radix pass on a permutation: digit(i) = (word[perm_in ? perm_in[i] : i] >> shift) & (2^bits-1), bits<=8.
+size_t radix_tmp_words(uint32_t n);
+void launch_radix_pass(const uint32_t *word, uint32_t shift, uint32_t bits, const uint32_t *perm_in, uint32_t *perm_out,
+                       uint32_t n, uint32_t *tmp, hipStream_t stream);
+
+// ---- a7: segmented reduce ------------------------------------------------------------------------------------------
+struct UniqueSoA {
+    uint32_t *tid, *start, *end, *ts_min, *te_max, *count, *first_seen, *last_seen, *name_rank;
+    uint8_t  *strand;
+};
+// head[i] = 1 where sorted position i starts a new key
+void launch_heads(EventSoA ev, const uint32_t *perm, uint32_t n, uint32_t *head, hipStream_t stream);
+// seg_excl = exclusive scan of head. ts_min must be pre-filled with 0xffffffff, te_max with 0.
+void launch_reduce(EventSoA ev, const uint32_t *perm, const uint32_t *head, const uint32_t *seg_excl, uint32_t n, UniqueSoA u,
+                   uint32_t *head_pos, hipStream_t stream);
+// count / last_seen / strand per row; first_flag[first_seen[row]] = 1 (first_flag zeroed by the caller, n entries)
+void launch_reduce_finish(EventSoA ev, const uint32_t *perm, uint32_t n, uint32_t n_unique, const uint32_t *head_pos, UniqueSoA u,
+                          uint32_t *first_flag, hipStream_t stream);
+// name_rank[row] = 1 + exclusive_scan(first_flag)[first_seen[row]]
+void launch_name_rank(uint32_t n_unique, const uint32_t *flag_scan, UniqueSoA u, hipStream_t stream);
+void launch_gather_u32(uint32_t n, const uint32_t *table, const uint32_t *idx, uint32_t *out, hipStream_t stream);
+void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t stream);
+
+}  // namespace rgx

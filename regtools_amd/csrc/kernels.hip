@@ -1,0 +1,608 @@
+// kernels.hip -- hand-written gfx950 (CDNA4) kernels of the junctions-extract hot path.
+//
+// Everything here is integer/byte work bounded by HBM traffic or (for DEFLATE) by per-lane latency; there is
+// deliberately no MFMA.  Wave width is 64 everywhere (ballot masks are 64-bit).
+#include "kernels.h"
+
+#include "bam_core.h"
+#include "inflate_core.h"
+
+namespace rgx {
+
+// =====================================================================================================
+// wave helpers
+// =====================================================================================================
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v += t;
+    }
+    return v;
+}
+
+// =====================================================================================================
+// a1. BGZF inflate: ONE LANE PER MEMBER (64 members per wavefront, one wave per workgroup)
+// =====================================================================================================
+// Per-lane Huffman scratch in LDS, lane-interleaved so that lane L only ever touches bank L % 32:
+//   ll_sym  : 288 x u16  -> dword (i>>1)*64 + L, half i&1      (144 dwords / lane)
+//   d_sym   :  32 x u8   -> dword (i>>2)*64 + L, byte i&3      (  8 dwords / lane)
+//   ll_base :  16 x u16, d_base : 16 x u16                     ( 16 dwords / lane)
+//   lens    : 320 x u4   -> dword (i>>3)*64 + L, nibble i&7    ( 40 dwords / lane)
+// 208 dwords * 64 lanes * 4 B = 53,248 B per wave  ->  3 waves (192 members in flight) per CU of 160 KiB.
+constexpr uint32_t kLdsLLSym = 0, kLdsDSym = 144, kLdsLLBase = 152, kLdsDBase = 160, kLdsLens = 168, kLdsDwordsPerLane = 208;
+constexpr uint32_t kInflateLdsBytes = kLdsDwordsPerLane * 64 * 4;
+
+struct LdsTab {
+    uint32_t *base;   // LDS, already offset by lane
+    __device__ __forceinline__ uint32_t rd(uint32_t dw) const { return base[dw * 64]; }
+    __device__ __forceinline__ void wr(uint32_t dw, uint32_t v) { base[dw * 64] = v; }
+    __device__ __forceinline__ uint32_t get_ll_sym(uint32_t i) const { return (rd(kLdsLLSym + (i >> 1)) >> ((i & 1) * 16)) & 0xffff; }
+    __device__ __forceinline__ void set_ll_sym(uint32_t i, uint32_t v) {
+        uint32_t dw = kLdsLLSym + (i >> 1), sh = (i & 1) * 16, old = rd(dw);
+        wr(dw, (old & ~(0xffffu << sh)) | (v << sh));
+    }
+    __device__ __forceinline__ uint32_t get_d_sym(uint32_t i) const { return (rd(kLdsDSym + (i >> 2)) >> ((i & 3) * 8)) & 0xff; }
+    __device__ __forceinline__ void set_d_sym(uint32_t i, uint32_t v) {
+        uint32_t dw = kLdsDSym + (i >> 2), sh = (i & 3) * 8, old = rd(dw);
+        wr(dw, (old & ~(0xffu << sh)) | (v << sh));
+    }
+    __device__ __forceinline__ uint32_t get_ll_base(uint32_t l) const { return (rd(kLdsLLBase + (l >> 1)) >> ((l & 1) * 16)) & 0xffff; }
+    __device__ __forceinline__ void set_ll_base(uint32_t l, uint32_t v) {
+        uint32_t dw = kLdsLLBase + (l >> 1), sh = (l & 1) * 16, old = rd(dw);
+        wr(dw, (old & ~(0xffffu << sh)) | (v << sh));
+    }
+    __device__ __forceinline__ uint32_t get_d_base(uint32_t l) const { return (rd(kLdsDBase + (l >> 1)) >> ((l & 1) * 16)) & 0xffff; }
+    __device__ __forceinline__ void set_d_base(uint32_t l, uint32_t v) {
+        uint32_t dw = kLdsDBase + (l >> 1), sh = (l & 1) * 16, old = rd(dw);
+        wr(dw, (old & ~(0xffffu << sh)) | (v << sh));
+    }
+    __device__ __forceinline__ uint32_t get_len(uint32_t i) const { return (rd(kLdsLens + (i >> 3)) >> ((i & 7) * 4)) & 0xf; }
+    __device__ __forceinline__ void set_len(uint32_t i, uint32_t v) {
+        uint32_t dw = kLdsLens + (i >> 3), sh = (i & 7) * 4, old = rd(dw);
+        wr(dw, (old & ~(0xfu << sh)) | (v << sh));
+    }
+};
+
+__global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
+                                                uint32_t n_members, uint8_t *__restrict__ arena, uint32_t *status) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= n_members) return;
+    Member mb = members[m];
+    LdsTab T{lds + threadIdx.x};
+    uint32_t out_len = 0;
+    int st = inflate_raw(comp + mb.cpos, mb.clen, arena + mb.upos, mb.isize, &out_len, T);
+    if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
+    if (st != INF_OK) {
+        uint32_t prev = atomicMin(&status[0], m);
+        if (m < prev) status[1] = (uint32_t)st;   // best effort: status of (one of) the earliest bad members
+    }
+}
+
+void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint32_t *status,
+                    hipStream_t stream) {
+    if (!n_members) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+        attr_set = true;
+    }
+    uint32_t blocks = (n_members + 63) / 64;
+    hipLaunchKernelGGL(k_inflate, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, status);
+}
+
+// =====================================================================================================
+// a2. record framing: speculative per-segment chains, verified exactly
+// =====================================================================================================
+// Walk the block_size chain from `o` until it leaves [.., seg_end). Returns the first record start >= seg_end
+// (or kChainEnd when the chain hits an unreadable record / the end of the stream) and counts the records started.
+__device__ __forceinline__ uint64_t walk_chain(const uint8_t *arena, uint64_t o, uint64_t seg_end, uint64_t lim, uint32_t &cnt) {
+    cnt = 0;
+    while (o < seg_end) {
+        if (o + 36 > lim) return kChainEnd;             // bam_read1: short read of the fixed part
+        RecHead h; rec_head(arena + o, h);
+        if (!rec_sane(h)) return kChainEnd;             // sam.c:421-423 -> iteration ends
+        uint64_t nxt = o + 4 + (uint64_t)(uint32_t)h.block_len;
+        if (nxt > lim) return kChainEnd;                // truncated record body
+        ++cnt;
+        o = nxt;
+    }
+    return o;
+}
+
+__global__ void k_seg_walk(const uint8_t *__restrict__ arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, int32_t n_ref,
+                           uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    uint64_t a = pos0 + (uint64_t)s * kSegBytes, b = a + kSegBytes;
+    if (b > lim) b = lim;
+    uint64_t o = a;
+    if (s > 0) {
+        // guess: first offset in the segment where three chained records all look like records
+        uint64_t g = kChainEnd;
+        for (uint64_t c = a; c < b; ++c) {
+            if (!rec_plausible(arena, c, lim, n_ref)) continue;
+            uint64_t c2 = c + 4 + (uint64_t)ld32(arena + c);
+            if (c2 < lim) {
+                if (!rec_plausible(arena, c2, lim, n_ref)) continue;
+                uint64_t c3 = c2 + 4 + (uint64_t)ld32(arena + c2);
+                if (c3 < lim && !rec_plausible(arena, c3, lim, n_ref)) continue;
+            }
+            g = c; break;
+        }
+        o = g;
+    }
+    uint32_t cnt = 0;
+    uint64_t ex;
+    if (o == kChainEnd) { ex = kChainEnd; o = b; }      // nothing plausible: verification will settle it
+    else ex = walk_chain(arena, o, b, lim, cnt);
+    seg_start[s] = o; seg_exit[s] = ex; seg_cnt[s] = cnt;
+}
+
+__global__ void k_seg_verify(const uint8_t *__restrict__ arena, uint64_t pos0, uint64_t lim, uint32_t n_seg,
+                             const uint64_t *__restrict__ st_in, const uint64_t *__restrict__ ex_in, const uint32_t *__restrict__ cnt_in,
+                             uint64_t *st_out, uint64_t *ex_out, uint32_t *cnt_out, uint32_t *changed) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    uint64_t st = st_in[s], ex = ex_in[s];
+    uint32_t cnt = cnt_in[s];
+    if (s > 0) {
+        uint64_t a = pos0 + (uint64_t)s * kSegBytes, b = a + kSegBytes;
+        if (b > lim) b = lim;
+        uint64_t expect = ex_in[s - 1];                 // where the exact chain enters this segment (if s-1 is right)
+        bool pass_through = expect >= b;                // includes kChainEnd: no record starts in this segment
+        uint64_t want_start = pass_through ? b : expect;
+        if (pass_through) {
+            if (!(st == b && ex == expect && cnt == 0)) { st = b; ex = expect; cnt = 0; atomicAdd(changed, 1u); }
+        } else if (st != want_start) {
+            st = want_start;
+            ex = walk_chain(arena, st, b, lim, cnt);
+            atomicAdd(changed, 1u);
+        }
+    }
+    st_out[s] = st; ex_out[s] = ex; cnt_out[s] = cnt;
+}
+
+__global__ void k_seg_fill(const uint8_t *__restrict__ arena, uint64_t pos0, uint64_t lim, uint32_t n_seg,
+                           const uint64_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_base, uint64_t *rec_off) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    uint64_t a = pos0 + (uint64_t)s * kSegBytes, b = a + kSegBytes;
+    if (b > lim) b = lim;
+    uint64_t o = seg_start[s];
+    uint32_t k = seg_base[s];
+    while (o < b) {
+        if (o + 36 > lim) break;
+        RecHead h; rec_head(arena + o, h);
+        if (!rec_sane(h)) break;
+        uint64_t nxt = o + 4 + (uint64_t)(uint32_t)h.block_len;
+        if (nxt > lim) break;
+        rec_off[k++] = o;
+        o = nxt;
+    }
+}
+
+void launch_seg_walk(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, int32_t n_ref, uint64_t *seg_start,
+                     uint64_t *seg_exit, uint32_t *seg_cnt, hipStream_t stream) {
+    if (!n_seg) return;
+    hipLaunchKernelGGL(k_seg_walk, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, pos0, lim, n_seg, n_ref, seg_start, seg_exit, seg_cnt);
+}
+void launch_seg_verify(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, const uint64_t *seg_start_in,
+                       const uint64_t *seg_exit_in, const uint32_t *seg_cnt_in, uint64_t *seg_start_out, uint64_t *seg_exit_out,
+                       uint32_t *seg_cnt_out, uint32_t *changed, hipStream_t stream) {
+    if (!n_seg) return;
+    hipLaunchKernelGGL(k_seg_verify, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, pos0, lim, n_seg, seg_start_in, seg_exit_in,
+                       seg_cnt_in, seg_start_out, seg_exit_out, seg_cnt_out, changed);
+}
+void launch_seg_fill(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, const uint64_t *seg_start,
+                     const uint32_t *seg_base, uint64_t *rec_off, hipStream_t stream) {
+    if (!n_seg) return;
+    hipLaunchKernelGGL(k_seg_fill, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, pos0, lim, n_seg, seg_start, seg_base, rec_off);
+}
+
+// =====================================================================================================
+// a2/a3/a5/a6. decode to SoA (one lane per record) + per-read junction-event count
+// =====================================================================================================
+__global__ void k_decode(const uint8_t *__restrict__ arena, const uint64_t *__restrict__ rec_off, uint32_t n_rec, ExtractCfg cfg,
+                         ReadSoA soa, uint32_t *long_list, uint32_t *long_count, unsigned long long *n_iterated) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool iterated = false;
+    if (i < n_rec) {
+        uint64_t o = rec_off[i];
+        RecHead h; rec_head(arena + o, h);
+        const uint8_t *data = arena + o + 36;
+        const uint8_t *cig = data + h.l_qname;
+        soa.tid[i] = h.tid; soa.pos[i] = h.pos;
+        soa.flag_nc[i] = h.flag << 16 | h.n_cigar;
+        soa.cig_off[i] = o + 36 + h.l_qname;
+        // region iterator (hts.c:1946-1957): tid == t && pos < end && endpos > beg
+        bool in_region = true;
+        if (cfg.region_tid != -2) {
+            in_region = h.tid == cfg.region_tid && h.pos < cfg.region_end;
+            if (in_region) in_region = rec_endpos(cig, h.n_cigar, h.flag, h.pos) > cfg.region_beg;
+        }
+        iterated = in_region;
+        uint32_t nev = 0;
+        char strand = '?';
+        if (in_region && h.n_cigar > 1 && h.tid >= 0 && h.tid < cfg.n_ref) {     // junctions_extractor.cc:378-380
+            for (uint32_t k = 0; k < h.n_cigar; ++k) {
+                uint32_t c = ld32(cig + 4 * (size_t)k);
+                // junction_qc (cc:160-170): the intron length is the N op's own length
+                if (cig_is_N(c)) { uint32_t len = c >> 4; nev += !(len < cfg.min_intron || len > cfg.max_intron); }
+            }
+            if (nev) {
+                if (cfg.strandness == 0) {
+                    int64_t l_data = (int64_t)h.block_len - 32;
+                    strand = strand_from_tag(data + h.aux_off, data + l_data, cfg.tag0, cfg.tag1);
+                } else strand = strand_from_flag(h.flag, cfg.strandness);
+                if (h.n_cigar > cfg.long_threshold) { uint32_t slot = atomicAdd(long_count, 1u); long_list[slot] = i; }
+            }
+        }
+        soa.strand[i] = (uint8_t)strand;
+        soa.n_ev[i] = nev;
+    }
+    // alignments iterated = records that pass the region filter (all of them for ".")
+    uint64_t bal = __ballot(iterated);
+    if (lane_id() == 0 && bal) atomicAdd(n_iterated, (unsigned long long)__popcll(bal));
+}
+
+void launch_decode(const uint8_t *arena, const uint64_t *rec_off, uint32_t n_rec, ExtractCfg cfg, ReadSoA soa,
+                   uint32_t *long_list, uint32_t *long_count, unsigned long long *n_iterated, hipStream_t stream) {
+    if (!n_rec) return;
+    hipLaunchKernelGGL(k_decode, dim3((n_rec + 255) / 256), dim3(256), 0, stream, arena, rec_off, n_rec, cfg, soa, long_list, long_count, n_iterated);
+}
+
+// =====================================================================================================
+// a4. CIGAR scan + junction emit
+// =====================================================================================================
+__device__ __forceinline__ void put_event(const EventSoA &ev, uint32_t slot, int32_t tid, uint32_t start, uint32_t end, uint32_t ts,
+                                          uint32_t te, char strand) {
+    ev.tid[slot] = (uint32_t)tid; ev.start[slot] = start;
+    ev.ilen_cls[slot] = (end - start) << 2 | strand_class(strand);
+    ev.ts[slot] = ts; ev.te[slot] = te; ev.strand[slot] = (uint8_t)strand;
+}
+
+// short reads: one lane per read, the serial state machine (config 2: 1 or 3 ops)
+__global__ void k_emit_short(const uint8_t *__restrict__ arena, uint32_t n_rec, ExtractCfg cfg, ReadSoA soa,
+                             const uint32_t *__restrict__ ev_base, EventSoA ev) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    uint32_t nev = soa.n_ev[i];
+    if (!nev) return;
+    uint32_t fnc = soa.flag_nc[i], n_cigar = fnc & 0xffff;
+    if (n_cigar > cfg.long_threshold) return;
+    const uint8_t *cig = arena + soa.cig_off[i];
+    int32_t tid = soa.tid[i];
+    char strand = (char)soa.strand[i];
+    uint32_t slot = ev_base[i];
+    cigar_walk(soa.pos[i], cig, n_cigar, [&](uint32_t s, uint32_t e, uint32_t ts, uint32_t te) {
+        if (intron_ok(s, e, cfg.min_intron, cfg.max_intron)) put_event(ev, slot++, tid, s, e, ts, te, strand);
+    });
+}
+
+// long reads: one WAVE per read. Ops are staged through LDS in tiles of 64, classified with ballots and
+// positioned with a wave prefix sum of reference advance (parallel form):
+//   for the N op at index i:  start = R[i], end = R[i+1],
+//                             thick_start = R[pb+1]  (pb = last breaker {N,D,X,I,S} before i, or read start),
+//                             thick_end   = R[nb]    (nb = first breaker after i, or read end).
+__global__ __launch_bounds__(256) void k_emit_long(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ long_list,
+                                                   const uint32_t *__restrict__ long_count, ExtractCfg cfg, ReadSoA soa,
+                                                   const uint32_t *__restrict__ ev_base, EventSoA ev) {
+    __shared__ uint32_t s_ops[4][64];
+    __shared__ uint32_t s_R[4][65];
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t n_long = *long_count;
+    for (uint32_t w = blockIdx.x * 4 + wave; w < n_long; w += gridDim.x * 4) {
+        const uint32_t i = long_list[w];
+        const uint32_t n_cigar = soa.flag_nc[i] & 0xffff;
+        const uint8_t *cig = arena + soa.cig_off[i];
+        const int32_t tid = soa.tid[i];
+        const char strand = (char)soa.strand[i];
+        uint32_t slot = ev_base[i];
+        uint32_t refpos = (uint32_t)soa.pos[i];      // R at the start of the tile
+        uint32_t ts_carry = refpos;                  // R[pb+1] for an N with no breaker earlier in the tile
+        // junction opened in an earlier tile and still waiting for its right anchor's end
+        bool pend = false; uint32_t p_start = 0, p_end = 0, p_ts = 0;
+        for (uint32_t t0 = 0; t0 < n_cigar; t0 += 64) {
+            const uint32_t k = t0 + lane;
+            const uint32_t c = k < n_cigar ? ld32(cig + 4 * (size_t)k) : 0x5u /* 0H: inert */;
+            s_ops[wave][lane] = c;
+            const uint32_t adv = cig_advances_junction_state(c) ? (c >> 4) : 0u;
+            const uint32_t incl = wave_incl_scan(adv);
+            const uint32_t R_before = refpos + incl - adv, R_after = refpos + incl;
+            s_R[wave][lane] = R_before;
+            if (lane == 63) s_R[wave][64] = R_after;
+            const bool brk = k < n_cigar && cig_is_breaker(c);
+            const bool isN = k < n_cigar && cig_is_N(c);
+            const uint64_t B = __ballot(brk);
+            __builtin_amdgcn_wave_barrier();
+            // close the pending junction at this tile's first breaker
+            if (pend && B) {
+                const uint32_t nb = (uint32_t)__ffsll((unsigned long long)B) - 1;
+                const uint32_t te = s_R[wave][nb];
+                if (lane == 0 && intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) put_event(ev, slot, tid, p_start, p_end, p_ts, te, strand);
+                if (intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) ++slot;
+                pend = false;
+            }
+            // per-lane junction geometry
+            const uint64_t below = B & lanemask_lt();
+            const uint64_t above = lane == 63 ? 0ull : (B >> (lane + 1)) << (lane + 1);
+            const uint32_t ts = below ? s_R[wave][(63 - (uint32_t)__clzll((long long)below)) + 1] : ts_carry;
+            const bool closed = above != 0;
+            const uint32_t te = closed ? s_R[wave][(uint32_t)__ffsll((unsigned long long)above) - 1] : 0u;
+            const bool ok = isN && intron_ok(R_before, R_after, cfg.min_intron, cfg.max_intron);
+            // events keep CIGAR order: rank among the qc-passing N lanes that close inside this tile
+            const uint64_t emit_mask = __ballot(ok && closed);
+            if (ok && closed) put_event(ev, slot + (uint32_t)__popcll(emit_mask & lanemask_lt()), tid, R_before, R_after, ts, te, strand);
+            slot += (uint32_t)__popcll(emit_mask);
+            // the last breaker of the tile: if it is an N it stays open into the next tile
+            if (B) {
+                const uint32_t lastb = 63 - (uint32_t)__clzll((long long)B);
+                const uint32_t lc = s_ops[wave][lastb];
+                ts_carry = s_R[wave][lastb + 1];
+                if (cig_is_N(lc)) {
+                    pend = true;
+                    p_start = s_R[wave][lastb]; p_end = s_R[wave][lastb + 1];
+                    const uint64_t bl = B & ((1ull << lastb) - 1ull);
+                    p_ts = __shfl(ts, lastb, 64);
+                    (void)bl;
+                }
+            }
+            refpos = __shfl(R_after, 63, 64);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (pend && lane == 0 && intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) put_event(ev, slot, tid, p_start, p_end, p_ts, refpos, strand);
+    }
+}
+
+void launch_emit_short(const uint8_t *arena, uint32_t n_rec, ExtractCfg cfg, ReadSoA soa, const uint32_t *ev_base, EventSoA ev,
+                       hipStream_t stream) {
+    if (!n_rec) return;
+    hipLaunchKernelGGL(k_emit_short, dim3((n_rec + 255) / 256), dim3(256), 0, stream, arena, n_rec, cfg, soa, ev_base, ev);
+}
+void launch_emit_long(const uint8_t *arena, const uint32_t *long_list, const uint32_t *long_count, uint32_t max_long, ExtractCfg cfg,
+                      ReadSoA soa, const uint32_t *ev_base, EventSoA ev, hipStream_t stream) {
+    if (!max_long) return;
+    uint32_t blocks = (max_long + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;       // grid-stride: 8 workgroups per CU
+    hipLaunchKernelGGL(k_emit_long, dim3(blocks), dim3(256), 0, stream, arena, long_list, long_count, cfg, soa, ev_base, ev);
+}
+
+// =====================================================================================================
+// primitives: exclusive scan (3 kernels), stable 8-bit LSD radix pass on a permutation
+// =====================================================================================================
+constexpr uint32_t kScanTile = 4096;   // 256 threads x 16 items
+
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *s_wave /*[4]*/, uint32_t &block_total) {
+    const uint32_t incl = wave_incl_scan(v);
+    const uint32_t w = threadIdx.x >> 6;
+    if (lane_id() == 63) s_wave[w] = incl;
+    __syncthreads();
+    uint32_t off = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) off += (k < w) ? s_wave[k] : 0u;
+    block_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    return off + incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *__restrict__ in, uint32_t n, uint32_t *tile_sum) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 16;
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) sum += (base + k < n) ? in[base + k] : 0u;
+    uint32_t tot; block_excl_scan_256(sum, s_wave, tot);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_scan_tiles(uint32_t *tile_sum, uint32_t n_tiles, uint32_t *total) {
+    __shared__ uint32_t s_wave[4];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_tiles; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n_tiles ? tile_sum[i] : 0u;
+        uint32_t tot; const uint32_t ex = block_excl_scan_256(v, s_wave, tot);
+        if (i < n_tiles) tile_sum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__ in, uint32_t *out, uint32_t n, const uint32_t *__restrict__ tile_sum) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 16;
+    uint32_t v[16], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) { v[k] = (base + k < n) ? in[base + k] : 0u; sum += v[k]; }
+    uint32_t tot; uint32_t run = block_excl_scan_256(sum, s_wave, tot) + tile_sum[blockIdx.x];
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+}
+
+size_t scan_tmp_words(uint32_t n) { return (size_t)(n + kScanTile - 1) / kScanTile + 1; }
+
+void launch_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, uint32_t *tmp, hipStream_t stream) {
+    if (!n) { if (total) (void)hipMemsetAsync(total, 0, 4, stream); return; }
+    const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(256), 0, stream, in, n, tmp);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(256), 0, stream, tmp, tiles, total);
+    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(256), 0, stream, in, out, n, tmp);
+}
+
+// ---- radix pass ------------------------------------------------------------------------------------------
+constexpr uint32_t kRadixRows = 32;                   // one wave per workgroup, 64 x 32 = 2048 keys per tile
+constexpr uint32_t kRadixTile = 64 * kRadixRows;
+
+__device__ __forceinline__ uint32_t radix_digit(const uint32_t *__restrict__ word, const uint32_t *__restrict__ perm_in, uint32_t i,
+                                                uint32_t shift, uint32_t mask, uint32_t &src) {
+    src = perm_in ? perm_in[i] : i;
+    return (word[src] >> shift) & mask;
+}
+
+// lanes holding the same digit as me (8 ballots)
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (uint32_t b = 0; b < 8; ++b) {
+        const uint64_t bal = __ballot((d >> b) & 1u);
+        m &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(64) void k_radix_hist(const uint32_t *__restrict__ word, uint32_t shift, uint32_t mask,
+                                                   const uint32_t *__restrict__ perm_in, uint32_t n, uint32_t n_tiles, uint32_t *hist) {
+    __shared__ uint32_t s_cnt[256];
+    for (uint32_t k = threadIdx.x; k < 256; k += 64) s_cnt[k] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kRadixTile;
+    for (uint32_t r = 0; r < kRadixRows; ++r) {
+        const uint32_t i = base + r * 64 + threadIdx.x;
+        if (i < n) { uint32_t src; atomicAdd(&s_cnt[radix_digit(word, perm_in, i, shift, mask, src)], 1u); }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 256; k += 64) hist[(size_t)k * n_tiles + blockIdx.x] = s_cnt[k];   // digit-major
+}
+
+__global__ __launch_bounds__(64) void k_radix_scatter(const uint32_t *__restrict__ word, uint32_t shift, uint32_t mask,
+                                                      const uint32_t *__restrict__ perm_in, uint32_t *perm_out, uint32_t n,
+                                                      uint32_t n_tiles, const uint32_t *__restrict__ hist_scan) {
+    __shared__ uint32_t s_base[256];
+    for (uint32_t k = threadIdx.x; k < 256; k += 64) s_base[k] = hist_scan[(size_t)k * n_tiles + blockIdx.x];
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kRadixTile;
+    for (uint32_t r = 0; r < kRadixRows; ++r) {
+        const uint32_t i = base + r * 64 + threadIdx.x;
+        const bool valid = i < n;
+        uint32_t src = 0;
+        const uint32_t d = valid ? radix_digit(word, perm_in, i, shift, mask, src) : 0u;
+        const uint64_t m = match_digit(d, valid);
+        if (valid) {
+            const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt());
+            const uint32_t leader = (uint32_t)__ffsll((unsigned long long)m) - 1;
+            uint32_t b = 0;
+            if (lane_id() == leader) { b = s_base[d]; s_base[d] = b + (uint32_t)__popcll(m); }
+            b = __shfl(b, leader, 64);
+            perm_out[b + rank] = src;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+size_t radix_tmp_words(uint32_t n) {
+    const size_t tiles = ((size_t)n + kRadixTile - 1) / kRadixTile;
+    return 256 * tiles + scan_tmp_words((uint32_t)(256 * tiles)) + 4;
+}
+
+void launch_radix_pass(const uint32_t *word, uint32_t shift, uint32_t bits, const uint32_t *perm_in, uint32_t *perm_out, uint32_t n,
+                       uint32_t *tmp, hipStream_t stream) {
+    if (!n) return;
+    const uint32_t tiles = (n + kRadixTile - 1) / kRadixTile;
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t *hist = tmp, *scan_tmp = tmp + (size_t)256 * tiles;
+    hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(64), 0, stream, word, shift, mask, perm_in, n, tiles, hist);
+    launch_scan_u32(hist, hist, 256 * tiles, nullptr, scan_tmp, stream);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(64), 0, stream, word, shift, mask, perm_in, perm_out, n, tiles, hist);
+}
+
+// =====================================================================================================
+// a7. group-by: head flags, segmented reduce, first-seen naming
+// =====================================================================================================
+__global__ void k_heads(EventSoA ev, const uint32_t *__restrict__ perm, uint32_t n, uint32_t *head) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t h = 1;
+    if (i > 0) {
+        const uint32_t a = perm[i], b = perm[i - 1];
+        h = (ev.tid[a] != ev.tid[b]) || (ev.start[a] != ev.start[b]) || (ev.ilen_cls[a] != ev.ilen_cls[b]);
+    }
+    head[i] = h;
+}
+
+// seg_excl = exclusive scan of head; the row of sorted position i is seg_excl[i] + head[i] - 1.
+// ts_min must be pre-filled with 0xffffffff and te_max with 0.
+__global__ void k_reduce(EventSoA ev, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ head,
+                         const uint32_t *__restrict__ seg_excl, uint32_t n, UniqueSoA u, uint32_t *head_pos) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    uint32_t row = 0, ts = 0xffffffffu, te = 0, hd = 0;
+    if (valid) {
+        const uint32_t e = perm[i];
+        hd = head[i];
+        row = seg_excl[i] + hd - 1;
+        ts = ev.ts[e]; te = ev.te[e];
+        if (hd) {
+            head_pos[row] = i;
+            u.tid[row] = ev.tid[e]; u.start[row] = ev.start[e]; u.end[row] = ev.start[e] + (ev.ilen_cls[e] >> 2);
+            u.first_seen[row] = e;          // stable sort: the first event of the run is the earliest read
+        }
+    }
+    // wave-segmented min/max: runs are contiguous in lane order (keys are sorted)
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t r2 = __shfl_down(row, d, 64), ts2 = __shfl_down(ts, d, 64), te2 = __shfl_down(te, d, 64);
+        const bool v2 = __shfl_down((uint32_t)valid, d, 64) != 0;
+        if (lane + d < 64 && v2 && r2 == row) { ts = min(ts, ts2); te = max(te, te2); }
+    }
+    // the first lane of each run in this wave publishes
+    const uint32_t prev_row = __shfl_up(row, 1, 64);
+    const bool run_head = valid && (lane == 0 || prev_row != row);
+    if (run_head) { atomicMin(&u.ts_min[row], ts); atomicMax(&u.te_max[row], te); }
+}
+
+__global__ void k_reduce_finish(EventSoA ev, const uint32_t *__restrict__ perm, uint32_t n, uint32_t n_unique,
+                                const uint32_t *__restrict__ head_pos, UniqueSoA u, uint32_t *first_flag) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_unique) return;
+    const uint32_t hp = head_pos[r], nx = (r + 1 < n_unique) ? head_pos[r + 1] : n;
+    u.count[r] = nx - hp;
+    const uint32_t last = perm[nx - 1];
+    u.last_seen[r] = last;
+    u.strand[r] = ev.strand[last];          // newest read's strand wins (junctions_extractor.cc:233)
+    first_flag[u.first_seen[r]] = 1;
+}
+
+__global__ void k_name_rank(uint32_t n_unique, const uint32_t *__restrict__ flag_scan, UniqueSoA u) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_unique) u.name_rank[r] = flag_scan[u.first_seen[r]] + 1;   // 1-based rank of first occurrence
+}
+
+__global__ void k_gather_u32(uint32_t n, const uint32_t *__restrict__ table, const uint32_t *__restrict__ idx, uint32_t *out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) out[r] = table[idx[r]];
+}
+
+__global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+void launch_heads(EventSoA ev, const uint32_t *perm, uint32_t n, uint32_t *head, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_heads, dim3((n + 255) / 256), dim3(256), 0, stream, ev, perm, n, head);
+}
+void launch_reduce(EventSoA ev, const uint32_t *perm, const uint32_t *head, const uint32_t *seg_excl, uint32_t n, UniqueSoA u,
+                   uint32_t *head_pos, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_reduce, dim3((n + 255) / 256), dim3(256), 0, stream, ev, perm, head, seg_excl, n, u, head_pos);
+}
+void launch_reduce_finish(EventSoA ev, const uint32_t *perm, uint32_t n, uint32_t n_unique, const uint32_t *head_pos, UniqueSoA u,
+                          uint32_t *first_flag, hipStream_t stream) {
+    if (n_unique) hipLaunchKernelGGL(k_reduce_finish, dim3((n_unique + 255) / 256), dim3(256), 0, stream, ev, perm, n, n_unique, head_pos, u, first_flag);
+}
+void launch_name_rank(uint32_t n_unique, const uint32_t *flag_scan, UniqueSoA u, hipStream_t stream) {
+    if (n_unique) hipLaunchKernelGGL(k_name_rank, dim3((n_unique + 255) / 256), dim3(256), 0, stream, n_unique, flag_scan, u);
+}
+void launch_gather_u32(uint32_t n, const uint32_t *table, const uint32_t *idx, uint32_t *out, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_gather_u32, dim3((n + 255) / 256), dim3(256), 0, stream, n, table, idx, out);
+}
+void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, v, n);
+}
+
+}  // namespace rgx

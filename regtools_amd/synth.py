@@ -1,0 +1,48 @@
+"""Synthetic BAM/BAI inputs of SURVEY.md section 8(d) (tooling; libregtools_synth.so)."""
+import ctypes as C
+
+from . import _ffi
+
+SHAPES = {"short": 0, "long": 1, "fuzz": 2}
+
+
+def _params(n_reads, shape, seed, level, threads, n_introns, realistic):
+    p = _ffi.SynthParams()
+    p.shape, p.n_reads, p.seed, p.level, p.threads = SHAPES[shape], n_reads, seed, level, threads
+    p.n_introns, p.spliced_frac, p.realistic_payload = n_introns, 0.0, 1 if realistic else 0
+    return p
+
+
+def generate(n_reads, shape="short", seed=1, level=6, threads=0, n_introns=0, realistic=False):
+    """Returns (bam_bytes, bai_bytes, stats)."""
+    L = _ffi.synth()
+    p = _params(n_reads, shape, seed, level, threads, n_introns, realistic)
+    r = _ffi.SynthResult()
+    rc = L.rgx_synth_generate(C.byref(p), C.byref(r))
+    if rc:
+        raise RuntimeError("synthetic BAM generation failed (%d)" % rc)
+    try:
+        bam = C.string_at(r.bam, r.bam_len)
+        bai = C.string_at(r.bai, r.bai_len)
+        stats = dict(n_reads=r.n_reads, n_spliced=r.n_spliced, n_members=r.n_blocks, inflated_bytes=r.inflated_bytes,
+                     cigar_ops=r.cigar_ops, bam_bytes=r.bam_len)
+    finally:
+        L.rgx_synth_free(C.byref(r))
+    return bam, bai, stats
+
+
+def write(path, n_reads, shape="short", seed=1, level=6, threads=0, n_introns=0, realistic=False):
+    L = _ffi.synth()
+    p = _params(n_reads, shape, seed, level, threads, n_introns, realistic)
+    r = _ffi.SynthResult()
+    rc = L.rgx_synth_write(C.byref(p), path.encode(), C.byref(r))
+    if rc:
+        raise RuntimeError("synthetic BAM generation failed (%d)" % rc)
+    return dict(n_reads=r.n_reads, n_spliced=r.n_spliced, n_members=r.n_blocks, inflated_bytes=r.inflated_bytes,
+                cigar_ops=r.cigar_ops, bam_bytes=r.bam_len)
+
+
+def index(bam_path):
+    rc = _ffi.synth().rgx_synth_index(bam_path.encode())
+    if rc:
+        raise RuntimeError("indexing %s failed (%d)" % (bam_path, rc))
