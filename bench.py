@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""bench.py -- `junctions extract` hot path on N MI355X GPUs (one process per GPU).
+
+A "step" is one complete pass of the hot path over one synthetic BAM (SURVEY.md 8d, config 2 shape):
+BGZF members already resident in HBM -> inflate -> record framing -> SoA decode -> CIGAR scan/emit ->
+radix sort + segmented reduce -> sorted junction table on the host.  N > 1 is weak scaling: every rank
+holds its own coordinate slice (same read count) of one big coordinate-sorted BAM, the per-rank tables are
+exchanged with one RCCL all-gather of packed rows and merged.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel: the
+DEFLATE kernel, timed with HIP events on the pipeline's own stream) and `cpu_baseline` (the real
+reference built into oracle/_ref when present, else the oracle port; rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(bam_path, n_reads, n_events):
+    """Time the reference (or the oracle port) on the host cores: single thread, because the reference has
+    no threads at all."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "regtools_ref")
+    orc = os.path.join(ROOT, "oracle", "oracle_cli")
+    out = os.path.join(os.path.dirname(bam_path), "cpu_baseline.bed")
+    if os.path.exists(ref):
+        t0 = time.time()
+        r = subprocess.run([ref, "junctions", "extract", "-s", "XS", "-o", out, bam_path], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dt = time.time() - t0
+        if r.returncode == 0 and dt > 0:
+            return dict(value=n_reads / dt, unit="alignments/s", cores=1, kind="reference", seconds=round(dt, 3),
+                        junction_events_per_s=n_events / dt,
+                        sample="the full bench workload (%d reads), reference regtools built from /root/reference by oracle/Makefile, 1 thread" % n_reads), out
+    if not os.path.exists(orc):
+        subprocess.run(["make", "-s"], cwd=os.path.join(ROOT, "oracle"), check=True)
+    t0 = time.time()
+    subprocess.run([orc, "extract", "-s", "XS", "-o", out, bam_path], check=True)
+    dt = time.time() - t0
+    return dict(value=n_reads / dt, unit="alignments/s", cores=1, kind="port", seconds=round(dt, 3), junction_events_per_s=n_events / dt,
+                sample="the full bench workload (%d reads), oracle/ C restatement, 1 thread" % n_reads), out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU (config 2: 50M)")
+    ap.add_argument("--shape", default="short", choices=["short", "long"])
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--realistic", action="store_true", help="random bases + binned qualities instead of the named constant payload")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    import regtools_amd
+    from regtools_amd import _ffi, synth
+    from regtools_amd import distributed as rdist
+
+    # ---- synthetic input: this rank's coordinate slice of the job ---------------------------------------------
+    t_gen = time.time()
+    threads = max(1, (os.cpu_count() or 8) // max(1, world))
+    bam, bai, st = synth.generate(args.reads, shape=args.shape, seed=args.seed, threads=threads, realistic=args.realistic,
+                                  slice_index=rank, n_slices=world)
+    t_gen = time.time() - t_gen
+    n_reads = st["n_reads"]
+    d_bam = torch.zeros(len(bam) + 64, dtype=torch.uint8, device="cuda")
+    d_bam[: len(bam)].copy_(torch.frombuffer(bytearray(bam), dtype=torch.uint8))
+    torch.cuda.synchronize()
+
+    ctx = regtools_amd.Context(local_rank)
+    je = regtools_amd.JunctionsExtractor(strandness=0, ctx=ctx)
+
+    def step():
+        je.identify_junctions_from_BAM(bam_bytes=bam, bai_bytes=bai, device_ptr=d_bam.data_ptr())
+        if world > 1:
+            return rdist.gather_and_merge(je, min_anchor=8)
+        return je.table
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    inflate_ms, stage_ms = [], dict(inflate=0.0, records=0.0, scan=0.0, reduce=0.0, total=0.0)
+    fence()
+    t0 = time.time()
+    for _ in range(args.steps):
+        step()
+        s = je.stats
+        inflate_ms.append(s["ms_inflate"])
+        for k in stage_ms:
+            stage_ms[k] += s["ms_" + k] / args.steps
+    fence()
+    dt = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        cnt = torch.tensor([float(n_reads), float(je.stats["n_events"])], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        total_reads, total_events = cnt[0].item(), cnt[1].item()
+    else:
+        total_reads, total_events = float(n_reads), float(je.stats["n_events"])
+
+    if rank == 0:
+        s = je.stats
+        ms_step = 1e3 * dt / args.steps
+        aln_per_s = total_reads * args.steps / dt
+        # dominant kernel: k_inflate. Algorithmic bytes per launch: every compressed byte read once
+        # + every inflated byte written once = (C + U) * alignments in the launch.
+        alg_bytes = s["compressed_bytes"] + s["inflated_bytes"]
+        k_ms = sum(inflate_ms) / len(inflate_ms)
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "alignments/sec + junctions/sec, junctions extract, 1/2/4/8 MI355X",
+            "value": aln_per_s, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/u32 integer", "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic %d-read 101 bp BAM per GPU, ~15%% reads with one N-op, junctions extract -s XS%s" % (n_reads, " (realistic payload)" if args.realistic else ""),
+                       "reads_per_gpu": n_reads, "shape": args.shape, "seed": args.seed, "sharding": "coordinate slice per GPU, all-gather of packed junction rows" if world > 1 else "single GPU",
+                       "bgzf_members": s["n_members"], "compressed_bytes_per_gpu": s["compressed_bytes"], "inflated_bytes_per_gpu": s["inflated_bytes"],
+                       "bytes_per_alignment": {"compressed": s["compressed_bytes"] / n_reads, "inflated": s["inflated_bytes"] / n_reads}},
+            "junction_events_per_s": total_events * args.steps / dt,
+            "junction_rows": s["n_junctions"],
+            "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+            "input_generation_s": round(t_gen, 2),
+            "roofline": {"bound": "hbm", "kernel": "rgx::k_inflate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
+                         "note": "DEFLATE is a serial bit stream per member: bound by per-lane latency, far below the HBM line (SURVEY 8d)",
+                         "pipeline_frac": aln_per_s / world * (alg_bytes / n_reads) / (HBM_PEAK_GBS * 1e9)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "bench.bam")
+                with open(path, "wb") as f:
+                    f.write(bam)
+                with open(path + ".bai", "wb") as f:
+                    f.write(bai)
+                cb, bed = cpu_baseline(path, n_reads, s["n_events"])
+                # while we are here: the GPU table must equal the CPU one on the full-size workload
+                with open(bed, "rb") as f:
+                    cb["bed12_identical_to_gpu"] = f.read() == je.bed12()
+                line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,7 +77,7 @@ def lib():
 class SynthParams(C.Structure):
     _fields_ = [("shape", C.c_int), ("n_reads", C.c_uint64), ("seed", C.c_uint64), ("level", C.c_int),
                 ("threads", C.c_int), ("n_introns", C.c_uint32), ("spliced_frac", C.c_double),
-                ("realistic_payload", C.c_int)]
+                ("realistic_payload", C.c_int), ("slice_index", C.c_int), ("n_slices", C.c_int)]
 
 
 class SynthResult(C.Structure):

@@ -76,7 +76,9 @@ enum { M = 0, I = 1, D = 2, N = 3, S = 4, H = 5, P = 6, EQ = 7, X = 8 };
 void pick_locus(const Ctx &c, Rng &r, uint32_t span, int32_t &tid, uint32_t &pos) {
     // length-weighted contig, then uniform position that leaves `span` bases of room
     for (int tries = 0; tries < 64; ++tries) {
-        uint64_t g = (uint64_t)(r.unit() * (double)c.genome_len);
+        double uu = r.unit();
+        if (c.p.n_slices > 1) uu = ((double)c.p.slice_index + uu) / (double)c.p.n_slices;   // coordinate window of this slice
+        uint64_t g = (uint64_t)(uu * (double)c.genome_len);
         size_t t = std::upper_bound(c.contig_off.begin(), c.contig_off.end(), g) - c.contig_off.begin() - 1;
         if (t >= c.contigs.size()) t = c.contigs.size() - 1;
         uint32_t len = c.contigs[t].len;

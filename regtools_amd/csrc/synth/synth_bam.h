@@ -29,6 +29,8 @@ typedef struct {
     uint32_t n_introns;    // size of the intron table (0 = 300000, clamped to the number of spliced reads)
     double   spliced_frac; // 0 = 0.15
     int      realistic_payload; // 0 = seq 0x11 / qual 0xff (the named shape); 1 = random bases + binned quals
+    int      slice_index;  // this file holds the slice_index-th of n_slices equal coordinate windows of the genome
+    int      n_slices;     // 0/1 = whole genome (multi-GPU weak scaling: rank r generates slice r of the big BAM)
 } rgx_synth_params;
 
 typedef struct {

@@ -22,6 +22,7 @@ int main(int argc, char **argv) {
         else if (a == "--threads" && i + 1 < argc) p.threads = atoi(argv[++i]);
         else if (a == "--introns" && i + 1 < argc) p.n_introns = (uint32_t)atoi(argv[++i]);
         else if (a == "--realistic") p.realistic_payload = 1;
+        else if (a == "--slice" && i + 2 < argc) { p.slice_index = atoi(argv[++i]); p.n_slices = atoi(argv[++i]); }
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
     }
     rgx_synth_result st;

@@ -1,0 +1,92 @@
+"""Multi-GPU exchange of SURVEY.md 8e: every rank extracts its own shard (contiguous BGZF member range or its
+own coordinate slice), the per-rank unique-junction tables -- 48 bytes per row, at most a few hundred thousand
+rows -- are exchanged with ONE all-gather (RCCL over xGMI when the backend is "nccl"; gloo on CPU in the unit
+tests) and merged: sum counts, min/max thick bounds, earliest first_seen names the row, latest last_seen gives
+the strand.  Shard order = rank order = file order, so the result does not depend on the number of GPUs.
+No data-path collective exists anywhere else: alignments never leave the GPU that inflated them.
+"""
+import ctypes as C
+
+from . import _ffi
+
+ROW = 48  # RGX_PACKED_ROW_BYTES
+
+
+class MergedTable(object):
+    def __init__(self, ptr):
+        self._table = ptr
+
+    @property
+    def table(self):
+        return self._table
+
+    @property
+    def n(self):
+        return self._table.contents.n
+
+    def bed12(self, only_anchored=True):
+        lib = _ffi.lib()
+        n = lib.rgx_table_format_bed12(self._table, 1 if only_anchored else 0, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib.rgx_table_format_bed12(self._table, 1 if only_anchored else 0, buf, n)
+        return buf.raw[:n]
+
+    def __del__(self):
+        try:
+            if self._table:
+                _ffi.lib().rgx_table_free(self._table)
+                self._table = None
+        except Exception:
+            pass
+
+
+def pack_table(table_ptr):
+    lib = _ffi.lib()
+    n = table_ptr.contents.n
+    buf = (C.c_uint8 * max(1, n * ROW))()
+    lib.rgx_table_pack(table_ptr, buf, n * ROW)
+    return bytes(buf)[: n * ROW], n
+
+
+def merge_packed(parts, names_from, min_anchor):
+    """parts: list of (bytes, n_rows) in shard order; names_from: any JunctionTable* carrying the contig table."""
+    lib = _ffi.lib()
+    ptrs = (C.POINTER(_ffi.JunctionTable) * len(parts))()
+    for i, (b, n) in enumerate(parts):
+        t = C.POINTER(_ffi.JunctionTable)()
+        raw = (C.c_uint8 * max(1, len(b))).from_buffer_copy(b if len(b) else b"\0")
+        lib.rgx_table_unpack(raw, n, names_from, C.byref(t))
+        ptrs[i] = t
+    out = C.POINTER(_ffi.JunctionTable)()
+    err = C.create_string_buffer(256)
+    rc = lib.rgx_table_merge(ptrs, len(parts), min_anchor, C.byref(out), err, len(err))
+    for i in range(len(parts)):
+        lib.rgx_table_free(ptrs[i])
+    if rc:
+        raise RuntimeError(err.value.decode())
+    return MergedTable(out)
+
+
+def gather_and_merge(je_or_table, min_anchor=8, group=None):
+    """All-gather the packed per-rank tables and merge them; every rank returns the same MergedTable."""
+    import torch
+    import torch.distributed as dist
+
+    table = je_or_table.table if hasattr(je_or_table, "table") else je_or_table
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    payload, n = pack_table(table)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(1, max(sizes)) * ROW
+    local = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    if n:
+        local[: n * ROW].copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+    gathered = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(gathered, local, group=group)          # the one collective of the whole job
+    parts = []
+    for r in range(world):
+        raw = gathered[r][: sizes[r] * ROW].cpu().numpy().tobytes()
+        parts.append((raw, sizes[r]))
+    return merge_packed(parts, table, min_anchor)

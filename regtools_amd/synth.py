@@ -6,17 +6,18 @@ from . import _ffi
 SHAPES = {"short": 0, "long": 1, "fuzz": 2}
 
 
-def _params(n_reads, shape, seed, level, threads, n_introns, realistic):
+def _params(n_reads, shape, seed, level, threads, n_introns, realistic, slice_index=0, n_slices=1):
     p = _ffi.SynthParams()
     p.shape, p.n_reads, p.seed, p.level, p.threads = SHAPES[shape], n_reads, seed, level, threads
     p.n_introns, p.spliced_frac, p.realistic_payload = n_introns, 0.0, 1 if realistic else 0
+    p.slice_index, p.n_slices = slice_index, n_slices
     return p
 
 
-def generate(n_reads, shape="short", seed=1, level=6, threads=0, n_introns=0, realistic=False):
+def generate(n_reads, shape="short", seed=1, level=6, threads=0, n_introns=0, realistic=False, slice_index=0, n_slices=1):
     """Returns (bam_bytes, bai_bytes, stats)."""
     L = _ffi.synth()
-    p = _params(n_reads, shape, seed, level, threads, n_introns, realistic)
+    p = _params(n_reads, shape, seed, level, threads, n_introns, realistic, slice_index, n_slices)
     r = _ffi.SynthResult()
     rc = L.rgx_synth_generate(C.byref(p), C.byref(r))
     if rc:
@@ -31,9 +32,9 @@ def generate(n_reads, shape="short", seed=1, level=6, threads=0, n_introns=0, re
     return bam, bai, stats
 
 
-def write(path, n_reads, shape="short", seed=1, level=6, threads=0, n_introns=0, realistic=False):
+def write(path, n_reads, shape="short", seed=1, level=6, threads=0, n_introns=0, realistic=False, slice_index=0, n_slices=1):
     L = _ffi.synth()
-    p = _params(n_reads, shape, seed, level, threads, n_introns, realistic)
+    p = _params(n_reads, shape, seed, level, threads, n_introns, realistic, slice_index, n_slices)
     r = _ffi.SynthResult()
     rc = L.rgx_synth_write(C.byref(p), path.encode(), C.byref(r))
     if rc:
