@@ -44,6 +44,21 @@ EXPORTS = ["rgx_extract_params_default", "rgx_ctx_create", "rgx_ctx_destroy", "r
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so and ask for it by file name, while this library asks for
+    the SONAME libamdhip64.so.7: loaded in the wrong order the process ends up with TWO HIP runtimes and the second
+    one sees no GPU.  Loading torch's copy first (when torch is installed) makes both resolve to the same object."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.submodule_search_locations:
+            cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Load libregtools_amd.so (raises if it was not built: no fallback)."""
     global _lib
@@ -51,6 +66,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("regtools_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        _preload_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         P = C.POINTER
         L.rgx_version.restype = C.c_char_p

@@ -183,15 +183,20 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const double t_begin = now_ms();
+    const bool trace = getenv("REGTOOLS_AMD_TRACE") != nullptr;
+    double t_last = t_begin;
+    auto mark = [&](const char *what) { if (trace) { double t = now_ms(); fprintf(stderr, "[rgx trace] %-28s +%8.3f ms  (at %8.3f)\n", what, t - t_last, t - t_begin); t_last = t; } };
 
     // -- container structure (host: locating bytes only) ------------------------------------------------------
     if (bam_len < 18) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
     std::vector<HostMember> hm;
     walk_members(h_bam, bam_len, hm);
     if (hm.empty()) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
+    mark("walk_members");
     BaiInfo bi;
     if (!bai || !parse_bai(bai, bai_len, bi)) return fail(err, errlen, RGX_ERR_INDEX, "%s", kMsgIndex);
 
+    mark("parse_bai");
     const bool whole = !strcmp(p->region ? p->region : ".", ".");
     // where the record stream starts (hts.c:1721-1731 for ".")
     bool seek = false; uint64_t seek_voff = 0;
@@ -261,6 +266,7 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     HIP_TRY(hipEventRecord(c->ev[0], st));
     launch_inflate(d_bam, b_members.as<Member>(), (uint32_t)members.size(), b_arena.as<uint8_t>(), d_sc, st);
     HIP_TRY(hipEventRecord(c->ev[1], st));
+    mark("members+launch inflate");
 
     // -- header (sam.c:114-223): inflate the head of the file into its own small arena until it parses ------------------
     BamHeader hdr;
@@ -296,6 +302,7 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
         }
     }
     const int32_t n_ref = (int32_t)hdr.names.size();
+    mark("header (sync: inflate done)");
 
     // -- stream bounds inside the arena -------------------------------------------------------------------------------------
     auto arena_of = [&](uint64_t voff) -> uint64_t {     // arena offset of a virtual offset inside [m_lo, m_hi)
@@ -359,6 +366,7 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
         n_rec = h_sc[3];
     }
     HIP_TRY(hipEventRecord(c->ev[3], st));
+    mark("framing (sync)");
 
     // -- decode + count -----------------------------------------------------------------------------------------------------
     DevBuf &b_rec = c->buf("rec"), &b_soa = c->buf("soa");
@@ -385,6 +393,7 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
         memcpy(&n_iterated, h_sc + 8, 8);
     }
     HIP_TRY(hipEventRecord(c->ev[4], st));
+    mark("decode+count (sync)");
 
     // -- emit -----------------------------------------------------------------------------------------------------------------
     DevBuf &b_ev = c->buf("events"), &b_sort = c->buf("sort"), &b_uni = c->buf("unique");
@@ -483,6 +492,7 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
         HIP_TRY(hipStreamSynchronize(st));   // rank_of_tid (host vector) must outlive the async copy
     }
     HIP_TRY(hipEventRecord(c->ev[6], st));
+    mark("emit+sort+reduce (sync)");
 
     // -- rows to the host ------------------------------------------------------------------------------------------------------
     rgx_junction_table *t = table_alloc(hdr, n_unique);
@@ -509,6 +519,7 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
         }
         if (n_unique >= 100000000u) host_sort_rows(t);   // names wider than 8 digits compare as strings upstream
     }
+    mark("rows to host");
     t->n_records = n_iterated;
     t->n_events = n_events; t->inflated_bytes = total; t->compressed_bytes = bam_len; t->n_members = members.size();
     float ms = 0;

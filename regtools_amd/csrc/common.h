@@ -25,6 +25,12 @@ RGX_HD uint64_t ld64(const uint8_t *p) { return *(const u64_unaligned *)p; }
 RGX_HD uint16_t ld16(const uint8_t *p) { return *(const u16_unaligned *)p; }
 RGX_HD void st64(uint8_t *p, uint64_t v) { *(u64_unaligned *)p = v; }
 RGX_HD void st32(uint8_t *p, uint32_t v) { *(u32_unaligned *)p = v; }
+RGX_HD void st16(uint8_t *p, uint16_t v) { *(u16_unaligned *)p = v; }
+// 16-byte unaligned access (one global_load/store_dwordx4 on gfx950)
+typedef uint32_t u32x4 __attribute__((vector_size(16)));
+typedef u32x4 u32x4_unaligned __attribute__((aligned(1), may_alias));
+RGX_HD u32x4 ld128(const uint8_t *p) { return *(const u32x4_unaligned *)p; }
+RGX_HD void st128(uint8_t *p, u32x4 v) { *(u32x4_unaligned *)p = v; }
 
 constexpr uint32_t kBgzfMaxBlock = 0x10000;  // htslib/bgzf.h:42 BGZF_MAX_BLOCK_SIZE
 

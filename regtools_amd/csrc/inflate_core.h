@@ -40,27 +40,34 @@ struct HostTab {
 // 15 canonical upper bounds (left-justified to 15 bits, exclusive, cumulative over lengths)
 struct Bounds { uint32_t lim[16]; };
 
+// LSB-first bit reader with a one-word look-ahead: the load for the NEXT 32 bits is issued when the current
+// word is merged, so its latency hides behind the decode of the following symbols (a lane has no other
+// wave to hide behind: 3 waves per CU).  Reads may run up to 8 bytes past the payload (the caller pads the
+// buffer; in a BGZF file the footer and the next member follow anyway); consuming bits past the end is
+// detected by overran().
 struct BitReader {
-    const uint8_t *p;      // next byte to load
-    const uint8_t *end;    // one past the payload
+    const uint8_t *p;      // address of the word held in `next`
+    const uint8_t *in;     // payload start
+    uint32_t in_len;
     uint64_t buf;          // LSB-first bit buffer
     uint32_t cnt;          // valid bits in buf
-    uint32_t overrun;      // bytes consumed past `end` (zero-filled)
-    RGX_HD void init(const uint8_t *in, uint32_t n) { p = in; end = in + n; buf = 0; cnt = 0; overrun = 0; }
-    // keep >= 32 valid bits; callers needing up to 48 call refill twice-safe variant below
+    uint32_t next;         // prefetched word at p
+    RGX_HD void init(const uint8_t *i, uint32_t n) { in = i; in_len = n; p = i; buf = 0; cnt = 0; next = ld32(p); }
+    // afterwards cnt >= 33: enough for a 15-bit code + 13 extra bits
     RGX_HD void refill() {
         if (cnt <= 32) {
-            uint32_t w;
-            if (p + 4 <= end) { w = ld32(p); }
-            else { w = 0; for (int k = 0; k < 4; ++k) if (p + k < end) w |= (uint32_t)p[k] << (8 * k); else overrun++; }
-            buf |= (uint64_t)w << cnt; cnt += 32; p += 4;
+            buf |= (uint64_t)next << cnt; cnt += 32; p += 4;
+            next = ld32(p);
         }
     }
     RGX_HD uint32_t peek(uint32_t n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
     RGX_HD void drop(uint32_t n) { buf >>= n; cnt -= n; }
     RGX_HD uint32_t bits(uint32_t n) { uint32_t v = peek(n); drop(n); return v; }
-    // bytes actually consumed from the payload (for the stored-block path and the overrun check)
-    RGX_HD bool overran() const { return overrun * 8 > cnt; }
+    // bits consumed so far = 8 * (p - in) - cnt
+    RGX_HD bool overran() const { return (uint64_t)(p - in) * 8 > (uint64_t)in_len * 8 + cnt; }
+    // byte-aligned raw access for stored blocks: address of the next unconsumed byte once cnt == 0
+    RGX_HD const uint8_t *byte_ptr() const { return p; }
+    RGX_HD void restart_at(const uint8_t *q) { p = q; buf = 0; cnt = 0; next = ld32(p); }
 };
 
 RGX_HD uint32_t rev15(uint32_t v) {
@@ -128,18 +135,55 @@ RGX_HD int build_code(Tab &T, uint32_t off, uint32_t n, int kind, Bounds &B) {
 }
 
 // Copy a match inside the output (out[o .. o+len) = out[o-dist ..]), byte-exact LZ77 semantics.
-RGX_HD void lz_copy(uint8_t *out, uint32_t o, uint32_t dist, uint32_t len) {
+// The chain load -> store -> dependent load is what a lone lane spends its life on, so copies move 16 bytes per
+// memory round trip and, when the distance allows, 64 bytes per round trip (four independent loads in flight).
+// `slack` = bytes this lane may scribble past o+len inside its own member (they are rewritten by later symbols
+// before anything reads them); with less than 16 bytes of slack the exact tail path is used.
+RGX_HD void lz_copy(uint8_t *out, uint32_t o, uint32_t dist, uint32_t len, uint32_t slack) {
     uint8_t *d = out + o;
     const uint8_t *s = d - dist;
-    if (dist >= 8) {
-        while (len >= 8) { st64(d, ld64(s)); d += 8; s += 8; len -= 8; }
-        while (len) { *d++ = *s++; --len; }
-    } else {
-        // short period: carry the pattern in a register, no reload of freshly written bytes
-        uint64_t pat = 0;
-        for (uint32_t k = 0; k < dist; ++k) pat |= (uint64_t)s[k] << (8 * k);
-        uint32_t sh = 8 * (dist - 1);
-        while (len) { uint8_t b = (uint8_t)pat; *d++ = b; pat = (pat >> 8) | ((uint64_t)b << sh); --len; }
+    if (dist < 16) {
+        // grow the period to D = k*dist >= 16 by writing the first D bytes narrowly, then fall into the wide path
+        uint32_t D = dist;
+        while (D < 16) D += dist;
+        uint32_t n0 = len < D ? len : D;
+        if (dist >= 8) {
+            uint32_t n = n0;
+            while (n >= 8) { st64(d, ld64(s)); d += 8; s += 8; n -= 8; }
+            while (n) { *d++ = *s++; --n; }
+        } else {
+            uint64_t pat = 0;
+            for (uint32_t k = 0; k < dist; ++k) pat |= (uint64_t)s[k] << (8 * k);
+            const uint32_t sh = 8 * (dist - 1);
+            for (uint32_t n = n0; n; --n) { uint8_t b = (uint8_t)pat; *d++ = b; pat = (pat >> 8) | ((uint64_t)b << sh); }
+        }
+        len -= n0;
+        if (!len) return;
+        dist = D; s = d - dist;
+    }
+    if (dist >= 64) {
+        while (len >= 64) {
+            u32x4 a = ld128(s), b = ld128(s + 16), c = ld128(s + 32), e = ld128(s + 48);
+            st128(d, a); st128(d + 16, b); st128(d + 32, c); st128(d + 48, e);
+            d += 64; s += 64; len -= 64;
+        }
+    }
+    if (slack >= 16) {
+        // whole 16-byte chunks, overshooting by at most 15 bytes
+        for (uint32_t n = 0; n < len; n += 16) { st128(d + n, ld128(s + n)); }
+        return;
+    }
+    while (len >= 16) { st128(d, ld128(s)); d += 16; s += 16; len -= 16; }
+    if (len) {
+        // exact tail from two 8-byte loads (no dependent byte loop)
+        if (len >= 8) { st64(d, ld64(s)); d += 8; s += 8; len -= 8; }
+        if (len) {
+            uint64_t v = 0;
+            for (uint32_t k = 0; k < len; ++k) v |= (uint64_t)s[k] << (8 * k);
+            if (len & 4) { st32(d, (uint32_t)v); d += 4; v >>= 32; }
+            if (len & 2) { st16(d, (uint16_t)v); d += 2; v >>= 16; }
+            if (len & 1) *d = (uint8_t)v;
+        }
     }
 }
 
@@ -166,10 +210,10 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
             // bytes still buffered come first
             while (len && br.cnt >= 8) { out[o++] = (uint8_t)br.bits(8); --len; }
             if (len) {
-                const uint8_t *src = br.p;            // cnt == 0 here: p is exactly the next payload byte
-                if (src + len > br.end) { status = INF_IN_OVERRUN; break; }
+                const uint8_t *src = br.byte_ptr();   // cnt == 0 here: the prefetched word starts at the next payload byte
+                if ((uint64_t)(src - in) + len > in_len) { status = INF_IN_OVERRUN; break; }
                 for (uint32_t k = 0; k < len; ++k) out[o + k] = src[k];
-                o += len; br.p = src + len; br.buf = 0; br.cnt = 0;
+                o += len; br.restart_at(src + len);
             }
             continue;
         }
@@ -300,7 +344,7 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
             else { uint32_t e = (dsym >> 1) - 1; dist = ((2 + (dsym & 1)) << e) + 1 + br.bits(e); }
             if (dist > o) { status = INF_BAD_DIST; break; }
             if (o + len > out_cap) { status = INF_OUT_OVERFLOW; break; }
-            lz_copy(out, o, dist, len);
+            lz_copy(out, o, dist, len, out_cap - (o + len));
             o += len;
         }
         if (status == INF_OK && br.overran()) status = INF_IN_OVERRUN;

@@ -1,0 +1,183 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the reference's golden files, the
+reference outputs stored by tests/golden/make_golden.py, and the CPU oracle on seeded inputs.  Bit-exact: every
+comparison is on BED12 bytes.  Run with `-m gpu` on an MI355X."""
+import ctypes as C
+import os
+import subprocess
+import zlib
+
+import pytest
+
+import bamio
+import cases
+from conftest import run_oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def synth_dir(tmp_path_factory):
+    return tmp_path_factory.mktemp("synth")
+
+
+def gpu_extract(ctx, bam, args, **kw):
+    """(rc, bed12 bytes) the way `regtools junctions extract <args> bam` would produce them."""
+    import regtools_amd
+    je = regtools_amd.JunctionsExtractor(ctx=ctx, **kw)
+    try:
+        je.parse_options(list(args) + [bam])
+        je.identify_junctions_from_BAM()
+    except regtools_amd.RegtoolsError as e:
+        return (0 if e.code == 0 else 1), b"", je
+    return 0, je.bed12(), je
+
+
+@pytest.mark.parametrize("args,golden", cases.REF_GOLDENS, ids=[g for _, g in cases.REF_GOLDENS])
+def test_reference_integration_goldens(gpu_ctx, args, golden):
+    rc, out, _ = gpu_extract(gpu_ctx, os.path.join(cases.GOLD, "test_hcc1395.bam"), args)
+    assert rc == 0
+    assert out == open(os.path.join(cases.GOLD, "junctions-extract", golden), "rb").read()
+
+
+@pytest.mark.parametrize("case", cases.MANIFEST, ids=[c["name"] for c in cases.MANIFEST])
+def test_equals_reference_outputs(gpu_ctx, case, synth_dir):
+    rc, out, _ = gpu_extract(gpu_ctx, cases.case_bam(case, synth_dir), case["args"])
+    assert rc == case["rc"]
+    assert out == cases.expected(case)
+
+
+def test_error_contract(gpu_ctx, tmp_path):
+    import regtools_amd
+    je = regtools_amd.JunctionsExtractor(bam="does_not_exist.bam", strandness=0, ctx=gpu_ctx)
+    with pytest.raises(regtools_amd.RegtoolsError) as e:
+        je.identify_junctions_from_BAM()
+    assert str(e.value) == "Unable to open BAM/SAM file.\n\n"                       # junctions_extractor.cc:505
+    p = tmp_path / "noidx.bam"
+    p.write_bytes(open(os.path.join(cases.GOLD, "strand.bam"), "rb").read())
+    je = regtools_amd.JunctionsExtractor(bam=str(p), strandness=0, ctx=gpu_ctx)
+    with pytest.raises(regtools_amd.RegtoolsError) as e:
+        je.identify_junctions_from_BAM()
+    assert str(e.value) == "Unable to open BAM/SAM index. Make sure alignments are indexed\n\n"   # cc:510-511
+    je = regtools_amd.JunctionsExtractor(bam=os.path.join(cases.GOLD, "contigs.bam"), region="nope:1-5", strandness=0, ctx=gpu_ctx)
+    with pytest.raises(regtools_amd.RegtoolsError) as e:
+        je.identify_junctions_from_BAM()
+    assert str(e.value) == "Unable to iterate to region within BAM.\n\n"             # cc:521
+    p = tmp_path / "garbage.bam"
+    p.write_bytes(b"not a bam at all" * 10)
+    (tmp_path / "garbage.bam.bai").write_bytes(open(os.path.join(cases.GOLD, "strand.bam.bai"), "rb").read())
+    je = regtools_amd.JunctionsExtractor(bam=str(p), strandness=0, ctx=gpu_ctx)
+    with pytest.raises(regtools_amd.RegtoolsError):
+        je.identify_junctions_from_BAM()
+
+
+@pytest.mark.parametrize("shape,n,seed", [("short", 200000, 101), ("short", 1000000, 102), ("long", 3000, 103), ("fuzz", 150000, 104), ("fuzz", 150000, 105)])
+def test_against_oracle_on_seeded_inputs(gpu_ctx, synth_dir, shape, n, seed):
+    from regtools_amd import synth
+    p = os.path.join(str(synth_dir), "o_%s_%d.bam" % (shape, seed))
+    synth.write(p, n, shape=shape, seed=seed)
+    for args in (["-s", "XS"], ["-s", "RF", "-a", "3"], ["-s", "FR", "-m", "90", "-M", "20000"]):
+        rc, out, je = gpu_extract(gpu_ctx, p, args)
+        orc, exp, _ = run_oracle(args + [p])
+        assert rc == orc == 0
+        assert out == exp, (shape, seed, args)
+        assert je.stats["n_records"] == n
+
+
+def test_realistic_payload_and_every_zlib_level(gpu_ctx, synth_dir):
+    # different DEFLATE shapes (stored blocks at level 0, fixed/dynamic mixes) must decode identically
+    from regtools_amd import synth
+    for level, realistic in ((1, True), (6, True), (9, False), (1, False)):
+        p = os.path.join(str(synth_dir), "lvl%d_%d.bam" % (level, realistic))
+        synth.write(p, 60000, shape="short", seed=7, level=level, realistic=realistic)
+        rc, out, _ = gpu_extract(gpu_ctx, p, ["-s", "XS"])
+        assert rc == 0 and out == run_oracle(["-s", "XS", p])[1]
+
+
+def test_stored_deflate_blocks(gpu_ctx, tmp_path):
+    # level-0 members are pure stored blocks (BTYPE 00): hand-made file
+    recs = [bamio.record(0, 100 + 50 * k, "%dM%dN%dM" % (20 + k % 5, 100 + k, 30), qname="s%03d" % k, aux=bamio.tagA("XS", "+")) for k in range(500)]
+    p = str(tmp_path / "stored.bam")
+    bamio.write_bam(p, [("chrZ", 1000000)], recs, level=0, block=3000)
+    from regtools_amd import synth
+    synth.index(p)
+    rc, out, _ = gpu_extract(gpu_ctx, p, ["-s", "XS"])
+    assert rc == 0 and out == run_oracle(["-s", "XS", p])[1] and out.count(b"\n") > 100
+
+
+def test_shard_merge_is_independent_of_shard_count(gpu_ctx, synth_dir):
+    # member-range shards cut at index offsets; merged output must not depend on G
+    from regtools_amd import synth, distributed
+    for shape, n, seed in (("short", 300000, 201), ("fuzz", 100000, 202)):
+        p = os.path.join(str(synth_dir), "shard_%s.bam" % shape)
+        synth.write(p, n, shape=shape, seed=seed)
+        _, single, je1 = gpu_extract(gpu_ctx, p, ["-s", "XS"])
+        for G in (2, 3, 8):
+            parts, recs, keep = [], 0, []
+            for g in range(G):
+                rc, _, je = gpu_extract(gpu_ctx, p, ["-s", "XS"], shard=g, n_shards=G)
+                assert rc == 0
+                keep.append(je)
+                parts.append(distributed.pack_table(je.table))
+                recs += je.stats["n_records"]
+            assert recs == n
+            merged = distributed.merge_packed(parts, keep[0].table, 8)
+            assert merged.bed12() == single, (shape, G)
+
+
+def test_cli_binary_writes_identical_file(gpu_ctx, tmp_path):
+    exe = os.path.join(ROOT, "bin", "regtools-amd")
+    out = str(tmp_path / "o.bed")
+    bam = os.path.join(cases.GOLD, "test_hcc1395.bam")
+    r = subprocess.run([exe, "junctions", "extract", "-s", "RF", "-a", "30", "-o", out, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0
+    assert open(out, "rb").read() == open(os.path.join(cases.GOLD, "junctions-extract", "expected-stranded-a30.out"), "rb").read()
+    r = subprocess.run([exe, "junctions", "extract", "-s", "XS", "-r", "1:22405013-22405020", bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout == open(os.path.join(cases.GOLD, "junctions-extract", "expected-r1:22405013-22405020.out"), "rb").read()
+    assert subprocess.run([exe, "junctions", "extract", "-s", "XS", "missing.bam"], stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode == 1
+
+
+def test_inflate_kernel_against_zlib(gpu_ctx):
+    # the dominant kernel in isolation, through its C-ABI stage entry point
+    import torch
+    from regtools_amd import _ffi, synth
+    bam, _, _ = synth.generate(40000, shape="short", seed=31, realistic=True)
+    members, upos, expect = [], 0, []
+    for off, payload, isize in bamio.bgzf_members(bam):
+        members.append((off + 18, upos, len(payload), isize))
+        expect.append(zlib.decompress(payload, -15))
+        upos += isize
+    arr = (_ffi.Member * len(members))(*[_ffi.Member(*m) for m in members])
+    d_comp = torch.zeros(len(bam) + 64, dtype=torch.uint8, device="cuda")
+    d_comp[: len(bam)].copy_(torch.frombuffer(bytearray(bam), dtype=torch.uint8))
+    d_mem = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    d_arena = torch.zeros(upos + 256, dtype=torch.uint8, device="cuda")
+    d_status = torch.tensor([0xffffffff, 0], dtype=torch.int64).to(torch.uint32).cuda() if hasattr(torch, "uint32") else None
+    if d_status is None:
+        pytest.skip("torch without uint32")
+    torch.cuda.synchronize()
+    rc = _ffi.lib().rgx_k_inflate(d_comp.data_ptr(), d_mem.data_ptr(), len(members), d_arena.data_ptr(), d_status.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rc == 0
+    assert d_status.cpu().tolist()[0] == 0xffffffff
+    assert bytes(d_arena[:upos].cpu().numpy().tobytes()) == b"".join(expect)
+
+
+def test_full_size_properties(gpu_ctx, synth_dir):
+    """Size-independent properties at a multi-million-read scale (the 50M-read identity check lives in bench.py)."""
+    from regtools_amd import synth
+    n = 5_000_000
+    bam, bai, st = synth.generate(n, shape="short", seed=1)
+    import regtools_amd
+    je = regtools_amd.JunctionsExtractor(strandness=0, ctx=gpu_ctx)
+    je.identify_junctions_from_BAM(bam_bytes=bam, bai_bytes=bai)
+    rows = je.get_all_junctions()
+    assert je.stats["n_records"] == n
+    assert sum(j.read_count for j in rows) == je.stats["n_events"] == st["n_spliced"]     # every spliced read has one N in range
+    assert sorted(int(j.name[4:]) for j in rows) == list(range(1, len(rows) + 1))         # names are a permutation of 1..J
+    keys = [(j.chrom, j.thick_start, j.thick_end, j.name) for j in rows]
+    assert keys == sorted(keys)                                                           # compare_junctions order
+    assert all(j.thick_start <= j.start < j.end <= j.thick_end for j in rows)
+    first = je.bed12()
+    je.identify_junctions_from_BAM(bam_bytes=bam, bai_bytes=bai)                          # idempotent on a warm workspace
+    assert je.bed12() == first

@@ -1,0 +1,103 @@
+"""CPU unit tests of the per-lane device cores compiled for the host (tests/hostemu): the DEFLATE decoder
+against zlib, on real BGZF members and on adversarial streams.  No GPU needed."""
+import ctypes
+import os
+import random
+import zlib
+
+import pytest
+
+import bamio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emu(built):
+    return ctypes.CDLL(os.path.join(ROOT, "tests", "hostemu", "libhostemu.so"))
+
+
+def inflate(emu, payload, cap=65536):
+    out = ctypes.create_string_buffer(cap + 64)
+    n = ctypes.c_uint32(0)
+    buf = ctypes.create_string_buffer(payload + b"\0" * 16, len(payload) + 16)
+    st = emu.emu_inflate(buf, len(payload), out, cap, ctypes.byref(n))
+    return st, out.raw[:n.value]
+
+
+def test_members_of_synthetic_bams(emu, tmp_path):
+    from regtools_amd import synth
+    for shape, n in (("short", 6000), ("fuzz", 4000), ("long", 60)):
+        bam, _, _ = synth.generate(n, shape=shape, seed=5)
+        k = 0
+        for _, payload, isize in bamio.bgzf_members(bam):
+            st, got = inflate(emu, payload)
+            assert st == 0 and got == zlib.decompress(payload, -15) and len(got) == isize
+            k += 1
+        assert k > 2
+
+
+def test_realistic_payload_members(emu):
+    from regtools_amd import synth
+    bam, _, _ = synth.generate(3000, shape="short", seed=9, realistic=True)
+    for _, payload, isize in bamio.bgzf_members(bam):
+        st, got = inflate(emu, payload)
+        assert st == 0 and got == zlib.decompress(payload, -15)
+
+
+@pytest.mark.parametrize("strategy", [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED])
+def test_block_types_and_strategies(emu, strategy):
+    rnd = random.Random(strategy + 17)
+    for trial in range(60):
+        n = rnd.choice([0, 1, 2, 7, 8, 15, 16, 17, 63, 64, 65, 300, 5000, 65280, 65536])
+        kind = rnd.randrange(5)
+        if kind == 0: data = bytes(rnd.getrandbits(8) for _ in range(n))                # incompressible -> stored blocks
+        elif kind == 1: data = bytes(rnd.choice(b"ACGT") for _ in range(n))
+        elif kind == 2: data = (b"abcdefghij" * 7000)[:n]                                  # period 10
+        elif kind == 3: data = bytes([rnd.randrange(2)]) * n                               # distance-1 runs
+        else: data = bytes((i * 7) % 251 for i in range(n))
+        for lvl in (0, 1, 6, 9):
+            c = zlib.compressobj(lvl, zlib.DEFLATED, -15, 8, strategy)
+            p = c.compress(data) + c.flush()
+            st, got = inflate(emu, p)
+            assert st == 0 and got == data, (trial, n, kind, lvl)
+
+
+def test_every_short_distance_and_length(emu):
+    # matches with distance 1..40 and every tail length: exercises the period-widening and exact-tail paths
+    for dist in list(range(1, 41)) + [63, 64, 65, 127, 128, 129, 300]:
+        seed = bytes((i * 37 + 11) % 256 for i in range(dist))
+        for total in (dist + 3, dist + 15, dist + 16, dist + 17, dist + 64, dist + 257, dist + 258, dist + 700):
+            data = (seed * (total // dist + 2))[:total]
+            c = zlib.compressobj(9, zlib.DEFLATED, -15, 9)
+            p = c.compress(data) + c.flush()
+            st, got = inflate(emu, p, cap=len(data))     # cap == exact size: no slack at the end
+            assert st == 0 and got == data, (dist, total)
+
+
+def test_output_capacity_is_respected(emu):
+    data = b"xyz" * 1000
+    p = zlib.compress(data, 6)[2:-4]
+    st, got = inflate(emu, p, cap=100)
+    assert st != 0 and len(got) <= 100
+
+
+def test_corrupt_streams_never_crash_and_agree_with_zlib_when_valid(emu):
+    rnd = random.Random(3)
+    for trial in range(1500):
+        data = bytes(rnd.choice(b"ACGTN") for _ in range(rnd.choice([50, 2000])))
+        p = bytearray(zlib.compress(data, 6)[2:-4])
+        k = rnd.randrange(len(p))
+        p[k] ^= 1 << rnd.randrange(8)
+        try:
+            exp = zlib.decompress(bytes(p), -15)
+        except zlib.error:
+            exp = None
+        st, got = inflate(emu, bytes(p))
+        if exp is not None and len(exp) <= 65536:
+            assert st == 0 and got == exp
+    # truncated payloads
+    p = zlib.compress(b"hello world " * 500, 6)[2:-4]
+    for cut in range(0, len(p), 7):
+        st, got = inflate(emu, p[:cut])
+        assert st != 0
