@@ -95,7 +95,7 @@ def main():
     je = regtools_amd.JunctionsExtractor(strandness=0, ctx=ctx)
 
     def step():
-        je.identify_junctions_from_BAM(bam_bytes=bam, bai_bytes=bai, device_ptr=d_bam.data_ptr())
+        je.identify_junctions_from_BAM(bai_bytes=bai, device_ptr=d_bam.data_ptr(), device_len=len(bam))
         if world > 1:
             return rdist.gather_and_merge(je, min_anchor=8)
         return je.table

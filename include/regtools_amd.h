@@ -90,11 +90,11 @@ int  rgx_extract(rgx_ctx *ctx, const char *bam_path, const rgx_extract_params *p
 int  rgx_extract_mem(rgx_ctx *ctx, const void *bam, size_t bam_len, const void *bai, size_t bai_len,
                      const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen);
 
-/* Same, with the .bam bytes ALREADY RESIDENT IN HBM at d_bam (the measured configuration: bench.py and a
- * pipeline that DMA'd the file straight to the device).  h_bam must hold the same bytes on the host: the
- * BGZF member chain (BSIZE at +16 of every member, bgzf.c:525) is walked there while the GPU already
- * inflates the members found so far.  d_bam must be readable up to bam_len + 8 bytes. */
-int  rgx_extract_device(rgx_ctx *ctx, const void *d_bam, const void *h_bam, size_t bam_len,
+/* Same, with the .bam bytes ALREADY RESIDENT IN HBM at d_bam (the measured configuration: bench.py, or a
+ * pipeline that DMA'd the file straight to the device).  No host copy of the BAM is needed: even the BGZF
+ * member chain (BSIZE at +16 of every member, bgzf.c:525) is discovered on the device.  Only the (small) .bai is
+ * read on the host.  d_bam must be readable up to bam_len + 8 bytes. */
+int  rgx_extract_device(rgx_ctx *ctx, const void *d_bam, size_t bam_len,
                         const void *bai, size_t bai_len, const rgx_extract_params *p,
                         rgx_junction_table **out, char *err, size_t errlen);
 

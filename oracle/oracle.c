@@ -503,7 +503,7 @@ static void junction_emit(void *vc, uint32_t start, uint32_t end, uint32_t ts, u
     uint32_t ilen = end - start;
     if (ilen < p->min_intron || ilen > p->max_intron) return;
     uint8_t l_ok = (uint32_t)(start - ts) >= p->min_anchor, r_ok = (uint32_t)(te - end) >= p->min_anchor;
-    (*c->n_events)++;
+    uint64_t order = (*c->n_events)++;
 
     jmap *m = c->m;
     int cls = sclass(strand);
@@ -516,6 +516,7 @@ static void junction_emit(void *vc, uint32_t start, uint32_t end, uint32_t ts, u
             if (te > j->thick_end) j->thick_end = te;
             j->left_ok |= l_ok; j->right_ok |= r_ok;
             j->strand = strand;           /* newest read overwrites (cc:233) */
+            j->last_seen = order;
             return;
         }
         h = (h + 1) & (m->nslot - 1);
@@ -524,6 +525,7 @@ static void junction_emit(void *vc, uint32_t start, uint32_t end, uint32_t ts, u
     orc_junction *j = &m->rows[m->n];
     j->tid = c->tid; j->start = start; j->end = end; j->thick_start = ts; j->thick_end = te;
     j->read_count = 1; j->name_index = (uint64_t)m->n + 1; j->strand = strand; j->left_ok = l_ok; j->right_ok = r_ok;
+    j->first_seen = order; j->last_seen = order;
     m->slot[h] = (int64_t)m->n;
     m->n++;
     if (m->n * 2 > m->nslot) jmap_grow(m);

@@ -76,7 +76,7 @@ def lib():
         L.rgx_extract.argtypes = [C.c_void_p, C.c_char_p, P(ExtractParams), P(P(JunctionTable)), C.c_char_p, C.c_size_t]
         L.rgx_extract_mem.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, P(ExtractParams),
                                       P(P(JunctionTable)), C.c_char_p, C.c_size_t]
-        L.rgx_extract_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+        L.rgx_extract_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                          P(ExtractParams), P(P(JunctionTable)), C.c_char_p, C.c_size_t]
         L.rgx_table_free.argtypes = [P(JunctionTable)]
         L.rgx_table_merge.argtypes = [P(P(JunctionTable)), C.c_int, C.c_uint32, P(P(JunctionTable)), C.c_char_p, C.c_size_t]

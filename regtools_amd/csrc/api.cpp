@@ -187,15 +187,10 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     double t_last = t_begin;
     auto mark = [&](const char *what) { if (trace) { double t = now_ms(); fprintf(stderr, "[rgx trace] %-28s +%8.3f ms  (at %8.3f)\n", what, t - t_last, t - t_begin); t_last = t; } };
 
-    // -- container structure (host: locating bytes only) ------------------------------------------------------
-    if (bam_len < 18) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
-    std::vector<HostMember> hm;
-    walk_members(h_bam, bam_len, hm);
-    if (hm.empty()) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
-    mark("walk_members");
+    // -- index (host: ~10 MB, needed before anything that depends on where the record stream starts) ------------------
+    if (bam_len < 28) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
     BaiInfo bi;
-    if (!bai || !parse_bai(bai, bai_len, bi)) return fail(err, errlen, RGX_ERR_INDEX, "%s", kMsgIndex);
-
+    if (!bai || !parse_bai(bai, bai_len, bi, /*collect_anchors=*/false)) return fail(err, errlen, RGX_ERR_INDEX, "%s", kMsgIndex);
     mark("parse_bai");
     const bool whole = !strcmp(p->region ? p->region : ".", ".");
     // where the record stream starts (hts.c:1721-1731 for ".")
@@ -204,40 +199,24 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
         if (bi.have_start) { seek_voff = bi.start_voff; seek = seek_voff != 0; }
         else if (!bi.n_no_coor) return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion);
     }
-    auto member_of = [&](uint64_t coff) -> size_t {       // index of the member starting at coff, or hm.size()
-        auto it = std::lower_bound(hm.begin(), hm.end(), coff, [](const HostMember &m, uint64_t v) { return m.coff < v; });
-        return (it != hm.end() && it->coff == coff) ? (size_t)(it - hm.begin()) : hm.size();
-    };
-    const size_t first_member = seek ? member_of(seek_voff >> 16) : 0;
-    // the stream ends at the first empty (or oversized = corrupt) member at/after the first one read (bgzf.c:548-578)
-    size_t stop = hm.size();
-    for (size_t k = first_member; k < hm.size(); ++k) if (hm[k].isize == 0 || hm[k].isize > kBgzfMaxBlock) { stop = k; break; }
-
-    // -- member range of this call: everything, or one shard cut at record starts taken from the index --
-    // A record belongs to the shard in which its first byte lies; cut points are virtual offsets the BAI lists
-    // (every chunk begin and linear-index entry is a record start), so no shard ever guesses its first record.
-    uint64_t cut_lo = seek ? seek_voff : 0, cut_hi = UINT64_MAX;          // virtual offsets; 0 = "right after the header"
+    // shard cut points: virtual offsets the BAI lists (every chunk begin / linear-index entry is a record start), so
+    // no shard ever guesses its first record.  A record belongs to the shard in which its first byte lies.
+    uint64_t cut_lo = seek ? seek_voff : 0, cut_hi = UINT64_MAX;          // 0 = "right after the header"
     if (p->n_shards > 1) {
-        auto cut = [&](int g) -> uint64_t {
-            if (g <= 0) return seek ? seek_voff : 0;
-            if (g >= p->n_shards) return UINT64_MAX;
-            const uint64_t target = (uint64_t)((double)bam_len * g / p->n_shards) << 16;
-            auto it = std::lower_bound(bi.anchors.begin(), bi.anchors.end(), std::max<uint64_t>(target, seek ? seek_voff : 1));
-            return it == bi.anchors.end() ? UINT64_MAX : *it;
-        };
         if (p->shard < 0 || p->shard >= p->n_shards) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: shard %d of %d\n", p->shard, p->n_shards);
-        cut_lo = cut(p->shard); cut_hi = cut(p->shard + 1);
+        uint64_t tgt[2], got[2];
+        for (int k = 0; k < 2; ++k) {
+            const int g = p->shard + k;
+            tgt[k] = std::max<uint64_t>((uint64_t)((double)bam_len * g / p->n_shards) << 16, seek ? seek_voff : 1);
+        }
+        bai_first_anchor_ge(bai, bai_len, tgt, 2, got);
+        if (p->shard > 0) cut_lo = got[0];
+        if (p->shard + 1 < p->n_shards) cut_hi = got[1];
         if (cut_hi < cut_lo) cut_hi = cut_lo;
+        mark("shard cuts");
     }
-    size_t m_lo = cut_lo ? member_of(cut_lo >> 16) : 0;
-    size_t m_hi = stop;                                                  // exclusive
-    if (cut_hi != UINT64_MAX) {
-        const size_t mh = member_of(cut_hi >> 16);
-        m_hi = std::min(stop, (cut_hi & 0xffff) ? mh + 1 : mh);
-    }
-    if (m_lo > m_hi) m_lo = m_hi;
 
-    // header members: enough of the file head to hold the BAM header (grown on demand below)
+    // -- upload ----------------------------------------------------------------------------------------------------------
     const uint8_t *d_bam = d_bam_in;
     if (!d_bam) {
         DevBuf &b = c->buf("bam");
@@ -245,80 +224,148 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
         HIP_TRY(hipMemcpyAsync(b.p, h_bam, bam_len, hipMemcpyHostToDevice, st));
         d_bam = b.as<uint8_t>();
     }
-    DevBuf &b_arena = c->buf("arena"), &b_members = c->buf("members"), &b_scalars = c->buf("scalars"), &b_hdr = c->buf("hdr_arena");
-    HIP_TRY(b_scalars.ensure(256));
-    uint32_t *d_sc = b_scalars.as<uint32_t>();   // [0]=first bad member [1]=its status [2]=changed [3]=n_rec [4]=n_events [5]=n_long [6]=n_unique [8..9]=n_iterated(u64) [12..13]=header inflate status
+    DevBuf &b_arena = c->buf("arena"), &b_members = c->buf("members"), &b_scalars = c->buf("scalars"), &b_hdr = c->buf("hdr_arena"), &b_disc = c->buf("discover");
+    HIP_TRY(b_scalars.ensure(512));
+    // u32 scalars: [0]=first bad member [1]=its status [2]=changed [3]=n_rec [4]=n_events [5]=n_long [6]=n_unique [8..9]=n_iterated(u64)
+    //              [12..13]=header inflate status [16]=n_cand [17]=n_members [18]=stop [20..21]=total inflated (u64)
+    //              [24..26]=q_index [32..37]=q_upos (u64 x3) [40..45]=q_coff (u64 x3)
+    uint32_t *d_sc = b_scalars.as<uint32_t>();
     uint32_t *h_sc = (uint32_t *)c->pinned;
-    HIP_TRY(hipMemsetAsync(d_sc, 0, 256, st));
+    HIP_TRY(hipMemsetAsync(d_sc, 0, 512, st));
     HIP_TRY(hipMemsetAsync(d_sc, 0xff, 4, st));
     HIP_TRY(hipMemsetAsync(d_sc + 12, 0xff, 4, st));
+    HIP_TRY(hipMemsetAsync(d_sc + 18, 0xff, 4, st));
 
-    std::vector<Member> members(m_hi - m_lo);
-    uint64_t total = 0;
-    for (size_t k = m_lo; k < m_hi; ++k) {
-        Member &m = members[k - m_lo];
-        m.cpos = hm[k].coff + 18; m.clen = hm[k].blen - 26; m.upos = total; m.isize = hm[k].isize;
-        total += hm[k].isize;
+    // -- BGZF member discovery on the device (replaces the serial BSIZE walk, bgzf.c:421-546) -------------------------------
+    const uint32_t n_tiles = (uint32_t)((bam_len + kMagicTile - 1) / kMagicTile);
+    HIP_TRY(b_disc.ensure((size_t)n_tiles * 4 + scan_tmp_words(n_tiles) * 4 + 256));
+    uint32_t *tile_cnt = b_disc.as<uint32_t>(), *tile_tmp = tile_cnt + n_tiles;
+    launch_magic_count(d_bam, bam_len, n_tiles, tile_cnt, st);
+    launch_scan_u32(tile_cnt, tile_cnt, n_tiles, d_sc + 16, tile_tmp, st);
+    HIP_TRY(hipMemcpyAsync(h_sc + 16, d_sc + 16, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t n_cand = h_sc[16];
+    if (n_cand == 0) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
+    DevBuf &b_cand = c->buf("cand");
+    {
+        const size_t N = n_cand;
+        HIP_TRY(b_cand.ensure(N * 8 + N * 4 * 6 + scan_tmp_words(n_cand) * 4 + 256));
+        HIP_TRY(b_members.ensure((N + 1) * sizeof(Member)));
     }
-    HIP_TRY(b_arena.ensure(total + 256));
-    HIP_TRY(b_members.ensure((members.size() + 1) * sizeof(Member)));
-    if (!members.empty()) HIP_TRY(hipMemcpyAsync(b_members.p, members.data(), members.size() * sizeof(Member), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipEventRecord(c->ev[0], st));
-    launch_inflate(d_bam, b_members.as<Member>(), (uint32_t)members.size(), b_arena.as<uint8_t>(), d_sc, st);
-    HIP_TRY(hipEventRecord(c->ev[1], st));
-    mark("members+launch inflate");
+    uint64_t *cand = b_cand.as<uint64_t>();
+    uint32_t *nx[2] = {(uint32_t *)(cand + n_cand), (uint32_t *)(cand + n_cand) + n_cand};
+    uint32_t *c_isize = nx[1] + n_cand, *c_reach = c_isize + n_cand, *c_rank = c_reach + n_cand, *c_isz2 = c_rank + n_cand, *c_tmp = c_isz2 + n_cand;
+    launch_magic_fill(d_bam, bam_len, n_tiles, tile_cnt, cand, st);
+    launch_member_link(d_bam, bam_len, cand, n_cand, nx[0], c_isize, c_reach, st);
+    {
+        int cur = 0;
+        for (uint32_t span = 1; span < n_cand; span <<= 1) { launch_member_jump(n_cand, nx[cur], nx[cur ^ 1], c_reach, st); cur ^= 1; }
+        launch_member_jump(n_cand, nx[cur], nx[cur ^ 1], c_reach, st);
+    }
+    launch_scan_u32(c_reach, c_rank, n_cand, d_sc + 17, c_tmp, st);
+    Member *d_members = b_members.as<Member>();
+    launch_member_compact(d_bam, cand, c_isize, c_reach, c_rank, n_cand, d_members, c_isz2, st);
+    launch_member_upos(d_members, c_isz2, d_sc + 17, (uint64_t *)(d_sc + 20), st);
+    {
+        uint64_t q[3] = {seek ? (seek_voff >> 16) : 0, cut_lo >> 16, cut_hi == UINT64_MAX ? UINT64_MAX - 64 : (cut_hi >> 16)};
+        memcpy(h_sc + 40, q, sizeof q);
+        HIP_TRY(hipMemcpyAsync(d_sc + 40, h_sc + 40, sizeof q, hipMemcpyHostToDevice, st));
+        launch_member_query(d_members, d_sc + 17, (const uint64_t *)(d_sc + 40), 3, d_sc + 24, (uint64_t *)(d_sc + 32), st);
+        // the stream ends at the first empty (or oversized = corrupt) member at/after the first one read (bgzf.c:548-578)
+        launch_member_stop(d_members, n_cand, d_sc + 17, d_sc + 24, d_sc + 18, st);
+    }
+    HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 256, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t n_members_all = h_sc[17];
+    if (n_members_all == 0) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);     // offset 0 is not a BGZF member
+    uint64_t total_all; memcpy(&total_all, h_sc + 20, 8);
+    const uint32_t first_member = seek ? h_sc[24] : 0;                                    // == n_members_all when the seek target is no member
+    const uint32_t stop = std::min(h_sc[18], n_members_all);
+    uint64_t q_upos[3]; memcpy(q_upos, h_sc + 32, sizeof q_upos);
+    mark("member discovery (2 syncs)");
 
-    // -- header (sam.c:114-223): inflate the head of the file into its own small arena until it parses ------------------
+    // -- member range of this call ---------------------------------------------------------------------------------------------
+    uint32_t m_lo = cut_lo ? h_sc[25] : 0;
+    uint32_t m_hi = stop;                                                  // exclusive
+    if (cut_hi != UINT64_MAX) {
+        const uint32_t mh = h_sc[26];
+        m_hi = std::min(stop, (mh < n_members_all && (cut_hi & 0xffff)) ? mh + 1 : mh);
+    }
+    if (m_lo > m_hi) m_lo = m_hi;
+    (void)first_member;
+    // arena offsets of the range ends
+    auto upos_of = [&](uint32_t k, uint64_t &out_v) -> hipError_t {
+        if (k >= n_members_all) { out_v = total_all; return hipSuccess; }
+        Member m;
+        hipError_t e = hipMemcpy(&m, d_members + k, sizeof m, hipMemcpyDeviceToHost);
+        out_v = m.upos;
+        return e;
+    };
+    uint64_t upos_lo = 0, upos_hi = 0;
+    HIP_TRY(upos_of(m_lo, upos_lo));
+    HIP_TRY(upos_of(m_hi, upos_hi));
+    const uint64_t total = upos_hi - upos_lo;
+    const uint32_t n_range = m_hi - m_lo;
+    HIP_TRY(b_arena.ensure(total + 256));
+    HIP_TRY(hipEventRecord(c->ev[0], st));
+    launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, d_sc, st);
+    HIP_TRY(hipEventRecord(c->ev[1], st));
+    mark("launch inflate");
+
+    // -- header (sam.c:114-223): it sits at the start of the arena when the range starts at member 0; otherwise the head of
+    //    the file is inflated into its own small arena -----------------------------------------------------------------------
     BamHeader hdr;
     {
-        size_t n_h = std::min<size_t>(hm.size(), 4);
+        uint32_t n_h = std::min<uint32_t>(n_members_all, 4);
         for (;;) {
+            const uint8_t *src; uint64_t have;
+            uint32_t bad_h = 0xffffffffu;
             std::vector<Member> hmem(n_h);
-            uint64_t htot = 0;
-            size_t used = 0;
-            for (size_t k = 0; k < n_h; ++k) {
-                if (hm[k].isize == 0 || hm[k].isize > kBgzfMaxBlock) break;      // the header read stops at an empty/corrupt member
-                hmem[k].cpos = hm[k].coff + 18; hmem[k].clen = hm[k].blen - 26; hmem[k].upos = htot; hmem[k].isize = hm[k].isize;
-                htot += hm[k].isize; ++used;
-            }
+            HIP_TRY(hipMemcpyAsync(hmem.data(), d_members, (size_t)n_h * sizeof(Member), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            uint32_t used = 0;
+            for (; used < n_h; ++used) if (hmem[used].isize == 0 || hmem[used].isize > kBgzfMaxBlock) break;   // the header read stops there
             if (!used) return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion);
-            DevBuf &b_hm = c->buf("hdr_members");
-            HIP_TRY(b_hm.ensure(used * sizeof(Member)));
-            HIP_TRY(b_hdr.ensure(htot + 256));
-            HIP_TRY(hipMemcpyAsync(b_hm.p, hmem.data(), used * sizeof(Member), hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemsetAsync(d_sc + 12, 0xff, 4, st));
-            launch_inflate(d_bam, b_hm.as<Member>(), (uint32_t)used, b_hdr.as<uint8_t>(), d_sc + 12, st);
-            std::vector<uint8_t> hbuf(htot);
-            HIP_TRY(hipMemcpyAsync(hbuf.data(), b_hdr.p, htot, hipMemcpyDeviceToHost, st));
+            have = hmem[used - 1].upos + hmem[used - 1].isize;
+            if (m_lo == 0 && used <= n_range) src = b_arena.as<uint8_t>();
+            else {
+                HIP_TRY(b_hdr.ensure(have + 256));
+                HIP_TRY(hipMemsetAsync(d_sc + 12, 0xff, 4, st));
+                launch_inflate(d_bam, d_members, used, b_hdr.as<uint8_t>(), 0, d_sc + 12, st);
+                src = b_hdr.as<uint8_t>();
+            }
+            std::vector<uint8_t> hbuf(have);
+            HIP_TRY(hipMemcpyAsync(hbuf.data(), src, have, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 64, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            uint64_t have = htot;
-            if (h_sc[12] != 0xffffffffu) have = hmem[h_sc[12]].upos;             // a corrupt member ends the header read
+            bad_h = (src == b_arena.as<uint8_t>()) ? h_sc[0] : h_sc[12];
+            if (bad_h != 0xffffffffu && bad_h < used) have = hmem[bad_h].upos;          // a corrupt member ends the header read
             uint64_t need = 0;
             int r = parse_bam_header(hbuf.data(), have, hdr, need);
             if (r == 0) break;
-            if (r == 2 || used < n_h || n_h == hm.size() || have < htot) return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion);  // sam_hdr_read == NULL (cc:519-522)
-            n_h = std::min(hm.size(), n_h * 4);
+            if (r == 2 || used < n_h || n_h == n_members_all || (bad_h != 0xffffffffu && bad_h < used))
+                return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion);   // sam_hdr_read == NULL (cc:519-522)
+            n_h = std::min(n_members_all, n_h * 4);
         }
     }
     const int32_t n_ref = (int32_t)hdr.names.size();
     mark("header (sync: inflate done)");
 
     // -- stream bounds inside the arena -------------------------------------------------------------------------------------
-    auto arena_of = [&](uint64_t voff) -> uint64_t {     // arena offset of a virtual offset inside [m_lo, m_hi)
-        const size_t k = member_of(voff >> 16);
-        if (k < m_lo || k >= m_hi) return total;
-        return std::min<uint64_t>(total, members[k - m_lo].upos + (voff & 0xffff));
-    };
     uint64_t lim = total;
-    if (h_sc[0] != 0xffffffffu) lim = members[h_sc[0]].upos;    // a member failed to inflate: the stream ends where it starts
-    uint64_t pos0;
-    if (cut_lo) pos0 = arena_of(cut_lo);
-    else {
-        // no seek: records start right after the header, which lies inside member range starting at 0
-        pos0 = hdr.end;
+    if (h_sc[0] != 0xffffffffu) {       // a member of the range failed to inflate: the stream ends where it starts
+        uint64_t u = 0;
+        HIP_TRY(upos_of(m_lo + h_sc[0], u));
+        lim = u - upos_lo;
     }
-    if (cut_hi != UINT64_MAX) lim = std::min(lim, arena_of(cut_hi));
+    auto arena_of = [&](uint64_t voff, uint32_t idx, uint64_t upos) -> uint64_t {   // virtual offset -> arena offset (idx/upos from the query)
+        if (idx >= n_members_all || idx < m_lo || idx >= m_hi) return total;
+        return std::min<uint64_t>(total, upos - upos_lo + (voff & 0xffff));
+    };
+    uint64_t pos0;
+    if (cut_lo) pos0 = arena_of(cut_lo, h_sc[25], q_upos[1]);
+    else pos0 = hdr.end;                 // no seek: records start right after the header (range starts at member 0)
+    if (cut_hi != UINT64_MAX) lim = std::min(lim, arena_of(cut_hi, h_sc[26], q_upos[2]));
     if (pos0 > lim) pos0 = lim;
 
     ExtractCfg cfg;
@@ -521,7 +568,7 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     }
     mark("rows to host");
     t->n_records = n_iterated;
-    t->n_events = n_events; t->inflated_bytes = total; t->compressed_bytes = bam_len; t->n_members = members.size();
+    t->n_events = n_events; t->inflated_bytes = total; t->compressed_bytes = bam_len; t->n_members = n_range;
     float ms = 0;
     HIP_TRY(hipEventSynchronize(c->ev[6]));
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); t->ms_inflate = ms;
@@ -533,10 +580,10 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     return RGX_OK;
 }
 
-extern "C" int rgx_extract_device(rgx_ctx *ctx, const void *d_bam, const void *h_bam, size_t bam_len, const void *bai, size_t bai_len,
+extern "C" int rgx_extract_device(rgx_ctx *ctx, const void *d_bam, size_t bam_len, const void *bai, size_t bai_len,
                                   const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen) {
-    if (!ctx || !h_bam || !out) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
-    return run_pipeline(ctx, (const uint8_t *)d_bam, (const uint8_t *)h_bam, bam_len, (const uint8_t *)bai, bai_len, p, out, err, errlen);
+    if (!ctx || !d_bam || !out) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
+    return run_pipeline(ctx, (const uint8_t *)d_bam, nullptr, bam_len, (const uint8_t *)bai, bai_len, p, out, err, errlen);
 }
 
 extern "C" int rgx_extract_mem(rgx_ctx *ctx, const void *bam, size_t bam_len, const void *bai, size_t bai_len, const rgx_extract_params *p,
@@ -557,7 +604,7 @@ extern "C" int rgx_extract(rgx_ctx *ctx, const char *bam_path, const rgx_extract
 
 extern "C" int rgx_k_inflate(const void *d_comp, const rgx_member *d_members, uint32_t n_members, void *d_arena, uint32_t *d_status, void *stream) {
     static_assert(sizeof(rgx_member) == sizeof(Member), "rgx_member layout");
-    launch_inflate((const uint8_t *)d_comp, (const Member *)d_members, n_members, (uint8_t *)d_arena, d_status, (hipStream_t)stream);
+    launch_inflate((const uint8_t *)d_comp, (const Member *)d_members, n_members, (uint8_t *)d_arena, 0, d_status, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? RGX_OK : RGX_ERR_DEVICE;
 }
 

@@ -29,7 +29,7 @@ void walk_members(const uint8_t *bam, size_t len, std::vector<HostMember> &out) 
     }
 }
 
-bool parse_bai(const uint8_t *d, size_t len, BaiInfo &bi) {
+bool parse_bai(const uint8_t *d, size_t len, BaiInfo &bi, bool collect_anchors) {
     bi = BaiInfo();
     if (len < 8 || memcmp(d, "BAI\1", 4)) return false;
     size_t p = 4;
@@ -44,7 +44,7 @@ bool parse_bai(const uint8_t *d, size_t len, BaiInfo &bi) {
             if (n_chunk < 0 || p + (size_t)n_chunk * 16 > len) return false;
             if (bin == 37450) {                                  // pseudo-bin: chunk 0 = (first offset, last offset)
                 if (n_chunk > 0) { uint64_t u = h64(d + p); bi.have_start = true; if (u < bi.start_voff) bi.start_voff = u; }
-            } else {
+            } else if (collect_anchors) {
                 for (int32_t c = 0; c < n_chunk; ++c) bi.anchors.push_back(h64(d + p + (size_t)c * 16));
             }
             p += (size_t)n_chunk * 16;
@@ -52,13 +52,37 @@ bool parse_bai(const uint8_t *d, size_t len, BaiInfo &bi) {
         if (p + 4 > len) return false;
         int32_t n_intv = (int32_t)h32(d + p); p += 4;
         if (n_intv < 0 || p + (size_t)n_intv * 8 > len) return false;
-        for (int32_t i = 0; i < n_intv; ++i) { uint64_t v = h64(d + p + (size_t)i * 8); if (v) bi.anchors.push_back(v); }
+        if (collect_anchors) for (int32_t i = 0; i < n_intv; ++i) { uint64_t v = h64(d + p + (size_t)i * 8); if (v) bi.anchors.push_back(v); }
         p += (size_t)n_intv * 8;
     }
     bi.n_no_coor = (p + 8 <= len) ? h64(d + p) : 0;
     std::sort(bi.anchors.begin(), bi.anchors.end());
     bi.anchors.erase(std::unique(bi.anchors.begin(), bi.anchors.end()), bi.anchors.end());
     return true;
+}
+
+void bai_first_anchor_ge(const uint8_t *d, size_t len, const uint64_t *targets, int n, uint64_t *out) {
+    for (int k = 0; k < n; ++k) out[k] = UINT64_MAX;
+    if (len < 8 || memcmp(d, "BAI\1", 4)) return;
+    auto see = [&](uint64_t v) { for (int k = 0; k < n; ++k) if (v >= targets[k] && v < out[k]) out[k] = v; };
+    size_t p = 4;
+    int32_t n_ref = (int32_t)h32(d + p); p += 4;
+    for (int32_t r = 0; r < n_ref; ++r) {
+        if (p + 4 > len) return;
+        int32_t n_bin = (int32_t)h32(d + p); p += 4;
+        for (int32_t b = 0; b < n_bin; ++b) {
+            if (p + 8 > len) return;
+            uint32_t bin = h32(d + p); int32_t n_chunk = (int32_t)h32(d + p + 4); p += 8;
+            if (n_chunk < 0 || p + (size_t)n_chunk * 16 > len) return;
+            if (bin != 37450) for (int32_t c = 0; c < n_chunk; ++c) see(h64(d + p + (size_t)c * 16));
+            p += (size_t)n_chunk * 16;
+        }
+        if (p + 4 > len) return;
+        int32_t n_intv = (int32_t)h32(d + p); p += 4;
+        if (n_intv < 0 || p + (size_t)n_intv * 8 > len) return;
+        for (int32_t i = 0; i < n_intv; ++i) { uint64_t v = h64(d + p + (size_t)i * 8); if (v) see(v); }
+        p += (size_t)n_intv * 8;
+    }
 }
 
 static bool readable(const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (!f) return false; fclose(f); return true; }

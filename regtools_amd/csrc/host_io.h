@@ -25,7 +25,10 @@ struct BaiInfo {
     uint64_t n_no_coor = 0;
     std::vector<uint64_t> anchors;   // sorted unique virtual offsets that are record starts (linear index + chunk begins)
 };
-bool parse_bai(const uint8_t *bai, size_t len, BaiInfo &out);
+bool parse_bai(const uint8_t *bai, size_t len, BaiInfo &out, bool collect_anchors = true);
+// for each target virtual offset: the smallest record-start offset listed in the index that is >= target
+// (UINT64_MAX when none); one linear pass, no sorting.
+void bai_first_anchor_ge(const uint8_t *bai, size_t len, const uint64_t *targets, int n, uint64_t *out);
 
 // hts.c:2009-2042 index file name resolution ("<fn>.bai" then "<fn minus extension>.bai"); csi is detected, not read.
 // returns 0 found, 1 none, 2 only a .csi exists

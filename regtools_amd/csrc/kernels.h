@@ -10,8 +10,35 @@ constexpr uint32_t kSegBytes = 16384;   // arena segment walked by one lane duri
 constexpr uint64_t kChainEnd = ~0ull;   // "the record chain ended before this point" (truncated/corrupt stream)
 
 // ---- a1: BGZF inflate (one lane per member) -----------------------------------------------------------
-void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena,
+// member m writes its bytes at arena + (members[m].upos - upos_bias)
+void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias,
                     uint32_t *status /* [0]=first bad member (min), [1]=its status */, hipStream_t stream);
+
+// ---- a1 (container): BGZF member discovery on the device --------------------------------------------------
+// The member chain (bgzf.c:525: next = this + BSIZE + 1) is serial on a CPU (one dependent cache miss per member).
+// Here: (1) every byte offset is tested against check_header's predicate (bgzf.c:348-355) -> sorted candidate list
+// (two passes: count per 4 KiB tile, scan, fill); (2) each candidate links to the candidate at off+BSIZE+1 (binary
+// search); (3) reachability from offset 0 by pointer doubling (log2 n rounds) keeps exactly the members the serial walk
+// would visit -- false positives inside compressed data are unreachable and drop out; (4) compaction + scan of ISIZE.
+constexpr uint32_t kMagicTile = 4096;
+void launch_magic_count(const uint8_t *bam, uint64_t len, uint32_t n_tiles, uint32_t *tile_cnt, hipStream_t stream);
+void launch_magic_fill(const uint8_t *bam, uint64_t len, uint32_t n_tiles, const uint32_t *tile_base, uint64_t *cand, hipStream_t stream);
+// next[i] = index of the candidate at cand[i] + BSIZE + 1, or n when the chain ends there; isize[i] = ISIZE footer
+void launch_member_link(const uint8_t *bam, uint64_t len, const uint64_t *cand, uint32_t n, uint32_t *next, uint32_t *isize,
+                        uint32_t *reach, hipStream_t stream);
+void launch_member_jump(uint32_t n, const uint32_t *next_in, uint32_t *next_out, uint32_t *reach, hipStream_t stream);
+// members[rank] for reachable candidates (rank = exclusive scan of reach); upos filled later by launch_member_upos
+void launch_member_compact(const uint8_t *bam, const uint64_t *cand, const uint32_t *isize, const uint32_t *reach, const uint32_t *rank,
+                           uint32_t n, Member *members, uint32_t *isize_compact, hipStream_t stream);
+// 64-bit exclusive scan of isize over the compacted members (single workgroup; n is ~1e5) -> Member::upos, total
+void launch_member_upos(Member *members, const uint32_t *isize_compact, const uint32_t *n_members /*device*/, uint64_t *total, hipStream_t stream);
+// answers host questions about the member list without copying it: q_coff[k] -> index of the member whose file offset is
+// q_coff[k]-18+18 (exact match) or n; also the first index >= from[k] whose isize is 0 or > 65536 (stream stop rule)
+void launch_member_query(const Member *members, const uint32_t *n_members /*device*/, const uint64_t *q_coff, uint32_t n_q, uint32_t *q_index,
+                         uint64_t *q_upos, hipStream_t stream);
+// *stop = min(*stop, first index >= *from whose ISIZE is 0 or > 65536)
+void launch_member_stop(const Member *members, uint32_t max_members, const uint32_t *n_members /*device*/, const uint32_t *from /*device*/, uint32_t *stop,
+                        hipStream_t stream);
 
 // ---- a2: record framing ---------------------------------------------------------------------------------
 // Segment s covers arena [pos0 + s*kSegBytes, +kSegBytes) clipped to lim. seg_start[s] = guessed (s>0) or exact

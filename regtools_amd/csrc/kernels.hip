@@ -69,14 +69,14 @@ struct LdsTab {
 };
 
 __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
-                                                uint32_t n_members, uint8_t *__restrict__ arena, uint32_t *status) {
+                                                uint32_t n_members, uint8_t *__restrict__ arena, uint64_t upos_bias, uint32_t *status) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t m = blockIdx.x * 64 + threadIdx.x;
     if (m >= n_members) return;
     Member mb = members[m];
     LdsTab T{lds + threadIdx.x};
     uint32_t out_len = 0;
-    int st = inflate_raw(comp + mb.cpos, mb.clen, arena + mb.upos, mb.isize, &out_len, T);
+    int st = inflate_raw(comp + mb.cpos, mb.clen, arena + (mb.upos - upos_bias), mb.isize, &out_len, T);
     if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
     if (st != INF_OK) {
         uint32_t prev = atomicMin(&status[0], m);
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
     }
 }
 
-void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint32_t *status,
+void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *status,
                     hipStream_t stream) {
     if (!n_members) return;
     static bool attr_set = false;
@@ -93,7 +93,7 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
         attr_set = true;
     }
     uint32_t blocks = (n_members + 63) / 64;
-    hipLaunchKernelGGL(k_inflate, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, status);
+    hipLaunchKernelGGL(k_inflate, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, status);
 }
 
 // =====================================================================================================
@@ -509,6 +509,151 @@ void launch_radix_pass(const uint32_t *word, uint32_t shift, uint32_t bits, cons
     hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(64), 0, stream, word, shift, mask, perm_in, n, tiles, hist);
     launch_scan_u32(hist, hist, 256 * tiles, nullptr, scan_tmp, stream);
     hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(64), 0, stream, word, shift, mask, perm_in, perm_out, n, tiles, hist);
+}
+
+
+// =====================================================================================================
+// a1 (container). BGZF member discovery on the device
+// =====================================================================================================
+// check_header (bgzf.c:348-355): ID1 ID2 CM, FLG&4, XLEN == 6, 'B' 'C', SLEN == 2  (bytes 0,1,2,3,10..15)
+__device__ __forceinline__ bool bgzf_magic_at(const uint8_t *__restrict__ p) {
+    if (p[0] != 31 || p[1] != 139) return false;
+    return p[2] == 8 && (p[3] & 4) && p[10] == 6 && p[11] == 0 && p[12] == 'B' && p[13] == 'C' && p[14] == 2 && p[15] == 0;
+}
+
+// one thread tests 16 consecutive offsets; a 256-thread workgroup covers one 4 KiB tile
+__device__ __forceinline__ uint32_t magic_mask16(const uint8_t *__restrict__ bam, uint64_t len, uint64_t base) {
+    uint32_t m = 0;
+    if (base + 16 + 18 <= len) {
+        // cheap prefilter on the two ID bytes using two aligned-agnostic 16-byte loads
+        u32x4 a = ld128(bam + base), b = ld128(bam + base + 16);
+        uint8_t w[32];
+        *(u32x4 *)w = a; *(u32x4 *)(w + 16) = b;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (w[k] == 31 && w[k + 1] == 139) { if (bgzf_magic_at(bam + base + k)) m |= 1u << k; }
+    } else {
+        for (int k = 0; k < 16; ++k) if (base + k + 18 <= len && bgzf_magic_at(bam + base + k)) m |= 1u << k;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_magic_count(const uint8_t *__restrict__ bam, uint64_t len, uint32_t *tile_cnt) {
+    __shared__ uint32_t s_wave[4];
+    const uint64_t base = (uint64_t)blockIdx.x * kMagicTile + threadIdx.x * 16;
+    const uint32_t c = (uint32_t)__popc(magic_mask16(bam, len, base));
+    uint32_t tot; block_excl_scan_256(c, s_wave, tot);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_magic_fill(const uint8_t *__restrict__ bam, uint64_t len, const uint32_t *__restrict__ tile_base, uint64_t *cand) {
+    __shared__ uint32_t s_wave[4];
+    const uint64_t base = (uint64_t)blockIdx.x * kMagicTile + threadIdx.x * 16;
+    uint32_t m = magic_mask16(bam, len, base);
+    uint32_t tot; uint32_t slot = tile_base[blockIdx.x] + block_excl_scan_256((uint32_t)__popc(m), s_wave, tot);
+    while (m) { const uint32_t k = (uint32_t)__ffs((int)m) - 1; m &= m - 1; cand[slot++] = base + k; }
+}
+
+__global__ void k_member_link(const uint8_t *__restrict__ bam, uint64_t len, const uint64_t *__restrict__ cand, uint32_t n, uint32_t *next,
+                              uint32_t *isize, uint32_t *reach) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t off = cand[i];
+    const uint64_t blen = (uint64_t)ld16(bam + off + 16) + 1;       // bgzf.c:525
+    uint32_t nx = n, isz = 0xffffffffu;                              // malformed member: chain ends, never inflated
+    if (blen >= 26 && off + blen <= len) {
+        isz = ld32(bam + off + blen - 4);
+        const uint64_t want = off + blen;
+        uint32_t lo = i + 1, hi = n;                                 // candidates are sorted by offset
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cand[mid] < want) lo = mid + 1; else hi = mid; }
+        if (lo < n && cand[lo] == want) nx = lo;
+    } else nx = 0xffffffffu;                                         // marks "this candidate itself is unusable"
+    next[i] = nx; isize[i] = isz;
+    reach[i] = (i == 0 && off == 0) ? 1u : 0u;
+}
+
+__global__ void k_member_jump(uint32_t n, const uint32_t *__restrict__ next_in, uint32_t *next_out, uint32_t *reach) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t nx = next_in[i];
+    if (nx < n) {
+        if (reach[i]) reach[nx] = 1u;                                // 0 -> 1 only: benign race
+        next_out[i] = next_in[nx];
+    } else next_out[i] = nx;
+}
+
+__global__ void k_member_compact(const uint8_t *__restrict__ bam, const uint64_t *__restrict__ cand, const uint32_t *__restrict__ isize,
+                                 const uint32_t *__restrict__ reach, const uint32_t *__restrict__ rank, uint32_t n, Member *members, uint32_t *isize_compact) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !reach[i]) return;
+    const uint64_t off = cand[i];
+    const uint32_t blen = (uint32_t)ld16(bam + off + 16) + 1;
+    const uint32_t r = rank[i];
+    Member m; m.cpos = off + 18; m.upos = 0; m.clen = blen >= 26 ? blen - 26 : 0; m.isize = isize[i];
+    members[r] = m;
+    isize_compact[r] = (isize[i] <= kBgzfMaxBlock) ? isize[i] : 0u;  // oversized/unusable members hold no bytes in the arena
+}
+
+__global__ __launch_bounds__(256) void k_member_upos(Member *members, const uint32_t *__restrict__ isz, const uint32_t *__restrict__ n_ptr, uint64_t *total) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t n = *n_ptr;
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? isz[i] : 0u;
+        uint32_t tot; const uint32_t ex = block_excl_scan_256(v, s_wave, tot);   // 256 * 65536 < 2^32
+        if (i < n) members[i].upos = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void k_member_query(const Member *__restrict__ members, const uint32_t *__restrict__ n_ptr, const uint64_t *__restrict__ q_coff, uint32_t n_q,
+                               uint32_t *q_index, uint64_t *q_upos) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_q) return;
+    const uint32_t n = *n_ptr;
+    const uint64_t want = q_coff[k] + 18;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (members[mid].cpos < want) lo = mid + 1; else hi = mid; }
+    const bool hit = lo < n && members[lo].cpos == want;
+    q_index[k] = hit ? lo : n;
+    q_upos[k] = hit ? members[lo].upos : ~0ull;
+}
+
+__global__ void k_member_stop(const Member *__restrict__ members, const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ from_ptr, uint32_t *stop) {
+    const uint32_t n = *n_ptr;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < *from_ptr) return;
+    if (i < n && (members[i].isize == 0 || members[i].isize > kBgzfMaxBlock)) atomicMin(stop, i);
+}
+
+void launch_magic_count(const uint8_t *bam, uint64_t len, uint32_t n_tiles, uint32_t *tile_cnt, hipStream_t stream) {
+    if (n_tiles) hipLaunchKernelGGL(k_magic_count, dim3(n_tiles), dim3(256), 0, stream, bam, len, tile_cnt);
+}
+void launch_magic_fill(const uint8_t *bam, uint64_t len, uint32_t n_tiles, const uint32_t *tile_base, uint64_t *cand, hipStream_t stream) {
+    if (n_tiles) hipLaunchKernelGGL(k_magic_fill, dim3(n_tiles), dim3(256), 0, stream, bam, len, tile_base, cand);
+}
+void launch_member_link(const uint8_t *bam, uint64_t len, const uint64_t *cand, uint32_t n, uint32_t *next, uint32_t *isize, uint32_t *reach,
+                        hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_member_link, dim3((n + 255) / 256), dim3(256), 0, stream, bam, len, cand, n, next, isize, reach);
+}
+void launch_member_jump(uint32_t n, const uint32_t *next_in, uint32_t *next_out, uint32_t *reach, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_member_jump, dim3((n + 255) / 256), dim3(256), 0, stream, n, next_in, next_out, reach);
+}
+void launch_member_compact(const uint8_t *bam, const uint64_t *cand, const uint32_t *isize, const uint32_t *reach, const uint32_t *rank, uint32_t n,
+                           Member *members, uint32_t *isize_compact, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_member_compact, dim3((n + 255) / 256), dim3(256), 0, stream, bam, cand, isize, reach, rank, n, members, isize_compact);
+}
+void launch_member_upos(Member *members, const uint32_t *isize_compact, const uint32_t *n_members, uint64_t *total, hipStream_t stream) {
+    hipLaunchKernelGGL(k_member_upos, dim3(1), dim3(256), 0, stream, members, isize_compact, n_members, total);
+}
+void launch_member_query(const Member *members, const uint32_t *n_members, const uint64_t *q_coff, uint32_t n_q, uint32_t *q_index, uint64_t *q_upos,
+                         hipStream_t stream) {
+    if (n_q) hipLaunchKernelGGL(k_member_query, dim3((n_q + 63) / 64), dim3(64), 0, stream, members, n_members, q_coff, n_q, q_index, q_upos);
+}
+void launch_member_stop(const Member *members, uint32_t max_members, const uint32_t *n_members, const uint32_t *from, uint32_t *stop, hipStream_t stream) {
+    if (max_members) hipLaunchKernelGGL(k_member_stop, dim3((max_members + 255) / 256), dim3(256), 0, stream, members, n_members, from, stop);
 }
 
 // =====================================================================================================

@@ -120,19 +120,19 @@ class JunctionsExtractor(object):
         return p
 
     # -- identify_junctions_from_BAM (junctions_extractor.cc:500-535) -------------------------------------------------
-    def identify_junctions_from_BAM(self, bam_bytes=None, bai_bytes=None, device_ptr=None):
+    def identify_junctions_from_BAM(self, bam_bytes=None, bai_bytes=None, device_ptr=None, device_len=0):
         lib = _ffi.lib()
         if self._ctx is None:
             self._ctx = Context(self._device)
         p = self._params()
         tab = C.POINTER(_ffi.JunctionTable)()
         err = C.create_string_buffer(512)
-        if bam_bytes is None:
+        if bam_bytes is None and device_ptr is None:
             rc = lib.rgx_extract(self._ctx._h, self.bam_.encode(), C.byref(p), C.byref(tab), err, len(err))
         elif device_ptr is None:
             rc = lib.rgx_extract_mem(self._ctx._h, bam_bytes, len(bam_bytes), bai_bytes, len(bai_bytes), C.byref(p), C.byref(tab), err, len(err))
         else:
-            rc = lib.rgx_extract_device(self._ctx._h, C.c_void_p(device_ptr), bam_bytes, len(bam_bytes), bai_bytes, len(bai_bytes),
+            rc = lib.rgx_extract_device(self._ctx._h, C.c_void_p(device_ptr), device_len, bai_bytes, len(bai_bytes),
                                         C.byref(p), C.byref(tab), err, len(err))
         if rc != 0:
             raise RegtoolsError(rc, err.value.decode())

@@ -1,0 +1,94 @@
+"""The N > 1 path on CPU: two processes, gloo backend.  Each rank holds one half of a BAM (cut at a record
+boundary, i.e. what a coordinate shard is), produces its partial junction table -- here with the CPU oracle,
+since no GPU is available in this tier -- and the product's exchange code (regtools_amd.distributed: pack rows,
+ONE all-gather, C-ABI merge) must reproduce the single-process result bit for bit."""
+import ctypes as C
+import os
+import struct
+import subprocess
+import sys
+
+import pytest
+
+import bamio
+from conftest import run_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import ctypes as C, os, struct, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch, torch.distributed as dist
+from regtools_amd import _ffi, distributed
+from test_distributed_gloo import oracle_partial_table
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+parts_dir, strand = sys.argv[1], sys.argv[2]
+tab = oracle_partial_table(os.path.join(parts_dir, "part%d.bam" % rank), strand)
+merged = distributed.gather_and_merge(tab, min_anchor=8)
+open(os.path.join(parts_dir, "merged_rank%d.bed" % rank), "wb").write(merged.bed12())
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+class OrcJunction(C.Structure):
+    _fields_ = [("tid", C.c_int32), ("start", C.c_uint32), ("end", C.c_uint32), ("thick_start", C.c_uint32), ("thick_end", C.c_uint32),
+                ("read_count", C.c_uint32), ("name_index", C.c_uint64), ("strand", C.c_char), ("left_ok", C.c_uint8), ("right_ok", C.c_uint8),
+                ("first_seen", C.c_uint64), ("last_seen", C.c_uint64)]
+
+
+class OrcTable(C.Structure):
+    _fields_ = [("n_ref", C.c_int32), ("ref_name", C.POINTER(C.c_char_p)), ("ref_len", C.POINTER(C.c_uint32)), ("n", C.c_size_t),
+                ("rows", C.POINTER(OrcJunction)), ("n_records", C.c_uint64), ("n_records_total", C.c_uint64), ("n_events", C.c_uint64),
+                ("inflated_bytes", C.c_uint64)]
+
+
+class OrcParams(C.Structure):
+    _fields_ = [("bam", C.c_char_p), ("region", C.c_char_p), ("strandness", C.c_int), ("strand_tag", C.c_char * 2), ("min_anchor", C.c_uint32),
+                ("min_intron", C.c_uint32), ("max_intron", C.c_uint32), ("fasta", C.c_char_p)]
+
+
+def oracle_partial_table(bam_path, strand):
+    """Runs the oracle on one shard file and re-expresses its rows as a product JunctionTable* (via the packed-row
+    wire format), carrying first_seen/last_seen exactly as a GPU shard would."""
+    from regtools_amd import _ffi
+    O = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    p = OrcParams()
+    O.orc_default_params(C.byref(p))
+    p.bam = bam_path.encode(); p.strandness = {"XS": 0, "RF": 1, "FR": 2}[strand]
+    t = C.POINTER(OrcTable)()
+    err = C.create_string_buffer(256)
+    assert O.orc_extract(C.byref(p), C.byref(t), err, 256) == 0, err.value
+    tt = t.contents
+    raw = b"".join(struct.pack("<12I", r.tid & 0xffffffff, r.start, r.end, r.thick_start, r.thick_end, r.read_count,
+                               r.first_seen & 0xffffffff, r.first_seen >> 32, r.last_seen & 0xffffffff, r.last_seen >> 32, ord(r.strand), 0)
+                   for r in (tt.rows[i] for i in range(tt.n)))
+    proto = _ffi.JunctionTable()
+    proto.n_ref, proto.ref_name, proto.ref_len = tt.n_ref, tt.ref_name, tt.ref_len
+    out = C.POINTER(_ffi.JunctionTable)()
+    buf = (C.c_uint8 * max(1, len(raw))).from_buffer_copy(raw or b"\0")
+    assert _ffi.lib().rgx_table_unpack(buf, tt.n, C.byref(proto), C.byref(out)) == 0
+    return out
+
+
+@pytest.mark.parametrize("shape,n,seed,strand", [("fuzz", 30000, 41, "XS"), ("short", 40000, 42, "RF"), ("fuzz", 20000, 43, "FR")])
+def test_two_rank_gloo_merge_equals_single_process(tmp_path, shape, n, seed, strand):
+    from regtools_amd import synth
+    whole = str(tmp_path / "whole.bam")
+    synth.write(whole, n, shape=shape, seed=seed)
+    contigs, recs = bamio.split_records(bamio.inflate_all(whole))
+    cut = len(recs) // 2 + 7
+    for r, part in enumerate((recs[:cut], recs[cut:])):
+        p = str(tmp_path / ("part%d.bam" % r))
+        bamio.write_bam(p, contigs, part)
+        synth.index(p)
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + seed), PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29500 + seed), str(script), str(tmp_path), strand], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    rc, expect, _ = run_oracle(["-s", strand, whole])
+    assert rc == 0 and expect.count(b"\n") > 50
+    for rank in (0, 1):
+        assert open(str(tmp_path / ("merged_rank%d.bed" % rank)), "rb").read() == expect
