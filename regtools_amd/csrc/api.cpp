@@ -308,7 +308,9 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     const uint32_t n_range = m_hi - m_lo;
     HIP_TRY(b_arena.ensure(total + 256));
     HIP_TRY(hipEventRecord(c->ev[0], st));
-    launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, d_sc, st);
+    DevBuf &b_lens = c->buf("inflate_scratch");
+    HIP_TRY(b_lens.ensure(inflate_scratch_bytes(std::max<uint32_t>(n_range, 64))));
+    launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st);
     HIP_TRY(hipEventRecord(c->ev[1], st));
     mark("launch inflate");
 
@@ -331,7 +333,7 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
             else {
                 HIP_TRY(b_hdr.ensure(have + 256));
                 HIP_TRY(hipMemsetAsync(d_sc + 12, 0xff, 4, st));
-                launch_inflate(d_bam, d_members, used, b_hdr.as<uint8_t>(), 0, d_sc + 12, st);
+                launch_inflate(d_bam, d_members, used, b_hdr.as<uint8_t>(), 0, b_lens.as<uint32_t>(), d_sc + 12, st);
                 src = b_hdr.as<uint8_t>();
             }
             std::vector<uint8_t> hbuf(have);
@@ -604,7 +606,15 @@ extern "C" int rgx_extract(rgx_ctx *ctx, const char *bam_path, const rgx_extract
 
 extern "C" int rgx_k_inflate(const void *d_comp, const rgx_member *d_members, uint32_t n_members, void *d_arena, uint32_t *d_status, void *stream) {
     static_assert(sizeof(rgx_member) == sizeof(Member), "rgx_member layout");
-    launch_inflate((const uint8_t *)d_comp, (const Member *)d_members, n_members, (uint8_t *)d_arena, 0, d_status, (hipStream_t)stream);
+    // stage entry point: the code-length scratch is a process-lifetime buffer grown on demand
+    static void *scratch = nullptr; static size_t scratch_cap = 0;
+    const size_t need = inflate_scratch_bytes(n_members);
+    if (need > scratch_cap) {
+        if (scratch) (void)hipFree(scratch);
+        if (hipMalloc(&scratch, need) != hipSuccess) { scratch = nullptr; scratch_cap = 0; return RGX_ERR_DEVICE; }
+        scratch_cap = need;
+    }
+    launch_inflate((const uint8_t *)d_comp, (const Member *)d_members, n_members, (uint8_t *)d_arena, 0, (uint32_t *)scratch, d_status, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? RGX_OK : RGX_ERR_DEVICE;
 }
 

@@ -7,9 +7,9 @@
 // which on the device is lane-interleaved LDS (bank = lane % 32, conflict-free) and on the host a plain
 // array -- the same code is compiled by g++ for the CPU-side unit tests against zlib.
 //
-// Huffman decode is table-free in the hot loop: the 15 left-justified canonical upper bounds of each
-// code live in registers; a symbol's length is 1 + #(bounds <= next-15-bits), found with 14 compares
-// and no memory access, then ONE symbol-list lookup.  Length/distance bases are computed arithmetically.
+// Huffman decode is table-free in the hot loop: each canonical code is 16 sorted register words (bound, length and
+// list offset packed together); 15 compare+select steps on the next 15 bits yield the code's length AND its index in
+// the sorted symbol list with no memory access, then ONE symbol-list lookup.  Length/distance bases are arithmetic.
 #pragma once
 #include "common.h"
 
@@ -23,22 +23,90 @@ enum InflateStatus : int {
 };
 
 // ---- host-side table storage (unit tests) ---------------------------------------------------------
+// The `Tab` accessor hides where the per-member tables live.  Device (kernels.hip, LdsTab): the two canonical symbol
+// lists sit bit-packed in lane-interleaved LDS (288 x 9 bits + 32 x 5 bits = 344 B per lane -> 22 KB per wave -> 7 waves
+// per CU) and the code-length scratch (needed only while a block header is parsed) in a global, lane-interleaved buffer.
 struct HostTab {
-    uint16_t ll_sym[288]; uint8_t d_sym[32]; uint16_t ll_base[16]; uint16_t d_base[16]; uint8_t lens[320];
+    uint16_t ll_sym[288]; uint8_t d_sym[32]; uint32_t len_words[40];
     RGX_HD uint32_t get_ll_sym(uint32_t i) const { return ll_sym[i]; }
     RGX_HD void set_ll_sym(uint32_t i, uint32_t v) { ll_sym[i] = (uint16_t)v; }
     RGX_HD uint32_t get_d_sym(uint32_t i) const { return d_sym[i]; }
     RGX_HD void set_d_sym(uint32_t i, uint32_t v) { d_sym[i] = (uint8_t)v; }
-    RGX_HD uint32_t get_ll_base(uint32_t l) const { return ll_base[l]; }
-    RGX_HD void set_ll_base(uint32_t l, uint32_t v) { ll_base[l] = (uint16_t)v; }
-    RGX_HD uint32_t get_d_base(uint32_t l) const { return d_base[l]; }
-    RGX_HD void set_d_base(uint32_t l, uint32_t v) { d_base[l] = (uint16_t)v; }
-    RGX_HD uint32_t get_len(uint32_t i) const { return lens[i]; }
-    RGX_HD void set_len(uint32_t i, uint32_t v) { lens[i] = (uint8_t)v; }
+    RGX_HD uint32_t get_len_word(uint32_t w) const { return len_words[w]; }     // 8 code lengths (4 bits each) per word
+    RGX_HD void set_len_word(uint32_t w, uint32_t v) { len_words[w] = v; }
+    RGX_HD void clear_syms() {}
 };
+constexpr uint32_t kLenWordsLL = 36, kLenWordsD = 4;   // literal/length lengths in words 0..35, distance lengths in 36..39
 
-// 15 canonical upper bounds (left-justified to 15 bits, exclusive, cumulative over lengths)
-struct Bounds { uint32_t lim[16]; };
+// One canonical Huffman code, entirely in registers: 16 words sorted ascending,
+//   c[k] = lim[k] << 13 | (k+1) << 9 | offs[k+1]        k = 0..14   (codes of length k+1)
+//   c[15] = lim[15] << 13                                 (length field 0 = "no such code")
+// lim[k] = exclusive upper bound, left-justified to 15 bits, of all codes of length <= k (lim[0] = 0);
+// offs[k+1] = number of symbols with length <= k = index of the first length-(k+1) symbol in the sorted list.
+// For the next 15 bits v (MSB-first): the last entry with lim <= v names the code's length and where it sits.
+struct Code { uint32_t c[16]; };
+
+// returns the index into the sorted symbol list; len = 0 when v starts no code
+RGX_HD uint32_t code_lookup(const Code &C, uint32_t v15, uint32_t &len) {
+    const uint32_t key = v15 << 13 | 0x1fffu;
+    uint32_t m = C.c[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) m = (C.c[k] <= key) ? C.c[k] : m;
+    len = (m >> 9) & 15u;
+    return (m & 0x1ffu) + ((v15 - (m >> 13)) >> (15u - len));
+}
+
+// Build one canonical code from n code lengths stored 8 per word starting at word w0.
+// kind 0 = literal/length (symbol list via set_ll_sym), 1 = distance (set_d_sym).
+// Returns INF_OK, INF_OVERSUBSCRIBED or INF_INCOMPLETE (zlib inftrees.c: an incomplete set is legal only when it is
+// empty or a single 1-bit code).
+template <class Tab>
+RGX_HD int build_code(Tab &T, uint32_t w0, uint32_t n, int kind, Code &C) {
+    uint32_t count[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) count[l] = 0;
+    for (uint32_t w = 0; w * 8 < n; ++w) {
+        uint32_t word = T.get_len_word(w0 + w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t l = (w * 8 + (uint32_t)j < n) ? (word & 15u) : 0u;
+            word >>= 4;
+#pragma unroll
+            for (int k = 1; k < 16; ++k) count[k] += (l == (uint32_t)k) ? 1u : 0u;
+        }
+    }
+    int left = 1;
+    uint32_t code = 0, offs = 0;
+    uint32_t offs_of[16];
+    offs_of[0] = 0;
+#pragma unroll
+    for (int l = 1; l <= 15; ++l) {
+        left <<= 1; left -= (int)count[l];
+        C.c[l - 1] = (code << (15 - l)) << 13 | (uint32_t)l << 9 | offs;   // lim[l-1] = first code of length l, left-justified to 15 bits
+        offs_of[l] = offs;
+        code += count[l]; offs += count[l];
+        code <<= 1;
+    }
+    C.c[15] = (code >> 1) << 13;   // lim[15]: bound of all codes (15 bits wide already)
+    if (left < 0) return INF_OVERSUBSCRIBED;
+    if (left > 0 && !(offs == 0 || (offs == 1 && count[1] == 1))) return INF_INCOMPLETE;
+    for (uint32_t w = 0; w * 8 < n; ++w) {
+        uint32_t word = T.get_len_word(w0 + w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t i = w * 8 + (uint32_t)j;
+            const uint32_t l = (i < n) ? (word & 15u) : 0u;
+            word >>= 4;
+            if (l) {
+                uint32_t slot = 0;
+#pragma unroll
+                for (int k = 1; k < 16; ++k) if (l == (uint32_t)k) { slot = offs_of[k]; offs_of[k] = slot + 1; }
+                if (kind == 0) T.set_ll_sym(slot, i); else T.set_d_sym(slot, i);
+            }
+        }
+    }
+    return INF_OK;
+}
 
 // LSB-first bit reader with a one-word look-ahead: the load for the NEXT 32 bits is issued when the current
 // word is merged, so its latency hides behind the decode of the following symbols (a lane has no other
@@ -80,274 +148,276 @@ RGX_HD uint32_t rev15(uint32_t v) {
 #endif
 }
 
-// length (1..15) of the code at the head of v15 (MSB-first, left-justified); 16 = invalid
-RGX_HD uint32_t code_len(const Bounds &b, uint32_t v15) {
-    uint32_t l = 1;
-#pragma unroll
-    for (int k = 1; k <= 15; ++k) l += (v15 >= b.lim[k]) ? 1u : 0u;
-    return l;
-}
-
-// Build canonical decode data from code lengths lens[off .. off+n) held in Tab.
-// kind 0 = literal/length (symbol list via set_ll_sym / base via set_ll_base), 1 = distance.
-// Returns INF_OK, INF_OVERSUBSCRIBED or INF_INCOMPLETE (zlib's rules: inftrees.c -- an incomplete set is
-// only legal for a distance code with a single length-1 code or no codes at all).
+// ---- block header ------------------------------------------------------------------------------------------------
+// Parses one DEFLATE block header.  Dynamic/fixed blocks: builds the two canonical codes (returns 1 = symbols follow).
+// Stored blocks: copies the raw bytes and returns 0 (= another header follows, or the stream ends if *last).
 template <class Tab>
-RGX_HD int build_code(Tab &T, uint32_t off, uint32_t n, int kind, Bounds &B) {
-    uint32_t count[16];
-#pragma unroll
-    for (int l = 0; l < 16; ++l) count[l] = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        uint32_t l = T.get_len(off + i);
-        // count[l]++ without dynamic register indexing
-#pragma unroll
-        for (int k = 0; k < 16; ++k) count[k] += (l == (uint32_t)k) ? 1u : 0u;
+RGX_HD int block_header(BitReader &br, Tab &T, Code &LL, Code &DD, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t &o,
+                        uint32_t out_cap, uint32_t &last, int &status) {
+    br.refill();
+    last = br.bits(1);
+    const uint32_t btype = br.bits(2);
+    if (btype == 0) {
+        // stored: skip to byte boundary, LEN, NLEN, raw bytes
+        br.drop(br.cnt & 7);
+        br.refill();
+        uint32_t len = br.bits(16);
+        br.refill();
+        const uint32_t nlen = br.bits(16);
+        if ((len ^ 0xffff) != nlen) { status = INF_BAD_STORED; return 0; }
+        if (o + len > out_cap) { status = INF_OUT_OVERFLOW; return 0; }
+        while (len && br.cnt >= 8) { out[o++] = (uint8_t)br.bits(8); --len; }     // bytes still in the bit buffer
+        if (len) {
+            const uint8_t *src = br.byte_ptr();   // cnt == 0 here: the prefetched word starts at the next payload byte
+            if ((uint64_t)(src - in) + len > in_len) { status = INF_IN_OVERRUN; return 0; }
+            uint32_t k = 0;
+            for (; k + 16 <= len; k += 16) st128(out + o + k, ld128(src + k));
+            for (; k < len; ++k) out[o + k] = src[k];
+            o += len; br.restart_at(src + len);
+        }
+        return 0;
     }
-    int left = 1;
-    uint32_t code = 0, offs = 0;
-    uint32_t offs_of[16];
-    B.lim[0] = 0;
-    offs_of[0] = 0;
-#pragma unroll
-    for (int l = 1; l <= 15; ++l) {
-        left <<= 1; left -= (int)count[l];
-        uint32_t base = (offs - code) & 0xffff;     // symbol index = base + code (mod 2^16)
-        if (kind == 0) T.set_ll_base((uint32_t)l, base); else T.set_d_base((uint32_t)l, base);
-        offs_of[l] = offs;
-        code += count[l]; offs += count[l];
-        B.lim[l] = code << (15 - l);
-        code <<= 1;
+    if (btype == 3) { status = INF_BAD_BTYPE; return 0; }
+    T.clear_syms();
+    if (btype == 1) {
+        // fixed code (RFC 1951 3.2.6): lengths 8 x144, 9 x112, 7 x24, 8 x8; 32 distance codes of length 5 (30,31 rejected at decode)
+        for (uint32_t w = 0; w < 36; ++w) T.set_len_word(w, w < 18 ? 0x88888888u : w < 32 ? 0x99999999u : w < 35 ? 0x77777777u : 0x88888888u);
+        for (uint32_t w = 0; w < 4; ++w) T.set_len_word(kLenWordsLL + w, 0x55555555u);
+        build_code(T, 0, 288, 0, LL);
+        build_code(T, kLenWordsLL, 32, 1, DD);
+        return 1;
     }
-    if (left < 0) return INF_OVERSUBSCRIBED;
-    // zlib inftrees.c: an incomplete set is legal only when it is empty or a single 1-bit code
-    if (left > 0 && !(offs == 0 || (offs == 1 && count[1] == 1))) return INF_INCOMPLETE;
-    // symbol lists, in (length, symbol) order
-    for (uint32_t i = 0; i < n; ++i) {
-        uint32_t l = T.get_len(off + i);
+    br.refill();
+    const uint32_t hlit = br.bits(5) + 257, hdist = br.bits(5) + 1, hclen = br.bits(4) + 4;
+    if (hlit > 286 || hdist > 30) { status = INF_BAD_HEADER; return 0; }
+    // code-length code: 19 lengths of 3 bits, kept in a register (3 bits each)
+    uint64_t cl_lens = 0;
+    {
+        const uint8_t ord[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        for (uint32_t i = 0; i < hclen; ++i) {
+            br.refill();
+            const uint64_t l = br.bits(3);
+            cl_lens |= l << (3 * ord[i]);
+        }
+    }
+    // canonical data for the CL code, entirely in registers: 7 bounds, 19 symbols of 5 bits in 2 regs
+    uint32_t cl_count[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) cl_count[l] = 0;
+    for (uint32_t sy = 0; sy < 19; ++sy) {
+        const uint32_t l = (uint32_t)(cl_lens >> (3 * sy)) & 7;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cl_count[k] += (l == (uint32_t)k) ? 1u : 0u;
+    }
+    uint32_t cl_lim[8], cl_base[8], cl_off[8];
+    {
+        int left = 1; uint32_t code = 0, offs = 0;
+        cl_lim[0] = 0; cl_base[0] = 0; cl_off[0] = 0;
+#pragma unroll
+        for (int l = 1; l <= 7; ++l) {
+            left <<= 1; left -= (int)cl_count[l];
+            cl_base[l] = (offs - code) & 0xff; cl_off[l] = offs;
+            code += cl_count[l]; offs += cl_count[l];
+            cl_lim[l] = code << (7 - l);
+            code <<= 1;
+        }
+        if (left != 0) { status = left < 0 ? INF_OVERSUBSCRIBED : INF_INCOMPLETE; return 0; }
+    }
+    uint64_t cl_sym_lo = 0, cl_sym_hi = 0;  // symbol list, 5 bits per slot, slots 0..11 in lo, 12..18 in hi
+    for (uint32_t sy = 0; sy < 19; ++sy) {
+        const uint32_t l = (uint32_t)(cl_lens >> (3 * sy)) & 7;
         if (l) {
             uint32_t slot = 0;
 #pragma unroll
-            for (int k = 1; k < 16; ++k) if (l == (uint32_t)k) { slot = offs_of[k]; offs_of[k] = slot + 1; }
-            if (kind == 0) T.set_ll_sym(slot, i); else T.set_d_sym(slot, i);
+            for (int k = 1; k < 8; ++k) if (l == (uint32_t)k) { slot = cl_off[k]; cl_off[k] = slot + 1; }
+            if (slot < 12) cl_sym_lo |= (uint64_t)sy << (5 * slot); else cl_sym_hi |= (uint64_t)sy << (5 * (slot - 12));
         }
     }
-    return INF_OK;
+    // read hlit + hdist code lengths; they are buffered 8 per word (literal/length words 0.., distance words 36..)
+    const uint32_t n = hlit + hdist;
+    uint32_t i = 0, prev = 0;
+    uint32_t acc = 0, acc_n = 0, acc_w = 0;       // 4-bit lengths being packed, how many, destination word
+    uint32_t eob_len = 0;
+    while (i < n) {
+        br.refill();
+        const uint32_t v7 = rev15(br.peek(7)) >> 8;   // 7 bits MSB-first
+        uint32_t l = 1;
+#pragma unroll
+        for (int k = 1; k <= 7; ++k) l += (v7 >= cl_lim[k]) ? 1u : 0u;
+        if (l > 7) { status = INF_BAD_CODE; return 0; }
+        uint32_t base = 0;
+#pragma unroll
+        for (int k = 1; k <= 7; ++k) if (l == (uint32_t)k) base = cl_base[k];
+        const uint32_t slot = (base + (v7 >> (7 - l))) & 0xff;
+        const uint32_t sym = slot < 12 ? (uint32_t)(cl_sym_lo >> (5 * slot)) & 31 : (uint32_t)(cl_sym_hi >> (5 * (slot - 12))) & 31;
+        br.drop(l);
+        uint32_t rep = 1, val = sym;
+        if (sym >= 16) {
+            if (sym == 16) { if (i == 0) { status = INF_BAD_REPEAT; return 0; } val = prev; rep = 3 + br.bits(2); }
+            else if (sym == 17) { val = 0; rep = 3 + br.bits(3); }
+            else { val = 0; rep = 11 + br.bits(7); }
+            if (i + rep > n) { status = INF_BAD_REPEAT; return 0; }
+        }
+        prev = val;
+        for (uint32_t k = 0; k < rep; ++k) {
+            if (i == 256) eob_len = val;
+            acc |= val << (4 * acc_n); ++acc_n; ++i;
+            if (acc_n == 8 || i == hlit || i == n) {           // word full, or end of the literal/length or distance run
+                T.set_len_word(acc_w, acc);
+                acc = 0; acc_n = 0;
+                acc_w = (i == hlit) ? kLenWordsLL : acc_w + 1;   // the distance lengths restart on their own word
+            }
+        }
+    }
+    if (eob_len == 0) { status = INF_NO_EOB; return 0; }
+    status = build_code(T, 0, hlit, 0, LL);
+    if (status != INF_OK) return 0;
+    status = build_code(T, kLenWordsLL, hdist, 1, DD);
+    return status == INF_OK ? 1 : 0;
 }
 
-// Copy a match inside the output (out[o .. o+len) = out[o-dist ..]), byte-exact LZ77 semantics.
-// The chain load -> store -> dependent load is what a lone lane spends its life on, so copies move 16 bytes per
-// memory round trip and, when the distance allows, 64 bytes per round trip (four independent loads in flight).
-// `slack` = bytes this lane may scribble past o+len inside its own member (they are rewritten by later symbols
-// before anything reads them); with less than 16 bytes of slack the exact tail path is used.
-RGX_HD void lz_copy(uint8_t *out, uint32_t o, uint32_t dist, uint32_t len, uint32_t slack) {
-    uint8_t *d = out + o;
-    const uint8_t *s = d - dist;
-    if (dist < 16) {
-        // grow the period to D = k*dist >= 16 by writing the first D bytes narrowly, then fall into the wide path
-        uint32_t D = dist;
-        while (D < 16) D += dist;
-        uint32_t n0 = len < D ? len : D;
-        if (dist >= 8) {
-            uint32_t n = n0;
-            while (n >= 8) { st64(d, ld64(s)); d += 8; s += 8; n -= 8; }
-            while (n) { *d++ = *s++; --n; }
-        } else {
-            uint64_t pat = 0;
-            for (uint32_t k = 0; k < dist; ++k) pat |= (uint64_t)s[k] << (8 * k);
-            const uint32_t sh = 8 * (dist - 1);
-            for (uint32_t n = n0; n; --n) { uint8_t b = (uint8_t)pat; *d++ = b; pat = (pat >> 8) | ((uint64_t)b << sh); }
-        }
-        len -= n0;
-        if (!len) return;
-        dist = D; s = d - dist;
-    }
-    if (dist >= 64) {
-        while (len >= 64) {
-            u32x4 a = ld128(s), b = ld128(s + 16), c = ld128(s + 32), e = ld128(s + 48);
-            st128(d, a); st128(d + 16, b); st128(d + 32, c); st128(d + 48, e);
-            d += 64; s += 64; len -= 64;
-        }
-    }
-    if (slack >= 16) {
-        // whole 16-byte chunks, overshooting by at most 15 bytes
-        for (uint32_t n = 0; n < len; n += 16) { st128(d + n, ld128(s + n)); }
-        return;
-    }
-    while (len >= 16) { st128(d, ld128(s)); d += 16; s += 16; len -= 16; }
-    if (len) {
-        // exact tail from two 8-byte loads (no dependent byte loop)
-        if (len >= 8) { st64(d, ld64(s)); d += 8; s += 8; len -= 8; }
-        if (len) {
-            uint64_t v = 0;
-            for (uint32_t k = 0; k < len; ++k) v |= (uint64_t)s[k] << (8 * k);
-            if (len & 4) { st32(d, (uint32_t)v); d += 4; v >>= 32; }
-            if (len & 2) { st16(d, (uint16_t)v); d += 2; v >>= 16; }
-            if (len & 1) *d = (uint8_t)v;
-        }
-    }
+// store the low `len` (< 16) bytes of v at d, exactly
+RGX_HD void store_tail16(uint8_t *d, u32x4 v, uint32_t len) {
+    uint64_t lo = (uint64_t)v[0] | (uint64_t)v[1] << 32, hi = (uint64_t)v[2] | (uint64_t)v[3] << 32;
+    if (len & 8) { st64(d, lo); d += 8; lo = hi; }
+    if (len & 4) { st32(d, (uint32_t)lo); d += 4; lo >>= 32; }
+    if (len & 2) { st16(d, (uint16_t)lo); d += 2; lo >>= 16; }
+    if (len & 1) *d = (uint8_t)lo;
 }
+
+constexpr uint32_t kCopyBatch = 128;   // bytes moved per memory round trip (8 independent 16-byte loads in flight)
 
 // Inflate one raw-DEFLATE stream. Returns an InflateStatus; *out_len = bytes produced.
+//
+// The symbol loop is a per-lane state machine whose every trip does AT MOST ONE dependent memory round trip:
+//   A. issue the loads of this lane's pending LZ77 copy (up to kCopyBatch bytes whose sources are already written),
+//   B. while they are in flight, decode the lane's next symbol if the copy ends with this batch,
+//   C. store the copied bytes, then the decoded literal, or arm the next copy.
+// In a 64-lane wavefront every lane is at a different point of a different member; a lane in the middle of a long
+// match therefore no longer stalls the 63 others for a whole copy loop -- each trip costs one round trip for all.
 template <class Tab>
 RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len, Tab &T) {
     BitReader br; br.init(in, in_len);
     uint32_t o = 0;
     int status = INF_OK;
     uint32_t last = 0;
-    while (!last && status == INF_OK) {
-        br.refill();
-        last = br.bits(1);
-        uint32_t btype = br.bits(2);
-        if (btype == 0) {
-            // stored: skip to byte boundary, LEN, NLEN, raw bytes
-            br.drop(br.cnt & 7);
-            br.refill();
-            uint32_t len = br.bits(16);
-            br.refill();
-            uint32_t nlen = br.bits(16);
-            if ((len ^ 0xffff) != nlen) { status = INF_BAD_STORED; break; }
-            if (o + len > out_cap) { status = INF_OUT_OVERFLOW; break; }
-            // bytes still buffered come first
-            while (len && br.cnt >= 8) { out[o++] = (uint8_t)br.bits(8); --len; }
-            if (len) {
-                const uint8_t *src = br.byte_ptr();   // cnt == 0 here: the prefetched word starts at the next payload byte
-                if ((uint64_t)(src - in) + len > in_len) { status = INF_IN_OVERRUN; break; }
-                for (uint32_t k = 0; k < len; ++k) out[o + k] = src[k];
-                o += len; br.restart_at(src + len);
-            }
-            continue;
-        }
-        if (btype == 3) { status = INF_BAD_BTYPE; break; }
+    bool in_symbols = false, done = false;
+    uint32_t pend_len = 0, pend_dist = 0;
+    Code LL, DD;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { LL.c[k] = 0; DD.c[k] = 0; }
 
-        Bounds LL, DD;
-        if (btype == 1) {
-            // fixed code (RFC 1951 3.2.6): 288 literal/length lengths, 30 distance codes of length 5
-            for (uint32_t i = 0; i < 288; ++i) T.set_len(i, i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
-            for (uint32_t i = 0; i < 32; ++i) T.set_len(288 + i, 5);   // 30,31 never legal: rejected at decode
-            build_code(T, 0, 288, 0, LL);
-            build_code(T, 288, 32, 1, DD);
-        } else {
-            br.refill();
-            uint32_t hlit = br.bits(5) + 257, hdist = br.bits(5) + 1, hclen = br.bits(4) + 4;
-            if (hlit > 286 || hdist > 30) { status = INF_BAD_HEADER; break; }
-            // code-length code: 19 lengths of 3 bits, kept in a register (3 bits each)
-            uint64_t cl_lens = 0;
-            {
-                const uint8_t ord[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-                for (uint32_t i = 0; i < hclen; ++i) {
-                    br.refill();
-                    uint64_t l = br.bits(3);
-                    cl_lens |= l << (3 * ord[i]);
-                }
-            }
-            // canonical data for the CL code, entirely in registers: 7 bounds, 19 symbols of 5 bits in 2 regs
-            uint32_t cl_count[8];
-#pragma unroll
-            for (int l = 0; l < 8; ++l) cl_count[l] = 0;
-            for (uint32_t s = 0; s < 19; ++s) {
-                uint32_t l = (uint32_t)(cl_lens >> (3 * s)) & 7;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) cl_count[k] += (l == (uint32_t)k) ? 1u : 0u;
-            }
-            uint32_t cl_lim[8], cl_base[8], cl_off[8];
-            {
-                int left = 1; uint32_t code = 0, offs = 0;
-                cl_lim[0] = 0; cl_base[0] = 0; cl_off[0] = 0;
-#pragma unroll
-                for (int l = 1; l <= 7; ++l) {
-                    left <<= 1; left -= (int)cl_count[l];
-                    cl_base[l] = (offs - code) & 0xff; cl_off[l] = offs;
-                    code += cl_count[l]; offs += cl_count[l];
-                    cl_lim[l] = code << (7 - l);
-                    code <<= 1;
-                }
-                if (left != 0) { status = left < 0 ? INF_OVERSUBSCRIBED : INF_INCOMPLETE; break; }
-            }
-            uint64_t cl_sym_lo = 0, cl_sym_hi = 0;  // symbol list, 5 bits per slot, slots 0..11 in lo, 12..18 in hi
-            for (uint32_t s = 0; s < 19; ++s) {
-                uint32_t l = (uint32_t)(cl_lens >> (3 * s)) & 7;
-                if (l) {
-                    uint32_t slot = 0;
-#pragma unroll
-                    for (int k = 1; k < 8; ++k) if (l == (uint32_t)k) { slot = cl_off[k]; cl_off[k] = slot + 1; }
-                    if (slot < 12) cl_sym_lo |= (uint64_t)s << (5 * slot); else cl_sym_hi |= (uint64_t)s << (5 * (slot - 12));
-                }
-            }
-            // read hlit + hdist code lengths
-            uint32_t n = hlit + hdist, i = 0, prev = 0;
-            while (i < n) {
-                br.refill();
-                uint32_t v7 = rev15(br.peek(7)) >> 8;   // 7 bits MSB-first
-                uint32_t l = 1;
-#pragma unroll
-                for (int k = 1; k <= 7; ++k) l += (v7 >= cl_lim[k]) ? 1u : 0u;
-                if (l > 7) { status = INF_BAD_CODE; break; }
-                uint32_t base = 0;
-#pragma unroll
-                for (int k = 1; k <= 7; ++k) if (l == (uint32_t)k) base = cl_base[k];
-                uint32_t slot = (base + (v7 >> (7 - l))) & 0xff;
-                uint32_t sym = slot < 12 ? (uint32_t)(cl_sym_lo >> (5 * slot)) & 31 : (uint32_t)(cl_sym_hi >> (5 * (slot - 12))) & 31;
+    for (;;) {
+        // ---- A: loads of the pending copy -----------------------------------------------------------------------
+        const bool copying = pend_len != 0;
+        uint32_t n = 0;
+        u32x4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0, v4 = v0, v5 = v0, v6 = v0, v7 = v0;
+        if (copying) {
+            n = pend_len < kCopyBatch ? pend_len : kCopyBatch;
+            if (pend_dist < n) n = pend_dist;                       // pend_dist >= 16 always: sources of the batch are final
+            const uint8_t *s = out + o - pend_dist;
+            v0 = ld128(s);
+            if (n > 16) v1 = ld128(s + 16);
+            if (n > 32) v2 = ld128(s + 32);
+            if (n > 48) v3 = ld128(s + 48);
+            if (n > 64) v4 = ld128(s + 64);
+            if (n > 80) v5 = ld128(s + 80);
+            if (n > 96) v6 = ld128(s + 96);
+            if (n > 112) v7 = ld128(s + 112);
+        }
+        // ---- B: next symbol (only when the copy, if any, ends with this batch) -------------------------------------
+        uint32_t lit = 256, new_len = 0, new_dist = 0;
+        if (pend_len == n && !done) {
+            if (in_symbols) {
+                br.refill();                                   // >= 33 bits: 15 (code) + 5 (extra) fit
+                const uint32_t v = rev15(br.peek(15));
+                uint32_t l;
+                const uint32_t idx = code_lookup(LL, v, l);
+                if (l == 0 || idx >= 288) { status = INF_BAD_CODE; break; }
+                const uint32_t sym = T.get_ll_sym(idx);
                 br.drop(l);
-                if (sym < 16) { T.set_len(i++, sym); prev = sym; }
-                else {
-                    uint32_t rep, val;
-                    if (sym == 16) { if (i == 0) { status = INF_BAD_REPEAT; break; } val = prev; rep = 3 + br.bits(2); }
-                    else if (sym == 17) { val = 0; rep = 3 + br.bits(3); }
-                    else { val = 0; rep = 11 + br.bits(7); }
-                    if (i + rep > n) { status = INF_BAD_REPEAT; break; }
-                    for (uint32_t k = 0; k < rep; ++k) T.set_len(i++, val);
-                    prev = val;
+                if (sym < 256) lit = sym;
+                else if (sym == 256) {
+                    in_symbols = false;
+                    if (br.overran()) { status = INF_IN_OVERRUN; break; }
+                    if (last) done = true;
+                } else {
+                    const uint32_t c = sym - 257;
+                    if (c > 28) { status = INF_BAD_CODE; break; }
+                    if (c < 8) new_len = 3 + c;
+                    else if (c == 28) new_len = 258;
+                    else { const uint32_t e = (c >> 2) - 1; new_len = ((4 + (c & 3)) << e) + 3 + br.bits(e); }
+                    br.refill();                               // 15 (code) + 13 (extra)
+                    const uint32_t dv = rev15(br.peek(15));
+                    uint32_t dl;
+                    const uint32_t didx = code_lookup(DD, dv, dl);
+                    if (dl == 0 || didx >= 32) { status = INF_BAD_CODE; break; }
+                    const uint32_t dsym = T.get_d_sym(didx);
+                    br.drop(dl);
+                    if (dsym > 29) { status = INF_BAD_CODE; break; }
+                    if (dsym < 4) new_dist = 1 + dsym;
+                    else { const uint32_t e = (dsym >> 1) - 1; new_dist = ((2 + (dsym & 1)) << e) + 1 + br.bits(e); }
+                }
+            } else if (!copying) {
+                // block header (rare, heavy): only with no copy in flight, so that it may write output itself
+                const int r = block_header(br, T, LL, DD, in, in_len, out, o, out_cap, last, status);
+                if (status != INF_OK) break;
+                if (r) in_symbols = true;
+                else if (last) { if (br.overran()) { status = INF_IN_OVERRUN; break; } done = true; }
+            }
+        }
+        // ---- C: stores -----------------------------------------------------------------------------------------------
+        if (copying) {
+            uint8_t *d = out + o;
+            const uint32_t slack = out_cap - (o + n);
+            if (slack >= 16) {                                     // whole chunks, scribbling < 16 bytes past the copy
+                st128(d, v0);
+                if (n > 16) st128(d + 16, v1);
+                if (n > 32) st128(d + 32, v2);
+                if (n > 48) st128(d + 48, v3);
+                if (n > 64) st128(d + 64, v4);
+                if (n > 80) st128(d + 80, v5);
+                if (n > 96) st128(d + 96, v6);
+                if (n > 112) st128(d + 112, v7);
+            } else {                                               // end of the member: exact
+                const u32x4 vv[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t lo = 16u * (uint32_t)k;
+                    if (n >= lo + 16) st128(d + lo, vv[k]);
+                    else if (n > lo) store_tail16(d + lo, vv[k], n - lo);
                 }
             }
-            if (status != INF_OK) break;
-            if (T.get_len(256) == 0) { status = INF_NO_EOB; break; }
-            // distance lengths sit right after the hlit literal/length lengths
-            status = build_code(T, 0, hlit, 0, LL);
-            if (status != INF_OK) break;
-            status = build_code(T, hlit, hdist, 1, DD);
-            if (status != INF_OK) break;
+            o += n; pend_len -= n;
         }
-
-        // ---- symbol loop -------------------------------------------------------------------------------
-        for (;;) {
-            br.refill();                                   // >= 32 bits: 15 (code) + 5 (extra) fit
-            uint32_t v = rev15(br.peek(15));
-            uint32_t l = code_len(LL, v);
-            if (l > 15) { status = INF_BAD_CODE; break; }
-            uint32_t idx = (T.get_ll_base(l) + (v >> (15 - l))) & 0xffff;
-            if (idx >= 288) { status = INF_BAD_CODE; break; }
-            uint32_t sym = T.get_ll_sym(idx);
-            br.drop(l);
-            if (sym < 256) {
-                if (o >= out_cap) { status = INF_OUT_OVERFLOW; break; }
-                out[o++] = (uint8_t)sym;
-                continue;
+        if (lit < 256) {
+            if (o >= out_cap) { status = INF_OUT_OVERFLOW; break; }
+            out[o++] = (uint8_t)lit;
+        } else if (new_len) {
+            if (new_dist > o) { status = INF_BAD_DIST; break; }
+            if (o + new_len > out_cap) { status = INF_OUT_OVERFLOW; break; }
+            if (new_dist < 16) {
+                // short period: write the first D = k*dist >= 16 bytes narrowly, continue as a copy of distance D
+                uint32_t D = new_dist;
+                while (D < 16) D += new_dist;
+                const uint32_t n0 = new_len < D ? new_len : D;
+                uint8_t *d = out + o;
+                const uint8_t *s = d - new_dist;
+                if (new_dist >= 8) {
+                    uint32_t m = n0;
+                    while (m >= 8) { st64(d, ld64(s)); d += 8; s += 8; m -= 8; }
+                    while (m) { *d++ = *s++; --m; }
+                } else {
+                    uint64_t pat = 0;
+                    for (uint32_t k = 0; k < new_dist; ++k) pat |= (uint64_t)s[k] << (8 * k);
+                    const uint32_t sh = 8 * (new_dist - 1);
+                    for (uint32_t m = n0; m; --m) { const uint8_t b = (uint8_t)pat; *d++ = b; pat = (pat >> 8) | ((uint64_t)b << sh); }
+                }
+                o += n0; new_len -= n0; new_dist = D;
             }
-            if (sym == 256) break;
-            uint32_t c = sym - 257;
-            if (c > 28) { status = INF_BAD_CODE; break; }
-            uint32_t len;
-            if (c < 8) len = 3 + c;
-            else if (c == 28) len = 258;
-            else { uint32_t e = (c >> 2) - 1; len = ((4 + (c & 3)) << e) + 3 + br.bits(e); }
-            br.refill();                                   // 15 (code) + 13 (extra)
-            uint32_t dv = rev15(br.peek(15));
-            uint32_t dl = code_len(DD, dv);
-            if (dl > 15) { status = INF_BAD_CODE; break; }
-            uint32_t didx = (T.get_d_base(dl) + (dv >> (15 - dl))) & 0xffff;
-            if (didx >= 32) { status = INF_BAD_CODE; break; }
-            uint32_t dsym = T.get_d_sym(didx);
-            br.drop(dl);
-            if (dsym > 29) { status = INF_BAD_CODE; break; }
-            uint32_t dist;
-            if (dsym < 4) dist = 1 + dsym;
-            else { uint32_t e = (dsym >> 1) - 1; dist = ((2 + (dsym & 1)) << e) + 1 + br.bits(e); }
-            if (dist > o) { status = INF_BAD_DIST; break; }
-            if (o + len > out_cap) { status = INF_OUT_OVERFLOW; break; }
-            lz_copy(out, o, dist, len, out_cap - (o + len));
-            o += len;
+            pend_len = new_len; pend_dist = new_dist;
         }
-        if (status == INF_OK && br.overran()) status = INF_IN_OVERRUN;
+        if (done && pend_len == 0) break;
     }
     *out_len = o;
     return status;

@@ -11,7 +11,9 @@ constexpr uint64_t kChainEnd = ~0ull;   // "the record chain ended before this p
 
 // ---- a1: BGZF inflate (one lane per member) -----------------------------------------------------------
 // member m writes its bytes at arena + (members[m].upos - upos_bias)
-void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias,
+// len_scratch: inflate_scratch_bytes(n_members) bytes of device memory (code-length scratch of the block headers)
+size_t inflate_scratch_bytes(uint32_t n_members);
+void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
                     uint32_t *status /* [0]=first bad member (min), [1]=its status */, hipStream_t stream);
 
 // ---- a1 (container): BGZF member discovery on the device --------------------------------------------------

@@ -28,53 +28,52 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 // =====================================================================================================
 // a1. BGZF inflate: ONE LANE PER MEMBER (64 members per wavefront, one wave per workgroup)
 // =====================================================================================================
-// Per-lane Huffman scratch in LDS, lane-interleaved so that lane L only ever touches bank L % 32:
-//   ll_sym  : 288 x u16  -> dword (i>>1)*64 + L, half i&1      (144 dwords / lane)
-//   d_sym   :  32 x u8   -> dword (i>>2)*64 + L, byte i&3      (  8 dwords / lane)
-//   ll_base :  16 x u16, d_base : 16 x u16                     ( 16 dwords / lane)
-//   lens    : 320 x u4   -> dword (i>>3)*64 + L, nibble i&7    ( 40 dwords / lane)
-// 208 dwords * 64 lanes * 4 B = 53,248 B per wave  ->  3 waves (192 members in flight) per CU of 160 KiB.
-constexpr uint32_t kLdsLLSym = 0, kLdsDSym = 144, kLdsLLBase = 152, kLdsDBase = 160, kLdsLens = 168, kLdsDwordsPerLane = 208;
+// Per-lane Huffman symbol lists in LDS, lane-interleaved so that lane L only ever touches bank L % 32, bit-packed:
+//   ll_sym : 288 x 9 bits -> dwords  0..80   (symbol i at bit 9*i)
+//   d_sym  :  32 x 5 bits -> dwords 81..85   (symbol i at bit 5*i)      + 1 pad dword
+// 87 dwords * 64 lanes * 4 B = 22,272 B per wave -> 7 waves (448 members in flight) per CU of 160 KiB, i.e. two waves on
+// three of the four SIMDs: one wave's memory round trip hides behind the other's decode ALU work.
+// The canonical codes themselves (bounds, lengths, list offsets) are 2 x 16 REGISTER words (inflate_core.h Code), and the
+// code-length scratch that only a block header needs lives in a global lane-interleaved buffer (40 dwords per lane).
+constexpr uint32_t kLdsLL = 0, kLdsD = 81, kLdsDwordsPerLane = 87;
 constexpr uint32_t kInflateLdsBytes = kLdsDwordsPerLane * 64 * 4;
 
 struct LdsTab {
-    uint32_t *base;   // LDS, already offset by lane
+    uint32_t *base;       // LDS, already offset by lane
+    uint32_t *scratch;    // global, already offset by global lane
+    uint32_t stride;      // lanes in the grid (dword stride of the scratch)
     __device__ __forceinline__ uint32_t rd(uint32_t dw) const { return base[dw * 64]; }
     __device__ __forceinline__ void wr(uint32_t dw, uint32_t v) { base[dw * 64] = v; }
-    __device__ __forceinline__ uint32_t get_ll_sym(uint32_t i) const { return (rd(kLdsLLSym + (i >> 1)) >> ((i & 1) * 16)) & 0xffff; }
-    __device__ __forceinline__ void set_ll_sym(uint32_t i, uint32_t v) {
-        uint32_t dw = kLdsLLSym + (i >> 1), sh = (i & 1) * 16, old = rd(dw);
-        wr(dw, (old & ~(0xffffu << sh)) | (v << sh));
+    __device__ __forceinline__ uint32_t get_bits(uint32_t dw0, uint32_t bit, uint32_t width) const {
+        const uint32_t dw = dw0 + (bit >> 5), sh = bit & 31;
+        const uint64_t w = (uint64_t)rd(dw) | (uint64_t)rd(dw + 1) << 32;
+        return (uint32_t)(w >> sh) & ((1u << width) - 1u);
     }
-    __device__ __forceinline__ uint32_t get_d_sym(uint32_t i) const { return (rd(kLdsDSym + (i >> 2)) >> ((i & 3) * 8)) & 0xff; }
-    __device__ __forceinline__ void set_d_sym(uint32_t i, uint32_t v) {
-        uint32_t dw = kLdsDSym + (i >> 2), sh = (i & 3) * 8, old = rd(dw);
-        wr(dw, (old & ~(0xffu << sh)) | (v << sh));
+    __device__ __forceinline__ void set_bits(uint32_t dw0, uint32_t bit, uint32_t width, uint32_t v) {
+        const uint32_t dw = dw0 + (bit >> 5), sh = bit & 31;
+        uint64_t w = (uint64_t)rd(dw) | (uint64_t)rd(dw + 1) << 32;
+        const uint64_t m = (uint64_t)((1u << width) - 1u) << sh;
+        w = (w & ~m) | ((uint64_t)v << sh);
+        wr(dw, (uint32_t)w);
+        if (sh + width > 32) wr(dw + 1, (uint32_t)(w >> 32));
     }
-    __device__ __forceinline__ uint32_t get_ll_base(uint32_t l) const { return (rd(kLdsLLBase + (l >> 1)) >> ((l & 1) * 16)) & 0xffff; }
-    __device__ __forceinline__ void set_ll_base(uint32_t l, uint32_t v) {
-        uint32_t dw = kLdsLLBase + (l >> 1), sh = (l & 1) * 16, old = rd(dw);
-        wr(dw, (old & ~(0xffffu << sh)) | (v << sh));
-    }
-    __device__ __forceinline__ uint32_t get_d_base(uint32_t l) const { return (rd(kLdsDBase + (l >> 1)) >> ((l & 1) * 16)) & 0xffff; }
-    __device__ __forceinline__ void set_d_base(uint32_t l, uint32_t v) {
-        uint32_t dw = kLdsDBase + (l >> 1), sh = (l & 1) * 16, old = rd(dw);
-        wr(dw, (old & ~(0xffffu << sh)) | (v << sh));
-    }
-    __device__ __forceinline__ uint32_t get_len(uint32_t i) const { return (rd(kLdsLens + (i >> 3)) >> ((i & 7) * 4)) & 0xf; }
-    __device__ __forceinline__ void set_len(uint32_t i, uint32_t v) {
-        uint32_t dw = kLdsLens + (i >> 3), sh = (i & 7) * 4, old = rd(dw);
-        wr(dw, (old & ~(0xfu << sh)) | (v << sh));
-    }
+    __device__ __forceinline__ uint32_t get_ll_sym(uint32_t i) const { return get_bits(kLdsLL, i * 9, 9); }
+    __device__ __forceinline__ void set_ll_sym(uint32_t i, uint32_t v) { set_bits(kLdsLL, i * 9, 9, v); }
+    __device__ __forceinline__ uint32_t get_d_sym(uint32_t i) const { return get_bits(kLdsD, i * 5, 5); }
+    __device__ __forceinline__ void set_d_sym(uint32_t i, uint32_t v) { set_bits(kLdsD, i * 5, 5, v); }
+    __device__ __forceinline__ uint32_t get_len_word(uint32_t w) const { return scratch[(size_t)w * stride]; }
+    __device__ __forceinline__ void set_len_word(uint32_t w, uint32_t v) { scratch[(size_t)w * stride] = v; }
+    __device__ __forceinline__ void clear_syms() {}
 };
 
 __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
-                                                uint32_t n_members, uint8_t *__restrict__ arena, uint64_t upos_bias, uint32_t *status) {
+                                                uint32_t n_members, uint8_t *__restrict__ arena, uint64_t upos_bias, uint32_t *len_scratch,
+                                                uint32_t *status) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t m = blockIdx.x * 64 + threadIdx.x;
     if (m >= n_members) return;
     Member mb = members[m];
-    LdsTab T{lds + threadIdx.x};
+    LdsTab T{lds + threadIdx.x, len_scratch + m, gridDim.x * 64};
     uint32_t out_len = 0;
     int st = inflate_raw(comp + mb.cpos, mb.clen, arena + (mb.upos - upos_bias), mb.isize, &out_len, T);
     if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
@@ -84,8 +83,10 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
     }
 }
 
-void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *status,
-                    hipStream_t stream) {
+size_t inflate_scratch_bytes(uint32_t n_members) { return (size_t)((n_members + 63) / 64) * 64 * 40 * 4; }
+
+void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
+                    uint32_t *status, hipStream_t stream) {
     if (!n_members) return;
     static bool attr_set = false;
     if (!attr_set) {
@@ -93,7 +94,7 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
         attr_set = true;
     }
     uint32_t blocks = (n_members + 63) / 64;
-    hipLaunchKernelGGL(k_inflate, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, status);
+    hipLaunchKernelGGL(k_inflate, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status);
 }
 
 // =====================================================================================================
