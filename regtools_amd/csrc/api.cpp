@@ -286,6 +286,7 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
 
     // -- member range of this call ---------------------------------------------------------------------------------------------
     uint32_t m_lo = cut_lo ? h_sc[25] : 0;
+    if (m_lo <= 4) m_lo = 0;        // keep the file head (BAM header) in the same launch: a lone lane needs milliseconds per member
     uint32_t m_hi = stop;                                                  // exclusive
     if (cut_hi != UINT64_MAX) {
         const uint32_t mh = h_sc[26];
@@ -418,15 +419,13 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     mark("framing (sync)");
 
     // -- decode + count -----------------------------------------------------------------------------------------------------
-    DevBuf &b_rec = c->buf("rec"), &b_soa = c->buf("soa");
+    DevBuf &b_soa = c->buf("soa");
     ReadSoA soa; memset(&soa, 0, sizeof soa);
     uint32_t *ev_base = nullptr, *long_list = nullptr;
     uint32_t n_events = 0, n_long = 0;
     uint64_t n_iterated = 0;
     if (n_rec) {
         const size_t R = n_rec;
-        HIP_TRY(b_rec.ensure(R * 8 + 64));
-        launch_seg_fill(arena, pos0, lim, n_seg, seg_start[cur], seg_base, b_rec.as<uint64_t>(), st);
         HIP_TRY(b_soa.ensure(R * (4 + 4 + 4 + 8 + 1 + 4 + 4 + 4) + 256));
         uint8_t *q = b_soa.as<uint8_t>();
         soa.cig_off = (uint64_t *)q; q += R * 8;
@@ -434,12 +433,17 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
         soa.n_ev = (uint32_t *)q; q += R * 4; ev_base = (uint32_t *)q; q += R * 4; long_list = (uint32_t *)q; q += R * 4;
         soa.strand = q;
         HIP_TRY(b_tmp.ensure(scan_tmp_words(n_rec) * 4 + 64));
-        launch_decode(arena, b_rec.as<uint64_t>(), n_rec, cfg, soa, long_list, d_sc + 5, (unsigned long long *)(d_sc + 8), st);
+        // per-segment outputs (no hot atomics): reuse the spare segment arrays as seg_iter / seg_long
+        uint32_t *seg_iter = seg_cnt[cur ^ 1], *seg_long = (uint32_t *)seg_start[cur ^ 1], *seg_long_base = (uint32_t *)seg_exit[cur ^ 1];
+        launch_decode_seg(arena, pos0, lim, n_seg, seg_start[cur], seg_base, seg_cnt[cur], cfg, soa, seg_iter, seg_long, st);
         launch_scan_u32(soa.n_ev, ev_base, n_rec, d_sc + 4, b_tmp.as<uint32_t>(), st);
+        launch_scan_u32(seg_iter, seg_iter, n_seg, d_sc + 8, b_tmp.as<uint32_t>(), st);
+        launch_scan_u32(seg_long, seg_long_base, n_seg, d_sc + 5, b_tmp.as<uint32_t>(), st);
         HIP_TRY(hipMemcpyAsync(h_sc + 4, d_sc + 4, 24, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         n_events = h_sc[4]; n_long = h_sc[5];
-        memcpy(&n_iterated, h_sc + 8, 8);
+        n_iterated = h_sc[8];
+        if (n_long) launch_long_fill(n_seg, seg_base, seg_cnt[cur], seg_long_base, cfg, soa, long_list, st);
     }
     HIP_TRY(hipEventRecord(c->ev[4], st));
     mark("decode+count (sync)");
@@ -459,7 +463,7 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
         ev.tid = (uint32_t *)q; q += E * 4; ev.start = (uint32_t *)q; q += E * 4; ev.ilen_cls = (uint32_t *)q; q += E * 4;
         ev.ts = (uint32_t *)q; q += E * 4; ev.te = (uint32_t *)q; q += E * 4; ev.strand = q;
         launch_emit_short(arena, n_rec, cfg, soa, ev_base, ev, st);
-        launch_emit_long(arena, long_list, d_sc + 5, n_long, cfg, soa, ev_base, ev, st);
+        launch_emit_long(arena, long_list, n_long, cfg, soa, ev_base, ev, st);
     }
     HIP_TRY(hipEventRecord(c->ev[5], st));
 

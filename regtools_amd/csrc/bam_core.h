@@ -74,7 +74,7 @@ RGX_HD char strand_from_tag(const uint8_t *aux, const uint8_t *end, uint8_t t0, 
             case 'Z': case 'H': { while (s < end && *s) ++s; sz = 1; break; }
             case 'B': {
                 if (s + 5 > end) return '?';
-                uint8_t st = *s++; uint32_t n = ld32(s); s += 4;
+                uint8_t st = *s++; uint32_t n = (uint32_t)s[0] | (uint32_t)s[1] << 8 | (uint32_t)s[2] << 16 | (uint32_t)s[3] << 24; s += 4;   // bytes: s may point into LDS
                 uint32_t es = (st == 'c' || st == 'C' || st == 'A') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : (st == 'd') ? 8 : 0;
                 if ((uint64_t)es * n > (uint64_t)(end - s)) return '?';
                 sz = es * n; break;

@@ -54,8 +54,6 @@ void launch_seg_verify(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32
                        const uint64_t *seg_start_in, const uint64_t *seg_exit_in, const uint32_t *seg_cnt_in,
                        uint64_t *seg_start_out, uint64_t *seg_exit_out, uint32_t *seg_cnt_out,
                        uint32_t *changed, hipStream_t stream);
-void launch_seg_fill(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, const uint64_t *seg_start,
-                     const uint32_t *seg_base, uint64_t *rec_off, hipStream_t stream);
 
 // ---- a2/a3/a5/a6: SoA decode + per-read event count ---------------------------------------------------------
 struct ReadSoA {
@@ -74,8 +72,13 @@ struct ExtractCfg {
     int32_t  region_beg, region_end;
     uint32_t long_threshold;       // reads with more CIGAR ops than this go to the wave-per-read kernel
 };
-void launch_decode(const uint8_t *arena, const uint64_t *rec_off, uint32_t n_rec, ExtractCfg cfg, ReadSoA soa,
-                   uint32_t *long_list, uint32_t *long_count, unsigned long long *n_iterated, hipStream_t stream);
+
+// one wave per framing segment, segment bytes staged through LDS (replaces launch_seg_fill + launch_decode on the hot path)
+// seg_iter[s] = records of segment s that pass the region filter; seg_long[s] = its reads for the wave-per-read kernel
+void launch_decode_seg(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, const uint64_t *seg_start, const uint32_t *seg_base,
+                       const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, hipStream_t stream);
+void launch_long_fill(uint32_t n_seg, const uint32_t *seg_base, const uint32_t *seg_cnt, const uint32_t *seg_long_base, ExtractCfg cfg, ReadSoA soa,
+                      uint32_t *long_list, hipStream_t stream);
 
 // ---- a4: CIGAR scan + junction emit ---------------------------------------------------------------------------
 struct EventSoA {
@@ -85,7 +88,7 @@ struct EventSoA {
 };
 void launch_emit_short(const uint8_t *arena, uint32_t n_rec, ExtractCfg cfg, ReadSoA soa, const uint32_t *ev_base,
                        EventSoA ev, hipStream_t stream);
-void launch_emit_long(const uint8_t *arena, const uint32_t *long_list, const uint32_t *long_count, uint32_t max_long,
+void launch_emit_long(const uint8_t *arena, const uint32_t *long_list, uint32_t n_long,
                       ExtractCfg cfg, ReadSoA soa, const uint32_t *ev_base, EventSoA ev, hipStream_t stream);
 
 // ---- primitives --------------------------------------------------------------------------------------------------

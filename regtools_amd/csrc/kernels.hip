@@ -169,25 +169,6 @@ __global__ void k_seg_verify(const uint8_t *__restrict__ arena, uint64_t pos0, u
     st_out[s] = st; ex_out[s] = ex; cnt_out[s] = cnt;
 }
 
-__global__ void k_seg_fill(const uint8_t *__restrict__ arena, uint64_t pos0, uint64_t lim, uint32_t n_seg,
-                           const uint64_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_base, uint64_t *rec_off) {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_seg) return;
-    uint64_t a = pos0 + (uint64_t)s * kSegBytes, b = a + kSegBytes;
-    if (b > lim) b = lim;
-    uint64_t o = seg_start[s];
-    uint32_t k = seg_base[s];
-    while (o < b) {
-        if (o + 36 > lim) break;
-        RecHead h; rec_head(arena + o, h);
-        if (!rec_sane(h)) break;
-        uint64_t nxt = o + 4 + (uint64_t)(uint32_t)h.block_len;
-        if (nxt > lim) break;
-        rec_off[k++] = o;
-        o = nxt;
-    }
-}
-
 void launch_seg_walk(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, int32_t n_ref, uint64_t *seg_start,
                      uint64_t *seg_exit, uint32_t *seg_cnt, hipStream_t stream) {
     if (!n_seg) return;
@@ -200,63 +181,155 @@ void launch_seg_verify(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32
     hipLaunchKernelGGL(k_seg_verify, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, pos0, lim, n_seg, seg_start_in, seg_exit_in,
                        seg_cnt_in, seg_start_out, seg_exit_out, seg_cnt_out, changed);
 }
-void launch_seg_fill(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, const uint64_t *seg_start,
-                     const uint32_t *seg_base, uint64_t *rec_off, hipStream_t stream) {
-    if (!n_seg) return;
-    hipLaunchKernelGGL(k_seg_fill, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, pos0, lim, n_seg, seg_start, seg_base, rec_off);
-}
 
 // =====================================================================================================
 // a2/a3/a5/a6. decode to SoA (one lane per record) + per-read junction-event count
 // =====================================================================================================
-__global__ void k_decode(const uint8_t *__restrict__ arena, const uint64_t *__restrict__ rec_off, uint32_t n_rec, ExtractCfg cfg,
-                         ReadSoA soa, uint32_t *long_list, uint32_t *long_count, unsigned long long *n_iterated) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool iterated = false;
-    if (i < n_rec) {
-        uint64_t o = rec_off[i];
-        RecHead h; rec_head(arena + o, h);
-        const uint8_t *data = arena + o + 36;
-        const uint8_t *cig = data + h.l_qname;
+// ONE WAVE PER SEGMENT.  The segment's bytes are loaded once, coalesced (16 B per lane per
+// instruction), into LDS; lane 0 re-walks the (already verified) record chain there at LDS latency and leaves the
+// record offsets in LDS; then the 64 lanes decode the records in parallel from LDS and write the SoA rows coalesced.
+// Scattered 4-byte global reads of the record heads (one 64 B HBM sector per field group) become a streaming read.
+constexpr uint32_t kSegTail = 1024;                      // bytes past the segment end kept in LDS (record bodies)
+constexpr uint32_t kSegMaxRecs = kSegBytes / 36 + 2;     // a record is at least 36 bytes
+__global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ arena, uint64_t pos0, uint64_t lim, uint32_t n_seg,
+                                                   const uint64_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_base,
+                                                   const uint32_t *__restrict__ seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter,
+                                                   uint32_t *seg_long) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[kSegBytes + kSegTail + 48];
+    __shared__ uint32_t s_off[kSegMaxRecs];
+    const uint32_t s = blockIdx.x, lane = threadIdx.x;
+    const uint32_t cnt = seg_cnt[s];
+    if (cnt == 0) { if (lane == 0) { seg_iter[s] = 0; seg_long[s] = 0; } return; }
+    const uint64_t a = pos0 + (uint64_t)s * kSegBytes;
+    // window [w0, w1): 16-byte aligned start at/below the segment begin, end = segment end + tail, clipped to the arena
+    const uint64_t w0 = a & ~15ull;
+    uint64_t w1 = a + kSegBytes + kSegTail;
+    if (w1 > lim) w1 = lim;
+    {
+        // all loads of the window in flight at once (18 x 1 KiB per wave), then the LDS stores: one HBM latency, not eighteen
+        constexpr int kChunks = (kSegBytes + kSegTail + 16 + 1023) / 1024;
+        u32x4 r[kChunks];
+#pragma unroll
+        for (int j = 0; j < kChunks; ++j) {
+            const uint64_t o = w0 + (uint64_t)j * 1024 + (uint64_t)lane * 16;
+            if (o < w1) r[j] = ld128(arena + o);               // reads < 16 B past lim: the arena is padded
+        }
+#pragma unroll
+        for (int j = 0; j < kChunks; ++j) {
+            const uint64_t o = w0 + (uint64_t)j * 1024 + (uint64_t)lane * 16;
+            if (o < w1) *(u32x4 *)(s_buf + (o - w0)) = r[j];
+        }
+    }
+    __syncthreads();
+    // unaligned 32-bit read from the LDS window: two aligned dword reads + a byte funnel shift (v_alignbyte_b32)
+    const uint32_t *s_w = (const uint32_t *)s_buf;
+    auto lds32 = [&](uint32_t off) -> uint32_t { return __builtin_amdgcn_alignbyte(s_w[(off >> 2) + 1], s_w[off >> 2], off & 3u); };
+    // lane 0: chain walk inside LDS
+    if (lane == 0) {
+        uint64_t o = seg_start[s];
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const uint32_t ro = (uint32_t)(o - w0);
+            s_off[k] = ro;
+            o += 4 + (uint64_t)((o + 4 <= w1) ? lds32(ro) : ld32(arena + o));
+        }
+    }
+    __syncthreads();
+    const uint32_t base = seg_base[s];
+    uint32_t n_iter = 0, n_long = 0;
+    for (uint32_t k = lane; k < cnt; k += 64) {
+        const uint32_t ro = s_off[k];
+        const uint64_t o = w0 + ro;
+        // the 36-byte record head always lies inside the window (tail >= 36); CIGAR / aux of the spliced minority are read from the arena
+        RecHead h;
+        {
+            const uint32_t sh = ro & 3u, wi = ro >> 2;
+            uint32_t d[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) d[q] = s_w[wi + q];
+            uint32_t x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh);
+            h.block_len = (int32_t)x[0]; h.tid = (int32_t)x[1]; h.pos = (int32_t)x[2];
+            h.l_qname = x[3] & 0xff; h.n_cigar = x[4] & 0xffff; h.flag = x[4] >> 16;
+            h.l_qseq = (int32_t)x[5]; h.mtid = (int32_t)x[6];
+            h.aux_off = (int64_t)h.l_qname + 4 * (int64_t)h.n_cigar + (((int64_t)h.l_qseq + 1) >> 1) + h.l_qseq;
+        }
+        // body (CIGAR, aux) from the LDS window when the whole record is inside it, else straight from the arena
+        const uint64_t rec_end = o + 4 + (uint64_t)(uint32_t)h.block_len;
+        const bool in_win = rec_end <= w1;
+        const uint32_t cig_ro = ro + 36 + h.l_qname;
+        const uint8_t *g_data = arena + o + 36;
+        auto cigar_at = [&](uint32_t q) -> uint32_t { return in_win ? lds32(cig_ro + 4 * q) : ld32(g_data + h.l_qname + 4 * (size_t)q); };
+        const uint32_t i = base + k;
         soa.tid[i] = h.tid; soa.pos[i] = h.pos;
         soa.flag_nc[i] = h.flag << 16 | h.n_cigar;
         soa.cig_off[i] = o + 36 + h.l_qname;
-        // region iterator (hts.c:1946-1957): tid == t && pos < end && endpos > beg
         bool in_region = true;
         if (cfg.region_tid != -2) {
             in_region = h.tid == cfg.region_tid && h.pos < cfg.region_end;
-            if (in_region) in_region = rec_endpos(cig, h.n_cigar, h.flag, h.pos) > cfg.region_beg;
+            if (in_region) {                                   // bam_endpos (sam.c:336-342)
+                int32_t endpos = h.pos + 1;
+                if (!(h.flag & 4) && h.n_cigar > 0) {
+                    int32_t l = 0;
+                    for (uint32_t q = 0; q < h.n_cigar; ++q) l += (int32_t)cig_ref_len(cigar_at(q));
+                    endpos = h.pos + l;
+                }
+                in_region = endpos > cfg.region_beg;
+            }
         }
-        iterated = in_region;
+        n_iter += in_region ? 1u : 0u;
         uint32_t nev = 0;
         char strand = '?';
-        if (in_region && h.n_cigar > 1 && h.tid >= 0 && h.tid < cfg.n_ref) {     // junctions_extractor.cc:378-380
-            for (uint32_t k = 0; k < h.n_cigar; ++k) {
-                uint32_t c = ld32(cig + 4 * (size_t)k);
-                // junction_qc (cc:160-170): the intron length is the N op's own length
-                if (cig_is_N(c)) { uint32_t len = c >> 4; nev += !(len < cfg.min_intron || len > cfg.max_intron); }
+        if (in_region && h.n_cigar > 1 && h.tid >= 0 && h.tid < cfg.n_ref) {
+            for (uint32_t q = 0; q < h.n_cigar; ++q) {
+                const uint32_t c = cigar_at(q);
+                if (cig_is_N(c)) { const uint32_t len = c >> 4; nev += !(len < cfg.min_intron || len > cfg.max_intron); }
             }
             if (nev) {
                 if (cfg.strandness == 0) {
-                    int64_t l_data = (int64_t)h.block_len - 32;
-                    strand = strand_from_tag(data + h.aux_off, data + l_data, cfg.tag0, cfg.tag1);
+                    const int64_t l_data = (int64_t)h.block_len - 32;
+                    // two call sites on purpose: the LDS one compiles to ds_read_u8, the other to global loads (no flat/generic pointer)
+                    if (in_win) { const uint8_t *body = s_buf + ro + 36; strand = strand_from_tag(body + h.aux_off, body + l_data, cfg.tag0, cfg.tag1); }
+                    else strand = strand_from_tag(g_data + h.aux_off, g_data + l_data, cfg.tag0, cfg.tag1);
                 } else strand = strand_from_flag(h.flag, cfg.strandness);
-                if (h.n_cigar > cfg.long_threshold) { uint32_t slot = atomicAdd(long_count, 1u); long_list[slot] = i; }
+                n_long += h.n_cigar > cfg.long_threshold ? 1u : 0u;
             }
         }
         soa.strand[i] = (uint8_t)strand;
         soa.n_ev[i] = nev;
     }
-    // alignments iterated = records that pass the region filter (all of them for ".")
-    uint64_t bal = __ballot(iterated);
-    if (lane_id() == 0 && bal) atomicAdd(n_iterated, (unsigned long long)__popcll(bal));
+    // per-segment totals instead of global atomics: one hot address serialises at ~90 atomics/us
+    n_iter = wave_incl_scan(n_iter); n_long = wave_incl_scan(n_long);
+    if (lane == 63) { seg_iter[s] = n_iter; seg_long[s] = n_long; }
 }
 
-void launch_decode(const uint8_t *arena, const uint64_t *rec_off, uint32_t n_rec, ExtractCfg cfg, ReadSoA soa,
-                   uint32_t *long_list, uint32_t *long_count, unsigned long long *n_iterated, hipStream_t stream) {
-    if (!n_rec) return;
-    hipLaunchKernelGGL(k_decode, dim3((n_rec + 255) / 256), dim3(256), 0, stream, arena, rec_off, n_rec, cfg, soa, long_list, long_count, n_iterated);
+// list of the reads that go to the wave-per-read kernel, built without atomics: one wave per segment, positions from the
+// exclusive scan of the per-segment counts
+__global__ __launch_bounds__(64) void k_long_fill(uint32_t n_seg, const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
+                                                  const uint32_t *__restrict__ seg_long_base, ExtractCfg cfg, ReadSoA soa, uint32_t *long_list) {
+    const uint32_t s = blockIdx.x, lane = threadIdx.x;
+    const uint32_t cnt = seg_cnt[s], base = seg_base[s];
+    uint32_t out = seg_long_base[s];
+    for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        bool is_long = false;
+        if (k < cnt) is_long = soa.n_ev[base + k] != 0 && (soa.flag_nc[base + k] & 0xffff) > cfg.long_threshold;
+        const uint64_t m = __ballot(is_long);
+        if (is_long) long_list[out + (uint32_t)__popcll(m & lanemask_lt())] = base + k;
+        out += (uint32_t)__popcll(m);
+    }
 }
+
+void launch_decode_seg(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, const uint64_t *seg_start, const uint32_t *seg_base,
+                       const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, hipStream_t stream) {
+    if (!n_seg) return;
+    hipLaunchKernelGGL(k_decode_seg, dim3(n_seg), dim3(64), 0, stream, arena, pos0, lim, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long);
+}
+void launch_long_fill(uint32_t n_seg, const uint32_t *seg_base, const uint32_t *seg_cnt, const uint32_t *seg_long_base, ExtractCfg cfg, ReadSoA soa,
+                      uint32_t *long_list, hipStream_t stream) {
+    if (n_seg) hipLaunchKernelGGL(k_long_fill, dim3(n_seg), dim3(64), 0, stream, n_seg, seg_base, seg_cnt, seg_long_base, cfg, soa, long_list);
+}
+
 
 // =====================================================================================================
 // a4. CIGAR scan + junction emit
@@ -292,12 +365,11 @@ __global__ void k_emit_short(const uint8_t *__restrict__ arena, uint32_t n_rec, 
 //                             thick_start = R[pb+1]  (pb = last breaker {N,D,X,I,S} before i, or read start),
 //                             thick_end   = R[nb]    (nb = first breaker after i, or read end).
 __global__ __launch_bounds__(256) void k_emit_long(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ long_list,
-                                                   const uint32_t *__restrict__ long_count, ExtractCfg cfg, ReadSoA soa,
+                                                   uint32_t n_long, ExtractCfg cfg, ReadSoA soa,
                                                    const uint32_t *__restrict__ ev_base, EventSoA ev) {
     __shared__ uint32_t s_ops[4][64];
     __shared__ uint32_t s_R[4][65];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t n_long = *long_count;
     for (uint32_t w = blockIdx.x * 4 + wave; w < n_long; w += gridDim.x * 4) {
         const uint32_t i = long_list[w];
         const uint32_t n_cigar = soa.flag_nc[i] & 0xffff;
@@ -366,12 +438,12 @@ void launch_emit_short(const uint8_t *arena, uint32_t n_rec, ExtractCfg cfg, Rea
     if (!n_rec) return;
     hipLaunchKernelGGL(k_emit_short, dim3((n_rec + 255) / 256), dim3(256), 0, stream, arena, n_rec, cfg, soa, ev_base, ev);
 }
-void launch_emit_long(const uint8_t *arena, const uint32_t *long_list, const uint32_t *long_count, uint32_t max_long, ExtractCfg cfg,
+void launch_emit_long(const uint8_t *arena, const uint32_t *long_list, uint32_t n_long, ExtractCfg cfg,
                       ReadSoA soa, const uint32_t *ev_base, EventSoA ev, hipStream_t stream) {
-    if (!max_long) return;
-    uint32_t blocks = (max_long + 3) / 4;
+    if (!n_long) return;
+    uint32_t blocks = (n_long + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;       // grid-stride: 8 workgroups per CU
-    hipLaunchKernelGGL(k_emit_long, dim3(blocks), dim3(256), 0, stream, arena, long_list, long_count, cfg, soa, ev_base, ev);
+    hipLaunchKernelGGL(k_emit_long, dim3(blocks), dim3(256), 0, stream, arena, long_list, n_long, cfg, soa, ev_base, ev);
 }
 
 // =====================================================================================================
