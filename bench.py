@@ -138,6 +138,19 @@ def main():
         alg_bytes = s["compressed_bytes"] + s["inflated_bytes"]
         k_ms = sum(inflate_ms) / len(inflate_ms)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        # HBM-side traffic of the same kernel from rocprofv3 PMC passes (tools/pmc_traffic.sh; separate --pmc runs of this
+        # very command).  Only quoted when the committed measurement was taken on this exact workload.
+        traffic, traffic_note = None, None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if n_reads == 50_000_000 and args.shape == "short" and not args.realistic and world == 1:
+                traffic = (pm["inflate_FETCH_SIZE"][0] + pm["inflate_WRITE_SIZE"][0]) * 1024.0
+                traffic_note = ("(FETCH_SIZE + WRITE_SIZE) KiB of rgx::k_inflate, uncorrected: the guide's x2 FETCH correction is for wide coalesced "
+                                "streams; a calibration kernel with this kernel's scattered 16-B-per-lane pattern and known bytes reads "
+                                "%.2fx (FETCH) / %.2fx (WRITE) of its true bytes" % (pm["cal_FETCH_SIZE"][0] * 1024.0 / pm["cal_known_bytes_each_way"],
+                                                                                     pm["cal_WRITE_SIZE"][0] * 1024.0 / pm["cal_known_bytes_each_way"]))
+        except Exception:
+            pass
         line = {
             "metric": "alignments/sec + junctions/sec, junctions extract, 1/2/4/8 MI355X",
             "value": aln_per_s, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -152,7 +165,7 @@ def main():
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "input_generation_s": round(t_gen, 2),
             "roofline": {"bound": "hbm", "kernel": "rgx::k_inflate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
+                         "traffic": traffic, "traffic_note": traffic_note, "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
                          "note": "DEFLATE is a serial bit stream per member: bound by per-lane latency, far below the HBM line (SURVEY 8d)",
                          "pipeline_frac": aln_per_s / world * (alg_bytes / n_reads) / (HBM_PEAK_GBS * 1e9)},
         }

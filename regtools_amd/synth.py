@@ -23,8 +23,9 @@ def generate(n_reads, shape="short", seed=1, level=6, threads=0, n_introns=0, re
     if rc:
         raise RuntimeError("synthetic BAM generation failed (%d)" % rc)
     try:
-        bam = C.string_at(r.bam, r.bam_len)
-        bai = C.string_at(r.bai, r.bai_len)
+        # (c_ubyte * n).from_address handles buffers beyond 2 GiB, which C.string_at does not
+        bam = bytes((C.c_ubyte * r.bam_len).from_address(r.bam))
+        bai = bytes((C.c_ubyte * r.bai_len).from_address(r.bai))
         stats = dict(n_reads=r.n_reads, n_spliced=r.n_spliced, n_members=r.n_blocks, inflated_bytes=r.inflated_bytes,
                      cigar_ops=r.cigar_ops, bam_bytes=r.bam_len)
     finally:
