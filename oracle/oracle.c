@@ -24,7 +24,7 @@ static int fail(char *err, size_t errlen, const char *msg) {
     return 1;
 }
 
-static uint8_t *slurp(const char *path, size_t *len) {
+uint8_t *orc_slurp(const char *path, size_t *len) {
     FILE *f = fopen(path, "rb");
     if (!f) return NULL;
     fseek(f, 0, SEEK_END);
@@ -146,7 +146,7 @@ static int bai_load(const char *bam, bai_info *bi) {
     if (fn) { free(fn); return -2; } /* CSI not restated (out of scope) */
     fn = idx_name(bam, ".bai");
     if (!fn) return -1;
-    size_t len; uint8_t *d = slurp(fn, &len); free(fn);
+    size_t len; uint8_t *d = orc_slurp(fn, &len); free(fn);
     if (!d) return -1;
     if (len < 8 || memcmp(d, "BAI\1", 4)) { free(d); return -1; }
     size_t p = 4;
@@ -241,18 +241,17 @@ static int parse_region(const orc_table *hdr, const char *reg, int *tid, int *be
  * FASTA access for the intron-motif rule (faidx.c:288-339 fai_load, :341-413 fai_fetch;
  * junctions_extractor.cc:547-584).  Bytes are used raw; isgraph() filter as the reference does.
  * ---------------------------------------------------------------------------------------------- */
-typedef struct { char *name; int64_t len, offset; int line_blen, line_len; } fa_seq;
-typedef struct { uint8_t *data; size_t dlen; fa_seq *seq; int n; } fasta;
+#include "oracle_internal.h"
 
-static void fasta_free(fasta *fa) {
+void fasta_free(fasta *fa) {
     if (!fa) return;
     for (int i = 0; i < fa->n; ++i) free(fa->seq[i].name);
     free(fa->seq); free(fa->data); free(fa);
 }
 
-static fasta *fasta_load(const char *path) {
+fasta *fasta_load(const char *path) {
     fasta *fa = (fasta *)calloc(1, sizeof *fa);
-    fa->data = slurp(path, &fa->dlen);
+    fa->data = orc_slurp(path, &fa->dlen);
     if (!fa->data) { free(fa); return NULL; }
     char *fai = (char *)malloc(strlen(path) + 5);
     sprintf(fai, "%s.fai", path);
@@ -301,7 +300,7 @@ static fasta *fasta_load(const char *path) {
 
 /* fetch 0-based [beg,end) of contig `name`, clipped; returns number of bytes placed in out (<= cap).
  * returns -1 when the contig is missing (fai_fetch NULL -> runtime_error upstream). */
-static int fasta_fetch(const fasta *fa, const char *name, int64_t beg1, int64_t end1, char *out, int cap) {
+int fasta_fetch(const fasta *fa, const char *name, int64_t beg1, int64_t end1, char *out, int cap) {
     /* region string semantics of fai_fetch for "name:beg1-end1": beg = beg1>0 ? beg1-1 : beg1 */
     const fa_seq *s = NULL;
     for (int i = 0; i < fa->n; ++i) if (!strcmp(fa->seq[i].name, name)) { s = &fa->seq[i]; }
@@ -322,7 +321,7 @@ static int fasta_fetch(const fasta *fa, const char *name, int64_t beg1, int64_t 
 }
 
 /* common.h:59-83 rev_comp: reverse + complement, anything but ACGT -> N (upper-case only table) */
-static void rev_comp(char *s, int n) {
+void orc_rev_comp(char *s, int n) {
     for (int i = 0; i < n / 2; ++i) { char t = s[i]; s[i] = s[n - 1 - i]; s[n - 1 - i] = t; }
     for (int i = 0; i < n; ++i) {
         switch (s[i]) { case 'A': s[i] = 'T'; break; case 'C': s[i] = 'G'; break;
@@ -492,7 +491,7 @@ static void junction_emit(void *vc, uint32_t start, uint32_t end, uint32_t ts, u
         int l2 = fasta_fetch(c->fa, c->chrom, b1, b2, s2, 4);
         if (l1 < 0 || l2 < 0) { c->fa_error = 1; return; }
         s1[l1] = 0; s2[l2] = 0;
-        if (c->carried == '-') { rev_comp(s1, l1); rev_comp(s2, l2); snprintf(motif, sizeof motif, "%s-%s", s2, s1); }
+        if (c->carried == '-') { orc_rev_comp(s1, l1); orc_rev_comp(s2, l2); snprintf(motif, sizeof motif, "%s-%s", s2, s1); }
         else snprintf(motif, sizeof motif, "%s-%s", s1, s2);
         strand = strand_from_motif(motif);
         if (strand == '?') strand = c->xs_or_flag_strand;
@@ -555,7 +554,7 @@ static int cmp_rows(const void *a, const void *b) {
 int orc_extract(const orc_params *p, orc_table **out, char *err, size_t errlen) {
     *out = NULL;
     size_t flen = 0;
-    uint8_t *file = p->bam ? slurp(p->bam, &flen) : NULL;
+    uint8_t *file = p->bam ? orc_slurp(p->bam, &flen) : NULL;
     if (!file) return fail(err, errlen, "Unable to open BAM/SAM file.\n\n");
     if (flen < 18 || !bgzf_header_ok(file)) { free(file); return fail(err, errlen, "Unable to open BAM/SAM file.\n\n"); }
     bai_info bi;

@@ -11,7 +11,47 @@
 
 static double now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
+/* `regtools cis-splice-effects identify` option surface (cis_splice_effects_identifier.cc:112-219) */
+static int identify_main(int argc, char **argv) {
+    orc_cse_params p; orc_cse_default_params(&p);
+    int c;
+    optind = 2;
+    while ((c = getopt(argc, argv, "o:w:v:j:e:Ei:ISt:s:a:m:M:C")) != -1) {
+        switch (c) {
+            case 'o': p.out_tsv = optarg; break;
+            case 'w': p.window = (uint32_t)atoi(optarg); break;
+            case 'v': p.out_vcf = optarg; break;
+            case 'j': p.out_bed = optarg; break;
+            case 'i': p.intronic_min = (uint32_t)atoi(optarg); break;
+            case 'e': p.exonic_min = (uint32_t)atoi(optarg); break;
+            case 'I': p.all_intronic = 1; break;
+            case 'E': p.all_exonic = 1; break;
+            case 'S': p.skip_single = 0; break;
+            case 't': p.strand_tag[0] = optarg[0]; p.strand_tag[1] = optarg[0] ? optarg[1] : 0; break;
+            case 's':
+                if (!strcmp(optarg, "XS")) p.strandness = 0; else if (!strcmp(optarg, "RF")) p.strandness = 1;
+                else if (!strcmp(optarg, "FR")) p.strandness = 2; else if (!strcmp(optarg, "intron-motif")) p.strandness = 3;
+                else { fprintf(stderr, "Unrecognized strandness argument!\n\n"); return 1; }
+                break;
+            case 'a': p.min_anchor = (uint32_t)atoi(optarg); break;
+            case 'm': p.min_intron = (uint32_t)atoi(optarg); break;
+            case 'M': p.max_intron = (uint32_t)atoi(optarg); break;
+            case 'C': p.override_motif = 1; break;
+            default: fprintf(stderr, "Error parsing inputs!(1)\n\n"); return 1;
+        }
+    }
+    if (argc - optind >= 4) { p.vcf = argv[optind++]; p.bam = argv[optind++]; p.fasta = argv[optind++]; p.gtf = argv[optind++]; }
+    if (optind < argc || !p.vcf) { fprintf(stderr, "Error parsing inputs!(2)\n\n"); return 1; }
+    if (p.strandness == -1) { fprintf(stderr, "Please supply strand specificity with '-s' option!\n\n"); return 1; }
+    const char *files[4] = {p.vcf, p.bam, p.fasta, p.gtf};
+    for (int k = 0; k < 4; ++k) if (access(files[k], F_OK)) { fprintf(stderr, "Please make sure input files exist.\n\n"); return 1; }
+    char err[256] = "";
+    if (orc_identify(&p, err, sizeof err)) { fputs(err, stderr); return 1; }
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 2 && !strcmp(argv[1], "identify")) return identify_main(argc, argv);
     if (argc < 2 || (strcmp(argv[1], "extract") && strcmp(argv[1], "time"))) {
         fprintf(stderr, "usage: oracle_cli {extract|time} [-a N -m N -M N -o FILE -r REGION -t TAG -s XS|RF|FR|intron-motif] in.bam [ref.fa]\n");
         return 1;
