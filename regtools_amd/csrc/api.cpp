@@ -174,9 +174,19 @@ extern "C" size_t rgx_table_format_bed12(const rgx_junction_table *t, int only_a
 }
 
 // ---- the pipeline ------------------------------------------------------------------------------------------------
-static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_bam, size_t bam_len, const uint8_t *bai, size_t bai_len,
-                        const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen) {
-    *out = nullptr;
+// Everything the later stages need from the front half of the pipeline (file bytes -> junction events in file order).
+struct Prep {
+    BamHeader hdr;
+    const uint8_t *arena = nullptr;
+    ReadSoA soa{};
+    EventSoA ev{};
+    uint32_t n_rec = 0, n_events = 0, n_range = 0;
+    uint64_t n_iterated = 0, total = 0;
+    double t_begin = 0;
+};
+
+static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_bam, size_t bam_len, const uint8_t *bai, size_t bai_len,
+                          const rgx_extract_params *p, bool want_read_span, Prep &P, char *err, size_t errlen) {
     if (!p || p->strandness < 0 || p->strandness > 3) return fail(err, errlen, RGX_ERR_ARG, "Please supply strandness mode with '-s' option!\n\n");
     if (p->fasta_path || p->strandness == 3)
         return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: intron-motif / FASTA strand mode is not implemented on the device path yet\n");
@@ -449,25 +459,47 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     mark("decode+count (sync)");
 
     // -- emit -----------------------------------------------------------------------------------------------------------------
-    DevBuf &b_ev = c->buf("events"), &b_sort = c->buf("sort"), &b_uni = c->buf("unique");
+    DevBuf &b_ev = c->buf("events");
     EventSoA ev; memset(&ev, 0, sizeof ev);
-    uint32_t n_unique = 0;
-    UniqueSoA u; memset(&u, 0, sizeof u);
-    uint32_t *perm[2] = {nullptr, nullptr};
-    uint32_t *final_perm = nullptr;
-    uint32_t *chrom_rank_rows = nullptr;
     if (n_events) {
         const size_t E = n_events;
-        HIP_TRY(b_ev.ensure(E * (4 * 5 + 1) + 256));
+        HIP_TRY(b_ev.ensure(E * (4 * 7 + 1) + 256));
         uint8_t *q = b_ev.as<uint8_t>();
         ev.tid = (uint32_t *)q; q += E * 4; ev.start = (uint32_t *)q; q += E * 4; ev.ilen_cls = (uint32_t *)q; q += E * 4;
-        ev.ts = (uint32_t *)q; q += E * 4; ev.te = (uint32_t *)q; q += E * 4; ev.strand = q;
+        ev.ts = (uint32_t *)q; q += E * 4; ev.te = (uint32_t *)q; q += E * 4;
+        if (want_read_span) { ev.rpos = (uint32_t *)q; q += E * 4; ev.rend = (uint32_t *)q; q += E * 4; }
+        ev.strand = q;
         launch_emit_short(arena, n_rec, cfg, soa, ev_base, ev, st);
         launch_emit_long(arena, long_list, n_long, cfg, soa, ev_base, ev, st);
     }
     HIP_TRY(hipEventRecord(c->ev[5], st));
 
-    // -- group-by: radix sort on (tid, start, ilen|class), then segmented reduce ---------------------------------------------
+    P.hdr = hdr; P.arena = arena; P.soa = soa; P.ev = ev; P.n_rec = n_rec; P.n_events = n_events; P.n_range = n_range;
+    P.n_iterated = n_iterated; P.total = total; P.t_begin = t_begin;
+    return RGX_OK;
+}
+
+// Group-by of junction events + output order, generic over the leading key word `ev.tid` (the contig for
+// `junctions extract`, the window for `cis-splice-effects identify`): stable radix sort on (group, start, len*4+class),
+// segmented reduce, first-seen naming, then the order sort (rank of group, thick_start, thick_end, name).
+struct HostRows {
+    std::vector<uint32_t> group, start, end, ts, te, count, name_rank, first_seen, last_seen;
+    std::vector<uint8_t> strand;
+    size_t n = 0;
+};
+
+static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t group_bits, uint32_t ilen_bits, const uint32_t *rank_of_group_host,
+                         uint32_t n_groups, HostRows &R, char *err, size_t errlen) {
+    hipStream_t st = c->stream;
+    uint32_t *d_sc = c->buf("scalars").as<uint32_t>();
+    uint32_t *h_sc = (uint32_t *)c->pinned;
+    DevBuf &b_sort = c->buf("sort"), &b_uni = c->buf("unique");
+    uint32_t n_unique = 0;
+    UniqueSoA u; memset(&u, 0, sizeof u);
+    uint32_t *perm[2] = {nullptr, nullptr};
+    uint32_t *final_perm = nullptr;
+    uint32_t *chrom_rank_rows = nullptr;
+    R = HostRows();
     if (n_events) {
         const size_t E = n_events;
         const size_t rtmp = radix_tmp_words(n_events) + scan_tmp_words(n_events) + 64;
@@ -485,9 +517,9 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
                 pc = nxt;
             }
         };
-        sort_word(ev.ilen_cls, std::min<uint32_t>(32, bitlen(p->max_intron) + 2));
+        sort_word(ev.ilen_cls, ilen_bits);
         sort_word(ev.start, 32);
-        sort_word(ev.tid, std::max<uint32_t>(1, bitlen((uint32_t)std::max(n_ref - 1, 0))));
+        sort_word(ev.tid, group_bits);
         const uint32_t *sorted = perm[pc];
         launch_heads(ev, sorted, n_events, head, st);
         launch_scan_u32(head, seg_excl, n_events, d_sc + 6, tmp, st);
@@ -515,18 +547,12 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
         launch_scan_u32(first_flag, seg_excl, n_events, nullptr, tmp, st);
         launch_name_rank(n_unique, seg_excl, u, st);
 
-        // output order (junctions_extractor.h:117-140): chrom string rank, thick_start, thick_end, name
-        std::vector<uint32_t> order((size_t)n_ref), rank_of_tid((size_t)n_ref);
-        for (int32_t i = 0; i < n_ref; ++i) order[(size_t)i] = (uint32_t)i;
-        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hdr.names[a] < hdr.names[b]; });
+        // output order (junctions_extractor.h:117-140): rank of the group (chrom string order), thick_start, thick_end, name
         uint32_t rk = 0;
-        for (int32_t i = 0; i < n_ref; ++i) {
-            if (i > 0 && hdr.names[order[(size_t)i]] != hdr.names[order[(size_t)i - 1]]) ++rk;
-            rank_of_tid[order[(size_t)i]] = rk;
-        }
+        for (uint32_t i = 0; i < n_groups; ++i) rk = std::max(rk, rank_of_group_host[i]);
         DevBuf &b_rank = c->buf("rank");
-        HIP_TRY(b_rank.ensure((size_t)n_ref * 4 + 64));
-        HIP_TRY(hipMemcpyAsync(b_rank.p, rank_of_tid.data(), (size_t)n_ref * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(b_rank.ensure((size_t)n_groups * 4 + 64));
+        HIP_TRY(hipMemcpyAsync(b_rank.p, rank_of_group_host, (size_t)n_groups * 4, hipMemcpyHostToDevice, st));
         launch_gather_u32(n_unique, b_rank.as<uint32_t>(), u.tid, chrom_rank_rows, st);
         int upc = -1;
         auto usort = [&](const uint32_t *word, uint32_t nbits) {
@@ -542,46 +568,80 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
         usort(u.ts_min, 32);
         usort(chrom_rank_rows, std::max<uint32_t>(1, bitlen(rk)));
         final_perm = uperm[upc];
-        HIP_TRY(hipStreamSynchronize(st));   // rank_of_tid (host vector) must outlive the async copy
+        HIP_TRY(hipStreamSynchronize(st));   // the host rank table must outlive the async copy
     }
-    HIP_TRY(hipEventRecord(c->ev[6], st));
-    mark("emit+sort+reduce (sync)");
 
-    // -- rows to the host ------------------------------------------------------------------------------------------------------
-    rgx_junction_table *t = table_alloc(hdr, n_unique);
     if (n_unique) {
         const size_t U = n_unique;
         std::vector<uint32_t> col(U), fp(U);
         std::vector<uint8_t> sc(U);
         HIP_TRY(hipMemcpy(fp.data(), final_perm, U * 4, hipMemcpyDeviceToHost));
-        auto fetch32 = [&](const uint32_t *d, auto *dst) -> hipError_t {
+        auto fetch32 = [&](const uint32_t *d, std::vector<uint32_t> &dst) -> hipError_t {
             hipError_t e = hipMemcpy(col.data(), d, U * 4, hipMemcpyDeviceToHost);
             if (e != hipSuccess) return e;
-            for (size_t i = 0; i < U; ++i) dst[i] = (typename std::remove_reference<decltype(dst[0])>::type)col[fp[i]];
+            dst.resize(U);
+            for (size_t i = 0; i < U; ++i) dst[i] = col[fp[i]];
             return hipSuccess;
         };
-        HIP_TRY(fetch32(u.tid, t->tid)); HIP_TRY(fetch32(u.start, t->start)); HIP_TRY(fetch32(u.end, t->end));
-        HIP_TRY(fetch32(u.ts_min, t->thick_start)); HIP_TRY(fetch32(u.te_max, t->thick_end)); HIP_TRY(fetch32(u.count, t->read_count));
-        HIP_TRY(fetch32(u.name_rank, t->name_index)); HIP_TRY(fetch32(u.first_seen, t->first_seen)); HIP_TRY(fetch32(u.last_seen, t->last_seen));
+        HIP_TRY(fetch32(u.tid, R.group)); HIP_TRY(fetch32(u.start, R.start)); HIP_TRY(fetch32(u.end, R.end));
+        HIP_TRY(fetch32(u.ts_min, R.ts)); HIP_TRY(fetch32(u.te_max, R.te)); HIP_TRY(fetch32(u.count, R.count));
+        HIP_TRY(fetch32(u.name_rank, R.name_rank)); HIP_TRY(fetch32(u.first_seen, R.first_seen)); HIP_TRY(fetch32(u.last_seen, R.last_seen));
         HIP_TRY(hipMemcpy(sc.data(), u.strand, U, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < U; ++i) {
-            t->strand[i] = (char)sc[fp[i]];
-            // OR over reads of (start - thick_start >= a) == test on the minimum
-            t->left_ok[i] = (uint32_t)(t->start[i] - t->thick_start[i]) >= p->min_anchor;
-            t->right_ok[i] = (uint32_t)(t->thick_end[i] - t->end[i]) >= p->min_anchor;
-        }
-        if (n_unique >= 100000000u) host_sort_rows(t);   // names wider than 8 digits compare as strings upstream
+        R.strand.resize(U);
+        for (size_t i = 0; i < U; ++i) R.strand[i] = sc[fp[i]];
+        R.n = U;
     }
-    mark("rows to host");
-    t->n_records = n_iterated;
-    t->n_events = n_events; t->inflated_bytes = total; t->compressed_bytes = bam_len; t->n_members = n_range;
+    return RGX_OK;
+}
+
+static void chrom_string_ranks(const BamHeader &hdr, std::vector<uint32_t> &rank_of_tid) {
+    const size_t n = hdr.names.size();
+    std::vector<uint32_t> order(n);
+    rank_of_tid.assign(n ? n : 1, 0);
+    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hdr.names[a] < hdr.names[b]; });
+    uint32_t rk = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (i > 0 && hdr.names[order[i]] != hdr.names[order[i - 1]]) ++rk;
+        rank_of_tid[order[i]] = rk;
+    }
+}
+
+static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_bam, size_t bam_len, const uint8_t *bai, size_t bai_len,
+                        const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen) {
+    *out = nullptr;
+    Prep P;
+    int rc = prepare_events(c, d_bam_in, h_bam, bam_len, bai, bai_len, p, false, P, err, errlen);
+    if (rc != RGX_OK) return rc;
+    hipStream_t st = c->stream;
+    const int32_t n_ref = (int32_t)P.hdr.names.size();
+    std::vector<uint32_t> rank_of_tid;
+    chrom_string_ranks(P.hdr, rank_of_tid);
+    HostRows R;
+    rc = reduce_events(c, P.ev, P.n_events, std::max<uint32_t>(1, bitlen((uint32_t)std::max(n_ref - 1, 0))), std::min<uint32_t>(32, bitlen(p->max_intron) + 2),
+                       rank_of_tid.data(), (uint32_t)std::max(n_ref, 1), R, err, errlen);
+    if (rc != RGX_OK) return rc;
+    HIP_TRY(hipEventRecord(c->ev[6], st));
+    rgx_junction_table *t = table_alloc(P.hdr, R.n);
+    for (size_t i = 0; i < R.n; ++i) {
+        t->tid[i] = (int32_t)R.group[i]; t->start[i] = R.start[i]; t->end[i] = R.end[i]; t->thick_start[i] = R.ts[i]; t->thick_end[i] = R.te[i];
+        t->read_count[i] = R.count[i]; t->name_index[i] = R.name_rank[i]; t->first_seen[i] = R.first_seen[i]; t->last_seen[i] = R.last_seen[i];
+        t->strand[i] = (char)R.strand[i];
+        // OR over reads of (start - thick_start >= a) == test on the minimum
+        t->left_ok[i] = (uint32_t)(t->start[i] - t->thick_start[i]) >= p->min_anchor;
+        t->right_ok[i] = (uint32_t)(t->thick_end[i] - t->end[i]) >= p->min_anchor;
+    }
+    if (R.n >= 100000000u) host_sort_rows(t);   // names wider than 8 digits compare as strings upstream
+    t->n_records = P.n_iterated;
+    t->n_events = P.n_events; t->inflated_bytes = P.total; t->compressed_bytes = bam_len; t->n_members = P.n_range;
     float ms = 0;
     HIP_TRY(hipEventSynchronize(c->ev[6]));
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); t->ms_inflate = ms;
     (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[4]); t->ms_records = ms;
     (void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); t->ms_scan = ms;
     (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); t->ms_reduce = ms;
-    t->ms_total = now_ms() - t_begin;
+    t->ms_total = now_ms() - P.t_begin;
+    if (getenv("REGTOOLS_AMD_TRACE")) fprintf(stderr, "[rgx trace] total %.3f ms\n", t->ms_total);
     *out = t;
     return RGX_OK;
 }

@@ -84,6 +84,7 @@ void launch_long_fill(uint32_t n_seg, const uint32_t *seg_base, const uint32_t *
 struct EventSoA {
     uint32_t *tid, *start, *ilen_cls;   // key words: tid | start | (end-start) << 2 | strand class
     uint32_t *ts, *te;                  // thick_start / thick_end of this read's instance
+    uint32_t *rpos, *rend;              // optional (may be null): the supporting read's pos / bam_endpos (window join of `identify`)
     uint8_t  *strand;
 };
 void launch_emit_short(const uint8_t *arena, uint32_t n_rec, ExtractCfg cfg, ReadSoA soa, const uint32_t *ev_base,

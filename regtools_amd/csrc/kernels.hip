@@ -335,10 +335,11 @@ void launch_long_fill(uint32_t n_seg, const uint32_t *seg_base, const uint32_t *
 // a4. CIGAR scan + junction emit
 // =====================================================================================================
 __device__ __forceinline__ void put_event(const EventSoA &ev, uint32_t slot, int32_t tid, uint32_t start, uint32_t end, uint32_t ts,
-                                          uint32_t te, char strand) {
+                                          uint32_t te, char strand, uint32_t rpos, uint32_t rend) {
     ev.tid[slot] = (uint32_t)tid; ev.start[slot] = start;
     ev.ilen_cls[slot] = (end - start) << 2 | strand_class(strand);
     ev.ts[slot] = ts; ev.te[slot] = te; ev.strand[slot] = (uint8_t)strand;
+    if (ev.rpos) { ev.rpos[slot] = rpos; ev.rend[slot] = rend; }
 }
 
 // short reads: one lane per read, the serial state machine (config 2: 1 or 3 ops)
@@ -354,8 +355,10 @@ __global__ void k_emit_short(const uint8_t *__restrict__ arena, uint32_t n_rec, 
     int32_t tid = soa.tid[i];
     char strand = (char)soa.strand[i];
     uint32_t slot = ev_base[i];
-    cigar_walk(soa.pos[i], cig, n_cigar, [&](uint32_t s, uint32_t e, uint32_t ts, uint32_t te) {
-        if (intron_ok(s, e, cfg.min_intron, cfg.max_intron)) put_event(ev, slot++, tid, s, e, ts, te, strand);
+    const int32_t pos = soa.pos[i];
+    const uint32_t rend = ev.rpos ? (uint32_t)rec_endpos(cig, n_cigar, fnc >> 16, pos) : 0u;     // bam_endpos of the supporting read
+    cigar_walk(pos, cig, n_cigar, [&](uint32_t s, uint32_t e, uint32_t ts, uint32_t te) {
+        if (intron_ok(s, e, cfg.min_intron, cfg.max_intron)) put_event(ev, slot++, tid, s, e, ts, te, strand, (uint32_t)pos, rend);
     });
 }
 
@@ -377,7 +380,15 @@ __global__ __launch_bounds__(256) void k_emit_long(const uint8_t *__restrict__ a
         const int32_t tid = soa.tid[i];
         const char strand = (char)soa.strand[i];
         uint32_t slot = ev_base[i];
-        uint32_t refpos = (uint32_t)soa.pos[i];      // R at the start of the tile
+        const uint32_t rpos = (uint32_t)soa.pos[i];
+        uint32_t rend = 0;
+        if (ev.rpos) {                               // bam_endpos (sam.c:336-342): pos + reference span, or pos+1 for unmapped-flagged reads
+            uint32_t span = 0;
+            for (uint32_t t0 = lane; t0 < n_cigar; t0 += 64) span += cig_ref_len(ld32(cig + 4 * (size_t)t0));
+            span = __shfl(wave_incl_scan(span), 63, 64);
+            rend = ((soa.flag_nc[i] >> 16) & 4u) ? rpos + 1 : rpos + span;
+        }
+        uint32_t refpos = rpos;                      // R at the start of the tile
         uint32_t ts_carry = refpos;                  // R[pb+1] for an N with no breaker earlier in the tile
         // junction opened in an earlier tile and still waiting for its right anchor's end
         bool pend = false; uint32_t p_start = 0, p_end = 0, p_ts = 0;
@@ -398,7 +409,7 @@ __global__ __launch_bounds__(256) void k_emit_long(const uint8_t *__restrict__ a
             if (pend && B) {
                 const uint32_t nb = (uint32_t)__ffsll((unsigned long long)B) - 1;
                 const uint32_t te = s_R[wave][nb];
-                if (lane == 0 && intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) put_event(ev, slot, tid, p_start, p_end, p_ts, te, strand);
+                if (lane == 0 && intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) put_event(ev, slot, tid, p_start, p_end, p_ts, te, strand, rpos, rend);
                 if (intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) ++slot;
                 pend = false;
             }
@@ -411,7 +422,7 @@ __global__ __launch_bounds__(256) void k_emit_long(const uint8_t *__restrict__ a
             const bool ok = isN && intron_ok(R_before, R_after, cfg.min_intron, cfg.max_intron);
             // events keep CIGAR order: rank among the qc-passing N lanes that close inside this tile
             const uint64_t emit_mask = __ballot(ok && closed);
-            if (ok && closed) put_event(ev, slot + (uint32_t)__popcll(emit_mask & lanemask_lt()), tid, R_before, R_after, ts, te, strand);
+            if (ok && closed) put_event(ev, slot + (uint32_t)__popcll(emit_mask & lanemask_lt()), tid, R_before, R_after, ts, te, strand, rpos, rend);
             slot += (uint32_t)__popcll(emit_mask);
             // the last breaker of the tile: if it is an N it stays open into the next tile
             if (B) {
@@ -429,7 +440,7 @@ __global__ __launch_bounds__(256) void k_emit_long(const uint8_t *__restrict__ a
             refpos = __shfl(R_after, 63, 64);
             __builtin_amdgcn_wave_barrier();
         }
-        if (pend && lane == 0 && intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) put_event(ev, slot, tid, p_start, p_end, p_ts, refpos, strand);
+        if (pend && lane == 0 && intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) put_event(ev, slot, tid, p_start, p_end, p_ts, refpos, strand, rpos, rend);
     }
 }
 
