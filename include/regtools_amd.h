@@ -127,6 +127,73 @@ typedef struct { uint64_t cpos, upos; uint32_t clen, isize; } rgx_member;   /* =
 int  rgx_k_inflate(const void *d_comp, const rgx_member *d_members, uint32_t n_members,
                    void *d_arena, uint32_t *d_status, void *stream);
 
+/* =====================================================================================================
+ * `cis-splice-effects identify`.
+ * Replaces CisSpliceEffectsIdentifier::identify() + annotate_junctions()
+ * (src/cis-splice-effects/cis_splice_effects_identifier.cc:222-312) and the interval cores it drives:
+ * VariantsAnnotator::annotate_record_with_transcripts (src/variants/variants_annotator.cc:455-518),
+ * the per-variant JunctionsExtractor re-runs (identifier.cc:288-299) and
+ * JunctionsAnnotator::annotate_junction_with_gtf (src/junctions/junctions_annotator.cc:344-363).
+ * ===================================================================================================== */
+typedef struct {
+    const char *vcf_path, *bam_path, *fasta_path, *gtf_path;   /* the four positional arguments (identifier.cc:193-198) */
+    const char *out_tsv;       /* -o  annotated junctions; NULL = stdout */
+    const char *out_vcf;       /* -v  splice-relevant variants (VCF); NULL = not written */
+    const char *out_bed;       /* -j  junctions BED12; NULL = not written */
+    uint32_t    window;        /* -w  [0 = the cis-effect window between neighbouring exons] */
+    uint32_t    intronic_min;  /* -i  [2] */
+    uint32_t    exonic_min;    /* -e  [3] */
+    int32_t     all_intronic;  /* -I */
+    int32_t     all_exonic;    /* -E */
+    int32_t     skip_single;   /* 1 unless -S */
+    int32_t     strandness;    /* -s  0 XS, 1 RF, 2 FR, 3 intron-motif */
+    char        strand_tag[2]; /* -t */
+    uint32_t    min_anchor;    /* -a  (also the minimum intron length here: ctor quirk junctions_extractor.h:200) */
+    uint32_t    min_intron;    /* -m  accepted and ignored, as upstream */
+    uint32_t    max_intron;    /* -M */
+    int32_t     override_motif;/* -C */
+} rgx_identify_params;
+
+typedef struct {
+    uint64_t n_variants, n_relevant, n_windows, n_pairs, n_window_rows, n_junctions;
+    uint64_t n_records, n_events;
+    uint64_t exon_visits_variants;   /* E_v summed: exon records of all candidate transcripts (SURVEY 8d algorithmic bytes) */
+    uint64_t exon_visits_junctions;  /* E_j summed */
+    double   ms_total, ms_gtf, ms_variants, ms_extract, ms_join, ms_annotate, ms_output;
+} rgx_identify_stats;
+
+void rgx_identify_params_default(rgx_identify_params *p);   /* CisSpliceEffectsIdentifier ctor, identifier.h:101-117 */
+
+/* Whole command: reads the four files, runs the interval kernels and the extraction on the device, writes -o/-v/-j.
+ * Error texts and the exit-code mapping are the reference's (nonzero return == exit 1). */
+int  rgx_identify(rgx_ctx *ctx, const rgx_identify_params *p, rgx_identify_stats *stats, char *err, size_t errlen);
+
+/* Stage entry points over a loaded annotation (flat exon/transcript/bin arrays in HBM). */
+typedef struct rgx_gtf rgx_gtf;
+int  rgx_gtf_load(rgx_ctx *ctx, const char *gtf_path, rgx_gtf **out, char *err, size_t errlen);   /* GtfParser::load, gtf_parser.cc:257-263 */
+void rgx_gtf_free(rgx_gtf *g);
+int  rgx_gtf_info(const rgx_gtf *g, uint32_t *n_transcripts, uint32_t *n_exons, uint32_t *n_chroms);
+int  rgx_gtf_transcript_bin(const rgx_gtf *g, const char *transcript_id, uint32_t *bin);           /* GtfParser::bin_from_transcript */
+
+/* a10: one row per variant (chrom name + 0-based pos).  hit_off has n+1 entries; hits are in the reference's
+ * visitation order; annotation codes 1 exonic, 2 intronic, 3 splicing_exonic, 4 splicing_intronic. */
+typedef struct {
+    uint64_t n; uint32_t *cis_start, *cis_end; uint32_t *hit_off; uint32_t *hit_transcript, *hit_annotation, *hit_distance;
+} rgx_variant_hits;
+int  rgx_variant_windows(rgx_ctx *ctx, const rgx_gtf *g, uint64_t n, const char *const *chrom, const uint32_t *pos0, uint32_t intronic_min,
+                         uint32_t exonic_min, int all_intronic, int all_exonic, int skip_single, rgx_variant_hits **out, char *err, size_t errlen);
+void rgx_variant_hits_free(rgx_variant_hits *h);
+const char *rgx_gtf_transcript_id(const rgx_gtf *g, uint32_t t);
+
+/* a11: one row per junction (chrom, start, end = Junction.end + 1, strand).  flags bit0 known_donor, bit1 known_acceptor,
+ * bit2 known_junction; counts are of UNIQUE skipped elements; transcripts in id order, offsets n+1. */
+typedef struct {
+    uint64_t n; uint32_t *flags, *n_acceptors_skipped, *n_exons_skipped, *n_donors_skipped; uint32_t *tx_off, *tx;
+} rgx_junction_annot;
+int  rgx_annotate_junctions(rgx_ctx *ctx, const rgx_gtf *g, uint64_t n, const char *const *chrom, const uint32_t *start, const uint32_t *end1,
+                            const char *strand, rgx_junction_annot **out, char *err, size_t errlen);
+void rgx_junction_annot_free(rgx_junction_annot *a);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,5 +4,6 @@ Layout: csrc/ (HIP kernels, C ABI, host CLI, synthetic-input tooling), _ffi.py (
 extractor.py (host mirror of the reference's JunctionsExtractor interface), synth.py (synthetic BAM/BAI).
 """
 from .extractor import Context, Junction, JunctionsExtractor, RegtoolsError, junctions_extract  # noqa: F401
+from .cse import CisSpliceEffectsIdentifier, cis_splice_effects_identify  # noqa: F401
 
 __version__ = "0.1"

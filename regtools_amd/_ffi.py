@@ -39,7 +39,34 @@ class Member(C.Structure):
 # every symbol include/regtools_amd.h declares (tests check the library exports all of them)
 EXPORTS = ["rgx_extract_params_default", "rgx_ctx_create", "rgx_ctx_destroy", "rgx_extract", "rgx_extract_mem",
            "rgx_extract_device", "rgx_table_free", "rgx_table_merge", "rgx_table_pack", "rgx_table_unpack",
-           "rgx_table_format_bed12", "rgx_version", "rgx_k_inflate"]
+           "rgx_table_format_bed12", "rgx_version", "rgx_k_inflate",
+           "rgx_identify_params_default", "rgx_identify", "rgx_gtf_load", "rgx_gtf_free", "rgx_gtf_info", "rgx_gtf_transcript_bin",
+           "rgx_gtf_transcript_id", "rgx_variant_windows", "rgx_variant_hits_free", "rgx_annotate_junctions", "rgx_junction_annot_free"]
+
+
+class IdentifyParams(C.Structure):
+    _fields_ = [("vcf_path", C.c_char_p), ("bam_path", C.c_char_p), ("fasta_path", C.c_char_p), ("gtf_path", C.c_char_p),
+                ("out_tsv", C.c_char_p), ("out_vcf", C.c_char_p), ("out_bed", C.c_char_p), ("window", C.c_uint32),
+                ("intronic_min", C.c_uint32), ("exonic_min", C.c_uint32), ("all_intronic", C.c_int32), ("all_exonic", C.c_int32),
+                ("skip_single", C.c_int32), ("strandness", C.c_int32), ("strand_tag", C.c_char * 2), ("min_anchor", C.c_uint32),
+                ("min_intron", C.c_uint32), ("max_intron", C.c_uint32), ("override_motif", C.c_int32)]
+
+
+class IdentifyStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_variants", "n_relevant", "n_windows", "n_pairs", "n_window_rows", "n_junctions", "n_records", "n_events",
+                                          "exon_visits_variants", "exon_visits_junctions")] + \
+               [(n, C.c_double) for n in ("ms_total", "ms_gtf", "ms_variants", "ms_extract", "ms_join", "ms_annotate", "ms_output")]
+
+
+class VariantHits(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("cis_start", C.POINTER(C.c_uint32)), ("cis_end", C.POINTER(C.c_uint32)), ("hit_off", C.POINTER(C.c_uint32)),
+                ("hit_transcript", C.POINTER(C.c_uint32)), ("hit_annotation", C.POINTER(C.c_uint32)), ("hit_distance", C.POINTER(C.c_uint32))]
+
+
+class JunctionAnnot(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("flags", C.POINTER(C.c_uint32)), ("n_acceptors_skipped", C.POINTER(C.c_uint32)),
+                ("n_exons_skipped", C.POINTER(C.c_uint32)), ("n_donors_skipped", C.POINTER(C.c_uint32)), ("tx_off", C.POINTER(C.c_uint32)),
+                ("tx", C.POINTER(C.c_uint32))]
 
 _lib = None
 
@@ -86,6 +113,20 @@ def lib():
         L.rgx_table_format_bed12.argtypes = [P(JunctionTable), C.c_int, C.c_char_p, C.c_size_t]
         L.rgx_table_format_bed12.restype = C.c_size_t
         L.rgx_k_inflate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rgx_identify_params_default.argtypes = [P(IdentifyParams)]
+        L.rgx_identify.argtypes = [C.c_void_p, P(IdentifyParams), P(IdentifyStats), C.c_char_p, C.c_size_t]
+        L.rgx_gtf_load.argtypes = [C.c_void_p, C.c_char_p, P(C.c_void_p), C.c_char_p, C.c_size_t]
+        L.rgx_gtf_free.argtypes = [C.c_void_p]
+        L.rgx_gtf_info.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]
+        L.rgx_gtf_transcript_bin.argtypes = [C.c_void_p, C.c_char_p, P(C.c_uint32)]
+        L.rgx_gtf_transcript_id.argtypes = [C.c_void_p, C.c_uint32]
+        L.rgx_gtf_transcript_id.restype = C.c_char_p
+        L.rgx_variant_windows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_char_p), P(C.c_uint32), C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                          P(P(VariantHits)), C.c_char_p, C.c_size_t]
+        L.rgx_variant_hits_free.argtypes = [P(VariantHits)]
+        L.rgx_annotate_junctions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_char_p), P(C.c_uint32), P(C.c_uint32), C.c_char_p,
+                                             P(P(JunctionAnnot)), C.c_char_p, C.c_size_t]
+        L.rgx_junction_annot_free.argtypes = [P(JunctionAnnot)]
         _lib = L
     return _lib
 

@@ -86,6 +86,40 @@ RGX_HD char strand_from_tag(const uint8_t *aux, const uint8_t *end, uint8_t t0, 
     return '?';
 }
 
+// ---- intron-motif strand rule (junctions_extractor.cc:325-342, :564-584; faidx.c:341-413) --------------------------------
+// FASTA file bytes live in HBM; one descriptor per BAM contig (matched by name on the host).
+struct FaContig { int64_t offset, len; int32_t line_blen, line_len; int32_t present; int32_t pad; };
+
+// fai_fetch("chr:beg1-end1") for a two-base window: returns the number of bases (0..2) and the bases in b[0..1]
+RGX_HD int fa_fetch2(const uint8_t *fa, const FaContig &c, uint32_t beg1, uint32_t end1, uint8_t *b) {
+    int64_t beg = beg1, end = end1;
+    if (beg > 0) --beg;
+    if (beg >= c.len) beg = c.len;
+    if (end >= c.len) end = c.len;
+    if (beg > end) beg = end;
+    int n = 0;
+    if (c.line_blen <= 0) return 0;
+    for (int64_t p = beg; p < end && n < 2; ++p) b[n++] = fa[c.offset + p / c.line_blen * c.line_len + p % c.line_blen];
+    return n;
+}
+RGX_HD uint8_t base_comp(uint8_t c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }   // utils/common.h:59-83
+
+// strand of the junction [start,end) from its splice-site motif; `carried` is the strand of the previous junction of the same
+// read (upstream reuses the Junction object, cc:576-579).  '?' when the motif is not canonical.
+RGX_HD char strand_from_motif(const uint8_t *fa, const FaContig &c, uint32_t start, uint32_t end, char carried) {
+    uint8_t s1[2], s2[2];
+    const int l1 = fa_fetch2(fa, c, start + 1u, start + 2u, s1);
+    const int l2 = fa_fetch2(fa, c, end + 1u - 2u, end + 1u - 1u, s2);
+    if (l1 != 2 || l2 != 2) return '?';
+    uint8_t d0, d1, a0, a1;                       // motif = d0 d1 '-' a0 a1
+    if (carried == '-') { d0 = base_comp(s2[1]); d1 = base_comp(s2[0]); a0 = base_comp(s1[1]); a1 = base_comp(s1[0]); }
+    else { d0 = s1[0]; d1 = s1[1]; a0 = s2[0]; a1 = s2[1]; }
+    const uint32_t m = (uint32_t)d0 << 24 | (uint32_t)d1 << 16 | (uint32_t)a0 << 8 | a1;
+    if (m == 0x47544147u /*GT-AG*/ || m == 0x47434147u /*GC-AG*/ || m == 0x41544143u /*AT-AC*/) return '+';
+    if (m == 0x43544143u /*CT-AC*/ || m == 0x43544743u /*CT-GC*/ || m == 0x47544154u /*GT-AT*/) return '-';
+    return '?';
+}
+
 // key class of a strand char (junctions_extractor.cc:186-193)
 RGX_HD uint32_t strand_class(char c) { return c == '+' ? 0u : c == '-' ? 1u : 2u; }
 

@@ -134,6 +134,102 @@ int junctions_main(int argc, char **argv) {
     return junctions_usage(std::cerr);
 }
 
+// ---- cis-splice-effects identify (cis_splice_effects_identifier.cc:112-219, cis_splice_effects_main.cc:35-93) -------------
+void identify_usage(std::ostream &out) {
+    out << "Usage:\t\tregtools cis-splice-effects identify [options] variants.vcf alignments.bam ref.fa annotations.gtf\n"
+        << "Options:\n"
+        << "\t\t-o STR\tOutput file containing the aberrant splice junctions with annotations. [STDOUT]\n"
+        << "\t\t-v STR\tOutput file containing variants annotated as splice relevant (VCF format).\n"
+        << "\t\t-j STR\tOutput file containing the aberrant junctions in BED12 format.\n"
+        << "\t\t-s INT\tStrandness mode \n\t\t\t XS, use XS tags provided by aligner; RF, first-strand; FR, second-strand. intron-motif, infer strand using canonical intron motifs. REQUIRED\n"
+        << "\t\t-C\tOverride strand assignments by inferring based on canonical motifs.\n"
+        << "\t\t-t STR\tTag used in bam to label strand. [XS]\n"
+        << "\t\t-a INT\tMinimum anchor length. [8]\n\t\t-m INT\tMinimum intron length. [70]\n\t\t-M INT\tMaximum intron length. [500000]\n"
+        << "\t\t-w INT\tWindow size in b.p to identify splicing events in.\n"
+        << "\t\t-e INT\tMaximum exonic distance from an exon edge. [3]\n\t\t-i INT\tMaximum intronic distance from an exon edge. [2]\n"
+        << "\t\t-I\tAnnotate variants in intronic space within a transcript.\n\t\t-E\tAnnotate variants in exonic space within a transcript.\n"
+        << "\t\t-S\tDon't skip single exon transcripts.\n\n";
+}
+
+bool file_exists(const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (!f) return false; fclose(f); return true; }
+
+int cse_identify(int argc, char **argv) {
+    try {
+        rgx_identify_params p;
+        rgx_identify_params_default(&p);
+        std::string out_tsv = "NA", out_vcf = "NA", out_bed = "NA", tag = "XS", barcodes = "NA";
+        optind = 1;
+        int c;
+        while ((c = getopt(argc, argv, "o:w:v:j:e:Ei:ISht:s:a:m:M:b:C")) != -1) {
+            switch (c) {
+                case 'o': out_tsv = optarg; break;
+                case 'w': p.window = (uint32_t)atoi(optarg); break;
+                case 'v': out_vcf = optarg; break;
+                case 'j': out_bed = optarg; break;
+                case 'i': p.intronic_min = (uint32_t)atoi(optarg); break;
+                case 'e': p.exonic_min = (uint32_t)atoi(optarg); break;
+                case 'I': p.all_intronic = 1; break;
+                case 'E': p.all_exonic = 1; break;
+                case 'S': p.skip_single = 0; break;
+                case 'h': { std::ostringstream ss; identify_usage(ss); throw HelpRequested{ss.str()}; }
+                case 's': {
+                    std::string s = optarg;
+                    if (s == "XS") p.strandness = 0; else if (s == "RF") p.strandness = 1; else if (s == "FR") p.strandness = 2;
+                    else if (s == "intron-motif") p.strandness = 3;
+                    else throw std::runtime_error("Unrecognized strandness argument!\n\n");
+                    break;
+                }
+                case 't': tag = optarg; break;
+                case 'a': p.min_anchor = (uint32_t)atoi(optarg); break;
+                case 'm': p.min_intron = (uint32_t)atoi(optarg); break;
+                case 'M': p.max_intron = (uint32_t)atoi(optarg); break;
+                case 'b': barcodes = optarg; break;
+                case 'C': p.override_motif = 1; break;
+                default: identify_usage(std::cerr); throw std::runtime_error("Error parsing inputs!(1)\n\n");
+            }
+        }
+        std::string vcf = "NA", bam = "NA", ref = "NA", gtf = "NA";
+        if (argc - optind >= 4) { vcf = argv[optind++]; bam = argv[optind++]; ref = argv[optind++]; gtf = argv[optind++]; }
+        if (optind < argc || vcf == "NA" || bam == "NA" || ref == "NA" || gtf == "NA") { identify_usage(std::cerr); throw std::runtime_error("Error parsing inputs!(2)\n\n"); }
+        if (p.strandness == -1) { identify_usage(std::cerr); throw std::runtime_error("Please supply strand specificity with '-s' option!\n\n"); }
+        if (!file_exists(vcf) || !file_exists(bam) || !file_exists(ref) || !file_exists(gtf)) throw std::runtime_error("Please make sure input files exist.\n\n");
+        if (barcodes != "NA") throw std::runtime_error("regtools_amd: -b (single-cell barcodes) is outside the accelerated path\n\n");
+        std::cerr << "Variant file: " << vcf << "\nAlignment file: " << bam << "\nReference fasta file: " << ref << "\nAnnotation file: " << gtf << "\n\n";
+        p.vcf_path = vcf.c_str(); p.bam_path = bam.c_str(); p.fasta_path = ref.c_str(); p.gtf_path = gtf.c_str();
+        p.out_tsv = out_tsv == "NA" ? nullptr : out_tsv.c_str(); p.out_vcf = out_vcf == "NA" ? nullptr : out_vcf.c_str(); p.out_bed = out_bed == "NA" ? nullptr : out_bed.c_str();
+        p.strand_tag[0] = tag.size() > 0 ? tag[0] : 0; p.strand_tag[1] = tag.size() > 1 ? tag[1] : 0;
+        char err[512] = {0};
+        rgx_ctx *ctx = nullptr;
+        int dev = 0; if (const char *d = getenv("REGTOOLS_AMD_DEVICE")) dev = atoi(d);
+        if (rgx_ctx_create(dev, &ctx, err, sizeof err) != RGX_OK) throw std::runtime_error(err);
+        rgx_identify_stats st;
+        int rc = rgx_identify(ctx, &p, &st, err, sizeof err);
+        rgx_ctx_destroy(ctx);
+        if (rc != RGX_OK) throw std::runtime_error(err);
+        if (getenv("REGTOOLS_AMD_STATS"))
+            fprintf(stderr, "[regtools_amd] variants=%llu relevant=%llu windows=%llu pairs=%llu junctions=%llu total=%.3fms (gtf %.3f variants %.3f extract %.3f join %.3f annotate %.3f output %.3f)\n",
+                    (unsigned long long)st.n_variants, (unsigned long long)st.n_relevant, (unsigned long long)st.n_windows, (unsigned long long)st.n_pairs,
+                    (unsigned long long)st.n_junctions, st.ms_total, st.ms_gtf, st.ms_variants, st.ms_extract, st.ms_join, st.ms_annotate, st.ms_output);
+    } catch (const HelpRequested &h) {
+        std::cerr << h.text;
+        return 0;
+    } catch (const std::runtime_error &e) {
+        std::cerr << e.what();
+        return 1;
+    }
+    return 0;
+}
+
+int cse_main(int argc, char **argv) {
+    if (argc > 1) {
+        std::string sub = argv[1];
+        if (sub == "identify") return cse_identify(argc - 1, argv + 1);
+        if (sub == "associate") { std::cerr << "regtools_amd: `cis-splice-effects associate` is outside the accelerated path\n"; return 1; }
+    }
+    std::cerr << "\nUsage:\t\tregtools cis-splice-effects <command> [options]\nCommand:\tidentify\t\tIdentify cis splicing effects.\n\n";
+    return 0;
+}
+
 }  // namespace
 
 // regtools.cc:36-74
@@ -142,8 +238,10 @@ int main(int argc, char **argv) {
     if (argc > 1) {
         std::string sub = argv[1];
         if (sub == "junctions") return junctions_main(argc - 1, argv + 1);
+        if (sub == "cis-splice-effects") return cse_main(argc - 1, argv + 1);
     }
     std::cerr << "Usage:\t\tregtools <command> [options]\n"
-              << "Command:\tjunctions\t\tTools that operate on feature junctions (e.g. exon-exon junctions from RNA-seq).\n\n";
+              << "Command:\tjunctions\t\tTools that operate on feature junctions (e.g. exon-exon junctions from RNA-seq).\n"
+              << "\t\tcis-splice-effects\tTools related to splicing effects of variants.\n\n";
     return 0;
 }

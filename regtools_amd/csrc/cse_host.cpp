@@ -1,0 +1,221 @@
+// cse_host.cpp -- see cse_host.h.  Citations relative to /root/reference/src.
+#include "cse_host.h"
+
+#include <ctype.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <numeric>
+
+#include "cse_core.h"
+
+namespace rgx {
+
+static bool slurp(const std::string &path, std::string &out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    if (n < 0) { fclose(f); return false; }
+    out.resize((size_t)n);
+    bool ok = n == 0 || fread(&out[0], 1, (size_t)n, f) == (size_t)n;
+    fclose(f);
+    return ok;
+}
+
+// lineFileUtilities.h:24-33 Tokenize (std::getline: consecutive delimiters give empty fields, no trailing empty field)
+static void tokenize(const char *s, size_t len, char delim, std::vector<std::pair<const char *, size_t>> &out) {
+    out.clear();
+    if (!len) return;
+    size_t i = 0;
+    for (;;) {
+        size_t j = i;
+        while (j < len && s[j] != delim) ++j;
+        out.push_back({s + i, j - i});
+        if (j >= len) break;
+        i = j + 1;
+        if (i >= len) break;
+    }
+}
+
+// gtf_parser.cc:89-104 parse_attribute + utils/common.h:85-92 unquote
+static std::string gtf_attr(const char *attrs, size_t alen, const char *key) {
+    const size_t klen = strlen(key);
+    size_t i = 0;
+    while (i < alen) {
+        size_t j = i;
+        while (j < alen && attrs[j] != ';') ++j;
+        const char *p = attrs + i; size_t l = j - i;
+        if (l && p[0] == ' ') { ++p; --l; }
+        size_t a = 0; while (a < l && p[a] != ' ') ++a;
+        if (l > 0 && a == klen && !memcmp(p, key, klen)) {
+            size_t b = a < l ? a + 1 : l, c = b;
+            while (c < l && p[c] != ' ') ++c;
+            const char *v = p + b; size_t vl = c - b;
+            if (vl >= 1 && v[0] == '"' && v[vl - 1] == '"') { if (vl >= 2) { ++v; vl -= 2; } else vl = 0; }
+            return std::string(v, vl);
+        }
+        if (j >= alen) break;
+        i = j + 1;
+    }
+    return "NA";
+}
+
+std::string GtfModel::load(const std::string &path) {
+    std::string text;
+    if (!slurp(path, text)) return "\nUnable to open GTF file.";
+    struct Tmp { std::string id, gene_name, gene_id; int32_t chrom; uint8_t strand; std::vector<uint32_t> s, e; };
+    std::vector<Tmp> tmp;
+    std::unordered_map<std::string, uint32_t> by_id;
+    std::vector<std::pair<const char *, size_t>> f;
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t e = text.find('\n', pos); if (e == std::string::npos) e = text.size();
+        const char *line = text.data() + pos; const size_t ll = e - pos;
+        pos = e + 1;
+        if (ll == 0) return "basic_string::at";                                   // line.at(0) throws (gtf_parser.cc:230)
+        if (line[0] == '#') continue;
+        tokenize(line, ll, '\t', f);
+        if (f.size() != 9) return "Expected 9 fields in GTF line.";               // gtf_parser.cc:67-70
+        if (!(f[2].second == 4 && !memcmp(f[2].first, "exon", 4))) continue;
+        std::string tid = gtf_attr(f[8].first, f[8].second, "transcript_id");
+        if (tid == "NA") continue;                                                // gtf_parser.cc:118
+        auto it = by_id.find(tid);
+        uint32_t k;
+        if (it == by_id.end()) {
+            k = (uint32_t)tmp.size(); by_id.emplace(tid, k);
+            Tmp t; t.id = tid;
+            t.gene_name = gtf_attr(f[8].first, f[8].second, "gene_name");         // first exon line seen wins (gtf_parser.cc:266-273)
+            t.gene_id = gtf_attr(f[8].first, f[8].second, "gene_id");
+            std::string cn(f[0].first, f[0].second);
+            auto ci = chrom_index.find(cn);
+            if (ci == chrom_index.end()) { ci = chrom_index.emplace(cn, (int32_t)chroms.size()).first; chroms.push_back(cn); }
+            t.chrom = ci->second;
+            t.strand = f[6].second == 1 ? (uint8_t)f[6].first[0] : (uint8_t)'?';
+            tmp.push_back(std::move(t));
+        } else k = it->second;
+        tmp[k].s.push_back((uint32_t)atol(std::string(f[3].first, f[3].second).c_str()));
+        tmp[k].e.push_back((uint32_t)atol(std::string(f[4].first, f[4].second).c_str()));
+    }
+    std::vector<uint32_t> order(tmp.size());
+    std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return tmp[a].id < tmp[b].id; });   // std::map<string,Transcript>
+    for (uint32_t k : order) {
+        Tmp &t = tmp[k];
+        if (t.strand != '+' && t.strand != '-') return "Undefined strand for exon ";                          // gtf_parser.cc:193-197 exit(1)
+        std::vector<uint32_t> idx(t.s.size());
+        std::iota(idx.begin(), idx.end(), 0u);
+        // sort_exons_within_transcripts: '+' ascending start, '-' descending start
+        if (t.strand == '+') std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return t.s[a] < t.s[b]; });
+        else std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return t.s[a] > t.s[b]; });
+        tx_id.push_back(t.id); tx_gene_name.push_back(t.gene_name); tx_gene_id.push_back(t.gene_id);
+        tx_chrom.push_back(t.chrom); tx_strand.push_back(t.strand);
+        tx_exon_off.push_back((uint32_t)es.size()); tx_n_exons.push_back((uint32_t)idx.size());
+        for (uint32_t i : idx) { es.push_back(t.s[i]); ee.push_back(t.e[i]); }
+        tx_bin.push_back(ucsc_bin(es[tx_exon_off.back()], ee.back()));                                         // gtf_parser.cc:154-160
+    }
+    // chr -> bin -> [transcript ids ascending]
+    std::vector<uint32_t> bt(tx_id.size());
+    std::iota(bt.begin(), bt.end(), 0u);
+    std::stable_sort(bt.begin(), bt.end(), [&](uint32_t a, uint32_t b) {
+        const uint64_t ka = (uint64_t)(uint32_t)tx_chrom[a] << 32 | tx_bin[a], kb = (uint64_t)(uint32_t)tx_chrom[b] << 32 | tx_bin[b];
+        return ka < kb;
+    });
+    for (uint32_t t : bt) { bin_key.push_back((uint64_t)(uint32_t)tx_chrom[t] << 32 | tx_bin[t]); bin_tx.push_back(t); }
+    return "";
+}
+
+std::string VcfText::load(const std::string &path) {
+    if (!slurp(path, text)) return "Unable to open file.\n\n";
+    if (text.size() >= 2 && (uint8_t)text[0] == 0x1f && (uint8_t)text[1] == 0x8b) return "regtools_amd: compressed VCF/BCF input is not supported on this path yet\n\n";
+    size_t p = 0;
+    while (p < text.size()) {
+        line_off.push_back(p);
+        size_t e = text.find('\n', p); if (e == std::string::npos) e = text.size();
+        p = e + 1;
+    }
+    line_off.push_back(text.size() + (text.empty() || text.back() == '\n' ? 0 : 1));
+    for (size_t i = 0; i + 1 < line_off.size(); ++i) {
+        const char *l; size_t n; line(i, l, n);
+        if (!n || l[0] == '#') continue;
+        const char *t1 = (const char *)memchr(l, '\t', n);
+        if (!t1) continue;
+        const char *t2 = (const char *)memchr(t1 + 1, '\t', (size_t)(l + n - t1 - 1));
+        std::string ps(t1 + 1, t2 ? (size_t)(t2 - t1 - 1) : (size_t)(l + n - t1 - 1));
+        recs.push_back({i, std::string(l, (size_t)(t1 - l)), (uint32_t)(atoi(ps.c_str()) - 1)});
+    }
+    return "";
+}
+
+void VcfText::line(size_t i, const char *&p, size_t &len) const {
+    p = text.data() + line_off[i];
+    size_t end = line_off[i + 1];
+    len = end - line_off[i];
+    if (len) --len;                                   // the '\n' (or the virtual one after an unterminated last line)
+    if (len && p[len - 1] == '\r') --len;
+}
+
+bool Fasta::load(const std::string &path) {
+    if (!slurp(path, data)) return false;
+    std::string fai;
+    if (slurp(path + ".fai", fai)) {
+        size_t p = 0;
+        while (p < fai.size()) {
+            size_t e = fai.find('\n', p); if (e == std::string::npos) e = fai.size();
+            std::string line = fai.substr(p, e - p); p = e + 1;
+            size_t t = line.find('\t');
+            if (t == std::string::npos) continue;
+            Seq s; s.name = line.substr(0, t);
+            long long len, off; int lb, ll;
+            if (sscanf(line.c_str() + t + 1, "%lld\t%lld\t%d\t%d", &len, &off, &lb, &ll) != 4) continue;
+            s.len = len; s.offset = off; s.line_blen = lb; s.line_len = ll;
+            seqs.push_back(s);
+        }
+    } else {
+        size_t i = 0, n = data.size();
+        while (i < n) {
+            if (data[i] != '>') { while (i < n && data[i] != '\n') ++i; ++i; continue; }
+            size_t j = i + 1; while (j < n && !isspace((unsigned char)data[j])) ++j;
+            Seq s; s.name = data.substr(i + 1, j - i - 1);
+            while (j < n && data[j] != '\n') ++j;
+            ++j;
+            s.offset = (int64_t)j; s.len = 0; s.line_blen = 0; s.line_len = 0;
+            while (j < n && data[j] != '>') {
+                size_t k = j, bases = 0;
+                while (k < n && data[k] != '\n') { if (isgraph((unsigned char)data[k])) ++bases; ++k; }
+                const size_t ll = k - j + (k < n ? 1 : 0);
+                if (!s.line_len) { s.line_len = (int)ll; s.line_blen = (int)bases; }
+                s.len += (int64_t)bases;
+                j = k + 1;
+            }
+            seqs.push_back(s);
+            i = j;
+        }
+    }
+    return true;
+}
+
+bool Fasta::fetch(const std::string &name, int64_t beg1, int64_t end1, std::string &out) const {
+    const Seq *s = nullptr;
+    for (const Seq &q : seqs) if (q.name == name) s = &q;     // khash: a later duplicate replaces the earlier one
+    out.clear();
+    if (!s) return false;
+    int64_t beg = beg1, end = end1;
+    if (beg > 0) --beg;
+    if (beg >= s->len) beg = s->len;
+    if (end >= s->len) end = s->len;
+    if (beg > end) beg = end;
+    if (s->line_blen <= 0) return true;
+    size_t p = (size_t)(s->offset + beg / s->line_blen * s->line_len + beg % s->line_blen);
+    while (p < data.size() && (int64_t)out.size() < end - beg) { const int c = (unsigned char)data[p++]; if (isgraph(c)) out.push_back((char)c); }
+    return true;
+}
+
+std::string rev_comp(const std::string &s) {
+    std::string r(s.rbegin(), s.rend());
+    for (char &c : r) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+    return r;
+}
+
+}  // namespace rgx

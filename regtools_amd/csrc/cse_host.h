@@ -1,0 +1,52 @@
+// cse_host.h -- host-side text containers of `cis-splice-effects identify`: GTF -> flat arrays, VCF
+// lines, FASTA random access.  Parsing only; every interval computation happens in the kernels (cse_core.h).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace rgx {
+
+// gtf/gtf_parser.cc:63-263
+struct GtfModel {
+    std::vector<std::string> chroms;                      // GTF contig names, first-seen order
+    std::unordered_map<std::string, int32_t> chrom_index;
+    // transcripts in std::map<string,...> order (ascending id)
+    std::vector<std::string> tx_id, tx_gene_name, tx_gene_id;
+    std::vector<int32_t>  tx_chrom;
+    std::vector<uint8_t>  tx_strand;
+    std::vector<uint32_t> tx_exon_off, tx_n_exons, tx_bin;
+    std::vector<uint32_t> es, ee;                          // strand-sorted per transcript
+    std::vector<uint64_t> bin_key;                         // (chrom << 32 | bin), sorted, ties in transcript order
+    std::vector<uint32_t> bin_tx;
+    // returns "" on success, else the message the reference would die with
+    std::string load(const std::string &path);
+    int32_t chrom_of(const std::string &name) const { auto it = chrom_index.find(name); return it == chrom_index.end() ? -1 : it->second; }
+};
+
+// vcf.c:1782-1958: only CHROM and POS are consumed; the text is kept for the -v pass-through
+struct VcfText {
+    std::string text;
+    std::vector<size_t> line_off;      // n_lines + 1 entries
+    struct Rec { size_t line; std::string chrom; uint32_t pos0; };
+    std::vector<Rec> recs;
+    std::string load(const std::string &path);
+    size_t n_lines() const { return line_off.empty() ? 0 : line_off.size() - 1; }
+    void line(size_t i, const char *&p, size_t &len) const;
+};
+
+// faidx.c:288-413 (uncompressed FASTA + .fai, the index is built in memory when the file is missing)
+struct Fasta {
+    struct Seq { std::string name; int64_t len, offset; int line_blen, line_len; };
+    std::string data;
+    std::vector<Seq> seqs;
+    bool load(const std::string &path);
+    // fai_fetch("name:beg1-end1"): returns false when the contig is unknown
+    bool fetch(const std::string &name, int64_t beg1, int64_t end1, std::string &out) const;
+};
+
+std::string rev_comp(const std::string &s);   // utils/common.h:59-83
+
+}  // namespace rgx

@@ -1,0 +1,126 @@
+// cse_kernels.hip -- gfx950 kernels of the `cis-splice-effects identify` interval work.
+//   a10  k_variant_scan   one lane per variant: 7-level bin walk over the flat GTF, exon scan, splice window (min/max)
+//   a11  k_junction_scan  one lane per junction: same walk, order-dependent known-donor/acceptor flags, skipped elements
+//   a9   k_window_pairs   one wave per variant window: binary-search the event range, keep events whose READ overlaps it
+// All three are gather-dominated integer kernels (HBM/L2 latency bound); counts are produced first, offsets by the shared
+// scan, then a fill pass writes variable-length results -- deterministic, no atomics on the data path.
+#include "kernels.h"
+
+#include "cse_core.h"
+
+namespace rgx {
+
+__device__ __forceinline__ uint32_t lane_id2() { return threadIdx.x & 63u; }
+
+template <bool FILL>
+__global__ void k_variant_scan(GtfView g, uint32_t n, const int32_t *__restrict__ chrom, const uint32_t *__restrict__ pos0, VariantOpts o,
+                               uint32_t *count, const uint32_t *__restrict__ base, uint32_t *ces, uint32_t *cee, uint32_t *hit_tx, uint32_t *hit_ad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t a, b, k = 0;
+    const uint32_t off = FILL ? base[i] : 0u;
+    variant_scan(g, chrom[i], pos0[i], o, a, b, [&](uint32_t t, uint32_t ann, uint32_t dist) {
+        if (FILL) { hit_tx[off + k] = t; hit_ad[2 * (size_t)(off + k)] = ann; hit_ad[2 * (size_t)(off + k) + 1] = dist; }
+        ++k;
+    });
+    if (!FILL) { count[i] = k; ces[i] = a; cee[i] = b; }
+}
+
+template <bool FILL>
+__global__ void k_junction_scan(GtfView g, uint32_t n, const int32_t *__restrict__ chrom, const uint32_t *__restrict__ js, const uint32_t *__restrict__ je,
+                                const uint8_t *__restrict__ strand, uint32_t *count, const uint32_t *__restrict__ base, uint32_t *flags, uint32_t *item_kind,
+                                uint32_t *item_a, uint32_t *item_b) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    JunctionFlags f;
+    uint32_t k = 0;
+    const uint32_t off = FILL ? base[i] : 0u;
+    junction_scan(g, chrom[i], js[i], je[i], (char)strand[i], f, [&](uint32_t kind, uint32_t a, uint32_t b) {
+        if (FILL) { item_kind[off + k] = kind; item_a[off + k] = a; item_b[off + k] = b; }
+        ++k;
+    });
+    if (!FILL) { count[i] = k; flags[i] = f.known_donor | f.known_acceptor << 1 | f.known_junction << 2; }
+}
+
+// longest reference span of a read that supports an event: bounds how far before a window its overlapping reads can start
+__global__ __launch_bounds__(256) void k_max_span(EventSoA ev, uint32_t n, uint32_t *out) {
+    __shared__ uint32_t s_max[4];
+    uint32_t m = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { const uint32_t d = ev.rend[i] - ev.rpos[i]; m = m > d ? m : d; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(m, d, 64); m = m > o ? m : o; }
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { m = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])); atomicMax(out, m); }
+}
+
+// first event index whose (tid, read pos) >= (t, p); events are in file order = (tid, pos) order of the sorted BAM
+__device__ __forceinline__ uint32_t ev_lower_bound(const EventSoA &ev, uint32_t n, uint32_t t, uint32_t p) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t mt = ev.tid[mid], mp = ev.rpos[mid];
+        if (mt < t || (mt == t && (int32_t)mp < (int32_t)p)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// Window w = reads with tid == t, pos < end, endpos > beg (hts.c:1946-1957).  Pairs (window, event) are produced window-major
+// and in event (file) order inside a window, so the later stable group-by sees every window's reads in file order.
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_window_pairs(EventSoA ev, uint32_t n_events, uint32_t n_win, const int32_t *__restrict__ w_tid,
+                                                     const int32_t *__restrict__ w_beg, const int32_t *__restrict__ w_end, const uint32_t *__restrict__ max_span,
+                                                     uint32_t *count, const uint32_t *__restrict__ base, uint32_t *pair_ev, uint32_t *pair_win) {
+    const uint32_t w = blockIdx.x, lane = threadIdx.x;
+    if (w >= n_win) return;
+    const int32_t t = w_tid[w], beg = w_beg[w], end = w_end[w];
+    const uint32_t span = *max_span;
+    const int32_t lo_pos = beg > (int32_t)span ? beg - (int32_t)span : 0;
+    const uint32_t lo = ev_lower_bound(ev, n_events, (uint32_t)t, (uint32_t)lo_pos), hi = ev_lower_bound(ev, n_events, (uint32_t)t, (uint32_t)end);
+    uint32_t out = FILL ? base[w] : 0u, total = 0;
+    for (uint32_t e0 = lo; e0 < hi; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        const bool keep = e < hi && (int32_t)ev.rend[e] > beg;          // pos < end holds for the whole range
+        const uint64_t m = __ballot(keep);
+        if (FILL && keep) { const uint32_t k = out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); pair_ev[k] = e; pair_win[k] = w; }
+        out += (uint32_t)__popcll(m); total += (uint32_t)__popcll(m);
+    }
+    if (!FILL && lane == 0) count[w] = total;
+}
+
+// the events of the pairs, re-keyed by window (group word = window index)
+__global__ void k_pair_gather(EventSoA ev, const uint32_t *__restrict__ pair_ev, const uint32_t *__restrict__ pair_win, uint32_t n, EventSoA out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t e = pair_ev[i];
+    out.tid[i] = pair_win[i]; out.start[i] = ev.start[e]; out.ilen_cls[i] = ev.ilen_cls[e]; out.ts[i] = ev.ts[e]; out.te[i] = ev.te[e]; out.strand[i] = ev.strand[e];
+}
+
+void launch_variant_scan(bool fill, GtfView g, uint32_t n, const int32_t *chrom, const uint32_t *pos0, VariantOpts o, uint32_t *count, const uint32_t *base,
+                         uint32_t *ces, uint32_t *cee, uint32_t *hit_tx, uint32_t *hit_ad, hipStream_t stream) {
+    if (!n) return;
+    if (fill) hipLaunchKernelGGL(k_variant_scan<true>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, pos0, o, count, base, ces, cee, hit_tx, hit_ad);
+    else hipLaunchKernelGGL(k_variant_scan<false>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, pos0, o, count, base, ces, cee, hit_tx, hit_ad);
+}
+void launch_junction_scan(bool fill, GtfView g, uint32_t n, const int32_t *chrom, const uint32_t *js, const uint32_t *je, const uint8_t *strand, uint32_t *count,
+                          const uint32_t *base, uint32_t *flags, uint32_t *item_kind, uint32_t *item_a, uint32_t *item_b, hipStream_t stream) {
+    if (!n) return;
+    if (fill) hipLaunchKernelGGL(k_junction_scan<true>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, js, je, strand, count, base, flags, item_kind, item_a, item_b);
+    else hipLaunchKernelGGL(k_junction_scan<false>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, js, je, strand, count, base, flags, item_kind, item_a, item_b);
+}
+void launch_max_span(EventSoA ev, uint32_t n, uint32_t *out, hipStream_t stream) {
+    if (!n) return;
+    uint32_t blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_max_span, dim3(blocks), dim3(256), 0, stream, ev, n, out);
+}
+void launch_window_pairs(bool fill, EventSoA ev, uint32_t n_events, uint32_t n_win, const int32_t *w_tid, const int32_t *w_beg, const int32_t *w_end,
+                         const uint32_t *max_span, uint32_t *count, const uint32_t *base, uint32_t *pair_ev, uint32_t *pair_win, hipStream_t stream) {
+    if (!n_win) return;
+    if (fill) hipLaunchKernelGGL(k_window_pairs<true>, dim3(n_win), dim3(64), 0, stream, ev, n_events, n_win, w_tid, w_beg, w_end, max_span, count, base, pair_ev, pair_win);
+    else hipLaunchKernelGGL(k_window_pairs<false>, dim3(n_win), dim3(64), 0, stream, ev, n_events, n_win, w_tid, w_beg, w_end, max_span, count, base, pair_ev, pair_win);
+}
+void launch_pair_gather(EventSoA ev, const uint32_t *pair_ev, const uint32_t *pair_win, uint32_t n, EventSoA out, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_pair_gather, dim3((n + 255) / 256), dim3(256), 0, stream, ev, pair_ev, pair_win, n, out);
+}
+
+}  // namespace rgx

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "bam_core.h"
 
 namespace rgx {
 
@@ -71,6 +72,10 @@ struct ExtractCfg {
     int32_t  region_tid;           // -2 = whole file
     int32_t  region_beg, region_end;
     uint32_t long_threshold;       // reads with more CIGAR ops than this go to the wave-per-read kernel
+    // intron-motif strand rule (a FASTA was given): file bytes + one descriptor per BAM contig, both in HBM
+    const uint8_t *fa_data;
+    const struct FaContig *fa_tab;
+    uint32_t *fa_missing;          // [0] set to 1+tid when a junction lies on a contig the FASTA does not have
 };
 
 // one wave per framing segment, segment bytes staged through LDS (replaces launch_seg_fill + launch_decode on the hot path)
@@ -119,5 +124,23 @@ void launch_reduce_finish(EventSoA ev, const uint32_t *perm, uint32_t n, uint32_
 void launch_name_rank(uint32_t n_unique, const uint32_t *flag_scan, UniqueSoA u, hipStream_t stream);
 void launch_gather_u32(uint32_t n, const uint32_t *table, const uint32_t *idx, uint32_t *out, hipStream_t stream);
 void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t stream);
+
+
+// ---- a9-a11: `cis-splice-effects identify` interval kernels (cse_kernels.hip; logic in cse_core.h) --------------------------
+struct GtfView;
+struct VariantOpts;
+}  // namespace rgx
+#include "cse_core.h"
+namespace rgx {
+// count pass (fill = false): count[i], ces[i], cee[i]; fill pass: hit_tx[base[i]+k], hit_ad[2*(base[i]+k)] = annotation, +1 = distance
+void launch_variant_scan(bool fill, GtfView g, uint32_t n, const int32_t *chrom, const uint32_t *pos0, VariantOpts o, uint32_t *count, const uint32_t *base,
+                         uint32_t *ces, uint32_t *cee, uint32_t *hit_tx, uint32_t *hit_ad, hipStream_t stream);
+// count pass: count[i], flags[i] = known_donor | known_acceptor<<1 | known_junction<<2; fill pass: items (kind,a,b) in visitation order
+void launch_junction_scan(bool fill, GtfView g, uint32_t n, const int32_t *chrom, const uint32_t *js, const uint32_t *je, const uint8_t *strand, uint32_t *count,
+                          const uint32_t *base, uint32_t *flags, uint32_t *item_kind, uint32_t *item_a, uint32_t *item_b, hipStream_t stream);
+void launch_max_span(EventSoA ev, uint32_t n, uint32_t *out /* zeroed by the caller */, hipStream_t stream);
+void launch_window_pairs(bool fill, EventSoA ev, uint32_t n_events, uint32_t n_win, const int32_t *w_tid, const int32_t *w_beg, const int32_t *w_end,
+                         const uint32_t *max_span, uint32_t *count, const uint32_t *base, uint32_t *pair_ev, uint32_t *pair_win, hipStream_t stream);
+void launch_pair_gather(EventSoA ev, const uint32_t *pair_ev, const uint32_t *pair_win, uint32_t n, EventSoA out, hipStream_t stream);
 
 }  // namespace rgx

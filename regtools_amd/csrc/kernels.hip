@@ -357,8 +357,18 @@ __global__ void k_emit_short(const uint8_t *__restrict__ arena, uint32_t n_rec, 
     uint32_t slot = ev_base[i];
     const int32_t pos = soa.pos[i];
     const uint32_t rend = ev.rpos ? (uint32_t)rec_endpos(cig, n_cigar, fnc >> 16, pos) : 0u;     // bam_endpos of the supporting read
+    char carried = 0;
     cigar_walk(pos, cig, n_cigar, [&](uint32_t s, uint32_t e, uint32_t ts, uint32_t te) {
-        if (intron_ok(s, e, cfg.min_intron, cfg.max_intron)) put_event(ev, slot++, tid, s, e, ts, te, strand, (uint32_t)pos, rend);
+        char st = strand;
+        if (cfg.fa_data) {
+            // set_junction_strand (junctions_extractor.cc:345-359): motif first, the tag/flag rule only when the motif says '?'.
+            // The strand is decided (and carried to the read's next junction) BEFORE junction_qc.
+            const FaContig fc = cfg.fa_tab[tid];
+            if (!fc.present) { cfg.fa_missing[0] = 1u + (uint32_t)tid; }
+            else { const char m = strand_from_motif(cfg.fa_data, fc, s, e, carried); if (m != '?') st = m; }
+            carried = st;
+        }
+        if (intron_ok(s, e, cfg.min_intron, cfg.max_intron)) put_event(ev, slot++, tid, s, e, ts, te, st, (uint32_t)pos, rend);
     });
 }
 
@@ -391,7 +401,8 @@ __global__ __launch_bounds__(256) void k_emit_long(const uint8_t *__restrict__ a
         uint32_t refpos = rpos;                      // R at the start of the tile
         uint32_t ts_carry = refpos;                  // R[pb+1] for an N with no breaker earlier in the tile
         // junction opened in an earlier tile and still waiting for its right anchor's end
-        bool pend = false; uint32_t p_start = 0, p_end = 0, p_ts = 0;
+        bool pend = false; uint32_t p_start = 0, p_end = 0, p_ts = 0; char p_strand = strand;
+        char carried = 0;                            // intron-motif rule: strand of the read's previous junction
         for (uint32_t t0 = 0; t0 < n_cigar; t0 += 64) {
             const uint32_t k = t0 + lane;
             const uint32_t c = k < n_cigar ? ld32(cig + 4 * (size_t)k) : 0x5u /* 0H: inert */;
@@ -409,7 +420,7 @@ __global__ __launch_bounds__(256) void k_emit_long(const uint8_t *__restrict__ a
             if (pend && B) {
                 const uint32_t nb = (uint32_t)__ffsll((unsigned long long)B) - 1;
                 const uint32_t te = s_R[wave][nb];
-                if (lane == 0 && intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) put_event(ev, slot, tid, p_start, p_end, p_ts, te, strand, rpos, rend);
+                if (lane == 0 && intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) put_event(ev, slot, tid, p_start, p_end, p_ts, te, p_strand, rpos, rend);
                 if (intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) ++slot;
                 pend = false;
             }
@@ -420,9 +431,32 @@ __global__ __launch_bounds__(256) void k_emit_long(const uint8_t *__restrict__ a
             const bool closed = above != 0;
             const uint32_t te = closed ? s_R[wave][(uint32_t)__ffsll((unsigned long long)above) - 1] : 0u;
             const bool ok = isN && intron_ok(R_before, R_after, cfg.min_intron, cfg.max_intron);
+            // strand of this lane's junction: per-read tag/flag rule, or the intron-motif rule with its carried-over state --
+            // a two-state chain over the N ops in CIGAR order, resolved lane by lane (a long read has a few dozen at most)
+            char my_strand = strand;
+            if (cfg.fa_data) {
+                const FaContig fc = cfg.fa_tab[tid];
+                char sA = strand, sB = strand;           // outcome if the carried strand is not '-' / is '-'
+                if (isN) {
+                    if (!fc.present) cfg.fa_missing[0] = 1u + (uint32_t)tid;
+                    else {
+                        const char mA = strand_from_motif(cfg.fa_data, fc, R_before, R_after, 0), mB = strand_from_motif(cfg.fa_data, fc, R_before, R_after, '-');
+                        if (mA != '?') sA = mA;
+                        if (mB != '?') sB = mB;
+                    }
+                }
+                uint64_t nm = __ballot(isN);
+                while (nm) {
+                    const uint32_t l = (uint32_t)__ffsll((unsigned long long)nm) - 1; nm &= nm - 1;
+                    const char a = (char)__shfl((int)sA, l, 64), b = (char)__shfl((int)sB, l, 64);
+                    const char s = carried == '-' ? b : a;
+                    if (lane == l) my_strand = s;
+                    carried = s;
+                }
+            }
             // events keep CIGAR order: rank among the qc-passing N lanes that close inside this tile
             const uint64_t emit_mask = __ballot(ok && closed);
-            if (ok && closed) put_event(ev, slot + (uint32_t)__popcll(emit_mask & lanemask_lt()), tid, R_before, R_after, ts, te, strand, rpos, rend);
+            if (ok && closed) put_event(ev, slot + (uint32_t)__popcll(emit_mask & lanemask_lt()), tid, R_before, R_after, ts, te, my_strand, rpos, rend);
             slot += (uint32_t)__popcll(emit_mask);
             // the last breaker of the tile: if it is an N it stays open into the next tile
             if (B) {
@@ -434,13 +468,14 @@ __global__ __launch_bounds__(256) void k_emit_long(const uint8_t *__restrict__ a
                     p_start = s_R[wave][lastb]; p_end = s_R[wave][lastb + 1];
                     const uint64_t bl = B & ((1ull << lastb) - 1ull);
                     p_ts = __shfl(ts, lastb, 64);
+                    p_strand = (char)__shfl((int)my_strand, lastb, 64);
                     (void)bl;
                 }
             }
             refpos = __shfl(R_after, 63, 64);
             __builtin_amdgcn_wave_barrier();
         }
-        if (pend && lane == 0 && intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) put_event(ev, slot, tid, p_start, p_end, p_ts, refpos, strand, rpos, rend);
+        if (pend && lane == 0 && intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) put_event(ev, slot, tid, p_start, p_end, p_ts, refpos, p_strand, rpos, rend);
     }
 }
 

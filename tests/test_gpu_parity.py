@@ -181,3 +181,25 @@ def test_full_size_properties(gpu_ctx, synth_dir):
     first = je.bed12()
     je.identify_junctions_from_BAM(bam_bytes=bam, bai_bytes=bai)                          # idempotent on a warm workspace
     assert je.bed12() == first
+
+
+def test_extract_with_fasta_strand_rule(gpu_ctx, tmp_path):
+    """`junctions extract ... ref.fa`: intron-motif first, tag/flag rule when the motif is not canonical (junctions_extractor.cc:345-359)."""
+    import cse_synth
+    q = cse_synth.build(str(tmp_path / "q"), seed=5, n_genes=14)
+    for args in (["-s", "XS"], ["-s", "intron-motif"], ["-s", "RF", "-a", "3"]):
+        import regtools_amd
+        je = regtools_amd.JunctionsExtractor(ctx=gpu_ctx)
+        je.parse_options(args + [q["bam"], q["fasta"]])
+        je.identify_junctions_from_BAM()
+        rc, exp, _ = run_oracle(args + [q["bam"], q["fasta"]])
+        assert rc == 0 and je.bed12() == exp and exp.count(b"\n") > 20, args
+    # long reads through the wave-per-read kernel with the carried-over strand state
+    from regtools_amd import synth
+    p = str(tmp_path / "long.bam")
+    synth.write(p, 400, shape="long", seed=9)
+    # a FASTA for the human contig names would be 3 GB; a missing contig must fail like the reference (exit 1)
+    je = regtools_amd.JunctionsExtractor(ctx=gpu_ctx)
+    je.parse_options(["-s", "XS", p, q["fasta"]])
+    with pytest.raises(regtools_amd.RegtoolsError):
+        je.identify_junctions_from_BAM()
