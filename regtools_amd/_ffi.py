@@ -134,7 +134,7 @@ def lib():
 class SynthParams(C.Structure):
     _fields_ = [("shape", C.c_int), ("n_reads", C.c_uint64), ("seed", C.c_uint64), ("level", C.c_int),
                 ("threads", C.c_int), ("n_introns", C.c_uint32), ("spliced_frac", C.c_double),
-                ("realistic_payload", C.c_int), ("slice_index", C.c_int), ("n_slices", C.c_int)]
+                ("realistic_payload", C.c_int), ("slice_index", C.c_int), ("n_slices", C.c_int), ("n_genes", C.c_uint32)]
 
 
 class SynthResult(C.Structure):
@@ -157,5 +157,6 @@ def synth():
         L.rgx_synth_free.argtypes = [P(SynthResult)]
         L.rgx_synth_write.argtypes = [P(SynthParams), C.c_char_p, P(SynthResult)]
         L.rgx_synth_index.argtypes = [C.c_char_p]
+        L.rgx_synth_annotation.argtypes = [P(SynthParams), C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p]
         _synth = L
     return _synth

@@ -402,8 +402,8 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             delete c->fasta; c->fasta = new Fasta(); c->fasta_path.clear();
             if (!c->fasta->load(p->fasta_path)) { delete c->fasta; c->fasta = nullptr; return fail(err, errlen, RGX_ERR_FASTA, "Unable to open FASTA file.\n\n"); }
             DevBuf &bf = c->buf("fasta");
-            HIP_TRY(bf.ensure(c->fasta->data.size() + 256));
-            HIP_TRY(hipMemcpy(bf.p, c->fasta->data.data(), c->fasta->data.size(), hipMemcpyHostToDevice));
+            HIP_TRY(bf.ensure(c->fasta->size + 256));
+            HIP_TRY(hipMemcpy(bf.p, c->fasta->data, c->fasta->size, hipMemcpyHostToDevice));
             c->fasta_path = p->fasta_path;
         }
         std::vector<FaContig> tab((size_t)std::max(n_ref, 1));

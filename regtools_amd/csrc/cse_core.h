@@ -90,8 +90,8 @@ RGX_HD uint32_t variant_vs_transcript(char strand, const uint32_t *s, const uint
 // One variant against every candidate transcript, in the reference's visitation order (level fine->coarse, bin ascending,
 // transcript id ascending) -- variants_annotator.cc:455-518.  `hit(t, ann, dist)` is called per hit, in order.
 template <class Hit>
-RGX_HD void variant_scan(const GtfView &g, int32_t chrom, uint32_t pos0, const VariantOpts &o, uint32_t &ces, uint32_t &cee, Hit &&hit) {
-    ces = 0xffffffffu; cee = 0;
+RGX_HD void variant_scan(const GtfView &g, int32_t chrom, uint32_t pos0, const VariantOpts &o, uint32_t &ces, uint32_t &cee, uint32_t &exon_visits, Hit &&hit) {
+    ces = 0xffffffffu; cee = 0; exon_visits = 0;
     if (chrom < 0) return;
     uint32_t sb = (uint32_t)(pos0 - o.intronic_min) >> 14, eb = (uint32_t)(pos0 + o.intronic_min) >> 14;
     for (int lvl = 0; lvl < 7; ++lvl) {
@@ -101,6 +101,7 @@ RGX_HD void variant_scan(const GtfView &g, int32_t chrom, uint32_t pos0, const V
             for (uint32_t j = bin_lower_bound(g, k0); j < g.n_bin && g.bin_key[j] <= k1; ++j) {
                 const uint32_t t = g.bin_tx[j], n = g.tx_n_exons[t];
                 if (o.skip_single && n == 1) continue;
+                exon_visits += n;
                 uint32_t dist = 0;
                 const uint32_t ann = variant_vs_transcript((char)g.tx_strand[t], g.es + g.tx_exon_off[t], g.ee + g.tx_exon_off[t], n, pos0 + 1, o, dist, ces, cee);
                 if (ann != ANN_NONE) hit(t, ann, dist);
@@ -160,8 +161,8 @@ RGX_HD bool junction_vs_transcript(char strand, const uint32_t *s, const uint32_
 
 // annotate_junction_with_gtf (:344-363) + check_for_overlap (:313-340): transcripts visited in (level, bin, id) order
 template <class Item>
-RGX_HD void junction_scan(const GtfView &g, int32_t chrom, uint32_t js, uint32_t je, char strand, JunctionFlags &f, Item &&item) {
-    f.known_donor = f.known_acceptor = f.known_junction = 0;
+RGX_HD void junction_scan(const GtfView &g, int32_t chrom, uint32_t js, uint32_t je, char strand, JunctionFlags &f, uint32_t &exon_visits, Item &&item) {
+    f.known_donor = f.known_acceptor = f.known_junction = 0; exon_visits = 0;
     if (chrom < 0 || (strand != '+' && strand != '-')) return;     // '?' matches no transcript (:322-323)
     uint32_t sb = js >> 14, eb = (uint32_t)(je - 1) >> 14;
     for (int lvl = 0; lvl < 7; ++lvl) {
@@ -171,6 +172,7 @@ RGX_HD void junction_scan(const GtfView &g, int32_t chrom, uint32_t js, uint32_t
             for (uint32_t j = bin_lower_bound(g, k0); j < g.n_bin && g.bin_key[j] <= k1; ++j) {
                 const uint32_t t = g.bin_tx[j];
                 if ((char)g.tx_strand[t] != strand) continue;
+                exon_visits += g.tx_n_exons[t];
                 if (junction_vs_transcript(strand, g.es + g.tx_exon_off[t], g.ee + g.tx_exon_off[t], g.tx_n_exons[t], js, je, f, item)) item(ITEM_TX, t, 0u);
             }
         }

@@ -5,6 +5,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <numeric>
@@ -156,8 +160,20 @@ void VcfText::line(size_t i, const char *&p, size_t &len) const {
     if (len && p[len - 1] == '\r') --len;
 }
 
+Fasta::~Fasta() { if (data && size) munmap(const_cast<char *>(data), size); }
+
 bool Fasta::load(const std::string &path) {
-    if (!slurp(path, data)) return false;
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return false; }
+    size = (size_t)st.st_size;
+    if (size) {
+        void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { size = 0; return false; }
+        data = static_cast<const char *>(m);
+    } else close(fd);
     std::string fai;
     if (slurp(path + ".fai", fai)) {
         size_t p = 0;
@@ -173,11 +189,11 @@ bool Fasta::load(const std::string &path) {
             seqs.push_back(s);
         }
     } else {
-        size_t i = 0, n = data.size();
+        size_t i = 0, n = size;
         while (i < n) {
             if (data[i] != '>') { while (i < n && data[i] != '\n') ++i; ++i; continue; }
             size_t j = i + 1; while (j < n && !isspace((unsigned char)data[j])) ++j;
-            Seq s; s.name = data.substr(i + 1, j - i - 1);
+            Seq s; s.name.assign(data + i + 1, j - i - 1);
             while (j < n && data[j] != '\n') ++j;
             ++j;
             s.offset = (int64_t)j; s.len = 0; s.line_blen = 0; s.line_len = 0;
@@ -208,7 +224,7 @@ bool Fasta::fetch(const std::string &name, int64_t beg1, int64_t end1, std::stri
     if (beg > end) beg = end;
     if (s->line_blen <= 0) return true;
     size_t p = (size_t)(s->offset + beg / s->line_blen * s->line_len + beg % s->line_blen);
-    while (p < data.size() && (int64_t)out.size() < end - beg) { const int c = (unsigned char)data[p++]; if (isgraph(c)) out.push_back((char)c); }
+    while (p < size && (int64_t)out.size() < end - beg) { const int c = (unsigned char)data[p++]; if (isgraph(c)) out.push_back((char)c); }
     return true;
 }
 

@@ -40,8 +40,13 @@ struct VcfText {
 // faidx.c:288-413 (uncompressed FASTA + .fai, the index is built in memory when the file is missing)
 struct Fasta {
     struct Seq { std::string name; int64_t len, offset; int line_blen, line_len; };
-    std::string data;
+    const char *data = nullptr;   // the file, mmap'd read-only: splice-site lookups touch a few pages of a multi-GB genome
+    size_t size = 0;
     std::vector<Seq> seqs;
+    Fasta() = default;
+    Fasta(const Fasta &) = delete;
+    Fasta &operator=(const Fasta &) = delete;
+    ~Fasta();
     bool load(const std::string &path);
     // fai_fetch("name:beg1-end1"): returns false when the contig is unknown
     bool fetch(const std::string &name, int64_t beg1, int64_t end1, std::string &out) const;

@@ -12,34 +12,46 @@ namespace rgx {
 
 __device__ __forceinline__ uint32_t lane_id2() { return threadIdx.x & 63u; }
 
+// exon records of the candidate transcripts (SURVEY 8d's E_v / E_j), one atomic per wave
+__device__ __forceinline__ void wave_add_visits(uint32_t v, unsigned long long *visits) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if (visits && (threadIdx.x & 63) == 0 && v) atomicAdd(visits, (unsigned long long)v);
+}
+
 template <bool FILL>
 __global__ void k_variant_scan(GtfView g, uint32_t n, const int32_t *__restrict__ chrom, const uint32_t *__restrict__ pos0, VariantOpts o,
-                               uint32_t *count, const uint32_t *__restrict__ base, uint32_t *ces, uint32_t *cee, uint32_t *hit_tx, uint32_t *hit_ad) {
+                               uint32_t *count, const uint32_t *__restrict__ base, uint32_t *ces, uint32_t *cee, uint32_t *hit_tx, uint32_t *hit_ad,
+                               unsigned long long *visits) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t a, b, k = 0;
-    const uint32_t off = FILL ? base[i] : 0u;
-    variant_scan(g, chrom[i], pos0[i], o, a, b, [&](uint32_t t, uint32_t ann, uint32_t dist) {
-        if (FILL) { hit_tx[off + k] = t; hit_ad[2 * (size_t)(off + k)] = ann; hit_ad[2 * (size_t)(off + k) + 1] = dist; }
-        ++k;
-    });
-    if (!FILL) { count[i] = k; ces[i] = a; cee[i] = b; }
+    uint32_t a, b, k = 0, ev = 0;
+    if (i < n) {
+        const uint32_t off = FILL ? base[i] : 0u;
+        variant_scan(g, chrom[i], pos0[i], o, a, b, ev, [&](uint32_t t, uint32_t ann, uint32_t dist) {
+            if (FILL) { hit_tx[off + k] = t; hit_ad[2 * (size_t)(off + k)] = ann; hit_ad[2 * (size_t)(off + k) + 1] = dist; }
+            ++k;
+        });
+        if (!FILL) { count[i] = k; ces[i] = a; cee[i] = b; }
+    }
+    if (!FILL) wave_add_visits(ev, visits);
 }
 
 template <bool FILL>
 __global__ void k_junction_scan(GtfView g, uint32_t n, const int32_t *__restrict__ chrom, const uint32_t *__restrict__ js, const uint32_t *__restrict__ je,
                                 const uint8_t *__restrict__ strand, uint32_t *count, const uint32_t *__restrict__ base, uint32_t *flags, uint32_t *item_kind,
-                                uint32_t *item_a, uint32_t *item_b) {
+                                uint32_t *item_a, uint32_t *item_b, unsigned long long *visits) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    JunctionFlags f;
-    uint32_t k = 0;
-    const uint32_t off = FILL ? base[i] : 0u;
-    junction_scan(g, chrom[i], js[i], je[i], (char)strand[i], f, [&](uint32_t kind, uint32_t a, uint32_t b) {
-        if (FILL) { item_kind[off + k] = kind; item_a[off + k] = a; item_b[off + k] = b; }
-        ++k;
-    });
-    if (!FILL) { count[i] = k; flags[i] = f.known_donor | f.known_acceptor << 1 | f.known_junction << 2; }
+    uint32_t k = 0, ev = 0;
+    if (i < n) {
+        JunctionFlags f;
+        const uint32_t off = FILL ? base[i] : 0u;
+        junction_scan(g, chrom[i], js[i], je[i], (char)strand[i], f, ev, [&](uint32_t kind, uint32_t a, uint32_t b) {
+            if (FILL) { item_kind[off + k] = kind; item_a[off + k] = a; item_b[off + k] = b; }
+            ++k;
+        });
+        if (!FILL) { count[i] = k; flags[i] = f.known_donor | f.known_acceptor << 1 | f.known_junction << 2; }
+    }
+    if (!FILL) wave_add_visits(ev, visits);
 }
 
 // longest reference span of a read that supports an event: bounds how far before a window its overlapping reads can start
@@ -97,16 +109,16 @@ __global__ void k_pair_gather(EventSoA ev, const uint32_t *__restrict__ pair_ev,
 }
 
 void launch_variant_scan(bool fill, GtfView g, uint32_t n, const int32_t *chrom, const uint32_t *pos0, VariantOpts o, uint32_t *count, const uint32_t *base,
-                         uint32_t *ces, uint32_t *cee, uint32_t *hit_tx, uint32_t *hit_ad, hipStream_t stream) {
+                         uint32_t *ces, uint32_t *cee, uint32_t *hit_tx, uint32_t *hit_ad, unsigned long long *visits, hipStream_t stream) {
     if (!n) return;
-    if (fill) hipLaunchKernelGGL(k_variant_scan<true>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, pos0, o, count, base, ces, cee, hit_tx, hit_ad);
-    else hipLaunchKernelGGL(k_variant_scan<false>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, pos0, o, count, base, ces, cee, hit_tx, hit_ad);
+    if (fill) hipLaunchKernelGGL(k_variant_scan<true>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, pos0, o, count, base, ces, cee, hit_tx, hit_ad, visits);
+    else hipLaunchKernelGGL(k_variant_scan<false>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, pos0, o, count, base, ces, cee, hit_tx, hit_ad, visits);
 }
 void launch_junction_scan(bool fill, GtfView g, uint32_t n, const int32_t *chrom, const uint32_t *js, const uint32_t *je, const uint8_t *strand, uint32_t *count,
-                          const uint32_t *base, uint32_t *flags, uint32_t *item_kind, uint32_t *item_a, uint32_t *item_b, hipStream_t stream) {
+                          const uint32_t *base, uint32_t *flags, uint32_t *item_kind, uint32_t *item_a, uint32_t *item_b, unsigned long long *visits, hipStream_t stream) {
     if (!n) return;
-    if (fill) hipLaunchKernelGGL(k_junction_scan<true>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, js, je, strand, count, base, flags, item_kind, item_a, item_b);
-    else hipLaunchKernelGGL(k_junction_scan<false>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, js, je, strand, count, base, flags, item_kind, item_a, item_b);
+    if (fill) hipLaunchKernelGGL(k_junction_scan<true>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, js, je, strand, count, base, flags, item_kind, item_a, item_b, visits);
+    else hipLaunchKernelGGL(k_junction_scan<false>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, js, je, strand, count, base, flags, item_kind, item_a, item_b, visits);
 }
 void launch_max_span(EventSoA ev, uint32_t n, uint32_t *out, hipStream_t stream) {
     if (!n) return;

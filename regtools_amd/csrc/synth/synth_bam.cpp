@@ -50,8 +50,12 @@ const Contig kFuzz[] = {{"1", 600000}, {"10", 300000}, {"2", 500000}, {"MT", 165
 
 struct Intron { int32_t tid; uint32_t donor, len; char strand; };
 
+// gene model shared by the BAM's intron table and rgx_synth_annotation
+struct Gene { int32_t tid; char strand; std::vector<uint32_t> es, ee; /* 1-based inclusive exons */ std::vector<std::vector<uint16_t>> tx; };
+
 struct Ctx {
     rgx_synth_params p;
+    std::vector<Gene> genes;
     std::vector<Contig> contigs;
     std::vector<uint64_t> contig_off;  // linear genome offsets
     uint64_t genome_len = 0;
@@ -92,6 +96,26 @@ void pick_locus(const Ctx &c, Rng &r, uint32_t span, int32_t &tid, uint32_t &pos
 void put_aux(Read &rd, const char *tag, char type, uint8_t v) {
     rd.aux[rd.l_aux++] = (uint8_t)tag[0]; rd.aux[rd.l_aux++] = (uint8_t)tag[1];
     rd.aux[rd.l_aux++] = (uint8_t)type; rd.aux[rd.l_aux++] = v;
+}
+
+void build_gene(const Ctx &c, uint64_t g, Gene &G) {
+    Rng r(c.p.seed, 7, g);
+    G.strand = (r.next() & 1) ? '+' : '-';
+    const uint32_t ne = 4 + r.below(9);                 // 4..12 exons
+    std::vector<uint32_t> el(ne), il(ne - 1);
+    uint64_t span = 0;
+    for (uint32_t e = 0; e < ne; ++e) { el[e] = 80 + r.below(321); span += el[e]; }
+    for (uint32_t i = 0; i + 1 < ne; ++i) { il[i] = (uint32_t)(70.0 * std::pow(50000.0 / 70.0, r.unit())); if (il[i] < 70) il[i] = 70; span += il[i]; }
+    uint32_t pos;
+    pick_locus(c, r, (uint32_t)std::min<uint64_t>(span + 400, 0x7fffffffu), G.tid, pos);
+    pos += 150;
+    G.es.resize(ne); G.ee.resize(ne);
+    for (uint32_t e = 0; e < ne; ++e) { G.es[e] = pos; G.ee[e] = pos + el[e] - 1; pos += el[e] + (e + 1 < ne ? il[e] : 0); }
+    G.tx.assign(4, {});
+    for (uint32_t t = 0; t < 4; ++t) {
+        for (uint32_t e = 0; e < ne; ++e)
+            if (t == 0 || e == 0 || e + 1 == ne || r.below(4) != 0) G.tx[t].push_back((uint16_t)e);
+    }
 }
 
 // ---- shape 0: config 2/3 ------------------------------------------------------------------------
@@ -421,7 +445,21 @@ void setup(Ctx &c) {
     uint64_t ni = c.p.n_introns ? c.p.n_introns : 300000;
     if (ni > c.n_spliced) ni = c.n_spliced;
     c.introns.resize(ni);
-    for (uint64_t k = 0; k < ni; ++k) {
+    if (c.p.n_genes) {
+        c.genes.resize(c.p.n_genes);
+        for (uint64_t g = 0; g < c.p.n_genes; ++g) build_gene(c, g, c.genes[g]);
+    }
+    for (uint64_t k = 0; k < ni && c.p.n_genes; ++k) {
+        Rng r(c.p.seed, 8, k);
+        const Gene &G = c.genes[r.below(c.p.n_genes)];
+        const uint32_t ne = (uint32_t)G.es.size();
+        uint32_t a = r.below(ne - 1), b = a + 1;
+        if (r.below(5) == 0 && a + 2 < ne) b = a + 2;            // exon skipping
+        uint32_t donor = G.ee[a], acc = G.es[b] - 1;             // 0-based intron [donor, acc)
+        if (r.below(10) == 0) donor += 1 + r.below(6);           // novel donor
+        c.introns[k] = {G.tid, donor, acc - donor, G.strand};
+    }
+    for (uint64_t k = 0; k < ni && !c.p.n_genes; ++k) {
         Rng r(c.p.seed, 5, k);
         uint32_t len = (uint32_t)(70.0 * std::pow(500000.0 / 70.0, r.unit()));
         if (len < 70) len = 70;
@@ -580,6 +618,90 @@ extern "C" int rgx_synth_write(const rgx_synth_params *p, const char *path, rgx_
     if (stats) { *stats = r; stats->bam = nullptr; stats->bai = nullptr; }
     free(r.bam); free(r.bai);
     return ok ? 0 : 4;
+}
+
+// ---- config 4 companions: GTF + VCF (+ FASTA) --------------------------------------------------------------------------------
+namespace {
+inline char synth_base(uint64_t seed, int32_t tid, uint32_t pos0) {
+    const uint64_t h = mix64(mix64(seed * 0x2545F4914F6CDD1Dull + 99) ^ ((uint64_t)(uint32_t)tid << 40) ^ (uint64_t)(pos0 >> 5));
+    return "ACGT"[(h >> (2 * (pos0 & 31))) & 3];
+}
+}
+
+extern "C" int rgx_synth_annotation(const rgx_synth_params *pp, uint32_t n_variants, const char *gtf_path, const char *vcf_path, const char *fasta_path) {
+    Ctx c; c.p = *pp; c.p.shape = RGX_SHAPE_SHORT; c.p.n_slices = 0; c.p.n_reads = 0;
+    if (!c.p.n_genes) return 2;
+    int T = c.p.threads > 0 ? c.p.threads : (int)std::thread::hardware_concurrency();
+    if (T < 1) T = 1;
+    setup(c);
+    if (gtf_path) {
+        FILE *f = fopen(gtf_path, "w");
+        if (!f) return 4;
+        fprintf(f, "#synthetic annotation: seed %llu, %u genes x 4 transcripts\n", (unsigned long long)c.p.seed, c.p.n_genes);
+        for (uint32_t g = 0; g < c.p.n_genes; ++g) {
+            const Gene &G = c.genes[g];
+            const char *chrom = c.contigs[(size_t)G.tid].name.c_str();
+            for (size_t t = 0; t < G.tx.size(); ++t)
+                for (uint16_t e : G.tx[t])
+                    fprintf(f, "%s\tsynth\texon\t%u\t%u\t.\t%c\t.\tgene_id \"G%06u\"; transcript_id \"G%06u.T%zu\"; gene_name \"GENE%u\";\n", chrom, G.es[e], G.ee[e],
+                            G.strand, g, g, t, g);
+        }
+        if (fclose(f) != 0) return 4;
+    }
+    if (vcf_path) {
+        std::vector<uint64_t> v(n_variants);
+        for (uint32_t i = 0; i < n_variants; ++i) {
+            Rng r(c.p.seed, 9, i);
+            int32_t tid; uint32_t pos1;
+            if (r.below(20) == 0) {
+                const Gene &G = c.genes[r.below(c.p.n_genes)];
+                const uint32_t e = r.below((uint32_t)G.es.size());
+                const uint32_t edge = (r.next() & 1) ? G.es[e] : G.ee[e];
+                tid = G.tid; pos1 = edge + r.below(7) - 3;
+            } else { pick_locus(c, r, 2, tid, pos1); }
+            v[i] = (uint64_t)(uint32_t)tid << 32 | pos1;
+        }
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        FILE *f = fopen(vcf_path, "w");
+        if (!f) return 4;
+        fputs("##fileformat=VCFv4.1\n", f);
+        for (auto &ct : c.contigs) fprintf(f, "##contig=<ID=%s,length=%u>\n", ct.name.c_str(), ct.len);
+        fputs("##INFO=<ID=DP,Number=1,Type=Integer,Description=\"Depth\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n", f);
+        for (uint64_t x : v) {
+            const int32_t tid = (int32_t)(x >> 32); const uint32_t pos1 = (uint32_t)x;
+            const char ref = synth_base(c.p.seed, tid, pos1 - 1);
+            const char alt = ref == 'A' ? 'G' : ref == 'G' ? 'A' : ref == 'C' ? 'T' : 'C';
+            fprintf(f, "%s\t%u\t.\t%c\t%c\t50\tPASS\tDP=%u\n", c.contigs[(size_t)tid].name.c_str(), pos1, ref, alt, 10 + (uint32_t)(x % 50));
+        }
+        if (fclose(f) != 0) return 4;
+    }
+    if (fasta_path) {
+        FILE *f = fopen(fasta_path, "wb");
+        FILE *fi = fopen((std::string(fasta_path) + ".fai").c_str(), "w");
+        if (!f || !fi) { if (f) fclose(f); if (fi) fclose(fi); return 4; }
+        uint64_t off = 0;
+        std::vector<char> buf;
+        for (size_t t = 0; t < c.contigs.size(); ++t) {
+            const uint32_t len = c.contigs[t].len;
+            off += (uint64_t)fprintf(f, ">%s\n", c.contigs[t].name.c_str());
+            fprintf(fi, "%s\t%u\t%llu\t60\t61\n", c.contigs[t].name.c_str(), len, (unsigned long long)off);
+            const uint64_t lines = ((uint64_t)len + 59) / 60, bytes = (uint64_t)len + lines;
+            buf.resize(bytes);
+            parallel_for(T, lines, [&](int, uint64_t a, uint64_t b) {
+                for (uint64_t l = a; l < b; ++l) {
+                    char *o = &buf[l * 61];
+                    const uint32_t p0 = (uint32_t)(l * 60), n = std::min<uint32_t>(60, len - p0);
+                    for (uint32_t k = 0; k < n; ++k) o[k] = synth_base(c.p.seed, (int32_t)t, p0 + k);
+                    o[n] = '\n';
+                }
+            });
+            if (fwrite(buf.data(), 1, bytes, f) != bytes) { fclose(f); fclose(fi); return 4; }
+            off += bytes;
+        }
+        if (fclose(f) != 0 || fclose(fi) != 0) return 4;
+    }
+    return 0;
 }
 
 // ---- index an existing BAM (zlib inflate; tooling only) -----------------------------------------------

@@ -31,6 +31,8 @@ typedef struct {
     int      realistic_payload; // 0 = seq 0x11 / qual 0xff (the named shape); 1 = random bases + binned quals
     int      slice_index;  // this file holds the slice_index-th of n_slices equal coordinate windows of the genome
     int      n_slices;     // 0/1 = whole genome (multi-GPU weak scaling: rank r generates slice r of the big BAM)
+    uint32_t n_genes;      // 0 = introns at independent random loci; >0 = SHORT-shape introns come from a gene model of this many
+                           //     genes (the one rgx_synth_annotation writes for the same seed), 10 % with a novel donor
 } rgx_synth_params;
 
 typedef struct {
@@ -45,6 +47,11 @@ void rgx_synth_free(rgx_synth_result *r);
 
 // Generate straight to <path> and <path>.bai.
 int  rgx_synth_write(const rgx_synth_params *p, const char *path, rgx_synth_result *stats);
+
+// config 4 companions of a SHORT-shape BAM generated with the same (seed, n_genes): a GTF of n_genes genes x 4 transcripts
+// (4-12 exons per gene, alternative transcripts skip internal exons), a sorted VCF of n_variants SNVs (5 % within 3 bp of an
+// exon edge, the rest uniform) and, when fasta_path is not NULL, the genome the REF alleles come from (+ .fai).
+int  rgx_synth_annotation(const rgx_synth_params *p, uint32_t n_variants, const char *gtf_path, const char *vcf_path, const char *fasta_path);
 
 // Build <path>.bai for an existing coordinate-sorted BAM (used for hand-made test BAMs).
 int  rgx_synth_index(const char *bam_path);
