@@ -76,6 +76,7 @@ typedef struct {
     /* partial (per-shard) tables also carry what a cross-shard merge needs */
     uint64_t  *first_seen;      /* event order of the first read of each row (shard-local) */
     uint64_t  *last_seen;       /* event order of the last read (its strand is the row's strand) */
+    uint64_t   framing_sweeps;  /* statistics: verification sweeps of the speculative record framing (1 = every guess was right) */
 } rgx_junction_table;
 
 int  rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errlen);

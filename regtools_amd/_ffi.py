@@ -29,7 +29,7 @@ class JunctionTable(C.Structure):
                 ("compressed_bytes", C.c_uint64), ("n_members", C.c_uint64),
                 ("ms_total", C.c_double), ("ms_inflate", C.c_double), ("ms_records", C.c_double),
                 ("ms_scan", C.c_double), ("ms_reduce", C.c_double),
-                ("first_seen", C.POINTER(C.c_uint64)), ("last_seen", C.POINTER(C.c_uint64))]
+                ("first_seen", C.POINTER(C.c_uint64)), ("last_seen", C.POINTER(C.c_uint64)), ("framing_sweeps", C.c_uint64)]
 
 
 class Member(C.Structure):

@@ -186,6 +186,7 @@ struct Prep {
     EventSoA ev{};
     uint32_t n_rec = 0, n_events = 0, n_range = 0;
     uint64_t n_iterated = 0, total = 0;
+    uint32_t framing_sweeps = 0;
     double t_begin = 0;
 };
 
@@ -436,15 +437,25 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         seg_base = (uint32_t *)q;
         HIP_TRY(b_tmp.ensure(scan_tmp_words(n_seg) * 4 + 64));
         launch_seg_walk(arena, pos0, lim, n_seg, n_ref, seg_start[0], seg_exit[0], seg_cnt[0], st);
+        // d_sc[10]: leftmost disagreeing segment, d_sc[11]: leftmost chain end, d_sc[3]: record total
         for (int iter = 0;; ++iter) {
-            HIP_TRY(hipMemsetAsync(d_sc + 2, 0, 4, st));
+            HIP_TRY(hipMemsetAsync(d_sc + 10, 0xff, 8, st));
             launch_seg_verify(arena, pos0, lim, n_seg, seg_start[cur], seg_exit[cur], seg_cnt[cur], seg_start[cur ^ 1], seg_exit[cur ^ 1],
-                              seg_cnt[cur ^ 1], d_sc + 2, st);
+                              seg_cnt[cur ^ 1], d_sc + 10, st);
             cur ^= 1;
             launch_scan_u32(seg_cnt[cur], seg_base, n_seg, d_sc + 3, b_tmp.as<uint32_t>(), st);
-            HIP_TRY(hipMemcpyAsync(h_sc + 2, d_sc + 2, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_sc + 3, d_sc + 3, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_sc + 10, d_sc + 10, 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            if (h_sc[2] == 0) break;
+            ++P.framing_sweeps;
+            if (h_sc[10] == 0xffffffffu) break;
+            if (h_sc[11] < h_sc[10]) {     // the chain ends inside the exact prefix: nothing starts after that segment
+                launch_seg_truncate(pos0, lim, n_seg, h_sc[11], seg_start[cur], seg_exit[cur], seg_cnt[cur], st);
+                launch_scan_u32(seg_cnt[cur], seg_base, n_seg, d_sc + 3, b_tmp.as<uint32_t>(), st);
+                HIP_TRY(hipMemcpyAsync(h_sc + 3, d_sc + 3, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                break;
+            }
             if (iter > 1 << 20) return fail(err, errlen, RGX_ERR_FORMAT, "regtools_amd: record framing did not converge\n");
         }
         n_rec = h_sc[3];
@@ -662,7 +673,7 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     }
     if (R.n >= 100000000u) host_sort_rows(t);   // names wider than 8 digits compare as strings upstream
     t->n_records = P.n_iterated;
-    t->n_events = P.n_events; t->inflated_bytes = P.total; t->compressed_bytes = bam_len; t->n_members = P.n_range;
+    t->n_events = P.n_events; t->inflated_bytes = P.total; t->compressed_bytes = bam_len; t->n_members = P.n_range; t->framing_sweeps = P.framing_sweeps;
     float ms = 0;
     HIP_TRY(hipEventSynchronize(c->ev[6]));
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); t->ms_inflate = ms;

@@ -41,7 +41,7 @@ RGX_HD bool rec_plausible(const uint8_t *arena, uint64_t o, uint64_t lim, int32_
     if (!rec_sane(h)) return false;
     if (h.block_len > (1 << 27)) return false;
     if (h.tid < -1 || h.tid >= n_ref || h.mtid < -1 || h.mtid >= n_ref) return false;
-    if (h.pos < -1) return false;
+    if (h.pos < -1 || h.pos > (1 << 29)) return false;       // a .bai cannot index beyond 2^29 (hts.c:1517)
     uint64_t q_end = o + 36 + h.l_qname - 1;
     if (q_end < lim && arena[q_end] != 0) return false;     // qname is NUL-terminated
     return true;

@@ -54,7 +54,8 @@ void launch_seg_walk(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t
 void launch_seg_verify(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg,
                        const uint64_t *seg_start_in, const uint64_t *seg_exit_in, const uint32_t *seg_cnt_in,
                        uint64_t *seg_start_out, uint64_t *seg_exit_out, uint32_t *seg_cnt_out,
-                       uint32_t *changed, hipStream_t stream);
+                       uint32_t *status /* [0] leftmost disagreeing segment, [1] leftmost chain end; both preset to ~0u */, hipStream_t stream);
+void launch_seg_truncate(uint64_t pos0, uint64_t lim, uint32_t n_seg, uint32_t last, uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, hipStream_t stream);
 
 // ---- a2/a3/a5/a6: SoA decode + per-read event count ---------------------------------------------------------
 struct ReadSoA {

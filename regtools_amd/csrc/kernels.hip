@@ -122,51 +122,83 @@ __global__ void k_seg_walk(const uint8_t *__restrict__ arena, uint64_t pos0, uin
     if (s >= n_seg) return;
     uint64_t a = pos0 + (uint64_t)s * kSegBytes, b = a + kSegBytes;
     if (b > lim) b = lim;
-    uint64_t o = a;
-    if (s > 0) {
-        // guess: first offset in the segment where three chained records all look like records
-        uint64_t g = kChainEnd;
-        for (uint64_t c = a; c < b; ++c) {
-            if (!rec_plausible(arena, c, lim, n_ref)) continue;
-            uint64_t c2 = c + 4 + (uint64_t)ld32(arena + c);
-            if (c2 < lim) {
-                if (!rec_plausible(arena, c2, lim, n_ref)) continue;
-                uint64_t c3 = c2 + 4 + (uint64_t)ld32(arena + c2);
-                if (c3 < lim && !rec_plausible(arena, c3, lim, n_ref)) continue;
-            }
-            g = c; break;
-        }
-        o = g;
-    }
+    uint64_t o = a, ex = kChainEnd;
     uint32_t cnt = 0;
-    uint64_t ex;
-    if (o == kChainEnd) { ex = kChainEnd; o = b; }      // nothing plausible: verification will settle it
-    else ex = walk_chain(arena, o, b, lim, cnt);
+    if (s > 0) {
+        // guess: first offset in the segment where three chained records all look like records AND the block_size chain from
+        // there leaves the segment through readable records.  A false start almost never survives that (a 16 KiB walk is dozens
+        // of records), so wrong exits -- the expensive kind of misprediction, see k_seg_verify -- are rare.
+        // (the search loop and the walk are kept apart so that the lanes of a wave walk their segments together)
+        o = kChainEnd;
+        uint64_t c = a;
+        for (;;) {
+            for (; c < b; ++c) {
+                if (!rec_plausible(arena, c, lim, n_ref)) continue;
+                uint64_t c2 = c + 4 + (uint64_t)ld32(arena + c);
+                if (c2 < lim) {
+                    if (!rec_plausible(arena, c2, lim, n_ref)) continue;
+                    uint64_t c3 = c2 + 4 + (uint64_t)ld32(arena + c2);
+                    if (c3 < lim && !rec_plausible(arena, c3, lim, n_ref)) continue;
+                }
+                break;
+            }
+            if (c >= b) break;
+            ex = walk_chain(arena, c, b, lim, cnt);
+            if (ex != kChainEnd) { o = c; break; }
+            ++c;
+        }
+        if (o == kChainEnd) { ex = kChainEnd; o = b; cnt = 0; }      // nothing usable: verification will settle it
+    } else ex = walk_chain(arena, o, b, lim, cnt);
     seg_start[s] = o; seg_exit[s] = ex; seg_cnt[s] = cnt;
 }
 
+// is segment s (> 0) framed the way its left neighbour's exit says it must be?
+__device__ __forceinline__ bool seg_consistent(uint64_t pos0, uint64_t lim, uint32_t s, uint64_t expect, uint64_t st, uint64_t ex, uint32_t cnt) {
+    uint64_t b = pos0 + (uint64_t)s * kSegBytes + kSegBytes;
+    if (b > lim) b = lim;
+    return expect >= b ? (st == b && ex == expect && cnt == 0) : st == expect;   // expect >= b (incl. kChainEnd): no record starts here
+}
+
+// One sweep.  A segment that disagrees with its left neighbour's exit is re-walked from that exit -- but only once the
+// neighbour itself agrees with ITS neighbour: a wrong exit (a speculative guess that landed on a false chain which never
+// re-joins the true one) is then repaired where it happened instead of being copied one segment to the right per sweep with the
+// repair trailing it to the end of the file.  Sweeps needed = longest run of consecutive disagreeing segments (+1 to see
+// "no change").  `changed` counts every disagreement, repaired or waiting, so the loop ends only when the whole chain agrees
+// -- which, segment 0 being exact, means it is exact.  status[0] = leftmost disagreeing segment (everything left of it is exact),
+// status[1] = leftmost segment whose chain ends (kChainEnd): when that one lies in the exact prefix the stream really ends
+// there (truncated / unreadable record, sam.c:421-423) and the host empties everything to its right in one launch instead of
+// one segment per sweep.
 __global__ void k_seg_verify(const uint8_t *__restrict__ arena, uint64_t pos0, uint64_t lim, uint32_t n_seg,
                              const uint64_t *__restrict__ st_in, const uint64_t *__restrict__ ex_in, const uint32_t *__restrict__ cnt_in,
-                             uint64_t *st_out, uint64_t *ex_out, uint32_t *cnt_out, uint32_t *changed) {
+                             uint64_t *st_out, uint64_t *ex_out, uint32_t *cnt_out, uint32_t *status) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seg) return;
     uint64_t st = st_in[s], ex = ex_in[s];
     uint32_t cnt = cnt_in[s];
+    if (ex == kChainEnd && (s == 0 || ex_in[s - 1] != kChainEnd)) atomicMin(status + 1, s);
     if (s > 0) {
-        uint64_t a = pos0 + (uint64_t)s * kSegBytes, b = a + kSegBytes;
-        if (b > lim) b = lim;
-        uint64_t expect = ex_in[s - 1];                 // where the exact chain enters this segment (if s-1 is right)
-        bool pass_through = expect >= b;                // includes kChainEnd: no record starts in this segment
-        uint64_t want_start = pass_through ? b : expect;
-        if (pass_through) {
-            if (!(st == b && ex == expect && cnt == 0)) { st = b; ex = expect; cnt = 0; atomicAdd(changed, 1u); }
-        } else if (st != want_start) {
-            st = want_start;
-            ex = walk_chain(arena, st, b, lim, cnt);
-            atomicAdd(changed, 1u);
+        const uint64_t expect = ex_in[s - 1];
+        if (!seg_consistent(pos0, lim, s, expect, st, ex, cnt)) {
+            atomicMin(status, s);
+            const bool left_settled = s == 1 || seg_consistent(pos0, lim, s - 1, ex_in[s - 2], st_in[s - 1], expect, cnt_in[s - 1]);
+            if (left_settled) {
+                uint64_t b = pos0 + (uint64_t)s * kSegBytes + kSegBytes;
+                if (b > lim) b = lim;
+                if (expect >= b) { st = b; ex = expect; cnt = 0; }
+                else { st = expect; ex = walk_chain(arena, st, b, lim, cnt); }
+            }
         }
     }
     st_out[s] = st; ex_out[s] = ex; cnt_out[s] = cnt;
+}
+
+// the record chain ended inside segment `last`: no record starts to its right
+__global__ void k_seg_truncate(uint64_t pos0, uint64_t lim, uint32_t n_seg, uint32_t last, uint64_t *st, uint64_t *ex, uint32_t *cnt) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg || s <= last) return;
+    uint64_t b = pos0 + (uint64_t)s * kSegBytes + kSegBytes;
+    if (b > lim) b = lim;
+    st[s] = b; ex[s] = kChainEnd; cnt[s] = 0;
 }
 
 void launch_seg_walk(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, int32_t n_ref, uint64_t *seg_start,
@@ -176,10 +208,14 @@ void launch_seg_walk(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t
 }
 void launch_seg_verify(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, const uint64_t *seg_start_in,
                        const uint64_t *seg_exit_in, const uint32_t *seg_cnt_in, uint64_t *seg_start_out, uint64_t *seg_exit_out,
-                       uint32_t *seg_cnt_out, uint32_t *changed, hipStream_t stream) {
+                       uint32_t *seg_cnt_out, uint32_t *status, hipStream_t stream) {
     if (!n_seg) return;
     hipLaunchKernelGGL(k_seg_verify, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, pos0, lim, n_seg, seg_start_in, seg_exit_in,
-                       seg_cnt_in, seg_start_out, seg_exit_out, seg_cnt_out, changed);
+                       seg_cnt_in, seg_start_out, seg_exit_out, seg_cnt_out, status);
+}
+void launch_seg_truncate(uint64_t pos0, uint64_t lim, uint32_t n_seg, uint32_t last, uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, hipStream_t stream) {
+    if (!n_seg) return;
+    hipLaunchKernelGGL(k_seg_truncate, dim3((n_seg + 255) / 256), dim3(256), 0, stream, pos0, lim, n_seg, last, seg_start, seg_exit, seg_cnt);
 }
 
 // =====================================================================================================

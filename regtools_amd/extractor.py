@@ -141,7 +141,7 @@ class JunctionsExtractor(object):
         t = tab.contents
         self.stats = dict(n_records=t.n_records, n_events=t.n_events, n_junctions=t.n, inflated_bytes=t.inflated_bytes,
                           compressed_bytes=t.compressed_bytes, n_members=t.n_members, ms_total=t.ms_total, ms_inflate=t.ms_inflate,
-                          ms_records=t.ms_records, ms_scan=t.ms_scan, ms_reduce=t.ms_reduce)
+                          ms_records=t.ms_records, ms_scan=t.ms_scan, ms_reduce=t.ms_reduce, framing_sweeps=t.framing_sweeps)
         return 0
 
     def _free(self):

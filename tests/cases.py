@@ -22,6 +22,12 @@ def case_bam(case, tmpdir):
     """Path of the case's BAM: a committed fixture, or a deterministic synthetic file generated on demand."""
     if case["bam"]:
         return os.path.join(GOLD, case["bam"])
+    if case.get("framing"):
+        import framing_cases
+        key = ("framing", case["framing"])
+        if key not in _synth_cache:
+            _synth_cache[key] = framing_cases.build(case["framing"], os.path.join(str(tmpdir), "framing_%s.bam" % case["framing"]))
+        return _synth_cache[key]
     from regtools_amd import synth
     s = case["synth"]
     key = (s["shape"], s["n_reads"], s["seed"])

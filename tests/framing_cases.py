@@ -1,0 +1,60 @@
+"""Inputs that stress the speculative record framing (TEST INFRASTRUCTURE): byte strings that look like BAM record heads are
+planted inside `B` aux arrays, so a segment's first plausible offset is often not a record start.
+
+variants
+  huge      decoy block_size 100,000,000: its chain runs past the end of the stream
+  to_end    decoy block_size patched so that its chain ends EXACTLY at the end of the stream: a readable chain with a wrong exit
+  insane    like to_end, plus one real record in the middle whose l_read_name is 0: bam_read1 gives up there
+            (htslib sam.c:421-423) and the reference silently reports only what came before
+"""
+import os
+import random
+import shutil
+import struct
+
+import bamio
+
+CONTIGS = [("chrA", 5000000), ("chrB", 3000000)]
+MAGIC = 123456789
+
+
+def build(variant, path, seed=5, n_records=4000):
+    rnd = random.Random(seed)
+    first = 100000000 if variant == "huge" else MAGIC
+    decoy = struct.pack("<iiiIIiiii", first, 0, 5, 1, 0, 0, -1, -1, 0) + b"\0"
+    recs, pos = [], 100
+    for i in range(n_records):
+        tid = 0 if i < n_records * 2 // 3 else 1
+        if i == n_records * 2 // 3:
+            pos = 100
+        pos += rnd.randint(1, 300)
+        aux = b""
+        if rnd.random() < 0.5:
+            body = bytes(rnd.randrange(1, 250) for _ in range(rnd.randint(0, 40))) + decoy + bytes(rnd.randrange(1, 250) for _ in range(rnd.randint(0, 9)))
+            aux += b"ZBBC" + struct.pack("<i", len(body)) + body
+        aux += bamio.tagA("XS", "+-"[i & 1])
+        cigar = "%dM%dN%dM" % (rnd.randint(8, 60), rnd.randint(70, 5000), rnd.randint(8, 60)) if rnd.random() < 0.4 else "%dM" % rnd.randint(30, 150)
+        recs.append(bamio.record(tid, pos, cigar, flag=rnd.choice([0, 16, 99, 147]), qname="q%d" % i, aux=aux))
+    hdr = bamio.header_bytes(CONTIGS)
+    stream = bytearray(b"".join(recs))
+    from regtools_amd import synth
+    bamio.write_bam(path, CONTIGS, [bytes(stream)])
+    synth.index(path)                                   # index of the clean layout; only `-r` would look inside it
+    if variant == "huge":
+        return path
+    lim = len(hdr) + len(stream)
+    key, k = struct.pack("<i", MAGIC), 0
+    while True:
+        k = stream.find(key, k)
+        if k < 0:
+            break
+        struct.pack_into("<i", stream, k, lim - (len(hdr) + k) - 4)
+        k += 4
+    if variant == "insane":
+        off = sum(len(r) for r in recs[: n_records // 2])
+        stream[off + 12] = 0                            # l_read_name = 0 in the middle record
+    bai = path + ".bai.keep"
+    shutil.copy(path + ".bai", bai)
+    bamio.write_bam(path, CONTIGS, [bytes(stream)])
+    os.replace(bai, path + ".bai")
+    return path

@@ -28,13 +28,13 @@ def run_ref(bam, args):
     return r.returncode, r.stdout
 
 
-def add_case(name, args, bam=None, synth_spec=None, tmp_bam=None):
+def add_case(name, args, bam=None, synth_spec=None, tmp_bam=None, framing=None):
     path = tmp_bam if tmp_bam else os.path.join(HERE, bam)
     rc, out = run_ref(path, args)
     exp = "%s.expected" % name
     with open(os.path.join(HERE, "expected", exp), "wb") as f:
         f.write(out)
-    cases.append(dict(name=name, args=args, bam=bam, synth=synth_spec, expected=exp, rc=rc, rows=out.count(b"\n")))
+    cases.append(dict(name=name, args=args, bam=bam, synth=synth_spec, framing=framing, expected=exp, rc=rc, rows=out.count(b"\n")))
     print("%-44s rc=%d rows=%d" % (name, rc, out.count(b"\n")))
 
 
@@ -137,6 +137,13 @@ def main():
                     add_case("synth_%s_%d.XS.r_%s" % (shape, seed, reg.replace(":", "_")), ["-s", "XS", "-r", reg], synth_spec=spec, tmp_bam=p)
             if shape == "short":
                 add_case("synth_%s_%d.XS.r_chr7" % (shape, seed), ["-s", "XS", "-r", "chr7:1000000-80000000"], synth_spec=spec, tmp_bam=p)
+
+        # (v) record-framing stress: decoy record heads inside aux arrays, and a chain that ends in the middle of the file
+        import framing_cases
+        for variant in ("huge", "to_end", "insane"):
+            p = framing_cases.build(variant, os.path.join(td, "framing_%s.bam" % variant))
+            add_case("framing_%s.XS" % variant, ["-s", "XS"], framing=variant, tmp_bam=p)
+            add_case("framing_%s.RF.a20" % variant, ["-s", "RF", "-a", "20"], framing=variant, tmp_bam=p)
 
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(cases, f, indent=1)

@@ -203,3 +203,14 @@ def test_extract_with_fasta_strand_rule(gpu_ctx, tmp_path):
     je.parse_options(["-s", "XS", p, q["fasta"]])
     with pytest.raises(regtools_amd.RegtoolsError):
         je.identify_junctions_from_BAM()
+
+
+@pytest.mark.parametrize("variant,max_sweeps", [("huge", 3), ("to_end", 24), ("insane", 24)])
+def test_record_framing_converges_quickly_on_decoys(gpu_ctx, synth_dir, variant, max_sweeps):
+    """The speculative framing is exact whatever it guessed; what decoys may cost is verification sweeps.  A wrong exit must be
+    repaired where it happened (sweeps ~ longest run of mispredicted segments), not chased to the end of the file, and a chain
+    that really ends in the middle of the file must not be walked one segment per sweep."""
+    case = [c for c in cases.MANIFEST if c["name"] == "framing_%s.XS" % variant][0]
+    rc, out, je = gpu_extract(gpu_ctx, cases.case_bam(case, synth_dir), case["args"])
+    assert rc == 0 and out == cases.expected(case)
+    assert 1 <= je.stats["framing_sweeps"] <= max_sweeps, je.stats
