@@ -53,9 +53,13 @@ struct Intron { int32_t tid; uint32_t donor, len; char strand; };
 // gene model shared by the BAM's intron table and rgx_synth_annotation
 struct Gene { int32_t tid; char strand; std::vector<uint32_t> es, ee; /* 1-based inclusive exons */ std::vector<std::vector<uint16_t>> tx; };
 
+constexpr uint32_t kLocusExons = 26;
+struct Locus { int32_t tid; char strand; uint32_t start[kLocusExons], len[kLocusExons]; };   // LONG shape, see make_long
+
 struct Ctx {
     rgx_synth_params p;
     std::vector<Gene> genes;
+    std::vector<Locus> loci;
     std::vector<Contig> contigs;
     std::vector<uint64_t> contig_off;  // linear genome offsets
     uint64_t genome_len = 0;
@@ -144,47 +148,59 @@ void make_short(const Ctx &c, uint64_t rid, Read &rd) {
 }
 
 // ---- shape 1: config 5 (long reads) ---------------------------------------------------------------
+// A locus is a fixed chain of kLocusExons exons; a read covers 6-21 consecutive exons of one locus end to end, so the junctions
+// of a locus repeat across the ~40 reads drawn from it (a long-read transcriptome, not 125 M unrelated introns).  What varies per
+// read is which exons it spans and how each exon's bases are spelled (M/=/X runs with small I/D edits, soft clips).
+void build_locus(const Ctx &c, uint64_t k, Locus &L) {
+    Rng r(c.p.seed, 6, k);
+    L.strand = (r.next() & 1) ? '+' : '-';
+    uint32_t il[kLocusExons];
+    uint64_t span = 0;
+    for (uint32_t e = 0; e < kLocusExons; ++e) {
+        L.len[e] = 170 + r.below(281);                // 170..450
+        il[e] = (uint32_t)(70.0 * std::pow(20000.0 / 70.0, r.unit()));
+        if (il[e] < 70) il[e] = 70;
+        span += L.len[e] + (e + 1 < kLocusExons ? il[e] : 0);
+    }
+    uint32_t pos;
+    pick_locus(c, r, (uint32_t)span + 64, L.tid, pos);
+    for (uint32_t e = 0; e < kLocusExons; ++e) { L.start[e] = pos; pos += L.len[e] + il[e]; }
+}
+
 void make_long(const Ctx &c, uint64_t rid, Read &rd) {
     Rng r(c.p.seed, 2, rid);
     rd.flag = (r.next() & 1) ? 16 : 0;
     rd.cigar.clear(); rd.l_aux = 0;
-    uint32_t n_introns = 5 + r.below(16);            // 5..20 N ops
-    uint32_t target_q = 1000 + r.below(9001);        // 1000..10000 query bases
-    uint32_t n_blocks = n_introns + 1;
-    uint32_t budget_ops = 64 - n_introns;            // non-N ops we may spend
-    uint32_t per_block = target_q / n_blocks;
-    uint32_t qlen = 0, rspan = 0;
+    const Locus &L = c.loci[r.below((uint32_t)c.loci.size())];
+    const uint32_t n_introns = 5 + r.below(16);           // 5..20 N ops
+    const uint32_t first = r.below(kLocusExons - n_introns);
+    uint32_t spare = 64 - (2 * n_introns + 1);            // ops left after one op per exon and the N ops
+    uint32_t qlen = 0;
     std::vector<uint32_t> &cg = rd.cigar;
-    if (r.below(4) == 0 && budget_ops > n_blocks + 2) { uint32_t s = 1 + r.below(30); cg.push_back(cig(s, S)); qlen += s; --budget_ops; }
-    for (uint32_t b = 0; b < n_blocks; ++b) {
-        uint32_t blocks_left = n_blocks - b;
-        uint32_t extra = (budget_ops > blocks_left) ? std::min<uint32_t>(2, (budget_ops - blocks_left) / blocks_left) : 0;
-        uint32_t len = std::max<uint32_t>(12, per_block);
-        // an exon block: M [ (I|D|X|=) M ]*extra   -- each extra costs two ops
-        uint32_t pieces = 1 + (extra >= 2 ? r.below(2) : 0);
-        for (uint32_t q = 0; q < pieces; ++q) {
-            uint32_t l = std::max<uint32_t>(4, len / pieces);
-            uint32_t opk = r.below(8);
-            cg.push_back(cig(l, opk == 7 ? EQ : M)); qlen += l; rspan += l; --budget_ops;
-            if (q + 1 < pieces) {
-                uint32_t k = r.below(3), el = 1 + r.below(4);
-                if (k == 0) { cg.push_back(cig(el, I)); qlen += el; }
-                else if (k == 1) { cg.push_back(cig(el, D)); rspan += el; }
-                else { cg.push_back(cig(el, X)); qlen += el; rspan += el; }
-                --budget_ops;
-            }
+    if (r.below(4) == 0 && spare) { const uint32_t sc = 1 + r.below(30); cg.push_back(cig(sc, S)); qlen += sc; --spare; }
+    const bool tail_clip = r.below(6) == 0 && spare;
+    if (tail_clip) --spare;
+    for (uint32_t b = 0; b <= n_introns; ++b) {
+        const uint32_t e = first + b;
+        uint32_t left = L.len[e];                         // reference bases of this exon still to spell
+        // optional edit in the middle of the exon: costs two ops (the edit and the second run)
+        if (spare >= 2 && r.below(3) == 0) {
+            const uint32_t head = 20 + r.below(left - 60), k = r.below(3), el = 1 + r.below(4);
+            cg.push_back(cig(head, r.below(8) == 7 ? EQ : M)); qlen += head; left -= head;
+            if (k == 0) { cg.push_back(cig(el, I)); qlen += el; }
+            else if (k == 1) { cg.push_back(cig(el, D)); left -= el; }
+            else { cg.push_back(cig(el, X)); qlen += el; left -= el; }
+            spare -= 2;
         }
-        if (b + 1 < n_blocks) {
-            uint32_t il = (uint32_t)(70.0 * std::pow(20000.0 / 70.0, r.unit()));
-            cg.push_back(cig(il, N)); rspan += il;
-        }
+        cg.push_back(cig(left, r.below(8) == 7 ? EQ : M)); qlen += left;
+        if (b < n_introns) cg.push_back(cig(L.start[e + 1] - (L.start[e] + L.len[e]), N));
     }
+    if (tail_clip) { const uint32_t sc = 1 + r.below(30); cg.push_back(cig(sc, S)); qlen += sc; }
     rd.l_qseq = qlen;
-    uint32_t pos;
-    pick_locus(c, r, rspan + 1, rd.tid, pos);
-    rd.pos = (int32_t)pos;
-    put_aux(rd, "NH", 'C', 1); put_aux(rd, "ts", 'A', (uint8_t)((r.next() & 1) ? '+' : '-'));
-    put_aux(rd, "XS", 'A', (uint8_t)((r.next() & 1) ? '+' : '-'));
+    rd.tid = L.tid; rd.pos = (int32_t)L.start[first];
+    const char other = L.strand == '+' ? '-' : '+';
+    put_aux(rd, "NH", 'C', 1); put_aux(rd, "ts", 'A', (uint8_t)(r.below(50) == 0 ? other : L.strand));
+    put_aux(rd, "XS", 'A', (uint8_t)(r.below(50) == 0 ? other : L.strand));
 }
 
 // ---- shape 2: fuzz (tests) -------------------------------------------------------------------------
@@ -439,6 +455,11 @@ void setup(Ctx &c) {
     else c.contigs.assign(std::begin(kHuman), std::end(kHuman));
     c.contig_off.clear(); c.genome_len = 0;
     for (auto &ct : c.contigs) { c.contig_off.push_back(c.genome_len); c.genome_len += ct.len; }
+    if (c.p.shape == RGX_SHAPE_LONG) {
+        uint64_t nl = c.p.n_introns ? c.p.n_introns : std::min<uint64_t>(20000, std::max<uint64_t>(64, c.p.n_reads / 40));   // <= 5x10^5 distinct junctions
+        c.loci.resize(nl);
+        for (uint64_t k = 0; k < nl; ++k) build_locus(c, k, c.loci[k]);
+    }
     if (c.p.shape != RGX_SHAPE_SHORT) return;
     double frac = c.p.spliced_frac > 0 ? c.p.spliced_frac : 0.15;
     c.n_spliced = (uint64_t)((double)c.p.n_reads * frac);

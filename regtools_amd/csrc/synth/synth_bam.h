@@ -16,7 +16,7 @@ extern "C" {
 
 enum {
     RGX_SHAPE_SHORT = 0, // config 2/3: 101 bp, 15 % `aMbNcM`, introns from a Zipf(1.0)-weighted table
-    RGX_SHAPE_LONG  = 1, // config 5: l_qseq 1000-10000, n_cigar <= 64, 5-20 N ops, M/I/D/S/=/X mix
+    RGX_SHAPE_LONG  = 1, // config 5: l_qseq 1000-10000, n_cigar <= 64, 5-20 N ops, M/I/D/S/=/X mix; reads span 6-21 exons of a locus table
     RGX_SHAPE_FUZZ  = 2, // tests: tiny contigs named 1,10,2,MT, every op code, odd tags/flags, unmapped tail
 };
 
