@@ -314,7 +314,7 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
         u32x4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0, v4 = v0, v5 = v0, v6 = v0, v7 = v0;
         if (copying) {
             n = pend_len < kCopyBatch ? pend_len : kCopyBatch;
-            if (pend_dist < n) n = pend_dist;                       // pend_dist >= 16 always: sources of the batch are final
+            if (pend_dist < n) n = pend_dist;                       // only bytes that are already written (any distance >= 1)
             const uint8_t *s = out + o - pend_dist;
             v0 = ld128(s);
             if (n > 16) v1 = ld128(s + 16);
@@ -389,6 +389,9 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
                 }
             }
             o += n; pend_len -= n;
+            // an overlapping copy is periodic with period pend_dist, so 2 * pend_dist is as good a distance for the rest: a run
+            // (distance 1) grows 1, 2, 4, ... bytes per trip and is at full 128-byte batches after eight
+            if (n == pend_dist) pend_dist += pend_dist;
         }
         if (lit < 256) {
             if (o >= out_cap) { status = INF_OUT_OVERFLOW; break; }
@@ -396,25 +399,6 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
         } else if (new_len) {
             if (new_dist > o) { status = INF_BAD_DIST; break; }
             if (o + new_len > out_cap) { status = INF_OUT_OVERFLOW; break; }
-            if (new_dist < 16) {
-                // short period: write the first D = k*dist >= 16 bytes narrowly, continue as a copy of distance D
-                uint32_t D = new_dist;
-                while (D < 16) D += new_dist;
-                const uint32_t n0 = new_len < D ? new_len : D;
-                uint8_t *d = out + o;
-                const uint8_t *s = d - new_dist;
-                if (new_dist >= 8) {
-                    uint32_t m = n0;
-                    while (m >= 8) { st64(d, ld64(s)); d += 8; s += 8; m -= 8; }
-                    while (m) { *d++ = *s++; --m; }
-                } else {
-                    uint64_t pat = 0;
-                    for (uint32_t k = 0; k < new_dist; ++k) pat |= (uint64_t)s[k] << (8 * k);
-                    const uint32_t sh = 8 * (new_dist - 1);
-                    for (uint32_t m = n0; m; --m) { const uint8_t b = (uint8_t)pat; *d++ = b; pat = (pat >> 8) | ((uint64_t)b << sh); }
-                }
-                o += n0; new_len -= n0; new_dist = D;
-            }
             pend_len = new_len; pend_dist = new_dist;
         }
         if (done && pend_len == 0) break;
