@@ -114,20 +114,23 @@ RGX_HD int build_code(Tab &T, uint32_t w0, uint32_t n, int kind, Code &C) {
 // buffer; in a BGZF file the footer and the next member follow anyway); consuming bits past the end is
 // detected by overran().
 struct BitReader {
-    const uint8_t *p;      // address of the word held in `next`
+    const uint8_t *p;      // address of the first payload byte that is not in `buf` yet (`next` was loaded from here)
     const uint8_t *in;     // payload start
     uint32_t in_len;
-    uint64_t buf;          // LSB-first bit buffer
+    uint64_t buf;          // LSB-first bit buffer; bits above cnt are already the right ones (they are OR-ed in again later)
     uint32_t cnt;          // valid bits in buf
-    uint32_t next;         // prefetched word at p
-    RGX_HD void init(const uint8_t *i, uint32_t n) { in = i; in_len = n; p = i; buf = 0; cnt = 0; next = ld32(p); }
-    // afterwards cnt >= 33: enough for a 15-bit code + 13 extra bits
+    uint64_t next;         // the 8 bytes at p, loaded one refill ahead of their use
+    RGX_HD void init(const uint8_t *i, uint32_t n) { in = i; in_len = n; p = i; buf = 0; cnt = 0; next = ld64(p); }
+    // Afterwards cnt >= 56: a whole symbol trip (15 + 5 + 15 + 13 bits) never needs memory in the middle.  Whole bytes
+    // only: (63 - cnt) >> 3 of them fit, and cnt + 8 * that == cnt | 56.  The load issued here is consumed by the NEXT
+    // refill, so the one wait it needs sits a full trip after its issue.
     RGX_HD void refill() {
-        if (cnt <= 32) {
-            buf |= (uint64_t)next << cnt; cnt += 32; p += 4;
-            next = ld32(p);
-        }
+        buf |= next << cnt;
+        p += (63u - cnt) >> 3;
+        cnt |= 56u;
+        next = ld64(p);
     }
+    RGX_HD void ensure(uint32_t n) { if (cnt < n) refill(); }
     RGX_HD uint32_t peek(uint32_t n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
     RGX_HD void drop(uint32_t n) { buf >>= n; cnt -= n; }
     RGX_HD uint32_t bits(uint32_t n) { uint32_t v = peek(n); drop(n); return v; }
@@ -135,7 +138,7 @@ struct BitReader {
     RGX_HD bool overran() const { return (uint64_t)(p - in) * 8 > (uint64_t)in_len * 8 + cnt; }
     // byte-aligned raw access for stored blocks: address of the next unconsumed byte once cnt == 0
     RGX_HD const uint8_t *byte_ptr() const { return p; }
-    RGX_HD void restart_at(const uint8_t *q) { p = q; buf = 0; cnt = 0; next = ld32(p); }
+    RGX_HD void restart_at(const uint8_t *q) { p = q; buf = 0; cnt = 0; next = ld64(p); }
 };
 
 RGX_HD uint32_t rev15(uint32_t v) {
@@ -154,15 +157,15 @@ RGX_HD uint32_t rev15(uint32_t v) {
 template <class Tab>
 RGX_HD int block_header(BitReader &br, Tab &T, Code &LL, Code &DD, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t &o,
                         uint32_t out_cap, uint32_t &last, int &status) {
-    br.refill();
+    if (br.overran()) { status = INF_IN_OVERRUN; return 0; }     // a run of empty stored blocks must not walk off the input
+    br.ensure(32);
     last = br.bits(1);
     const uint32_t btype = br.bits(2);
     if (btype == 0) {
         // stored: skip to byte boundary, LEN, NLEN, raw bytes
         br.drop(br.cnt & 7);
-        br.refill();
+        br.ensure(32);
         uint32_t len = br.bits(16);
-        br.refill();
         const uint32_t nlen = br.bits(16);
         if ((len ^ 0xffff) != nlen) { status = INF_BAD_STORED; return 0; }
         if (o + len > out_cap) { status = INF_OUT_OVERFLOW; return 0; }
@@ -187,7 +190,7 @@ RGX_HD int block_header(BitReader &br, Tab &T, Code &LL, Code &DD, const uint8_t
         build_code(T, kLenWordsLL, 32, 1, DD);
         return 1;
     }
-    br.refill();
+    br.ensure(16);
     const uint32_t hlit = br.bits(5) + 257, hdist = br.bits(5) + 1, hclen = br.bits(4) + 4;
     if (hlit > 286 || hdist > 30) { status = INF_BAD_HEADER; return 0; }
     // code-length code: 19 lengths of 3 bits, kept in a register (3 bits each)
@@ -195,7 +198,7 @@ RGX_HD int block_header(BitReader &br, Tab &T, Code &LL, Code &DD, const uint8_t
     {
         const uint8_t ord[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
         for (uint32_t i = 0; i < hclen; ++i) {
-            br.refill();
+            br.ensure(8);
             const uint64_t l = br.bits(3);
             cl_lens |= l << (3 * ord[i]);
         }
@@ -239,7 +242,7 @@ RGX_HD int block_header(BitReader &br, Tab &T, Code &LL, Code &DD, const uint8_t
     uint32_t acc = 0, acc_n = 0, acc_w = 0;       // 4-bit lengths being packed, how many, destination word
     uint32_t eob_len = 0;
     while (i < n) {
-        br.refill();
+        br.ensure(16);                                  // 7 (code) + 7 (repeat count)
         const uint32_t v7 = rev15(br.peek(7)) >> 8;   // 7 bits MSB-first
         uint32_t l = 1;
 #pragma unroll
@@ -307,11 +310,12 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
 #pragma unroll
     for (int k = 0; k < 16; ++k) { LL.c[k] = 0; DD.c[k] = 0; }
 
+    u32x4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0, v4 = v0, v5 = v0, v6 = v0, v7 = v0;   // copy registers: a chunk is loaded (A) and stored (C)
+                                                                                             // under the same predicate; never re-initialised
     for (;;) {
         // ---- A: loads of the pending copy -----------------------------------------------------------------------
         const bool copying = pend_len != 0;
         uint32_t n = 0;
-        u32x4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0, v4 = v0, v5 = v0, v6 = v0, v7 = v0;
         if (copying) {
             n = pend_len < kCopyBatch ? pend_len : kCopyBatch;
             if (pend_dist < n) n = pend_dist;                       // only bytes that are already written (any distance >= 1)
@@ -329,8 +333,7 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
         uint32_t lit = 256, new_len = 0, new_dist = 0;
         if (pend_len == n && !done) {
             if (in_symbols) {
-                br.refill();                                   // >= 33 bits: 15 (code) + 5 (extra) fit
-                const uint32_t v = rev15(br.peek(15));
+                const uint32_t v = rev15(br.peek(15));         // >= 48 valid bits here: the whole trip is fed from the buffer
                 uint32_t l;
                 const uint32_t idx = code_lookup(LL, v, l);
                 if (l == 0 || idx >= 288) { status = INF_BAD_CODE; break; }
@@ -347,7 +350,6 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
                     if (c < 8) new_len = 3 + c;
                     else if (c == 28) new_len = 258;
                     else { const uint32_t e = (c >> 2) - 1; new_len = ((4 + (c & 3)) << e) + 3 + br.bits(e); }
-                    br.refill();                               // 15 (code) + 13 (extra)
                     const uint32_t dv = rev15(br.peek(15));
                     uint32_t dl;
                     const uint32_t didx = code_lookup(DD, dv, dl);
@@ -366,6 +368,14 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
                 else if (last) { if (br.overran()) { status = INF_IN_OVERRUN; break; } done = true; }
             }
         }
+        // ---- R: the trip's one memory wait: fold in the word prefetched a trip ago, prefetch the next ----------------------
+        // The explicit vmcnt(0) tells the compiler's wait-count pass that no load is pending past this point on ANY path (it cannot
+        // see that the predicates of a chunk's load and of its store are the same); without it the pass drains the counter at the
+        // top of every trip -- which, the counter being shared, also waits for the stores issued a few instructions earlier.
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0), expcnt/lgkmcnt untouched
+#endif
+        br.ensure(48);
         // ---- C: stores -----------------------------------------------------------------------------------------------
         if (copying) {
             uint8_t *d = out + o;

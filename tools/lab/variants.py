@@ -28,14 +28,32 @@ def lds_bytes(nbytes):
     f.kernels = ("constexpr uint32_t kInflateLdsBytes = kLdsDwordsPerLane * 64 * 4;", "constexpr uint32_t kInflateLdsBytes = %d;" % nbytes)
     return f
 
+def hot_loads(s):      # every copy load hits the same (cached) place: what do the loads cost when they never miss?
+    return sub(s, "            const uint8_t *s = out + o - pend_dist;\n", "            const uint8_t *s = out + (pend_dist & 15u);\n")
+
+def aligned_loads(s):  # wrong bytes, right addresses rounded down to 16
+    return sub(s, "            const uint8_t *s = out + o - pend_dist;\n", "            const uint8_t *s = out + ((o - pend_dist) & ~15u);\n")
+
+def aligned_stores(s):
+    return sub(s, "            uint8_t *d = out + o;\n            const uint32_t slack", "            uint8_t *d = out + (o & ~15u);\n            const uint32_t slack")
+
+def batch(nb):
+    def f(s):
+        return sub(s, "constexpr uint32_t kCopyBatch = 128;", "constexpr uint32_t kCopyBatch = %d;" % nb)
+    return f
+
 VARIANTS = {
     "base": [],
     "noload": [no_copy_loads],
     "noload_nostore": [no_copy_loads, no_copy_stores],
     "decode_only": [no_copy_loads, no_copy_stores, no_literal_stores],
-    "occ5": [lds_bytes(32768)],
-    "occ3": [lds_bytes(54000)],
-    "occ2": [lds_bytes(81000)],
+    "batch64": [batch(64)],
+    "batch32": [batch(32)],
+    "batch96": [batch(96)],
+    "hotload": [hot_loads],
+    "alignload": [aligned_loads],
+    "alignstore": [aligned_stores],
+    "alignboth": [aligned_loads, aligned_stores],
 }
 
 if __name__ == "__main__":
