@@ -151,12 +151,79 @@ RGX_HD uint32_t rev15(uint32_t v) {
 #endif
 }
 
+// ---- output staging -------------------------------------------------------------------------------------------------
+// Every output byte goes through a 16-byte register chunk aligned on the DESTINATION ADDRESS and reaches memory exactly once,
+// as part of one aligned 16-byte store (the chunks cut by the two ends of the member are written byte-exactly).  Why: with one
+// lane per member a wave's stores land in 64 different cache lines; what the memory system then pays for is the NUMBER of
+// write requests -- a literal stored as a single byte or a 10-byte match stored as an unaligned, line-straddling chunk cost a
+// full request each, and tens of thousands of lanes per L2 each dribbling partial writes into their own line evict one another
+// (measured: one store per 16 output bytes instead of one per symbol takes a third off the kernel on real-looking payloads).
+// Invariant: bytes [0, k) of (lo, hi) are the chunk's valid bytes, k = (a + o) & 15; bytes >= k are zero.
+RGX_HD uint64_t shl64(uint64_t x, uint32_t s) { return s >= 64 ? 0 : x << s; }
+RGX_HD uint64_t shr64(uint64_t x, uint32_t s) { return s >= 64 ? 0 : x >> s; }
+
+struct OutStage {
+    uint8_t *out; uint32_t cap, a;
+    uint64_t lo, hi;
+    RGX_HD void init(uint8_t *o_, uint32_t cap_) { out = o_; cap = cap_; a = (uint32_t)((uintptr_t)o_ & 15u); lo = 0; hi = 0; }
+    // write the chunk that holds member offset o (any offset inside it); bytes outside [0, cap) are never touched
+    RGX_HD void store_chunk(uint32_t o, uint64_t l, uint64_t h) const {
+        const int32_t cb = (int32_t)((a + o) & ~15u) - (int32_t)a;        // member offset of the chunk's byte 0 (< 0 for the head chunk)
+        if (cb >= 0 && (uint32_t)cb + 16 <= cap) {
+            u32x4 v = {(uint32_t)l, (uint32_t)(l >> 32), (uint32_t)h, (uint32_t)(h >> 32)};
+            *(u32x4 *)(out + cb) = v;                                      // 16-byte aligned by construction
+        } else {
+            for (int i = 0; i < 16; ++i) {
+                const int32_t m = cb + i;
+                if (m >= 0 && (uint32_t)m < cap) out[m] = (uint8_t)((i < 8 ? l >> (8 * i) : h >> (8 * (i - 8))) & 0xff);
+            }
+        }
+    }
+    // make memory agree with the stage up to o (a copy is about to read bytes that are still in registers)
+    RGX_HD void flush_partial(uint32_t o) const { if ((a + o) & 15u) store_chunk(o, lo, hi); }
+    RGX_HD void put_byte(uint32_t o, uint32_t b) {
+        const uint32_t k = (a + o) & 15u;
+        if (k < 8) lo |= (uint64_t)b << (8 * k); else hi |= (uint64_t)b << (8 * (k - 8));
+        if (k == 15) { store_chunk(o, lo, hi); lo = 0; hi = 0; }
+    }
+    // append nb (1..16) bytes held in the low end of (dl, dh); whatever lies above them is ignored
+    RGX_HD void put_chunk(uint32_t o, uint64_t dl, uint64_t dh, uint32_t nb) {
+        if (nb < 8) { dl &= (1ull << (8 * nb)) - 1; dh = 0; }
+        else if (nb < 16) dh &= shl64(1ull, 8 * (nb - 8)) - 1;
+        const uint32_t k = (a + o) & 15u;
+        uint64_t cl, ch, rl, rh;                                           // (cl, ch) = this chunk, (rl, rh) = what spills into the next
+        if (k < 8) {
+            const uint32_t s = 8 * k;
+            cl = lo | (dl << s); ch = hi | shl64(dh, s) | shr64(dl, 64 - s);
+            if (s == 0) ch = hi | dh;
+            rl = s ? dh >> (64 - s) : 0; rh = 0;
+        } else {
+            const uint32_t s = 8 * (k - 8);
+            cl = lo; ch = hi | (dl << s);
+            rl = (s ? dl >> (64 - s) : 0) | (dh << s); rh = s ? dh >> (64 - s) : 0;
+        }
+        if (k + nb >= 16) { store_chunk(o, cl, ch); lo = rl; hi = rh; }
+        else { lo = cl; hi = ch; }
+    }
+    // after bytes were written straight to memory (stored blocks): pick the current chunk's valid bytes up again
+    RGX_HD void resync(uint32_t o) {
+        const uint32_t k = (a + o) & 15u;
+        lo = 0; hi = 0;
+        if (k) {
+            const uint8_t *c = out + o - k;                               // aligned; may start before `out`, inside the same 16-byte block
+            const u32x4 v = *(const u32x4 *)c;
+            lo = (uint64_t)v[0] | (uint64_t)v[1] << 32; hi = (uint64_t)v[2] | (uint64_t)v[3] << 32;
+            if (k < 8) { lo &= (1ull << (8 * k)) - 1; hi = 0; } else hi &= shl64(1ull, 8 * (k - 8)) - 1;
+        }
+    }
+};
+
 // ---- block header ------------------------------------------------------------------------------------------------
 // Parses one DEFLATE block header.  Dynamic/fixed blocks: builds the two canonical codes (returns 1 = symbols follow).
 // Stored blocks: copies the raw bytes and returns 0 (= another header follows, or the stream ends if *last).
 template <class Tab>
 RGX_HD int block_header(BitReader &br, Tab &T, Code &LL, Code &DD, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t &o,
-                        uint32_t out_cap, uint32_t &last, int &status) {
+                        uint32_t out_cap, uint32_t &last, int &status, OutStage &S) {
     if (br.overran()) { status = INF_IN_OVERRUN; return 0; }     // a run of empty stored blocks must not walk off the input
     br.ensure(32);
     last = br.bits(1);
@@ -169,6 +236,7 @@ RGX_HD int block_header(BitReader &br, Tab &T, Code &LL, Code &DD, const uint8_t
         const uint32_t nlen = br.bits(16);
         if ((len ^ 0xffff) != nlen) { status = INF_BAD_STORED; return 0; }
         if (o + len > out_cap) { status = INF_OUT_OVERFLOW; return 0; }
+        S.flush_partial(o);                                    // raw bytes go straight to memory; the stage is picked up again below
         while (len && br.cnt >= 8) { out[o++] = (uint8_t)br.bits(8); --len; }     // bytes still in the bit buffer
         if (len) {
             const uint8_t *src = br.byte_ptr();   // cnt == 0 here: the prefetched word starts at the next payload byte
@@ -178,6 +246,7 @@ RGX_HD int block_header(BitReader &br, Tab &T, Code &LL, Code &DD, const uint8_t
             for (; k < len; ++k) out[o + k] = src[k];
             o += len; br.restart_at(src + len);
         }
+        S.resync(o);
         return 0;
     }
     if (btype == 3) { status = INF_BAD_BTYPE; return 0; }
@@ -279,28 +348,21 @@ RGX_HD int block_header(BitReader &br, Tab &T, Code &LL, Code &DD, const uint8_t
     return status == INF_OK ? 1 : 0;
 }
 
-// store the low `len` (< 16) bytes of v at d, exactly
-RGX_HD void store_tail16(uint8_t *d, u32x4 v, uint32_t len) {
-    uint64_t lo = (uint64_t)v[0] | (uint64_t)v[1] << 32, hi = (uint64_t)v[2] | (uint64_t)v[3] << 32;
-    if (len & 8) { st64(d, lo); d += 8; lo = hi; }
-    if (len & 4) { st32(d, (uint32_t)lo); d += 4; lo >>= 32; }
-    if (len & 2) { st16(d, (uint16_t)lo); d += 2; lo >>= 16; }
-    if (len & 1) *d = (uint8_t)lo;
-}
-
 constexpr uint32_t kCopyBatch = 128;   // bytes moved per memory round trip (8 independent 16-byte loads in flight)
 
 // Inflate one raw-DEFLATE stream. Returns an InflateStatus; *out_len = bytes produced.
 //
 // The symbol loop is a per-lane state machine whose every trip does AT MOST ONE dependent memory round trip:
 //   A. issue the loads of this lane's pending LZ77 copy (up to kCopyBatch bytes whose sources are already written),
-//   B. while they are in flight, decode the lane's next symbol if the copy ends with this batch,
-//   C. store the copied bytes, then the decoded literal, or arm the next copy.
+//   B. while they are in flight, decode the lane's next symbol if the copy ends with this batch (bit buffer only),
+//   R. wait once, top the bit buffer up from the word prefetched a trip ago and prefetch the next one,
+//   C. push the copied bytes, then the decoded literal, through the output stage (OutStage), or arm the next copy.
 // In a 64-lane wavefront every lane is at a different point of a different member; a lane in the middle of a long
 // match therefore no longer stalls the 63 others for a whole copy loop -- each trip costs one round trip for all.
 template <class Tab>
 RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len, Tab &T) {
     BitReader br; br.init(in, in_len);
+    OutStage S; S.init(out, out_cap);
     uint32_t o = 0;
     int status = INF_OK;
     uint32_t last = 0;
@@ -310,7 +372,7 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
 #pragma unroll
     for (int k = 0; k < 16; ++k) { LL.c[k] = 0; DD.c[k] = 0; }
 
-    u32x4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0, v4 = v0, v5 = v0, v6 = v0, v7 = v0;   // copy registers: a chunk is loaded (A) and stored (C)
+    u32x4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0, v4 = v0, v5 = v0, v6 = v0, v7 = v0;   // copy registers: a chunk is loaded (A) and consumed (C)
                                                                                              // under the same predicate; never re-initialised
     for (;;) {
         // ---- A: loads of the pending copy -----------------------------------------------------------------------
@@ -318,7 +380,8 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
         uint32_t n = 0;
         if (copying) {
             n = pend_len < kCopyBatch ? pend_len : kCopyBatch;
-            if (pend_dist < n) n = pend_dist;                       // only bytes that are already written (any distance >= 1)
+            if (pend_dist < n) n = pend_dist;                       // only bytes that are already produced (any distance >= 1)
+            if (pend_dist < n + 16) S.flush_partial(o);             // ... and the last < 16 of those may still be in the stage
             const uint8_t *s = out + o - pend_dist;
             v0 = ld128(s);
             if (n > 16) v1 = ld128(s + 16);
@@ -362,7 +425,7 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
                 }
             } else if (!copying) {
                 // block header (rare, heavy): only with no copy in flight, so that it may write output itself
-                const int r = block_header(br, T, LL, DD, in, in_len, out, o, out_cap, last, status);
+                const int r = block_header(br, T, LL, DD, in, in_len, out, o, out_cap, last, status, S);
                 if (status != INF_OK) break;
                 if (r) in_symbols = true;
                 else if (last) { if (br.overran()) { status = INF_IN_OVERRUN; break; } done = true; }
@@ -370,34 +433,21 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
         }
         // ---- R: the trip's one memory wait: fold in the word prefetched a trip ago, prefetch the next ----------------------
         // The explicit vmcnt(0) tells the compiler's wait-count pass that no load is pending past this point on ANY path (it cannot
-        // see that the predicates of a chunk's load and of its store are the same); without it the pass drains the counter at the
+        // see that the predicates of a chunk's load and of its use are the same); without it the pass drains the counter at the
         // top of every trip -- which, the counter being shared, also waits for the stores issued a few instructions earlier.
 #if defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0), expcnt/lgkmcnt untouched
 #endif
         br.ensure(48);
-        // ---- C: stores -----------------------------------------------------------------------------------------------
+        // ---- C: output -------------------------------------------------------------------------------------------------
         if (copying) {
-            uint8_t *d = out + o;
-            const uint32_t slack = out_cap - (o + n);
-            if (slack >= 16) {                                     // whole chunks, scribbling < 16 bytes past the copy
-                st128(d, v0);
-                if (n > 16) st128(d + 16, v1);
-                if (n > 32) st128(d + 32, v2);
-                if (n > 48) st128(d + 48, v3);
-                if (n > 64) st128(d + 64, v4);
-                if (n > 80) st128(d + 80, v5);
-                if (n > 96) st128(d + 96, v6);
-                if (n > 112) st128(d + 112, v7);
-            } else {                                               // end of the member: exact
-                const u32x4 vv[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t lo = 16u * (uint32_t)k;
-                    if (n >= lo + 16) st128(d + lo, vv[k]);
-                    else if (n > lo) store_tail16(d + lo, vv[k], n - lo);
-                }
+#define RGX_PUT(J, V)                                                                                                            \
+            if (n > 16u * (J)) {                                                                                                 \
+                const uint32_t nb = n - 16u * (J) < 16u ? n - 16u * (J) : 16u;                                                   \
+                S.put_chunk(o + 16u * (J), (uint64_t)(V)[0] | (uint64_t)(V)[1] << 32, (uint64_t)(V)[2] | (uint64_t)(V)[3] << 32, nb); \
             }
+            RGX_PUT(0, v0) RGX_PUT(1, v1) RGX_PUT(2, v2) RGX_PUT(3, v3) RGX_PUT(4, v4) RGX_PUT(5, v5) RGX_PUT(6, v6) RGX_PUT(7, v7)
+#undef RGX_PUT
             o += n; pend_len -= n;
             // an overlapping copy is periodic with period pend_dist, so 2 * pend_dist is as good a distance for the rest: a run
             // (distance 1) grows 1, 2, 4, ... bytes per trip and is at full 128-byte batches after eight
@@ -405,7 +455,7 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
         }
         if (lit < 256) {
             if (o >= out_cap) { status = INF_OUT_OVERFLOW; break; }
-            out[o++] = (uint8_t)lit;
+            S.put_byte(o, lit); ++o;
         } else if (new_len) {
             if (new_dist > o) { status = INF_BAD_DIST; break; }
             if (o + new_len > out_cap) { status = INF_OUT_OVERFLOW; break; }
@@ -413,6 +463,7 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
         }
         if (done && pend_len == 0) break;
     }
+    S.flush_partial(o);                                             // the tail chunk (also on errors: what was produced is in memory)
     *out_len = o;
     return status;
 }

@@ -75,6 +75,35 @@ def test_every_short_distance_and_length(emu):
             assert st == 0 and got == data, (dist, total)
 
 
+def test_output_stage_respects_every_alignment_and_both_member_ends(emu):
+    """The decoder writes aligned 16-byte chunks cut on the DESTINATION address; the chunks cut by the two ends of the member
+    must be written byte-exactly (a neighbouring member's lane owns the bytes on the other side)."""
+    rnd = random.Random(11)
+    payloads = []
+    for size in (1, 2, 15, 16, 17, 31, 33, 100, 1000, 5000):
+        data = bytes(rnd.choice(b"ACGT") if rnd.random() < 0.7 else rnd.randrange(256) for _ in range(size))
+        payloads.append((data, zlib.compress(data, 6)[2:-4]))
+    stored = bytes(rnd.randrange(256) for _ in range(300))
+    c = zlib.compressobj(0, zlib.DEFLATED, -15)
+    payloads.append((stored, c.compress(stored) + c.flush()))
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)                      # deflate, sync flush (empty stored block), deflate
+    mixed = c.compress(b"abcabcabcabc" * 9) + c.flush(zlib.Z_SYNC_FLUSH) + c.compress(b"xyzzy" * 31) + c.flush()
+    payloads.append((b"abcabcabcabc" * 9 + b"xyzzy" * 31, mixed))
+    raw = ctypes.create_string_buffer(8192 + 256)
+    base = ctypes.addressof(raw)
+    for data, p in payloads:
+        src = ctypes.create_string_buffer(p + b"\0" * 16, len(p) + 16)
+        for mis in range(16):
+            off = (-base) % 16 + 64 + mis
+            ctypes.memset(base, 0xA5, len(raw))
+            n = ctypes.c_uint32(0)
+            st = emu.emu_inflate(src, len(p), ctypes.c_void_p(base + off), len(data), ctypes.byref(n))
+            got = raw.raw
+            assert st == 0 and n.value == len(data), (len(data), mis, st)
+            assert got[off:off + len(data)] == data, (len(data), mis)
+            assert got[:off] == b"\xa5" * off and got[off + len(data):] == b"\xa5" * (len(raw) - off - len(data)), (len(data), mis)
+
+
 def test_output_capacity_is_respected(emu):
     data = b"xyz" * 1000
     p = zlib.compress(data, 6)[2:-4]

@@ -42,14 +42,23 @@ def batch(nb):
         return sub(s, "constexpr uint32_t kCopyBatch = 128;", "constexpr uint32_t kCopyBatch = %d;" % nb)
     return f
 
+def lit_every8(s):      # one literal store in eight: what would combining literal writes buy?
+    return sub(s, "            out[o++] = (uint8_t)lit;", "            if ((o & 7u) == 0u) out[o] = (uint8_t)lit; ++o;")
+
+def chunk_on_boundary(s):   # copy stores only when the batch crosses a 16-byte boundary of the output (about one store per 16 output bytes)
+    s = sub(s, "            if (slack >= 16) {                                     // whole chunks, scribbling < 16 bytes past the copy\n                st128(d, v0);",
+            "            if (slack >= 16) {\n                if (((o + n) ^ o) & ~15u) st128(d, v0);")
+    return s
+
 VARIANTS = {
     "base": [],
     "noload": [no_copy_loads],
     "noload_nostore": [no_copy_loads, no_copy_stores],
     "decode_only": [no_copy_loads, no_copy_stores, no_literal_stores],
-    "batch64": [batch(64)],
-    "batch32": [batch(32)],
-    "batch96": [batch(96)],
+    "lit8": [lit_every8],
+    "wc16": [lit_every8, chunk_on_boundary],
+    "nolit": [no_literal_stores],
+    "nostore": [no_copy_stores, no_literal_stores],
     "hotload": [hot_loads],
     "alignload": [aligned_loads],
     "alignstore": [aligned_stores],
