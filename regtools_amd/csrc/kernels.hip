@@ -28,15 +28,20 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 // =====================================================================================================
 // a1. BGZF inflate: ONE LANE PER MEMBER (64 members per wavefront, one wave per workgroup)
 // =====================================================================================================
-// Per-lane Huffman symbol lists in LDS, lane-interleaved so that lane L only ever touches bank L % 32, bit-packed:
-//   ll_sym : 288 x 9 bits -> dwords  0..80   (symbol i at bit 9*i)
-//   d_sym  :  32 x 5 bits -> dwords 81..85   (symbol i at bit 5*i)      + 1 pad dword
-// 87 dwords * 64 lanes * 4 B = 22,272 B per wave -> 7 waves (448 members in flight) per CU of 160 KiB, i.e. two waves on
-// three of the four SIMDs: one wave's memory round trip hides behind the other's decode ALU work.
-// The canonical codes themselves (bounds, lengths, list offsets) are 2 x 16 REGISTER words (inflate_core.h Code), and the
-// code-length scratch that only a block header needs lives in a global lane-interleaved buffer (40 dwords per lane).
-constexpr uint32_t kLdsLL = 0, kLdsD = 81, kLdsDwordsPerLane = 87;
+// Per-lane Huffman symbol lists, lane-interleaved so that lane L only ever touches LDS bank L % 32, bit-packed:
+//   ll_sym : 288 x 9 bits, sorted by (code length, symbol): the first kHotSyms entries -- the SHORTEST, i.e. most frequent,
+//            codes -- in LDS dwords 0..kLdsD-1, the long-code tail in the global scratch (one dependent L2 read per rare symbol)
+//   d_sym  :  32 x 5 bits -> LDS dwords kLdsD..kLdsD+4                    + 1 pad dword
+// What the split buys is occupancy: LDS per wave = kLdsDwordsPerLane * 256 B decides how many waves (each 64 members) a CU of
+// 160 KiB holds, and a lane's trip is a chain of dependent ALU/LDS steps plus one memory round trip -- the other waves of
+// the SIMD are what fills those gaps (measured with the output stage in place: 5 -> 7 waves per CU is 1.3x).
+// The canonical codes themselves (bounds, lengths, list offsets) are 2 x 16 REGISTER words (inflate_core.h Code); the
+// code-length scratch that only a block header needs is global too (40 dwords per lane, before the cold symbols).
+constexpr uint32_t kHotSyms = 160;
+constexpr uint32_t kLdsLL = 0, kLdsD = (kHotSyms * 9 + 31) / 32, kLdsDwordsPerLane = kLdsD + 6;
 constexpr uint32_t kInflateLdsBytes = kLdsDwordsPerLane * 64 * 4;
+constexpr uint32_t kScratchLenWords = 40, kScratchColdWords = ((288 - kHotSyms) * 9 + 31) / 32 + 1;
+constexpr uint32_t kScratchWordsPerLane = kScratchLenWords + kScratchColdWords;
 
 struct LdsTab {
     uint32_t *base;       // LDS, already offset by lane
@@ -44,6 +49,8 @@ struct LdsTab {
     uint32_t stride;      // lanes in the grid (dword stride of the scratch)
     __device__ __forceinline__ uint32_t rd(uint32_t dw) const { return base[dw * 64]; }
     __device__ __forceinline__ void wr(uint32_t dw, uint32_t v) { base[dw * 64] = v; }
+    __device__ __forceinline__ uint32_t grd(uint32_t dw) const { return scratch[(size_t)dw * stride]; }
+    __device__ __forceinline__ void gwr(uint32_t dw, uint32_t v) { scratch[(size_t)dw * stride] = v; }
     __device__ __forceinline__ uint32_t get_bits(uint32_t dw0, uint32_t bit, uint32_t width) const {
         const uint32_t dw = dw0 + (bit >> 5), sh = bit & 31;
         const uint64_t w = (uint64_t)rd(dw) | (uint64_t)rd(dw + 1) << 32;
@@ -57,16 +64,28 @@ struct LdsTab {
         wr(dw, (uint32_t)w);
         if (sh + width > 32) wr(dw + 1, (uint32_t)(w >> 32));
     }
-    __device__ __forceinline__ uint32_t get_ll_sym(uint32_t i) const { return get_bits(kLdsLL, i * 9, 9); }
-    __device__ __forceinline__ void set_ll_sym(uint32_t i, uint32_t v) { set_bits(kLdsLL, i * 9, 9, v); }
+    __device__ __forceinline__ uint32_t get_cold(uint32_t i) const {
+        const uint32_t bit = i * 9, dw = kScratchLenWords + (bit >> 5), sh = bit & 31;
+        const uint64_t w = (uint64_t)grd(dw) | (uint64_t)grd(dw + 1) << 32;
+        return (uint32_t)(w >> sh) & 0x1ffu;
+    }
+    __device__ __forceinline__ void set_cold(uint32_t i, uint32_t v) {
+        const uint32_t bit = i * 9, dw = kScratchLenWords + (bit >> 5), sh = bit & 31;
+        uint64_t w = (uint64_t)grd(dw) | (uint64_t)grd(dw + 1) << 32;
+        w = (w & ~((uint64_t)0x1ffu << sh)) | ((uint64_t)v << sh);
+        gwr(dw, (uint32_t)w);
+        if (sh + 9 > 32) gwr(dw + 1, (uint32_t)(w >> 32));
+    }
+    __device__ __forceinline__ uint32_t get_ll_sym(uint32_t i) const { return i < kHotSyms ? get_bits(kLdsLL, i * 9, 9) : get_cold(i - kHotSyms); }
+    __device__ __forceinline__ void set_ll_sym(uint32_t i, uint32_t v) { if (i < kHotSyms) set_bits(kLdsLL, i * 9, 9, v); else set_cold(i - kHotSyms, v); }
     __device__ __forceinline__ uint32_t get_d_sym(uint32_t i) const { return get_bits(kLdsD, i * 5, 5); }
     __device__ __forceinline__ void set_d_sym(uint32_t i, uint32_t v) { set_bits(kLdsD, i * 5, 5, v); }
-    __device__ __forceinline__ uint32_t get_len_word(uint32_t w) const { return scratch[(size_t)w * stride]; }
-    __device__ __forceinline__ void set_len_word(uint32_t w, uint32_t v) { scratch[(size_t)w * stride] = v; }
+    __device__ __forceinline__ uint32_t get_len_word(uint32_t w) const { return grd(w); }
+    __device__ __forceinline__ void set_len_word(uint32_t w, uint32_t v) { gwr(w, v); }
     __device__ __forceinline__ void clear_syms() {}
 };
 
-__global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_inflate(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
                                                 uint32_t n_members, uint8_t *__restrict__ arena, uint64_t upos_bias, uint32_t *len_scratch,
                                                 uint32_t *status) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -83,7 +102,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
     }
 }
 
-size_t inflate_scratch_bytes(uint32_t n_members) { return (size_t)((n_members + 63) / 64) * 64 * 40 * 4; }
+size_t inflate_scratch_bytes(uint32_t n_members) { return (size_t)((n_members + 63) / 64) * 64 * kScratchWordsPerLane * 4; }
 
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
                     uint32_t *status, hipStream_t stream) {
