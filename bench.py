@@ -147,8 +147,9 @@ def main():
                 traffic = (pm["inflate_FETCH_SIZE"][0] + pm["inflate_WRITE_SIZE"][0]) * 1024.0
                 traffic_note = ("(FETCH_SIZE + WRITE_SIZE) KiB of rgx::k_inflate, uncorrected: the guide's x2 FETCH correction is for wide coalesced "
                                 "streams; a calibration kernel with this kernel's scattered 16-B-per-lane pattern and known bytes reads "
-                                "%.2fx (FETCH) / %.2fx (WRITE) of its true bytes" % (pm["cal_FETCH_SIZE"][0] * 1024.0 / pm["cal_known_bytes_each_way"],
-                                                                                     pm["cal_WRITE_SIZE"][0] * 1024.0 / pm["cal_known_bytes_each_way"]))
+                                "%.2fx (FETCH) / %.2fx (WRITE) of its true bytes (median of 8 launches)" % (
+                                    sorted(pm["cal_FETCH_SIZE"])[len(pm["cal_FETCH_SIZE"]) // 2] * 1024.0 / pm["cal_known_bytes_each_way"],
+                                    sorted(pm["cal_WRITE_SIZE"])[len(pm["cal_WRITE_SIZE"]) // 2] * 1024.0 / pm["cal_known_bytes_each_way"]))
         except Exception:
             pass
         line = {
@@ -156,7 +157,8 @@ def main():
             "value": aln_per_s, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32 integer", "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic %d-read 101 bp BAM per GPU, ~15%% reads with one N-op, junctions extract -s XS%s" % (n_reads, " (realistic payload)" if args.realistic else ""),
+            "config": {"workload": ("configs[1]: synthetic %d-read 101 bp BAM per GPU, ~15%% reads with one N-op, junctions extract -s XS%s" % (n_reads, " (realistic payload)" if args.realistic else "")) if args.shape == "short" else
+                                   "configs[4]-shape: synthetic %d long reads per GPU (l_qseq 1000-10000, n_cigar <= 64, 5-20 N ops), junctions extract -s XS" % n_reads,
                        "reads_per_gpu": n_reads, "shape": args.shape, "seed": args.seed, "sharding": "coordinate slice per GPU, all-gather of packed junction rows" if world > 1 else "single GPU",
                        "bgzf_members": s["n_members"], "compressed_bytes_per_gpu": s["compressed_bytes"], "inflated_bytes_per_gpu": s["inflated_bytes"],
                        "bytes_per_alignment": {"compressed": s["compressed_bytes"] / n_reads, "inflated": s["inflated_bytes"] / n_reads}},
@@ -166,7 +168,7 @@ def main():
             "input_generation_s": round(t_gen, 2),
             "roofline": {"bound": "hbm", "kernel": "rgx::k_inflate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_note": traffic_note, "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
-                         "note": "DEFLATE is a serial bit stream per member: bound by per-lane latency, far below the HBM line (SURVEY 8d)",
+                         "note": "DEFLATE is a serial bit stream per member: one lane per member, bound by per-lane dependent ALU/LDS chains plus one memory round trip per symbol trip, far below the HBM line (SURVEY 8d; DESIGN.md 5)",
                          "pipeline_frac": aln_per_s / world * (alg_bytes / n_reads) / (HBM_PEAK_GBS * 1e9)},
         }
         if world == 1 and not args.no_cpu_baseline:
