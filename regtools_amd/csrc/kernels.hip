@@ -151,20 +151,42 @@ __global__ void k_seg_walk(const uint8_t *__restrict__ arena, uint64_t pos0, uin
         o = kChainEnd;
         uint64_t c = a;
         for (;;) {
-            for (; c < b; ++c) {
-                if (!rec_plausible(arena, c, lim, n_ref)) continue;
-                uint64_t c2 = c + 4 + (uint64_t)ld32(arena + c);
-                if (c2 < lim) {
-                    if (!rec_plausible(arena, c2, lim, n_ref)) continue;
-                    uint64_t c3 = c2 + 4 + (uint64_t)ld32(arena + c2);
-                    if (c3 < lim && !rec_plausible(arena, c3, lim, n_ref)) continue;
+            // Coarse filter first, 16 candidate offsets per 20-byte load: the word at a record start is a block_size, i.e. in
+            // [32, 2^27] (rec_sane / rec_plausible).  Sequence and quality bytes (long reads: kilobytes of them before the next
+            // record) fail it without another memory access; only survivors get the full test below.
+            uint64_t cand = kChainEnd;
+            while (c < b) {
+                const u32x4 v = ld128(arena + c);
+                const uint32_t w[5] = {v[0], v[1], v[2], v[3], ld32(arena + c + 16)};
+                uint32_t mask = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t bl = (i & 3) ? __builtin_amdgcn_alignbyte(w[(i >> 2) + 1], w[i >> 2], (uint32_t)(i & 3)) : w[i >> 2];
+                    mask |= (bl - 32u <= (1u << 27) - 32u ? 1u : 0u) << i;
                 }
-                break;
+                const uint64_t room = b - c;
+                if (room < 16) mask &= (1u << (uint32_t)room) - 1u;
+                bool found = false;
+                while (mask) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(mask);
+                    mask &= mask - 1;
+                    const uint64_t q = c + i;
+                    if (!rec_plausible(arena, q, lim, n_ref)) continue;
+                    const uint64_t c2 = q + 4 + (uint64_t)ld32(arena + q);
+                    if (c2 < lim) {
+                        if (!rec_plausible(arena, c2, lim, n_ref)) continue;
+                        const uint64_t c3 = c2 + 4 + (uint64_t)ld32(arena + c2);
+                        if (c3 < lim && !rec_plausible(arena, c3, lim, n_ref)) continue;
+                    }
+                    cand = q; found = true; break;
+                }
+                if (found) break;
+                c += 16;
             }
-            if (c >= b) break;
-            ex = walk_chain(arena, c, b, lim, cnt);
-            if (ex != kChainEnd) { o = c; break; }
-            ++c;
+            if (cand == kChainEnd) break;
+            ex = walk_chain(arena, cand, b, lim, cnt);
+            if (ex != kChainEnd) { o = cand; break; }
+            c = cand + 1;
         }
         if (o == kChainEnd) { ex = kChainEnd; o = b; cnt = 0; }      // nothing usable: verification will settle it
     } else ex = walk_chain(arena, o, b, lim, cnt);
