@@ -11,12 +11,13 @@
 
 static double now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
-/* `regtools cis-splice-effects identify` option surface (cis_splice_effects_identifier.cc:112-219) */
-static int identify_main(int argc, char **argv) {
+/* `regtools cis-splice-effects identify` option surface (cis_splice_effects_identifier.cc:112-219); with associate = 1 the
+ * `cis-splice-effects associate` one (cis_splice_effects_associator.cc:104-180): no -s/-t/-C, second positional is a BED */
+static int identify_main(int argc, char **argv, int associate) {
     orc_cse_params p; orc_cse_default_params(&p);
     int c;
     optind = 2;
-    while ((c = getopt(argc, argv, "o:w:v:j:e:Ei:ISt:s:a:m:M:C")) != -1) {
+    while ((c = getopt(argc, argv, associate ? "o:w:v:j:e:Ei:ISa:m:M:" : "o:w:v:j:e:Ei:ISt:s:a:m:M:C")) != -1) {
         switch (c) {
             case 'o': p.out_tsv = optarg; break;
             case 'w': p.window = (uint32_t)atoi(optarg); break;
@@ -42,6 +43,7 @@ static int identify_main(int argc, char **argv) {
     }
     if (argc - optind >= 4) { p.vcf = argv[optind++]; p.bam = argv[optind++]; p.fasta = argv[optind++]; p.gtf = argv[optind++]; }
     if (optind < argc || !p.vcf) { fprintf(stderr, "Error parsing inputs!(2)\n\n"); return 1; }
+    if (associate) { p.bed = p.bam; p.strandness = 0; }
     if (p.strandness == -1) { fprintf(stderr, "Please supply strand specificity with '-s' option!\n\n"); return 1; }
     const char *files[4] = {p.vcf, p.bam, p.fasta, p.gtf};
     for (int k = 0; k < 4; ++k) if (access(files[k], F_OK)) { fprintf(stderr, "Please make sure input files exist.\n\n"); return 1; }
@@ -51,7 +53,40 @@ static int identify_main(int argc, char **argv) {
 }
 
 int main(int argc, char **argv) {
-    if (argc >= 2 && !strcmp(argv[1], "identify")) return identify_main(argc, argv);
+    if (argc >= 2 && !strcmp(argv[1], "identify")) return identify_main(argc, argv, 0);
+    if (argc >= 2 && !strcmp(argv[1], "associate")) return identify_main(argc, argv, 1);
+    if (argc >= 2 && !strcmp(argv[1], "junctions-annotate")) {          /* junctions_annotator.cc:385-428 */
+        const char *out = NULL; int c; optind = 2;
+        while ((c = getopt(argc, argv, "So:")) != -1) {
+            if (c == 'o') out = optarg;
+            else if (c == 'S') { fprintf(stderr, "oracle: -S is not restated (the reference reads past the exon vector there)\n"); return 1; }
+            else { fprintf(stderr, "Error parsing inputs!(1)\n\n"); return 1; }
+        }
+        if (argc - optind != 3) { fprintf(stderr, "Error parsing inputs!(2)\n\n"); return 1; }
+        char err[512] = "";
+        if (orc_junctions_annotate(argv[optind], argv[optind + 1], argv[optind + 2], out, err, sizeof err)) { fputs(err, stderr); return 1; }
+        return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "variants-annotate")) {           /* variants_annotator.cc:48-110 */
+        orc_cse_params p; orc_cse_default_params(&p);
+        int c; optind = 2;
+        while ((c = getopt(argc, argv, "e:Ei:ISo:")) != -1) {
+            switch (c) {
+                case 'i': p.intronic_min = (uint32_t)atoi(optarg); break;
+                case 'e': p.exonic_min = (uint32_t)atoi(optarg); break;
+                case 'I': p.all_intronic = 1; break;
+                case 'E': p.all_exonic = 1; break;
+                case 'S': p.skip_single = 0; break;
+                case 'o': p.out_vcf = optarg; break;
+                default: fprintf(stderr, "Error parsing inputs!(1)\n\n"); return 1;
+            }
+        }
+        if (argc - optind < 2) { fprintf(stderr, "Error parsing inputs!(2)\n\n"); return 1; }
+        p.vcf = argv[optind]; p.gtf = argv[optind + 1];
+        char err[512] = "";
+        if (orc_variants_annotate(&p, err, sizeof err)) { fputs(err, stderr); return 1; }
+        return 0;
+    }
     if (argc < 2 || (strcmp(argv[1], "extract") && strcmp(argv[1], "time"))) {
         fprintf(stderr, "usage: oracle_cli {extract|time} [-a N -m N -M N -o FILE -r REGION -t TAG -s XS|RF|FR|intron-motif] in.bam [ref.fa]\n");
         return 1;

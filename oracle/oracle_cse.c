@@ -363,12 +363,44 @@ static int text_load(const char *path, textfile *t) {
     return 0;
 }
 
+/* htslib's header normaliser (vcf.c:116 bcf_hdr_sync / :821 bcf_hdr_write): the PASS filter right after ##fileformat unless the header
+ * declares it, the four appended INFO lines right before #CHROM */
+static void vcf_header_line(FILE *fv, const textfile *vcf, size_t li, const char *line, size_t ll, int *header_done) {
+    if (ll >= 6 && !memcmp(line, "#CHROM", 6)) {
+        fputs("##INFO=<ID=genes,Number=1,Type=String,Description=\"The Variant falls in the splice region of these genes\">\n", fv);
+        fputs("##INFO=<ID=transcripts,Number=1,Type=String,Description=\"The Variant falls in the splice region of these transcripts\">\n", fv);
+        fputs("##INFO=<ID=distances,Number=1,Type=String,Description=\"Vector of Min(Distance from start/end of exon in the transcript.)\">\n", fv);
+        fputs("##INFO=<ID=annotations,Number=1,Type=String,Description=\"Does the variant fall in exonic/intronic splicing related space in the transcript.\">\n", fv);
+    }
+    fwrite(line, 1, ll, fv); fputc('\n', fv);
+    if (!*header_done && ll >= 12 && !memcmp(line, "##fileformat", 12)) {
+        int declared = 0;
+        for (size_t k = li + 1; k < vcf->n_lines && vcf->text[vcf->line_off[k]] == '#'; ++k)
+            if (!strncmp(vcf->text + vcf->line_off[k], "##FILTER=<ID=PASS", 17)) declared = 1;
+        if (!declared) fputs("##FILTER=<ID=PASS,Description=\"All filters passed\">\n", fv);
+        *header_done = 1;
+    }
+}
+/* bcf_update_info_string x4 + vcf_format (vcf.c:2783, :2069): the record text with the four tags appended to INFO (column 8) */
+static void vcf_record(FILE *fv, const char *line, size_t ll, const char **f, const size_t *fl, int nf, const ann_variant *v) {
+    for (int k = 0; k < nf && k < 16; ++k) {
+        if (k) fputc('\t', fv);
+        if (k == 7) {
+            if (!(fl[7] == 1 && f[7][0] == '.')) { fwrite(f[7], 1, fl[7], fv); fputc(';', fv); }
+            fprintf(fv, "genes=%s;transcripts=%s;distances=%s;annotations=%s", v->genes.buf, v->transcripts.buf, v->distances.buf, v->annotations.buf);
+        } else fwrite(f[k], 1, fl[k], fv);
+    }
+    if (nf > 16) { const char *rest = f[15] + fl[15]; fwrite(rest, 1, (size_t)(line + ll - rest), fv); }
+    fputc('\n', fv);
+}
+
 /* ==================================================================================================
  * the driver (cis-splice-effects/cis_splice_effects_identifier.cc:222-312)
  * ================================================================================================ */
 typedef struct {
     char *chrom; uint32_t start, end, ts, te, count; char strand;   /* first-inserted row for this (chrom,start,end) */
     ann_variant **vars; size_t n_vars;
+    const char *strand_s, *color; int nblocks;                      /* associate: strand string, colour and block count of the BED row */
 } cse_junction;
 
 static int cj_cmp(const void *a, const void *b) {     /* AnnotatedJunction operator< (junctions_annotator.h:169-177) on (chrom, start, end+1) */
@@ -384,6 +416,111 @@ static int var_cmp(const void *a, const void *b) {    /* AnnotatedVariant operat
     if (x->start != y->start) return x->start < y->start ? -1 : 1;
     if (x->end != y->end) return x->end < y->end ? -1 : 1;
     return 0;
+}
+
+/* ==================================================================================================
+ * BED12 junction rows as bedtools' BedFile hands them out (bedFile.cpp:103-260, bedFile.h:565-780) and
+ * JunctionsAnnotator::adjust_junction_ends moves them (junctions_annotator.cc:66-81)
+ * ================================================================================================ */
+typedef struct { char *chrom, *name, *score, *strand, *color; uint32_t start, end, ts, te; int nblocks; } bed_junc;
+
+static int bed_is_header(const char *s, size_t n) {
+    return (n >= 1 && s[0] == '#') || (n >= 7 && !memcmp(s, "browser", 7)) || (n >= 5 && !memcmp(s, "track", 5));
+}
+static int all_digits(const char *s, size_t n) { for (size_t i = 0; i < n; ++i) if (s[i] < '0' || s[i] > '9') return 0; return 1; }
+
+/* returns 0 ok, 1 = the reference exits with status 1 (message in err) */
+static int bed_load(const char *path, bed_junc **out, size_t *n_out, char *err, size_t errlen) {
+    textfile t;
+    *out = NULL; *n_out = 0;
+    if (text_load(path, &t)) { snprintf(err, errlen, "Error: The requested file (%s) could not be opened. Exiting!\n", path); return 1; }
+    size_t li = 0, bed_type = 0;
+    int rc = 0;
+    /* GetHeader: leading lines that start with #, browser or track */
+    for (; li < t.n_lines; ++li) {
+        const char *l = t.text + t.line_off[li]; size_t ll = t.line_off[li + 1] - t.line_off[li]; if (ll) --ll;
+        if (!bed_is_header(l, ll)) break;
+    }
+    for (int first = 1; li < t.n_lines; ++li, first = 0) {
+        const char *l = t.text + t.line_off[li]; size_t ll = t.line_off[li + 1] - t.line_off[li]; if (ll) --ll;
+        if (ll && l[ll - 1] == '\r') --ll;
+        const char *f[32]; size_t fl[32];
+        int nf = ll ? tokenize(l, ll, '\t', f, fl, 32) : 0;
+        if (first) bed_type = (size_t)nf;
+        if (nf == 0) break;                                                   /* BED_BLANK: get_single_junction() returns false */
+        if (bed_is_header(f[0], fl[0])) break;                                /* BED_HEADER after the first data line: iteration ends too */
+        if (nf < 3) { snprintf(err, errlen, "It looks as though you have less than 3 columns at line: %zu.  Are you sure your files are tab-delimited?\n", li + 1); rc = 1; break; }
+        if (!(all_digits(f[1], fl[1]) && all_digits(f[2], fl[2]))) { snprintf(err, errlen, "Unexpected file format.  Please use tab-delimited BED, GFF, or VCF.\n"); rc = 1; break; }
+        if ((size_t)nf != bed_type) { snprintf(err, errlen, "Differing number of BED fields encountered at line: %zu.  Exiting...\n", li + 1); rc = 1; break; }
+        char *a = xstrndup(f[1], fl[1]), *b = xstrndup(f[2], fl[2]);
+        uint32_t start = (uint32_t)atoi(a), end = (uint32_t)atoi(b);
+        free(a); free(b);
+        if (start == end) { --start; ++end; }                                 /* zero-length feature (bedFile.h:708-712) */
+        if (start > end) { snprintf(err, errlen, "Error: malformed BED entry at line %zu. Start was greater than end. Exiting.\n", li + 1); rc = 1; break; }
+        if (nf != 12 || fl[10] == 0) {                                        /* adjust_junction_ends */
+            char *c = xstrndup(f[0], fl[0]);
+            snprintf(err, errlen, "BED line not in BED12 format. start: %s:%u\n", c, start);
+            free(c); rc = 1; break;
+        }
+        bed_junc j; memset(&j, 0, sizeof j);
+        j.chrom = xstrndup(f[0], fl[0]); j.name = xstrndup(f[3], fl[3]); j.score = xstrndup(f[4], fl[4]); j.strand = xstrndup(f[5], fl[5]);
+        j.color = xstrndup(f[8], fl[8]);
+        char *nb = xstrndup(f[9], fl[9]); j.nblocks = atoi(nb); free(nb);
+        const char *bs[8]; size_t bl[8];
+        int nbs = tokenize(f[10], fl[10], ',', bs, bl, 8);
+        char *b0 = xstrndup(bs[0], bl[0]), *b1 = nbs > 1 ? xstrndup(bs[1], bl[1]) : xstrndup("0", 1);
+        j.ts = start; j.te = end;
+        j.start = start + (uint32_t)atoi(b0); j.end = end - (uint32_t)(atoi(b1) - 1);
+        free(b0); free(b1);
+        *out = (bed_junc *)realloc(*out, (*n_out + 1) * sizeof j); (*out)[(*n_out)++] = j;
+    }
+    free(t.text); free(t.line_off);
+    return rc;
+}
+static void bed_free(bed_junc *b, size_t n) { for (size_t i = 0; i < n; ++i) { free(b[i].chrom); free(b[i].name); free(b[i].score); free(b[i].strand); free(b[i].color); } free(b); }
+
+/* get_splice_site (junctions_annotator.cc:94-114); je = AnnotatedJunction.end.  0 ok, 1 = fai_fetch failed */
+static int splice_site(fasta *fa, const char *chrom, uint32_t js, uint32_t je, const char *strand, char *site, size_t cap, char *err, size_t errlen) {
+    char s1[8] = "", s2[8] = "";
+    int l1 = fa ? fasta_fetch(fa, chrom, (int64_t)js + 1, (int64_t)js + 2, s1, 4) : -1;
+    if (l1 < 0) { snprintf(err, errlen, "Unable to extract FASTA sequence for position %s:%u-%u\n\n", chrom, js + 1, js + 2); return 1; }
+    int l2 = fasta_fetch(fa, chrom, (int64_t)je - 2, (int64_t)je - 1, s2, 4);
+    if (l2 < 0) { snprintf(err, errlen, "Unable to extract FASTA sequence for position %s:%u-%u\n\n", chrom, je - 2, je - 1); return 1; }
+    s1[l1] = 0; s2[l2] = 0;
+    if (!strcmp(strand, "-")) { orc_rev_comp(s1, l1); orc_rev_comp(s2, l2); snprintf(site, cap, "%s-%s", s2, s1); }
+    else snprintf(site, cap, "%s-%s", s1, s2);
+    return 0;
+}
+
+/* AnnotatedJunction::print (junctions_annotator.h:84-126) up to the transcripts column; the caller ends the line */
+static void print_annotated_junction(FILE *fo, const gtf_model *gm, const char *chrom, uint32_t js, uint32_t je, const char *name, const char *score,
+                                     const char *strand, const char *site) {
+    jann a;
+    annotate_junction(gm, chrom, js, je, strand[0] && !strand[1] ? strand[0] : '?', &a);
+    fprintf(fo, "%s\t%u\t%u\t%s\t%s\t%s\t%s\t%zu\t%zu\t%zu\t%s\t%d\t%d\t%d", chrom, js, je, name, score, strand, site, a.n_acc, a.n_exo, a.n_don,
+            a.anchor, a.known_donor, a.known_acceptor, a.known_junction);
+    if (a.n_tx) {
+        /* set< vector<string> > genes_overlap: unique (name,id) pairs in lexicographic order; set<string> transcripts */
+        const gtf_tx **g = (const gtf_tx **)malloc(a.n_tx * sizeof(void *)); size_t ng = 0;
+        for (size_t q = 0; q < a.n_tx; ++q) {
+            int dup = 0;
+            for (size_t w = 0; w < ng; ++w) if (!strcmp(g[w]->gene_name, a.txs[q]->gene_name) && !strcmp(g[w]->gene_id, a.txs[q]->gene_id)) dup = 1;
+            if (!dup) g[ng++] = a.txs[q];
+        }
+        for (size_t x = 1; x < ng; ++x) { const gtf_tx *t = g[x]; size_t y = x; while (y > 0 && (strcmp(g[y - 1]->gene_name, t->gene_name) > 0 || (!strcmp(g[y - 1]->gene_name, t->gene_name) && strcmp(g[y - 1]->gene_id, t->gene_id) > 0))) { g[y] = g[y - 1]; --y; } g[y] = t; }
+        fputc('\t', fo);
+        for (size_t x = 0; x < ng; ++x) fprintf(fo, "%s%s", x ? "," : "", g[x]->gene_name);
+        fputc('\t', fo);
+        for (size_t x = 0; x < ng; ++x) fprintf(fo, "%s%s", x ? "," : "", g[x]->gene_id);
+        free(g);
+        const gtf_tx **tt = (const gtf_tx **)malloc(a.n_tx * sizeof(void *));
+        memcpy(tt, a.txs, a.n_tx * sizeof(void *));
+        for (size_t x = 1; x < a.n_tx; ++x) { const gtf_tx *t = tt[x]; size_t y = x; while (y > 0 && strcmp(tt[y - 1]->id, t->id) > 0) { tt[y] = tt[y - 1]; --y; } tt[y] = t; }
+        fputc('\t', fo);
+        for (size_t x = 0; x < a.n_tx; ++x) fprintf(fo, "%s%s", x ? "," : "", tt[x]->id);
+        free(tt);
+    } else fputs("\tNA\tNA\tNA", fo);
+    jann_free(&a);
 }
 
 void orc_cse_default_params(orc_cse_params *p) {
@@ -403,36 +540,15 @@ int orc_identify(const orc_cse_params *p, char *err, size_t errlen) {
     cse_junction *cj = NULL; size_t n_cj = 0, cap_cj = 0;
     ann_variant **all_vars = NULL; size_t n_all = 0;
     int rc = 0;
-    int header_done = 0, have_pass = 0;
+    bed_junc *bed = NULL; size_t n_bed = 0;
+    if (p->bed && bed_load(p->bed, &bed, &n_bed, err, errlen)) rc = 1;
+    int header_done = 0;
     for (size_t li = 0; li < vcf.n_lines && !rc; ++li) {
         const char *line = vcf.text + vcf.line_off[li];
         size_t ll = vcf.line_off[li + 1] - vcf.line_off[li]; if (ll && line[ll - 1] == '\n') --ll; else if (ll) --ll;
         if (ll && line[ll - 1] == '\r') --ll;
         if (ll == 0) continue;
-        if (line[0] == '#') {
-            if (fv) {
-                /* htslib's header normaliser (vcf.c:116 bcf_hdr_sync / :821 bcf_hdr_write): PASS filter right after ##fileformat,
-                 * the four appended INFO lines right before #CHROM */
-                if (ll >= 6 && !memcmp(line, "#CHROM", 6)) {
-                    fputs("##INFO=<ID=genes,Number=1,Type=String,Description=\"The Variant falls in the splice region of these genes\">\n", fv);
-                    fputs("##INFO=<ID=transcripts,Number=1,Type=String,Description=\"The Variant falls in the splice region of these transcripts\">\n", fv);
-                    fputs("##INFO=<ID=distances,Number=1,Type=String,Description=\"Vector of Min(Distance from start/end of exon in the transcript.)\">\n", fv);
-                    fputs("##INFO=<ID=annotations,Number=1,Type=String,Description=\"Does the variant fall in exonic/intronic splicing related space in the transcript.\">\n", fv);
-                }
-                if (strstr(line, "##FILTER=<ID=PASS") == line) have_pass = 1;
-                fwrite(line, 1, ll, fv); fputc('\n', fv);
-                if (!header_done && ll >= 12 && !memcmp(line, "##fileformat", 12)) {
-                    /* look ahead: does the header declare PASS itself? */
-                    int declared = 0;
-                    for (size_t k = li + 1; k < vcf.n_lines && vcf.text[vcf.line_off[k]] == '#'; ++k)
-                        if (!strncmp(vcf.text + vcf.line_off[k], "##FILTER=<ID=PASS", 17)) declared = 1;
-                    if (!declared) fputs("##FILTER=<ID=PASS,Description=\"All filters passed\">\n", fv);
-                    header_done = 1;
-                }
-            }
-            continue;
-        }
-        (void)have_pass;
+        if (line[0] == '#') { if (fv) vcf_header_line(fv, &vcf, li, line, ll, &header_done); continue; }
         const char *f[16]; size_t fl[16];
         int nf = tokenize(line, ll, '\t', f, fl, 16);
         if (nf < 2) continue;
@@ -445,17 +561,29 @@ int orc_identify(const orc_cse_params *p, char *err, size_t errlen) {
         free(chrom);
         all_vars = (ann_variant **)realloc(all_vars, (n_all + 1) * sizeof(void *)); all_vars[n_all++] = v;
         if (!v->relevant) continue;
-        if (fv) {
-            /* bcf_update_info_string x4 + vcf_format: the record text with the four tags appended to INFO (col 8) */
-            for (int k = 0; k < nf && k < 16; ++k) {
-                if (k) fputc('\t', fv);
-                if (k == 7) {
-                    if (!(fl[7] == 1 && f[7][0] == '.')) { fwrite(f[7], 1, fl[7], fv); fputc(';', fv); }
-                    fprintf(fv, "genes=%s;transcripts=%s;distances=%s;annotations=%s", v->genes.buf, v->transcripts.buf, v->distances.buf, v->annotations.buf);
-                } else fwrite(f[k], 1, fl[k], fv);
+        if (fv) vcf_record(fv, line, ll, f, fl, nf, v);
+        if (p->bed) {
+            /* associate (associator.cc:261-272): every BED junction of the variant's contig that starts or ends inside the cis window */
+            for (size_t i = 0; i < n_bed; ++i) {
+                const bed_junc *j = &bed[i];
+                const uint32_t jend = j->end - 1;                       /* Junction.end (parse_BED_to_junctions :221) */
+                if (strcmp(j->chrom, v->chrom)) continue;
+                if (!((j->start >= v->ces && j->start <= v->cee) || (jend <= v->cee && jend >= v->ces))) continue;
+                cse_junction key; key.chrom = j->chrom; key.start = j->start; key.end = jend;
+                size_t q = 0;
+                for (; q < n_cj; ++q) if (!cj_cmp(&cj[q], &key)) break;
+                if (q == n_cj) {
+                    if (n_cj == cap_cj) { cap_cj = cap_cj ? cap_cj * 2 : 64; cj = (cse_junction *)realloc(cj, cap_cj * sizeof *cj); }
+                    cse_junction *n = &cj[n_cj++];
+                    n->chrom = strdup(j->chrom); n->start = j->start; n->end = jend; n->ts = j->ts; n->te = j->te;
+                    n->count = (uint32_t)atoi(j->score); n->strand = j->strand[0] && !j->strand[1] ? j->strand[0] : '?';
+                    n->strand_s = j->strand; n->color = j->color; n->nblocks = j->nblocks; n->vars = NULL; n->n_vars = 0;
+                }
+                cse_junction *n = &cj[q];
+                int dup = 0; for (size_t w = 0; w < n->n_vars; ++w) if (!var_cmp(&n->vars[w], &v)) dup = 1;
+                if (!dup) { n->vars = (ann_variant **)realloc(n->vars, (n->n_vars + 1) * sizeof(void *)); n->vars[n->n_vars++] = v; }
             }
-            if (nf > 16) { const char *rest = f[15] + fl[15]; fwrite(rest, 1, (size_t)(line + ll - rest), fv); }
-            fputc('\n', fv);
+            continue;
         }
         /* region of the extraction (:270-274), uint32 arithmetic */
         char region[512];
@@ -478,6 +606,7 @@ int orc_identify(const orc_cse_params *p, char *err, size_t errlen) {
                 cse_junction *n = &cj[n_cj++];
                 n->chrom = strdup(key.chrom); n->start = j->start; n->end = j->end; n->ts = j->thick_start; n->te = j->thick_end;
                 n->count = j->read_count; n->strand = j->strand; n->vars = NULL; n->n_vars = 0;
+                n->strand_s = NULL; n->color = "255,0,0"; n->nblocks = 2;
             }
             cse_junction *n = &cj[q];
             int dup = 0; for (size_t w = 0; w < n->n_vars; ++w) if (!var_cmp(&n->vars[w], &v)) dup = 1;
@@ -502,42 +631,20 @@ int orc_identify(const orc_cse_params *p, char *err, size_t errlen) {
             int l2 = fa ? fasta_fetch(fa, j->chrom, (int64_t)je - 2, (int64_t)je - 1, s2, 4) : -1;
             if (l1 < 0 || l2 < 0) { snprintf(err, errlen, "Unable to extract FASTA sequence for position\n\n"); rc = 1; break; }
             s1[l1] = 0; s2[l2] = 0;
-            if (j->strand == '-') { orc_rev_comp(s1, l1); orc_rev_comp(s2, l2); snprintf(site, sizeof site, "%s-%s", s2, s1); }
+            char strand1[2] = { j->strand, 0 };
+            const char *strand = j->strand_s ? j->strand_s : strand1;
+            if (!strcmp(strand, "-")) { orc_rev_comp(s1, l1); orc_rev_comp(s2, l2); snprintf(site, sizeof site, "%s-%s", s2, s1); }
             else snprintf(site, sizeof site, "%s-%s", s1, s2);
-            jann a;
-            annotate_junction(&gm, j->chrom, js, je, j->strand, &a);
             char name[32]; snprintf(name, sizeof name, "JUNC%08zu", i + 1);
-            if (fj) fprintf(fj, "%s\t%u\t%u\t%s\t%u\t%c\t%u\t%u\t255,0,0\t2\t%u,%u\t0,%u\n", j->chrom, j->ts, j->te, name, j->count, j->strand, j->ts, j->te,
+            if (fj) fprintf(fj, "%s\t%u\t%u\t%s\t%u\t%s\t%u\t%u\t%s\t%d\t%u,%u\t0,%u\n", j->chrom, j->ts, j->te, name, j->count, strand, j->ts, j->te, j->color, j->nblocks,
                             (uint32_t)(j->start - j->ts), (uint32_t)(j->te - j->end), (uint32_t)(j->end - j->ts));
-            fprintf(fo, "%s\t%u\t%u\t%s\t%u\t%c\t%s\t%zu\t%zu\t%zu\t%s\t%d\t%d\t%d", j->chrom, js, je, name, j->count, j->strand, site, a.n_acc, a.n_exo, a.n_don,
-                    a.anchor, a.known_donor, a.known_acceptor, a.known_junction);
-            if (a.n_tx) {
-                /* set< vector<string> > genes_overlap: unique (name,id) pairs in lexicographic order; set<string> transcripts */
-                const gtf_tx **g = (const gtf_tx **)malloc(a.n_tx * sizeof(void *)); size_t ng = 0;
-                for (size_t q = 0; q < a.n_tx; ++q) {
-                    int dup = 0;
-                    for (size_t w = 0; w < ng; ++w) if (!strcmp(g[w]->gene_name, a.txs[q]->gene_name) && !strcmp(g[w]->gene_id, a.txs[q]->gene_id)) dup = 1;
-                    if (!dup) g[ng++] = a.txs[q];
-                }
-                for (size_t x = 1; x < ng; ++x) { const gtf_tx *t = g[x]; size_t y = x; while (y > 0 && (strcmp(g[y - 1]->gene_name, t->gene_name) > 0 || (!strcmp(g[y - 1]->gene_name, t->gene_name) && strcmp(g[y - 1]->gene_id, t->gene_id) > 0))) { g[y] = g[y - 1]; --y; } g[y] = t; }
-                fputc('\t', fo);
-                for (size_t x = 0; x < ng; ++x) fprintf(fo, "%s%s", x ? "," : "", g[x]->gene_name);
-                fputc('\t', fo);
-                for (size_t x = 0; x < ng; ++x) fprintf(fo, "%s%s", x ? "," : "", g[x]->gene_id);
-                free(g);
-                const gtf_tx **tt = (const gtf_tx **)malloc(a.n_tx * sizeof(void *));
-                memcpy(tt, a.txs, a.n_tx * sizeof(void *));
-                for (size_t x = 1; x < a.n_tx; ++x) { const gtf_tx *t = tt[x]; size_t y = x; while (y > 0 && strcmp(tt[y - 1]->id, t->id) > 0) { tt[y] = tt[y - 1]; --y; } tt[y] = t; }
-                fputc('\t', fo);
-                for (size_t x = 0; x < a.n_tx; ++x) fprintf(fo, "%s%s", x ? "," : "", tt[x]->id);
-                free(tt);
-            } else fputs("\tNA\tNA\tNA", fo);
+            char score[16]; snprintf(score, sizeof score, "%u", j->count);
+            print_annotated_junction(fo, &gm, j->chrom, js, je, name, score, strand, site);
             /* variant_set_to_string (variants_annotator.h:227-235): set order, "chrom:start-end" with int fields */
             qsort(j->vars, j->n_vars, sizeof(void *), var_cmp);
             fputc('\t', fo);
             for (size_t w = 0; w < j->n_vars; ++w) fprintf(fo, "%s%s:%d-%d", w ? "," : "", j->vars[w]->chrom, (int)j->vars[w]->start, (int)j->vars[w]->end);
             fputc('\n', fo);
-            jann_free(&a);
         }
         if (fo != stdout) fclose(fo);
         if (fj) fclose(fj);
@@ -545,9 +652,69 @@ int orc_identify(const orc_cse_params *p, char *err, size_t errlen) {
     }
     for (size_t i = 0; i < n_cj; ++i) { free(cj[i].chrom); free(cj[i].vars); }
     free(cj);
+    bed_free(bed, n_bed);
     for (size_t i = 0; i < n_all; ++i) { variant_free(all_vars[i]); free(all_vars[i]); }
     free(all_vars);
     free(vcf.text); free(vcf.line_off);
     gtf_free(&gm);
     return rc;
+}
+
+/* ==================================================================================================
+ * `junctions annotate` (junctions_main.cc:62-93)
+ * ================================================================================================ */
+int orc_junctions_annotate(const char *bed, const char *fasta_path, const char *gtf, const char *out, char *err, size_t errlen) {
+    gtf_model gm;
+    if (gtf_load(gtf, &gm, err, errlen)) return 1;
+    FILE *fo = out ? fopen(out, "w") : stdout;
+    if (!fo) { gtf_free(&gm); snprintf(err, errlen, "Unable to open %s", out); return 1; }
+    fputs("chrom\tstart\tend\tname\tscore\tstrand\tsplice_site\tacceptors_skipped\texons_skipped\tdonors_skipped\tanchor\tknown_donor\tknown_acceptor\tknown_junction\tgene_names\tgene_ids\ttranscripts\n", fo);
+    bed_junc *b = NULL; size_t nb = 0;
+    char berr[512] = "";
+    const int brc = bed_load(bed, &b, &nb, berr, sizeof berr);        /* rows before a bad line are still annotated and printed */
+    fasta *fa = fasta_load(fasta_path);
+    int rc = 0;
+    for (size_t i = 0; i < nb && !rc; ++i) {
+        char site[24];
+        if (splice_site(fa, b[i].chrom, b[i].start, b[i].end, b[i].strand, site, sizeof site, err, errlen)) { rc = 1; break; }
+        print_annotated_junction(fo, &gm, b[i].chrom, b[i].start, b[i].end, b[i].name, b[i].score, b[i].strand, site);
+        fputc('\n', fo);
+    }
+    if (!rc && brc) { snprintf(err, errlen, "%s", berr); rc = 1; }
+    if (fo != stdout) fclose(fo);
+    fasta_free(fa); bed_free(b, nb); gtf_free(&gm);
+    return rc;
+}
+
+/* ==================================================================================================
+ * `variants annotate` (variants_annotator.cc:541-550): every record, the four tags appended to INFO
+ * ================================================================================================ */
+int orc_variants_annotate(const orc_cse_params *p, char *err, size_t errlen) {
+    gtf_model gm;
+    if (gtf_load(p->gtf, &gm, err, errlen)) return 1;
+    textfile vcf;
+    if (text_load(p->vcf, &vcf)) { gtf_free(&gm); snprintf(err, errlen, "Unable to open file.\n\n"); return 1; }
+    va_opts vo = { p->intronic_min, p->exonic_min, p->all_intronic, p->all_exonic, p->skip_single };
+    FILE *fv = p->out_vcf ? fopen(p->out_vcf, "w") : stdout;
+    if (!fv) { gtf_free(&gm); free(vcf.text); free(vcf.line_off); snprintf(err, errlen, "Unable to open output VCF file.\n\n"); return 1; }
+    int header_done = 0;
+    for (size_t li = 0; li < vcf.n_lines; ++li) {
+        const char *line = vcf.text + vcf.line_off[li];
+        size_t ll = vcf.line_off[li + 1] - vcf.line_off[li]; if (ll) --ll;
+        if (ll && line[ll - 1] == '\r') --ll;
+        if (ll == 0) continue;
+        if (line[0] == '#') { vcf_header_line(fv, &vcf, li, line, ll, &header_done); continue; }
+        const char *f[16]; size_t fl[16];
+        int nf = tokenize(line, ll, '\t', f, fl, 16);
+        if (nf < 2) continue;
+        char *chrom = xstrndup(f[0], fl[0]), *ps = xstrndup(f[1], fl[1]);
+        ann_variant v;
+        annotate_variant(&gm, &vo, chrom, (uint32_t)(atoi(ps) - 1), &v);
+        vcf_record(fv, line, ll, f, fl, nf, &v);
+        variant_free(&v); free(chrom); free(ps);
+    }
+    if (fv != stdout) fclose(fv);
+    free(vcf.text); free(vcf.line_off);
+    gtf_free(&gm);
+    return 0;
 }
