@@ -153,6 +153,7 @@ typedef struct {
     uint32_t    min_intron;    /* -m  accepted and ignored, as upstream */
     uint32_t    max_intron;    /* -M */
     int32_t     override_motif;/* -C */
+    const char *bed_path;      /* rgx_associate only: junctions BED12 (second positional of `cis-splice-effects associate`) */
 } rgx_identify_params;
 
 typedef struct {
@@ -168,6 +169,20 @@ void rgx_identify_params_default(rgx_identify_params *p);   /* CisSpliceEffectsI
 /* Whole command: reads the four files, runs the interval kernels and the extraction on the device, writes -o/-v/-j.
  * Error texts and the exit-code mapping are the reference's (nonzero return == exit 1). */
 int  rgx_identify(rgx_ctx *ctx, const rgx_identify_params *p, rgx_identify_stats *stats, char *err, size_t errlen);
+
+/* SURVEY 8(f) rows f2/f3 -- the three sibling commands over the same kernels.
+ * `cis-splice-effects associate` (CisSpliceEffectsAssociator::associate, cis_splice_effects_associator.cc:234-276): the junctions come
+ * from p->bed_path (BED12, e.g. the output of `junctions extract`) instead of a BAM; bam_path/strandness/strand_tag are ignored. */
+int  rgx_associate(rgx_ctx *ctx, const rgx_identify_params *p, rgx_identify_stats *stats, char *err, size_t errlen);
+/* `variants annotate` (VariantsAnnotator::annotate_vcf, variants_annotator.cc:541-550): EVERY record of p->vcf_path written to
+ * p->out_vcf (NULL = stdout) with genes= transcripts= distances= annotations= appended to INFO ("NA" when not splice relevant).
+ * Uses vcf_path, gtf_path, out_vcf, intronic_min, exonic_min, all_intronic, all_exonic, skip_single. */
+int  rgx_variants_annotate(rgx_ctx *ctx, const rgx_identify_params *p, rgx_identify_stats *stats, char *err, size_t errlen);
+/* `junctions annotate` (junctions_main.cc:62-93): BED12 rows -> annotated TSV (out_path NULL = stdout); *n_rows = rows written.
+ * bedtools' reader semantics are kept: leading #/track/browser lines are skipped, a later one (or a blank line) ends the input,
+ * a malformed line ends the run with the reference's message after the rows before it were written. */
+int  rgx_junctions_annotate(rgx_ctx *ctx, const char *bed_path, const char *fasta_path, const char *gtf_path, const char *out_path,
+                            uint64_t *n_rows, char *err, size_t errlen);
 
 /* Stage entry points over a loaded annotation (flat exon/transcript/bin arrays in HBM). */
 typedef struct rgx_gtf rgx_gtf;

@@ -41,7 +41,8 @@ EXPORTS = ["rgx_extract_params_default", "rgx_ctx_create", "rgx_ctx_destroy", "r
            "rgx_extract_device", "rgx_table_free", "rgx_table_merge", "rgx_table_pack", "rgx_table_unpack",
            "rgx_table_format_bed12", "rgx_version", "rgx_k_inflate",
            "rgx_identify_params_default", "rgx_identify", "rgx_gtf_load", "rgx_gtf_free", "rgx_gtf_info", "rgx_gtf_transcript_bin",
-           "rgx_gtf_transcript_id", "rgx_variant_windows", "rgx_variant_hits_free", "rgx_annotate_junctions", "rgx_junction_annot_free"]
+           "rgx_gtf_transcript_id", "rgx_variant_windows", "rgx_variant_hits_free", "rgx_annotate_junctions", "rgx_junction_annot_free",
+           "rgx_associate", "rgx_variants_annotate", "rgx_junctions_annotate"]
 
 
 class IdentifyParams(C.Structure):
@@ -49,7 +50,7 @@ class IdentifyParams(C.Structure):
                 ("out_tsv", C.c_char_p), ("out_vcf", C.c_char_p), ("out_bed", C.c_char_p), ("window", C.c_uint32),
                 ("intronic_min", C.c_uint32), ("exonic_min", C.c_uint32), ("all_intronic", C.c_int32), ("all_exonic", C.c_int32),
                 ("skip_single", C.c_int32), ("strandness", C.c_int32), ("strand_tag", C.c_char * 2), ("min_anchor", C.c_uint32),
-                ("min_intron", C.c_uint32), ("max_intron", C.c_uint32), ("override_motif", C.c_int32)]
+                ("min_intron", C.c_uint32), ("max_intron", C.c_uint32), ("override_motif", C.c_int32), ("bed_path", C.c_char_p)]
 
 
 class IdentifyStats(C.Structure):
@@ -115,6 +116,9 @@ def lib():
         L.rgx_k_inflate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rgx_identify_params_default.argtypes = [P(IdentifyParams)]
         L.rgx_identify.argtypes = [C.c_void_p, P(IdentifyParams), P(IdentifyStats), C.c_char_p, C.c_size_t]
+        L.rgx_associate.argtypes = L.rgx_identify.argtypes
+        L.rgx_variants_annotate.argtypes = L.rgx_identify.argtypes
+        L.rgx_junctions_annotate.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, P(C.c_uint64), C.c_char_p, C.c_size_t]
         L.rgx_gtf_load.argtypes = [C.c_void_p, C.c_char_p, P(C.c_void_p), C.c_char_p, C.c_size_t]
         L.rgx_gtf_free.argtypes = [C.c_void_p]
         L.rgx_gtf_info.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]

@@ -59,14 +59,112 @@ class CisSpliceEffectsIdentifier(object):
 
     # cis_splice_effects_identifier.cc:256-312
     def identify(self):
+        return self._run(_ffi.lib().rgx_identify)
+
+    def _run(self, fn):
         if self._ctx is None:
             self._ctx = Context(self._device)
         st = _ffi.IdentifyStats()
         err = C.create_string_buffer(512)
-        rc = _ffi.lib().rgx_identify(self._ctx._h, C.byref(self.p), C.byref(st), err, len(err))
+        rc = fn(self._ctx._h, C.byref(self.p), C.byref(st), err, len(err))
         if rc != 0:
             raise RegtoolsError(rc, err.value.decode())
         self.stats = {n: getattr(st, n) for n, _ in st._fields_}
+        return 0
+
+
+class CisSpliceEffectsAssociator(CisSpliceEffectsIdentifier):
+    """Mirror of `CisSpliceEffectsAssociator` (src/cis-splice-effects/cis_splice_effects_associator.{h,cc}): junctions come from a BED12."""
+
+    # cis_splice_effects_associator.cc:104-180
+    def parse_options(self, argv):
+        try:
+            opts, args = getopt.getopt(list(argv), "o:w:v:j:e:Ei:ISha:m:M:")
+        except getopt.GetoptError:
+            raise RegtoolsError(1, "Error parsing inputs!(1)\n\n")
+        if len(args) != 4:
+            raise RegtoolsError(1, "Error parsing inputs!(2)\n\n")
+        CisSpliceEffectsIdentifier.parse_options(self, ["-s", "XS"] + list(argv))
+        self.p.bed_path = self.p.bam_path
+
+    # cis_splice_effects_associator.cc:234-276
+    def associate(self):
+        return self._run(_ffi.lib().rgx_associate)
+
+
+class VariantsAnnotator(object):
+    """Mirror of `VariantsAnnotator::annotate_vcf` (src/variants/variants_annotator.cc:48-110, 541-550)."""
+
+    def __init__(self, ctx=None, device=0):
+        self._ctx, self._device = ctx, device
+        self.p = _ffi.IdentifyParams()
+        _ffi.lib().rgx_identify_params_default(C.byref(self.p))
+        self.stats = {}
+        self._keep = []
+
+    def parse_options(self, argv):
+        try:
+            opts, args = getopt.getopt(list(argv), "e:Ei:ISho:")
+        except getopt.GetoptError:
+            raise RegtoolsError(1, "Error parsing inputs!(1)\n\n")
+        p = self.p
+        for k, v in opts:
+            if k == "-h": raise RegtoolsError(0, "help")
+            elif k == "-i": p.intronic_min = int(v) & 0xffffffff
+            elif k == "-e": p.exonic_min = int(v) & 0xffffffff
+            elif k == "-I": p.all_intronic = 1
+            elif k == "-E": p.all_exonic = 1
+            elif k == "-S": p.skip_single = 0
+            elif k == "-o":
+                self._keep.append(v.encode()); p.out_vcf = self._keep[-1]
+        if len(args) < 2:
+            raise RegtoolsError(1, "Error parsing inputs!(2)\n\n")
+        self._keep += [args[0].encode(), args[1].encode()]
+        p.vcf_path, p.gtf_path = self._keep[-2], self._keep[-1]
+
+    def annotate_vcf(self):
+        if self._ctx is None:
+            self._ctx = Context(self._device)
+        st = _ffi.IdentifyStats()
+        err = C.create_string_buffer(512)
+        rc = _ffi.lib().rgx_variants_annotate(self._ctx._h, C.byref(self.p), C.byref(st), err, len(err))
+        if rc != 0:
+            raise RegtoolsError(rc, err.value.decode())
+        self.stats = {n: getattr(st, n) for n, _ in st._fields_}
+        return 0
+
+
+class JunctionsAnnotator(object):
+    """Mirror of the `junctions annotate` driver (src/junctions/junctions_main.cc:62-93, junctions_annotator.cc:385-428)."""
+
+    def __init__(self, ctx=None, device=0):
+        self._ctx, self._device = ctx, device
+        self.bed = self.ref = self.gtf = self.output_file = None
+        self.n_rows = 0
+
+    def parse_options(self, argv):
+        try:
+            opts, args = getopt.getopt(list(argv), "So:h")
+        except getopt.GetoptError:
+            raise RegtoolsError(1, "Error parsing inputs!(1)\n\n")
+        for k, v in opts:
+            if k == "-h": raise RegtoolsError(0, "help")
+            elif k == "-o": self.output_file = v
+            elif k == "-S": raise RegtoolsError(1, "regtools_amd: -S is outside the accelerated path\n\n")
+        if len(args) != 3:
+            raise RegtoolsError(1, "Error parsing inputs!(2)\n\n")
+        self.bed, self.ref, self.gtf = args
+
+    def annotate(self):
+        if self._ctx is None:
+            self._ctx = Context(self._device)
+        err = C.create_string_buffer(512)
+        n = C.c_uint64(0)
+        rc = _ffi.lib().rgx_junctions_annotate(self._ctx._h, self.bed.encode(), self.ref.encode(), self.gtf.encode(),
+                                               self.output_file.encode() if self.output_file else None, C.byref(n), err, len(err))
+        self.n_rows = n.value
+        if rc != 0:
+            raise RegtoolsError(rc, err.value.decode())
         return 0
 
 

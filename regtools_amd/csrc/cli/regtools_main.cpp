@@ -117,10 +117,63 @@ int junctions_extract(int argc, char **argv) {
     return 0;
 }
 
+// ---- junctions annotate (junctions_annotator.cc:385-437, junctions_main.cc:62-93) ------------------------------------------------
+void annotate_usage(std::ostream &out) {
+    out << "Usage:\t\tregtools junctions annotate [options] junctions.bed ref.fa annotations.gtf\n"
+        << "Options:\t-S include single exon genes\n"
+        << "\t\t-o FILE\tThe file to write output to. [STDOUT]\n\n";
+}
+
+rgx_ctx *open_ctx() {
+    char err[512] = {0};
+    rgx_ctx *ctx = nullptr;
+    int dev = 0; if (const char *d = getenv("REGTOOLS_AMD_DEVICE")) dev = atoi(d);
+    if (rgx_ctx_create(dev, &ctx, err, sizeof err) != RGX_OK) throw std::runtime_error(err);
+    return ctx;
+}
+
+int junctions_annotate(int argc, char **argv) {
+    try {
+        std::string out = "NA";
+        bool skip_single = true;
+        optind = 1;
+        int c;
+        while ((c = getopt(argc, argv, "So:h")) != -1) {
+            switch (c) {
+                case 'S': skip_single = false; break;
+                case 'o': out = optarg; break;
+                case 'h': { std::ostringstream ss; annotate_usage(ss); throw HelpRequested{ss.str()}; }
+                default: annotate_usage(std::cout); throw std::runtime_error("Error parsing inputs!(1)\n\n");
+            }
+        }
+        std::string bed, ref = "NA", gtf;
+        if (argc - optind >= 3) { bed = argv[optind++]; ref = argv[optind++]; gtf = argv[optind++]; }
+        if (optind < argc || ref == "NA" || bed.empty() || gtf.empty()) { annotate_usage(std::cout); throw std::runtime_error("Error parsing inputs!(2)\n\n"); }
+        if (!skip_single) throw std::runtime_error("regtools_amd: -S is outside the accelerated path (upstream reads past the exon list of single exon transcripts there)\n\n");
+        std::cerr << "Reference: " << ref << "\nGTF: " << gtf << "\nJunctions: " << bed << "\nSkipping single exon genes.\n";
+        if (out != "NA") std::cerr << "Output file: " << out << "\n";
+        std::cerr << "\n";
+        rgx_ctx *ctx = open_ctx();
+        char err[512] = {0};
+        uint64_t n = 0;
+        int rc = rgx_junctions_annotate(ctx, bed.c_str(), ref.c_str(), gtf.c_str(), out == "NA" ? nullptr : out.c_str(), &n, err, sizeof err);
+        rgx_ctx_destroy(ctx);
+        if (rc != RGX_OK) throw std::runtime_error(err);
+        std::cerr << "\nAnnotated " << n << " lines.\n";
+    } catch (const HelpRequested &h) {
+        std::cerr << h.text;
+        return 0;
+    } catch (const std::runtime_error &e) {
+        std::cerr << e.what();
+        return 1;
+    }
+    return 0;
+}
+
 int junctions_usage(std::ostream &out) {
     out << "\nUsage:\t\tregtools junctions <command> [options]\n"
         << "Command:\textract\t\tIdentify exon-exon junctions from alignments.\n"
-        << "\t\tannotate\tAnnotate the junctions. (not part of the accelerated path)\n\n";
+        << "\t\tannotate\tAnnotate the junctions.\n\n";
     return 0;
 }
 
@@ -129,7 +182,7 @@ int junctions_main(int argc, char **argv) {
     if (argc > 1) {
         std::string sub = argv[1];
         if (sub == "extract") return junctions_extract(argc - 1, argv + 1);
-        if (sub == "annotate") { std::cerr << "regtools_amd: `junctions annotate` is outside the accelerated path\n"; return 1; }
+        if (sub == "annotate") return junctions_annotate(argc - 1, argv + 1);
     }
     return junctions_usage(std::cerr);
 }
@@ -153,14 +206,15 @@ void identify_usage(std::ostream &out) {
 
 bool file_exists(const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (!f) return false; fclose(f); return true; }
 
-int cse_identify(int argc, char **argv) {
+// associate = true: `cis-splice-effects associate` (cis_splice_effects_associator.cc:104-180): no -s/-t/-b/-C, the second positional is a BED12
+int cse_identify(int argc, char **argv, bool associate = false) {
     try {
         rgx_identify_params p;
         rgx_identify_params_default(&p);
         std::string out_tsv = "NA", out_vcf = "NA", out_bed = "NA", tag = "XS", barcodes = "NA";
         optind = 1;
         int c;
-        while ((c = getopt(argc, argv, "o:w:v:j:e:Ei:ISht:s:a:m:M:b:C")) != -1) {
+        while ((c = getopt(argc, argv, associate ? "o:w:v:j:e:Ei:ISha:m:M:" : "o:w:v:j:e:Ei:ISht:s:a:m:M:b:C")) != -1) {
             switch (c) {
                 case 'o': out_tsv = optarg; break;
                 case 'w': p.window = (uint32_t)atoi(optarg); break;
@@ -191,10 +245,12 @@ int cse_identify(int argc, char **argv) {
         std::string vcf = "NA", bam = "NA", ref = "NA", gtf = "NA";
         if (argc - optind >= 4) { vcf = argv[optind++]; bam = argv[optind++]; ref = argv[optind++]; gtf = argv[optind++]; }
         if (optind < argc || vcf == "NA" || bam == "NA" || ref == "NA" || gtf == "NA") { identify_usage(std::cerr); throw std::runtime_error("Error parsing inputs!(2)\n\n"); }
+        if (associate) p.strandness = 0;
         if (p.strandness == -1) { identify_usage(std::cerr); throw std::runtime_error("Please supply strand specificity with '-s' option!\n\n"); }
         if (!file_exists(vcf) || !file_exists(bam) || !file_exists(ref) || !file_exists(gtf)) throw std::runtime_error("Please make sure input files exist.\n\n");
         if (barcodes != "NA") throw std::runtime_error("regtools_amd: -b (single-cell barcodes) is outside the accelerated path\n\n");
-        std::cerr << "Variant file: " << vcf << "\nAlignment file: " << bam << "\nReference fasta file: " << ref << "\nAnnotation file: " << gtf << "\n\n";
+        std::cerr << "Variant file: " << vcf << (associate ? "\nJunctions BED file: " : "\nAlignment file: ") << bam << "\nReference fasta file: " << ref << "\nAnnotation file: " << gtf << "\n\n";
+        if (associate) p.bed_path = bam.c_str();
         p.vcf_path = vcf.c_str(); p.bam_path = bam.c_str(); p.fasta_path = ref.c_str(); p.gtf_path = gtf.c_str();
         p.out_tsv = out_tsv == "NA" ? nullptr : out_tsv.c_str(); p.out_vcf = out_vcf == "NA" ? nullptr : out_vcf.c_str(); p.out_bed = out_bed == "NA" ? nullptr : out_bed.c_str();
         p.strand_tag[0] = tag.size() > 0 ? tag[0] : 0; p.strand_tag[1] = tag.size() > 1 ? tag[1] : 0;
@@ -203,7 +259,7 @@ int cse_identify(int argc, char **argv) {
         int dev = 0; if (const char *d = getenv("REGTOOLS_AMD_DEVICE")) dev = atoi(d);
         if (rgx_ctx_create(dev, &ctx, err, sizeof err) != RGX_OK) throw std::runtime_error(err);
         rgx_identify_stats st;
-        int rc = rgx_identify(ctx, &p, &st, err, sizeof err);
+        int rc = associate ? rgx_associate(ctx, &p, &st, err, sizeof err) : rgx_identify(ctx, &p, &st, err, sizeof err);
         rgx_ctx_destroy(ctx);
         if (rc != RGX_OK) throw std::runtime_error(err);
         if (getenv("REGTOOLS_AMD_STATS"))
@@ -220,13 +276,68 @@ int cse_identify(int argc, char **argv) {
     return 0;
 }
 
+// ---- variants annotate (variants_annotator.cc:48-110, variants_main.cc) -------------------------------------------------------------
+void variants_usage(std::ostream &out) {
+    out << "Usage:\t\tregtools variants annotate [options] variants.vcf annotations.gtf\n"
+        << "Options:\t-e INT\tMaximum distance from the start/end of an exon to annotate a variant as relevant to splicing, the variant is in exonic space. [3]\n"
+        << "\t\t-i INT\tMaximum distance from the start/end of an exon to annotate a variant as relevant to splicing, the variant is in intronic space. [2]\n"
+        << "\t\t-I\tAnnotate variants in intronic space within a transcript(not to be used with -i).\n"
+        << "\t\t-E\tAnnotate variants in exonic space within a transcript(not to be used with -e).\n"
+        << "\t\t-S\tDon't skip single exon transcripts.\n"
+        << "\t\t-o\tFile to write output to. [STDOUT]\n\n";
+}
+
+int variants_annotate(int argc, char **argv) {
+    try {
+        rgx_identify_params p;
+        rgx_identify_params_default(&p);
+        std::string out = "NA";
+        optind = 1;
+        int c;
+        while ((c = getopt(argc, argv, "e:Ei:ISho:")) != -1) {
+            switch (c) {
+                case 'i': p.intronic_min = (uint32_t)atoi(optarg); break;
+                case 'e': p.exonic_min = (uint32_t)atoi(optarg); break;
+                case 'I': p.all_intronic = 1; break;
+                case 'E': p.all_exonic = 1; break;
+                case 'S': p.skip_single = 0; break;
+                case 'o': out = optarg; break;
+                case 'h': { std::ostringstream ss; variants_usage(ss); throw HelpRequested{ss.str()}; }
+                default: variants_usage(std::cerr); throw std::runtime_error("Error parsing inputs!(1)\n\n");
+            }
+        }
+        if (argc - optind < 2) { variants_usage(std::cerr); throw std::runtime_error("Error parsing inputs!(2)\n\n"); }
+        const std::string vcf = argv[optind], gtf = argv[optind + 1];
+        p.vcf_path = vcf.c_str(); p.gtf_path = gtf.c_str(); p.out_vcf = out == "NA" ? nullptr : out.c_str();
+        std::cerr << "Variant file: " << vcf << "\nGTF file: " << gtf << "\n\n";
+        rgx_ctx *ctx = open_ctx();
+        char err[512] = {0};
+        int rc = rgx_variants_annotate(ctx, &p, nullptr, err, sizeof err);
+        rgx_ctx_destroy(ctx);
+        if (rc != RGX_OK) throw std::runtime_error(err);
+    } catch (const HelpRequested &h) {
+        std::cerr << h.text;
+        return 0;
+    } catch (const std::runtime_error &e) {
+        std::cerr << e.what();
+        return 1;
+    }
+    return 0;
+}
+
+int variants_main(int argc, char **argv) {
+    if (argc > 1 && std::string(argv[1]) == "annotate") return variants_annotate(argc - 1, argv + 1);
+    std::cerr << "\nUsage:\t\tregtools variants <command> [options]\nCommand:\tannotate\tAnnotate variants with splicing information.\n\n";
+    return 0;
+}
+
 int cse_main(int argc, char **argv) {
     if (argc > 1) {
         std::string sub = argv[1];
         if (sub == "identify") return cse_identify(argc - 1, argv + 1);
-        if (sub == "associate") { std::cerr << "regtools_amd: `cis-splice-effects associate` is outside the accelerated path\n"; return 1; }
+        if (sub == "associate") return cse_identify(argc - 1, argv + 1, true);
     }
-    std::cerr << "\nUsage:\t\tregtools cis-splice-effects <command> [options]\nCommand:\tidentify\t\tIdentify cis splicing effects.\n\n";
+    std::cerr << "\nUsage:\t\tregtools cis-splice-effects <command> [options]\nCommand:\tidentify\t\tIdentify cis splicing effects.\n\t\tassociate\tAssociate splice junctions (BED12) with cis splicing effects.\n\n";
     return 0;
 }
 
@@ -239,9 +350,11 @@ int main(int argc, char **argv) {
         std::string sub = argv[1];
         if (sub == "junctions") return junctions_main(argc - 1, argv + 1);
         if (sub == "cis-splice-effects") return cse_main(argc - 1, argv + 1);
+        if (sub == "variants") return variants_main(argc - 1, argv + 1);
     }
     std::cerr << "Usage:\t\tregtools <command> [options]\n"
               << "Command:\tjunctions\t\tTools that operate on feature junctions (e.g. exon-exon junctions from RNA-seq).\n"
-              << "\t\tcis-splice-effects\tTools related to splicing effects of variants.\n\n";
+              << "\t\tcis-splice-effects\tTools related to splicing effects of variants.\n"
+              << "\t\tvariants\t\tTools that operate on variants.\n\n";
     return 0;
 }

@@ -228,6 +228,50 @@ bool Fasta::fetch(const std::string &name, int64_t beg1, int64_t end1, std::stri
     return true;
 }
 
+static bool bed_header(const char *s, size_t n) {
+    return (n >= 1 && s[0] == '#') || (n >= 7 && !memcmp(s, "browser", 7)) || (n >= 5 && !memcmp(s, "track", 5));
+}
+
+std::string BedJunctions::load(const std::string &path) {
+    std::string text;
+    if (!slurp(path, text)) return "Error: The requested file (" + path + ") could not be opened. Exiting!\n";
+    std::vector<std::pair<size_t, size_t>> lines;                       // (offset, length without the newline)
+    for (size_t p = 0; p < text.size();) {
+        size_t e = text.find('\n', p); if (e == std::string::npos) e = text.size();
+        lines.push_back({p, e - p});
+        p = e + 1;
+    }
+    size_t li = 0;
+    while (li < lines.size() && bed_header(text.data() + lines[li].first, lines[li].second)) ++li;    // GetHeader
+    size_t bed_type = 0;
+    for (bool first = true; li < lines.size(); ++li, first = false) {
+        const char *l = text.data() + lines[li].first; size_t ll = lines[li].second;
+        if (ll && l[ll - 1] == '\r') --ll;
+        std::vector<std::pair<const char *, size_t>> f;                 // std::getline-style split: no empty field after a trailing tab
+        for (size_t i = 0; i < ll;) { size_t j = i; while (j < ll && l[j] != '\t') ++j; f.push_back({l + i, j - i}); i = j + 1; }
+        if (first) bed_type = f.size();
+        if (f.empty() || bed_header(f[0].first, f[0].second)) break;    // BED_BLANK / BED_HEADER: get_single_junction() stops
+        const std::string line_no = std::to_string(li + 1);
+        if (f.size() < 3) return "It looks as though you have less than 3 columns at line: " + line_no + ".  Are you sure your files are tab-delimited?\n";
+        auto digits = [](const std::pair<const char *, size_t> &x) { for (size_t i = 0; i < x.second; ++i) if (x.first[i] < '0' || x.first[i] > '9') return false; return true; };
+        if (!digits(f[1]) || !digits(f[2])) return "Unexpected file format.  Please use tab-delimited BED, GFF, or VCF.\n";
+        if (f.size() != bed_type) return "Differing number of BED fields encountered at line: " + line_no + ".  Exiting...\n";
+        auto str = [&](size_t k) { return std::string(f[k].first, f[k].second); };
+        uint32_t s0 = (uint32_t)atoi(str(1).c_str()), e0 = (uint32_t)atoi(str(2).c_str());
+        if (s0 == e0) { --s0; ++e0; }                                   // zero-length feature (bedFile.h:708-712)
+        if (s0 > e0) return "Error: malformed BED entry at line " + line_no + ". Start was greater than end. Exiting.\n";
+        if (f.size() != 12 || f[10].second == 0) return "BED line not in BED12 format. start: " + str(0) + ":" + std::to_string(s0) + "\n";
+        const std::string bs = str(10);
+        const size_t comma = bs.find(',');
+        const int b0 = atoi(bs.c_str()), b1 = comma == std::string::npos ? 0 : atoi(bs.c_str() + comma + 1);
+        chrom.push_back(str(0)); name.push_back(str(3)); score.push_back(str(4)); strand.push_back(str(5)); color.push_back(str(8));
+        nblocks.push_back(atoi(str(9).c_str()));
+        ts.push_back(s0); te.push_back(e0);
+        start.push_back(s0 + (uint32_t)b0); end.push_back(e0 - (uint32_t)(b1 - 1));
+    }
+    return "";
+}
+
 std::string rev_comp(const std::string &s) {
     std::string r(s.rbegin(), s.rend());
     for (char &c : r) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';

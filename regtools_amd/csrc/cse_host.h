@@ -54,4 +54,16 @@ struct Fasta {
 
 std::string rev_comp(const std::string &s);   // utils/common.h:59-83
 
+// BED12 junction rows the way bedtools' BedFile::GetNextBed hands them out (bedFile.cpp:103-260, bedFile.h:565-780) after
+// JunctionsAnnotator::adjust_junction_ends (junctions_annotator.cc:66-81): start/end are the intron, ts/te the BED start/end.
+struct BedJunctions {
+    std::vector<std::string> chrom, name, score, strand, color;
+    std::vector<uint32_t> start, end, ts, te;
+    std::vector<int32_t> nblocks;
+    size_t n() const { return chrom.size(); }
+    // "" on success.  On a malformed line the rows before it are kept and the message is what the reference dies with
+    // (exit status 1 either way).
+    std::string load(const std::string &path);
+};
+
 }  // namespace rgx

@@ -100,6 +100,32 @@ __global__ __launch_bounds__(64) void k_window_pairs(EventSoA ev, uint32_t n_eve
     if (!FILL && lane == 0) count[w] = total;
 }
 
+// `cis-splice-effects associate` (cis_splice_effects_associator.cc:261-272): window w keeps every junction of its contig whose start
+// or end lies inside [ces, cee].  Junctions are bucketed by contig (file order kept inside a bucket), pairs come out window-major
+// and in file order inside a window -- the insertion order of the reference's set<Junction>.
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_assoc_pairs(uint32_t n_win, const int32_t *__restrict__ w_chrom, const uint32_t *__restrict__ w_ces,
+                                                    const uint32_t *__restrict__ w_cee, const uint32_t *__restrict__ chrom_off,
+                                                    const uint32_t *__restrict__ j_start, const uint32_t *__restrict__ j_end, uint32_t *count,
+                                                    const uint32_t *__restrict__ base, uint32_t *pair_j, uint32_t *pair_win) {
+    const uint32_t w = blockIdx.x, lane = threadIdx.x;
+    if (w >= n_win) return;
+    const int32_t ch = w_chrom[w];
+    uint32_t total = 0, out = FILL ? base[w] : 0u;
+    if (ch >= 0) {
+        const uint32_t ces = w_ces[w], cee = w_cee[w], lo = chrom_off[ch], hi = chrom_off[ch + 1];
+        for (uint32_t j0 = lo; j0 < hi; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            bool keep = false;
+            if (j < hi) { const uint32_t s = j_start[j], e = j_end[j]; keep = (s >= ces && s <= cee) || (e <= cee && e >= ces); }
+            const uint64_t m = __ballot(keep);
+            if (FILL && keep) { const uint32_t k = out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); pair_j[k] = j; pair_win[k] = w; }
+            out += (uint32_t)__popcll(m); total += (uint32_t)__popcll(m);
+        }
+    }
+    if (!FILL && lane == 0) count[w] = total;
+}
+
 // the events of the pairs, re-keyed by window (group word = window index)
 __global__ void k_pair_gather(EventSoA ev, const uint32_t *__restrict__ pair_ev, const uint32_t *__restrict__ pair_win, uint32_t n, EventSoA out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -130,6 +156,12 @@ void launch_window_pairs(bool fill, EventSoA ev, uint32_t n_events, uint32_t n_w
     if (!n_win) return;
     if (fill) hipLaunchKernelGGL(k_window_pairs<true>, dim3(n_win), dim3(64), 0, stream, ev, n_events, n_win, w_tid, w_beg, w_end, max_span, count, base, pair_ev, pair_win);
     else hipLaunchKernelGGL(k_window_pairs<false>, dim3(n_win), dim3(64), 0, stream, ev, n_events, n_win, w_tid, w_beg, w_end, max_span, count, base, pair_ev, pair_win);
+}
+void launch_assoc_pairs(bool fill, uint32_t n_win, const int32_t *w_chrom, const uint32_t *w_ces, const uint32_t *w_cee, const uint32_t *chrom_off,
+                        const uint32_t *j_start, const uint32_t *j_end, uint32_t *count, const uint32_t *base, uint32_t *pair_j, uint32_t *pair_win, hipStream_t stream) {
+    if (!n_win) return;
+    if (fill) hipLaunchKernelGGL(k_assoc_pairs<true>, dim3(n_win), dim3(64), 0, stream, n_win, w_chrom, w_ces, w_cee, chrom_off, j_start, j_end, count, base, pair_j, pair_win);
+    else hipLaunchKernelGGL(k_assoc_pairs<false>, dim3(n_win), dim3(64), 0, stream, n_win, w_chrom, w_ces, w_cee, chrom_off, j_start, j_end, count, base, pair_j, pair_win);
 }
 void launch_pair_gather(EventSoA ev, const uint32_t *pair_ev, const uint32_t *pair_win, uint32_t n, EventSoA out, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(k_pair_gather, dim3((n + 255) / 256), dim3(256), 0, stream, ev, pair_ev, pair_win, n, out);

@@ -144,6 +144,9 @@ void launch_junction_scan(bool fill, GtfView g, uint32_t n, const int32_t *chrom
 void launch_max_span(EventSoA ev, uint32_t n, uint32_t *out /* zeroed by the caller */, hipStream_t stream);
 void launch_window_pairs(bool fill, EventSoA ev, uint32_t n_events, uint32_t n_win, const int32_t *w_tid, const int32_t *w_beg, const int32_t *w_end,
                          const uint32_t *max_span, uint32_t *count, const uint32_t *base, uint32_t *pair_ev, uint32_t *pair_win, hipStream_t stream);
+// associate: (window, junction) pairs; junction arrays are bucketed by contig, chrom_off has n_chrom + 1 entries
+void launch_assoc_pairs(bool fill, uint32_t n_win, const int32_t *w_chrom, const uint32_t *w_ces, const uint32_t *w_cee, const uint32_t *chrom_off,
+                        const uint32_t *j_start, const uint32_t *j_end, uint32_t *count, const uint32_t *base, uint32_t *pair_j, uint32_t *pair_win, hipStream_t stream);
 void launch_pair_gather(EventSoA ev, const uint32_t *pair_ev, const uint32_t *pair_win, uint32_t n, EventSoA out, hipStream_t stream);
 
 }  // namespace rgx
