@@ -113,6 +113,12 @@ int  rgx_table_merge(const rgx_junction_table *const *parts, int n_parts, uint32
 size_t rgx_table_pack(const rgx_junction_table *t, void *dst, size_t dst_cap); /* returns bytes needed */
 int    rgx_table_unpack(const void *src, size_t n_rows, const rgx_junction_table *names_from,
                         rgx_junction_table **out);
+/* The same merge with the gathered rows STILL IN HBM (what an RCCL all-gather leaves there): shard g's packed rows start at
+ * d_rows + g * stride_rows * 48 bytes and there are part_rows[g] of them.  Sort, reduce, naming and output order run on the
+ * device; one copy of the final rows comes back.  first_seen/last_seen of the result are the merge's own order words. */
+int    rgx_table_merge_device(rgx_ctx *ctx, const void *d_rows, uint64_t stride_rows, const uint64_t *part_rows, int n_parts,
+                              uint32_t min_anchor, const rgx_junction_table *names_from, rgx_junction_table **out,
+                              char *err, size_t errlen);
 
 /* Replaces Junction::print / print_all_junctions (junctions_extractor.h:90-98, cc:249-280): BED12 text.
  * only_anchored != 0 keeps rows with both anchors (the `junctions extract` output).  Returns the number

@@ -68,6 +68,7 @@ struct rgx_ctx {
     hipEvent_t ev[8] = {};
     std::map<std::string, DevBuf> bufs;
     void *pinned = nullptr; size_t pinned_cap = 0;     // small pinned staging for scalar readbacks
+    void *pinned_rows = nullptr; size_t pinned_rows_cap = 0;   // grow-only pinned staging for whole result tables (device merge)
     std::string fasta_path;                            // FASTA currently resident in the "fasta" buffer
     rgx::Fasta *fasta = nullptr;
     DevBuf &buf(const char *name) { return bufs[name]; }
@@ -109,6 +110,7 @@ extern "C" void rgx_ctx_destroy(rgx_ctx *c) {
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     delete c->fasta;
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->pinned_rows) (void)hipHostFree(c->pinned_rows);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -730,7 +732,7 @@ extern "C" size_t rgx_table_pack(const rgx_junction_table *t, void *dst, size_t 
     for (uint64_t i = 0; i < t->n; ++i, q += RGX_PACKED_ROW_BYTES) {
         uint32_t w[12] = {(uint32_t)t->tid[i], t->start[i], t->end[i], t->thick_start[i], t->thick_end[i], t->read_count[i],
                           (uint32_t)t->first_seen[i], (uint32_t)(t->first_seen[i] >> 32), (uint32_t)t->last_seen[i], (uint32_t)(t->last_seen[i] >> 32),
-                          (uint32_t)(uint8_t)t->strand[i], 0};
+                          (uint32_t)(uint8_t)t->strand[i], (uint32_t)t->name_index[i]};
         memcpy(q, w, sizeof w);
     }
     return need;
@@ -745,6 +747,7 @@ extern "C" int rgx_table_unpack(const void *src, size_t n_rows, const rgx_juncti
         uint32_t w[12]; memcpy(w, q, sizeof w);
         t->tid[i] = (int32_t)w[0]; t->start[i] = w[1]; t->end[i] = w[2]; t->thick_start[i] = w[3]; t->thick_end[i] = w[4]; t->read_count[i] = w[5];
         t->first_seen[i] = (uint64_t)w[6] | (uint64_t)w[7] << 32; t->last_seen[i] = (uint64_t)w[8] | (uint64_t)w[9] << 32; t->strand[i] = (char)w[10];
+        t->name_index[i] = w[11];
     }
     *out = t;
     return RGX_OK;
@@ -793,6 +796,105 @@ extern "C" int rgx_table_merge(const rgx_junction_table *const *parts, int n_par
     for (int g = 0; g < n_parts; ++g) {
         t->n_records += parts[g]->n_records; t->n_events += parts[g]->n_events; t->inflated_bytes += parts[g]->inflated_bytes;
         t->compressed_bytes = parts[g]->compressed_bytes; t->n_members += parts[g]->n_members;
+    }
+    *out = t;
+    return RGX_OK;
+}
+
+// ---- multi-shard merge on the device (the gathered packed rows never leave HBM until the merged table is final) ----------------------
+extern "C" int rgx_table_merge_device(rgx_ctx *c, const void *d_rows, uint64_t stride_rows, const uint64_t *part_rows, int n_parts, uint32_t min_anchor,
+                                      const rgx_junction_table *names_from, rgx_junction_table **out, char *err, size_t errlen) {
+    if (!c || !d_rows || !part_rows || n_parts <= 0 || n_parts > 255 || !names_from || !out) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    std::vector<uint32_t> h_rows((size_t)n_parts), h_base((size_t)n_parts);
+    uint64_t total = 0;
+    for (int g = 0; g < n_parts; ++g) {
+        if (part_rows[g] > stride_rows || part_rows[g] >= (1u << 24)) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: shard table too large for the device merge\n");
+        h_rows[(size_t)g] = (uint32_t)part_rows[g]; h_base[(size_t)g] = (uint32_t)total; total += part_rows[g];
+    }
+    if (total >= (1ull << 31) || stride_rows * (uint64_t)n_parts >= (1ull << 32)) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: too many rows for the device merge\n");
+    BamHeader h;
+    for (int32_t i = 0; i < names_from->n_ref; ++i) { h.names.push_back(names_from->ref_name[i]); h.lens.push_back(names_from->ref_len[i]); }
+    const uint32_t N = (uint32_t)total;
+    if (!N) { *out = table_alloc(h, 0); return RGX_OK; }
+    std::vector<uint32_t> rank_of_tid;
+    chrom_string_ranks(h, rank_of_tid);
+    uint32_t rk = 0; for (uint32_t r : rank_of_tid) rk = std::max(rk, r);
+
+    DevBuf &b = c->buf("merge"), &sc = c->buf("scalars");
+    HIP_TRY(sc.ensure(512));
+    const size_t Nn = N, P = (size_t)n_parts, R = rank_of_tid.size();
+    const size_t tmp_words = radix_tmp_words(N) + scan_tmp_words(N) + 64;
+    HIP_TRY(b.ensure((Nn * (10 + 2 + 2 + 9 + 4 + 12) + 2 * P + R + tmp_words) * 4 + 1024));
+    uint32_t *w = b.as<uint32_t>();
+    MergeSoA m; m.tid = w; w += Nn; m.start = w; w += Nn; m.end = w; w += Nn; m.ts = w; w += Nn; m.te = w; w += Nn; m.count = w; w += Nn;
+    m.cls = w; w += Nn; m.first = w; w += Nn; m.shard = w; w += Nn; m.strand = w; w += Nn;
+    uint32_t *perm[2] = {w, w + Nn}; w += 2 * Nn;
+    uint32_t *head = w; w += Nn; uint32_t *seg = w; w += Nn;
+    MergeUnique u; u.tid = w; w += Nn; u.start = w; w += Nn; u.end = w; w += Nn; u.ts = w; w += Nn; u.te = w; w += Nn; u.count = w; w += Nn;
+    u.first = w; w += Nn; u.last_shard = w; w += Nn; u.strand = w; w += Nn;
+    uint32_t *name_rank = w; w += Nn; uint32_t *crank = w; w += Nn; uint32_t *uperm[2] = {w, w + Nn}; w += 2 * Nn;
+    uint32_t *packed = w; w += Nn * 12;
+    uint32_t *d_rows_n = w; w += P; uint32_t *d_base = w; w += P; uint32_t *d_rank = w; w += R;
+    uint32_t *tmp = w;
+    uint32_t *d_total = sc.as<uint32_t>() + 70;
+    HIP_TRY(hipMemcpyAsync(d_rows_n, h_rows.data(), P * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_base, h_base.data(), P * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_rank, rank_of_tid.data(), R * 4, hipMemcpyHostToDevice, st));
+    launch_merge_unpack((const uint32_t *)d_rows, (uint32_t)stride_rows, (uint32_t)n_parts, d_rows_n, d_base, m, st);
+    // stable LSD radix sort by (tid, start, end, class); rows of one key end up in shard order
+    int pc = -1;
+    auto sort_word = [&](const uint32_t *word, uint32_t nbits, uint32_t n, uint32_t **pp, int &cur) {
+        for (uint32_t sh = 0; sh < nbits; sh += 8) {
+            const uint32_t bits = std::min<uint32_t>(8, nbits - sh);
+            const int nxt = cur < 0 ? 0 : cur ^ 1;
+            launch_radix_pass(word, sh, bits, cur < 0 ? nullptr : pp[cur], pp[nxt], n, tmp, st);
+            cur = nxt;
+        }
+    };
+    sort_word(m.cls, 2, N, perm, pc);
+    sort_word(m.end, 32, N, perm, pc);
+    sort_word(m.start, 32, N, perm, pc);
+    sort_word(m.tid, std::max<uint32_t>(1, bitlen((uint32_t)std::max<int32_t>(1, names_from->n_ref))), N, perm, pc);
+    const uint32_t *sorted = perm[pc];
+    launch_merge_heads(m, sorted, N, head, st);
+    launch_scan_u32(head, seg, N, d_total, tmp, st);
+    uint32_t U = 0;
+    HIP_TRY(hipMemcpyAsync(&U, d_total, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    launch_fill_u32(u.ts, 0xffffffffu, U, st); launch_fill_u32(u.first, 0xffffffffu, U, st);
+    launch_fill_u32(u.te, 0u, U, st); launch_fill_u32(u.count, 0u, U, st); launch_fill_u32(u.last_shard, 0u, U, st);
+    launch_merge_reduce(m, sorted, head, seg, N, u, st);
+    // first-seen naming: rank by (first shard that has the key, the row's rank inside that shard)
+    int upc = -1;
+    sort_word(u.first, 32, U, uperm, upc);
+    launch_merge_rank(uperm[upc], U, name_rank, st);
+    // output order (junctions_extractor.h:117-140): chrom string rank, thick_start, thick_end, name
+    launch_gather_u32(U, d_rank, u.tid, crank, st);
+    upc = -1;
+    sort_word(name_rank, std::max<uint32_t>(1, bitlen(U)), U, uperm, upc);
+    sort_word(u.te, 32, U, uperm, upc);
+    sort_word(u.ts, 32, U, uperm, upc);
+    sort_word(crank, std::max<uint32_t>(1, bitlen(rk)), U, uperm, upc);
+    launch_merge_pack(u, uperm[upc], name_rank, U, packed, st);
+    if ((size_t)U * 48 > c->pinned_rows_cap) {
+        if (c->pinned_rows) (void)hipHostFree(c->pinned_rows);
+        c->pinned_rows = nullptr; c->pinned_rows_cap = 0;
+        const size_t want = (size_t)U * 48 + (size_t)U * 6 + 4096;
+        HIP_TRY(hipHostMalloc(&c->pinned_rows, want, hipHostMallocDefault));
+        c->pinned_rows_cap = want;
+    }
+    const uint32_t *hp = (const uint32_t *)c->pinned_rows;
+    HIP_TRY(hipMemcpyAsync(c->pinned_rows, packed, (size_t)U * 48, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    rgx_junction_table *t = table_alloc(h, U);
+    for (size_t i = 0; i < U; ++i) {
+        const uint32_t *r = &hp[i * 12];
+        t->tid[i] = (int32_t)r[0]; t->start[i] = r[1]; t->end[i] = r[2]; t->thick_start[i] = r[3]; t->thick_end[i] = r[4]; t->read_count[i] = r[5];
+        t->first_seen[i] = r[6]; t->last_seen[i] = r[8]; t->strand[i] = (char)r[10]; t->name_index[i] = r[11];
+        t->left_ok[i] = (uint32_t)(r[1] - r[3]) >= min_anchor; t->right_ok[i] = (uint32_t)(r[4] - r[2]) >= min_anchor;
     }
     *out = t;
     return RGX_OK;

@@ -67,12 +67,27 @@ def merge_packed(parts, names_from, min_anchor):
     return MergedTable(out)
 
 
-def gather_and_merge(je_or_table, min_anchor=8, group=None):
-    """All-gather the packed per-rank tables and merge them; every rank returns the same MergedTable."""
+def merge_device(ctx, d_rows_ptr, stride_rows, part_rows, names_from, min_anchor):
+    """Merge packed shard tables that are already in HBM (rgx_table_merge_device): shard g's rows at d_rows_ptr + g*stride_rows*48."""
+    lib = _ffi.lib()
+    out = C.POINTER(_ffi.JunctionTable)()
+    err = C.create_string_buffer(256)
+    sizes = (C.c_uint64 * len(part_rows))(*part_rows)
+    rc = lib.rgx_table_merge_device(ctx._h, C.c_void_p(d_rows_ptr), stride_rows, sizes, len(part_rows), min_anchor, names_from, C.byref(out), err, len(err))
+    if rc:
+        raise RuntimeError(err.value.decode())
+    return MergedTable(out)
+
+
+def gather_and_merge(je_or_table, min_anchor=8, group=None, ctx=None):
+    """All-gather the packed per-rank tables and merge them; every rank returns the same MergedTable.
+    With the nccl (RCCL) backend and a device context the gathered rows stay in HBM and are merged there."""
     import torch
     import torch.distributed as dist
 
     table = je_or_table.table if hasattr(je_or_table, "table") else je_or_table
+    if ctx is None:
+        ctx = getattr(je_or_table, "_ctx", None)
     world = dist.get_world_size(group)
     dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
     payload, n = pack_table(table)
@@ -83,6 +98,11 @@ def gather_and_merge(je_or_table, min_anchor=8, group=None):
     local = torch.zeros(cap, dtype=torch.uint8, device=dev)
     if n:
         local[: n * ROW].copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+    if dev == "cuda" and ctx is not None:
+        big = torch.empty(cap * world, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(big, local, group=group)   # the one collective of the whole job; the rows stay in HBM
+        torch.cuda.current_stream().synchronize()
+        return merge_device(ctx, big.data_ptr(), cap // ROW, sizes, table, min_anchor)
     gathered = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
     dist.all_gather(gathered, local, group=group)          # the one collective of the whole job
     parts = []

@@ -123,6 +123,17 @@ def test_shard_merge_is_independent_of_shard_count(gpu_ctx, synth_dir):
             assert recs == n
             merged = distributed.merge_packed(parts, keep[0].table, 8)
             assert merged.bed12() == single, (shape, G)
+            # the same merge with the packed rows resident in HBM, as the RCCL all-gather leaves them (rgx_table_merge_device)
+            import torch
+            stride = max(1, max(k for _, k in parts))
+            big = torch.zeros(G * stride * distributed.ROW, dtype=torch.uint8, device="cuda")
+            for g, (b, k) in enumerate(parts):
+                if k:
+                    big[g * stride * distributed.ROW: g * stride * distributed.ROW + len(b)].copy_(torch.frombuffer(bytearray(b), dtype=torch.uint8))
+            torch.cuda.synchronize()
+            dmerged = distributed.merge_device(gpu_ctx, big.data_ptr(), stride, [k for _, k in parts], keep[0].table, 8)
+            assert dmerged.bed12() == single, (shape, G, "device merge")
+            assert dmerged.bed12(False) == merged.bed12(False), (shape, G, "device merge, all rows")
 
 
 def test_cli_binary_writes_identical_file(gpu_ctx, tmp_path):
