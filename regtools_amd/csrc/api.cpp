@@ -143,15 +143,30 @@ extern "C" void rgx_table_free(rgx_junction_table *t) {
 
 // compare_junctions (junctions_extractor.h:117-140): chrom string, thick_start, thick_end, name string
 static void host_sort_rows(rgx_junction_table *t) {
+    // compare_junctions (junctions_extractor.h:117-140): chrom string, thick_start, thick_end, name string.  Names are "JUNC%08d":
+    // below 10^8 the string order is the numeric order; beyond, the longer decimal strings are compared as text.
+    std::vector<uint32_t> crank((size_t)std::max(t->n_ref, 1), 0);
+    {
+        std::vector<int32_t> order((size_t)t->n_ref);
+        for (int32_t i = 0; i < t->n_ref; ++i) order[(size_t)i] = i;
+        std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return strcmp(t->ref_name[a], t->ref_name[b]) < 0; });
+        uint32_t rk = 0;
+        for (int32_t i = 0; i < t->n_ref; ++i) { if (i > 0 && strcmp(t->ref_name[order[(size_t)i]], t->ref_name[order[(size_t)i - 1]]) != 0) ++rk; crank[(size_t)order[(size_t)i]] = rk; }
+    }
+    auto name_less = [](uint64_t a, uint64_t b) {
+        if (a < 100000000ull && b < 100000000ull) return a < b;
+        char na[32], nb[32];
+        snprintf(na, sizeof na, "%08llu", (unsigned long long)a); snprintf(nb, sizeof nb, "%08llu", (unsigned long long)b);
+        return strcmp(na, nb) < 0;
+    };
     std::vector<uint64_t> idx(t->n);
     for (uint64_t i = 0; i < t->n; ++i) idx[i] = i;
-    auto name_of = [&](uint64_t i, char *buf) { snprintf(buf, 32, "JUNC%08llu", (unsigned long long)t->name_index[i]); };
     std::sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) {
-        if (t->tid[a] != t->tid[b]) { int c = strcmp(t->ref_name[t->tid[a]], t->ref_name[t->tid[b]]); if (c) return c < 0; }
+        const uint32_t ca = crank[(size_t)t->tid[a]], cb = crank[(size_t)t->tid[b]];
+        if (ca != cb) return ca < cb;
         if (t->thick_start[a] != t->thick_start[b]) return t->thick_start[a] < t->thick_start[b];
         if (t->thick_end[a] != t->thick_end[b]) return t->thick_end[a] < t->thick_end[b];
-        char na[32], nb[32]; name_of(a, na); name_of(b, nb);
-        return strcmp(na, nb) < 0;
+        return name_less(t->name_index[a], t->name_index[b]);
     });
     auto permute = [&](auto *col) {
         typedef typename std::remove_reference<decltype(col[0])>::type T;
@@ -757,6 +772,8 @@ extern "C" int rgx_table_merge(const rgx_junction_table *const *parts, int n_par
     if (n_parts <= 0 || !parts || !parts[0]) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: nothing to merge\n");
     struct Row { int32_t tid; uint32_t start, end, ts, te, cnt; uint64_t first, last; char strand; };
     auto cls = [](char c) { return c == '+' ? 0 : c == '-' ? 1 : 2; };
+    const bool trace = getenv("REGTOOLS_AMD_TRACE") != nullptr; double tl = now_ms();
+    auto mark = [&](const char *w) { if (trace) { double t = now_ms(); fprintf(stderr, "[rgx trace] merge %-14s %8.3f ms\n", w, t - tl); tl = t; } };
     std::vector<Row> rows;
     for (int g = 0; g < n_parts; ++g) {
         const rgx_junction_table *t = parts[g];
@@ -764,12 +781,14 @@ extern "C" int rgx_table_merge(const rgx_junction_table *const *parts, int n_par
             rows.push_back({t->tid[i], t->start[i], t->end[i], t->thick_start[i], t->thick_end[i], t->read_count[i],
                             (uint64_t)g << 40 | t->first_seen[i], (uint64_t)g << 40 | t->last_seen[i], t->strand[i]});
     }
+    mark("collect");
     std::stable_sort(rows.begin(), rows.end(), [&](const Row &a, const Row &b) {
         if (a.tid != b.tid) return a.tid < b.tid;
         if (a.start != b.start) return a.start < b.start;
         if (a.end != b.end) return a.end < b.end;
         return cls(a.strand) < cls(b.strand);
     });
+    mark("key sort");
     std::vector<Row> uq;
     for (const Row &r : rows) {
         if (!uq.empty() && uq.back().tid == r.tid && uq.back().start == r.start && uq.back().end == r.end && cls(uq.back().strand) == cls(r.strand)) {
@@ -779,6 +798,7 @@ extern "C" int rgx_table_merge(const rgx_junction_table *const *parts, int n_par
             if (r.last > m.last) { m.last = r.last; m.strand = r.strand; }
         } else uq.push_back(r);
     }
+    mark("reduce");
     std::vector<size_t> by_first(uq.size());
     for (size_t i = 0; i < uq.size(); ++i) by_first[i] = i;
     std::sort(by_first.begin(), by_first.end(), [&](size_t a, size_t b) { return uq[a].first < uq[b].first; });
@@ -792,7 +812,9 @@ extern "C" int rgx_table_merge(const rgx_junction_table *const *parts, int n_par
         t->name_index[i] = k + 1; t->strand[i] = r.strand; t->first_seen[i] = r.first; t->last_seen[i] = r.last;
         t->left_ok[i] = (uint32_t)(r.start - r.ts) >= min_anchor; t->right_ok[i] = (uint32_t)(r.te - r.end) >= min_anchor;
     }
+    mark("name+fill");
     host_sort_rows(t);
+    mark("order sort");
     for (int g = 0; g < n_parts; ++g) {
         t->n_records += parts[g]->n_records; t->n_events += parts[g]->n_events; t->inflated_bytes += parts[g]->inflated_bytes;
         t->compressed_bytes = parts[g]->compressed_bytes; t->n_members += parts[g]->n_members;

@@ -90,6 +90,8 @@ def gather_and_merge(je_or_table, min_anchor=8, group=None, ctx=None):
         ctx = getattr(je_or_table, "_ctx", None)
     world = dist.get_world_size(group)
     dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    if dev == "cuda" and ctx is not None:
+        return _gather_and_merge_device(table, ctx, min_anchor, group, world)
     payload, n = pack_table(table)
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
@@ -98,11 +100,6 @@ def gather_and_merge(je_or_table, min_anchor=8, group=None, ctx=None):
     local = torch.zeros(cap, dtype=torch.uint8, device=dev)
     if n:
         local[: n * ROW].copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
-    if dev == "cuda" and ctx is not None:
-        big = torch.empty(cap * world, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(big, local, group=group)   # the one collective of the whole job; the rows stay in HBM
-        torch.cuda.current_stream().synchronize()
-        return merge_device(ctx, big.data_ptr(), cap // ROW, sizes, table, min_anchor)
     gathered = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
     dist.all_gather(gathered, local, group=group)          # the one collective of the whole job
     parts = []
@@ -110,3 +107,31 @@ def gather_and_merge(je_or_table, min_anchor=8, group=None, ctx=None):
         raw = gathered[r][: sizes[r] * ROW].cpu().numpy().tobytes()
         parts.append((raw, sizes[r]))
     return merge_packed(parts, table, min_anchor)
+
+
+_pinned = {}
+
+
+def _gather_and_merge_device(table, ctx, min_anchor, group, world):
+    """RCCL path: rows are packed straight into pinned memory, all-gathered into one HBM buffer and merged there."""
+    import torch
+    import torch.distributed as dist
+
+    lib = _ffi.lib()
+    n = int(table.contents.n)
+    sizes_t = torch.zeros(world, dtype=torch.int64, device="cuda")
+    dist.all_gather_into_tensor(sizes_t, torch.tensor([n], dtype=torch.int64, device="cuda"), group=group)
+    sizes = [int(x) for x in sizes_t.tolist()]
+    stride = max(1, max(sizes))
+    cap = stride * ROW
+    host = _pinned.get("rows")
+    if host is None or host.numel() < cap:
+        host = _pinned["rows"] = torch.empty(cap + cap // 8, dtype=torch.uint8, pin_memory=True)
+    if n:
+        lib.rgx_table_pack(table, C.c_void_p(host.data_ptr()), n * ROW)
+    local = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    local[: n * ROW].copy_(host[: n * ROW], non_blocking=True)
+    big = torch.empty(cap * world, dtype=torch.uint8, device="cuda")
+    dist.all_gather_into_tensor(big, local, group=group)      # the one data collective of the whole job; the rows stay in HBM
+    torch.cuda.current_stream().synchronize()
+    return merge_device(ctx, big.data_ptr(), stride, sizes, table, min_anchor)

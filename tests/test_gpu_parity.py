@@ -225,3 +225,22 @@ def test_record_framing_converges_quickly_on_decoys(gpu_ctx, synth_dir, variant,
     rc, out, je = gpu_extract(gpu_ctx, cases.case_bam(case, synth_dir), case["args"])
     assert rc == 0 and out == cases.expected(case)
     assert 1 <= je.stats["framing_sweeps"] <= max_sweeps, je.stats
+
+
+def test_rccl_gather_and_device_merge_single_rank(gpu_ctx, synth_dir):
+    """The bench's N > 1 path (one all-gather over the nccl = RCCL backend, then rgx_table_merge_device) with a process group of one:
+    the merged table of a single shard is the shard's own table."""
+    import socket
+    import torch.distributed as dist
+    from regtools_amd import synth, distributed
+    p = os.path.join(str(synth_dir), "rccl1.bam")
+    synth.write(p, 200000, shape="short", seed=77)
+    rc, single, je = gpu_extract(gpu_ctx, p, ["-s", "XS"])
+    assert rc == 0
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        merged = distributed.gather_and_merge(je, min_anchor=8)
+        assert merged.bed12() == single and merged.n == je.table.contents.n
+    finally:
+        dist.destroy_process_group()
