@@ -16,6 +16,7 @@
 #include <chrono>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cse_host.h"
@@ -912,11 +913,21 @@ extern "C" int rgx_table_merge_device(rgx_ctx *c, const void *d_rows, uint64_t s
     HIP_TRY(hipMemcpyAsync(c->pinned_rows, packed, (size_t)U * 48, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     rgx_junction_table *t = table_alloc(h, U);
-    for (size_t i = 0; i < U; ++i) {
-        const uint32_t *r = &hp[i * 12];
-        t->tid[i] = (int32_t)r[0]; t->start[i] = r[1]; t->end[i] = r[2]; t->thick_start[i] = r[3]; t->thick_end[i] = r[4]; t->read_count[i] = r[5];
-        t->first_seen[i] = r[6]; t->last_seen[i] = r[8]; t->strand[i] = (char)r[10]; t->name_index[i] = r[11];
-        t->left_ok[i] = (uint32_t)(r[1] - r[3]) >= min_anchor; t->right_ok[i] = (uint32_t)(r[4] - r[2]) >= min_anchor;
+    auto fill = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const uint32_t *r = &hp[i * 12];
+            t->tid[i] = (int32_t)r[0]; t->start[i] = r[1]; t->end[i] = r[2]; t->thick_start[i] = r[3]; t->thick_end[i] = r[4]; t->read_count[i] = r[5];
+            t->first_seen[i] = r[6]; t->last_seen[i] = r[8]; t->strand[i] = (char)r[10]; t->name_index[i] = r[11];
+            t->left_ok[i] = (uint32_t)(r[1] - r[3]) >= min_anchor; t->right_ok[i] = (uint32_t)(r[4] - r[2]) >= min_anchor;
+        }
+    };
+    // the rows of a large merged table are spread over a few host threads (first-touch page faults of the fresh columns dominate)
+    const size_t n_thr = U < (1u << 17) ? 1 : 8;
+    if (n_thr == 1) fill(0, U);
+    else {
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < n_thr; ++k) th.emplace_back(fill, (size_t)U * k / n_thr, (size_t)U * (k + 1) / n_thr);
+        for (auto &x : th) x.join();
     }
     *out = t;
     return RGX_OK;
