@@ -630,23 +630,25 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
     }
 
     if (n_unique) {
+        // rows in final order: gathered on the device into one block of ten columns, ONE copy into pinned memory
         const size_t U = n_unique;
-        std::vector<uint32_t> col(U), fp(U);
-        std::vector<uint8_t> sc(U);
-        HIP_TRY(hipMemcpy(fp.data(), final_perm, U * 4, hipMemcpyDeviceToHost));
-        auto fetch32 = [&](const uint32_t *d, std::vector<uint32_t> &dst) -> hipError_t {
-            hipError_t e = hipMemcpy(col.data(), d, U * 4, hipMemcpyDeviceToHost);
-            if (e != hipSuccess) return e;
-            dst.resize(U);
-            for (size_t i = 0; i < U; ++i) dst[i] = col[fp[i]];
-            return hipSuccess;
-        };
-        HIP_TRY(fetch32(u.tid, R.group)); HIP_TRY(fetch32(u.start, R.start)); HIP_TRY(fetch32(u.end, R.end));
-        HIP_TRY(fetch32(u.ts_min, R.ts)); HIP_TRY(fetch32(u.te_max, R.te)); HIP_TRY(fetch32(u.count, R.count));
-        HIP_TRY(fetch32(u.name_rank, R.name_rank)); HIP_TRY(fetch32(u.first_seen, R.first_seen)); HIP_TRY(fetch32(u.last_seen, R.last_seen));
-        HIP_TRY(hipMemcpy(sc.data(), u.strand, U, hipMemcpyDeviceToHost));
+        DevBuf &b_out = c->buf("rows_out");
+        HIP_TRY(b_out.ensure(U * 40 + 256));
+        launch_rows_out(u, final_perm, n_unique, b_out.as<uint32_t>(), st);
+        if (U * 40 > c->pinned_rows_cap) {
+            if (c->pinned_rows) (void)hipHostFree(c->pinned_rows);
+            c->pinned_rows = nullptr; c->pinned_rows_cap = 0;
+            const size_t want = U * 40 + U * 5 + 4096;
+            HIP_TRY(hipHostMalloc(&c->pinned_rows, want, hipHostMallocDefault));
+            c->pinned_rows_cap = want;
+        }
+        HIP_TRY(hipMemcpyAsync(c->pinned_rows, b_out.p, U * 40, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const uint32_t *hp = (const uint32_t *)c->pinned_rows;
+        auto col = [&](size_t k, std::vector<uint32_t> &dst) { dst.assign(hp + k * U, hp + (k + 1) * U); };
+        col(0, R.group); col(1, R.start); col(2, R.end); col(3, R.ts); col(4, R.te); col(5, R.count); col(6, R.name_rank); col(7, R.first_seen); col(8, R.last_seen);
         R.strand.resize(U);
-        for (size_t i = 0; i < U; ++i) R.strand[i] = sc[fp[i]];
+        for (size_t i = 0; i < U; ++i) R.strand[i] = (uint8_t)hp[9 * U + i];
         R.n = U;
     }
     return RGX_OK;

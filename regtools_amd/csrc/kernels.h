@@ -125,6 +125,8 @@ void launch_reduce_finish(EventSoA ev, const uint32_t *perm, uint32_t n, uint32_
 void launch_name_rank(uint32_t n_unique, const uint32_t *flag_scan, UniqueSoA u, hipStream_t stream);
 void launch_gather_u32(uint32_t n, const uint32_t *table, const uint32_t *idx, uint32_t *out, hipStream_t stream);
 void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t stream);
+// ten u32 columns of n rows each, in `order`: tid,start,end,ts,te,count,name_rank,first_seen,last_seen,strand
+void launch_rows_out(UniqueSoA u, const uint32_t *order, uint32_t n, uint32_t *out, hipStream_t stream);
 
 
 // ---- a9-a11: `cis-splice-effects identify` interval kernels (cse_kernels.hip; logic in cse_core.h) --------------------------

@@ -920,6 +920,18 @@ __global__ void k_gather_u32(uint32_t n, const uint32_t *__restrict__ table, con
     if (r < n) out[r] = table[idx[r]];
 }
 
+// the unique rows in final order as ten contiguous u32 columns (tid,start,end,ts,te,count,name_rank,first_seen,last_seen,strand):
+// one block, one copy to the host
+__global__ void k_rows_out(UniqueSoA u, const uint32_t *__restrict__ order, uint32_t n, uint32_t *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = order[i];
+    const size_t N = n;
+    out[i] = u.tid[s]; out[N + i] = u.start[s]; out[2 * N + i] = u.end[s]; out[3 * N + i] = u.ts_min[s]; out[4 * N + i] = u.te_max[s];
+    out[5 * N + i] = u.count[s]; out[6 * N + i] = u.name_rank[s]; out[7 * N + i] = u.first_seen[s]; out[8 * N + i] = u.last_seen[s];
+    out[9 * N + i] = u.strand[s];
+}
+
 __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -941,6 +953,9 @@ void launch_name_rank(uint32_t n_unique, const uint32_t *flag_scan, UniqueSoA u,
 }
 void launch_gather_u32(uint32_t n, const uint32_t *table, const uint32_t *idx, uint32_t *out, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(k_gather_u32, dim3((n + 255) / 256), dim3(256), 0, stream, n, table, idx, out);
+}
+void launch_rows_out(UniqueSoA u, const uint32_t *order, uint32_t n, uint32_t *out, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_rows_out, dim3((n + 255) / 256), dim3(256), 0, stream, u, order, n, out);
 }
 void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, v, n);
