@@ -181,29 +181,27 @@ struct OutStage {
     }
     // make memory agree with the stage up to o (a copy is about to read bytes that are still in registers)
     RGX_HD void flush_partial(uint32_t o) const { if ((a + o) & 15u) store_chunk(o, lo, hi); }
+    // The two appenders are written without data-dependent branches (selects and clamped shifts only): in a 64-lane wave every lane
+    // is at a different byte phase k, so an `if (k < 8)` costs both sides for everybody.
     RGX_HD void put_byte(uint32_t o, uint32_t b) {
-        const uint32_t k = (a + o) & 15u;
-        if (k < 8) lo |= (uint64_t)b << (8 * k); else hi |= (uint64_t)b << (8 * (k - 8));
+        const uint32_t k = (a + o) & 15u, s = 8 * k;
+        lo |= shl64((uint64_t)b, s);                        // k < 8, else shifted out
+        hi |= shl64((uint64_t)b, s - 64u);                  // k >= 8 (s - 64 wraps to a huge count for k < 8: shifted out)
         if (k == 15) { store_chunk(o, lo, hi); lo = 0; hi = 0; }
     }
     // append nb (1..16) bytes held in the low end of (dl, dh); whatever lies above them is ignored
     RGX_HD void put_chunk(uint32_t o, uint64_t dl, uint64_t dh, uint32_t nb) {
-        if (nb < 8) { dl &= (1ull << (8 * nb)) - 1; dh = 0; }
-        else if (nb < 16) dh &= shl64(1ull, 8 * (nb - 8)) - 1;
-        const uint32_t k = (a + o) & 15u;
-        uint64_t cl, ch, rl, rh;                                           // (cl, ch) = this chunk, (rl, rh) = what spills into the next
-        if (k < 8) {
-            const uint32_t s = 8 * k;
-            cl = lo | (dl << s); ch = hi | shl64(dh, s) | shr64(dl, 64 - s);
-            if (s == 0) ch = hi | dh;
-            rl = s ? dh >> (64 - s) : 0; rh = 0;
-        } else {
-            const uint32_t s = 8 * (k - 8);
-            cl = lo; ch = hi | (dl << s);
-            rl = (s ? dl >> (64 - s) : 0) | (dh << s); rh = s ? dh >> (64 - s) : 0;
-        }
-        if (k + nb >= 16) { store_chunk(o, cl, ch); lo = rl; hi = rh; }
-        else { lo = cl; hi = ch; }
+        const uint32_t mb = 8 * nb;                                        // keep the low nb bytes
+        dl &= mb >= 64 ? ~0ull : ((1ull << (mb & 63)) - 1);
+        dh &= mb >= 128 ? ~0ull : (mb <= 64 ? 0ull : ((1ull << ((mb - 64) & 63)) - 1));
+        const uint32_t k = (a + o) & 15u, s = 8 * k, r = s & 63u;
+        const bool q = s >= 64;
+        // (dh:dl) << s as four 64-bit words x0..x3: x0,x1 complete this chunk, x2,x3 spill into the next
+        const uint64_t a0 = dl << r, a1 = (dh << r) | shr64(dl, 64 - r), a2 = shr64(dh, 64 - r);
+        const uint64_t cl = lo | (q ? 0 : a0), ch = hi | (q ? a0 : a1), rl = q ? a1 : a2, rh = q ? a2 : 0;
+        const bool full = k + nb >= 16;
+        if (full) store_chunk(o, cl, ch);
+        lo = full ? rl : cl; hi = full ? rh : ch;
     }
     // after bytes were written straight to memory (stored blocks): pick the current chunk's valid bytes up again
     RGX_HD void resync(uint32_t o) {
