@@ -128,6 +128,9 @@ struct BitReader {
         buf |= next << cnt;
         p += (63u - cnt) >> 3;
         cnt |= 56u;
+        // a corrupt stream may ask for bits that do not exist: never read more than 16 bytes past the payload (the loads stay inside
+        // the caller's buffer + its 8-byte slack); overran() is true from here on and the run ends at the next check or at out_cap
+        if ((size_t)(p - in) > (size_t)in_len + 8) p = in + in_len + 8;
         next = ld64(p);
     }
     RGX_HD void ensure(uint32_t n) { if (cnt < n) refill(); }

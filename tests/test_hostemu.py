@@ -130,3 +130,36 @@ def test_corrupt_streams_never_crash_and_agree_with_zlib_when_valid(emu):
     for cut in range(0, len(p), 7):
         st, got = inflate(emu, p[:cut])
         assert st != 0
+
+
+def test_reads_stay_within_16_bytes_of_the_payload_even_on_corrupt_streams(emu):
+    """The decoder prefetches its bit stream; the C ABI promises the caller that nothing beyond bam_len + 8 is touched (the payload of the
+    last member ends 8 bytes before that).  The payload is placed so that the 17th byte after it is an unmapped page: an over-read would
+    kill the test process."""
+    import mmap
+    libc = ctypes.CDLL(None, use_errno=True)
+    page = mmap.PAGESIZE
+    m = mmap.mmap(-1, 3 * page)
+    base = ctypes.addressof(ctypes.c_char.from_buffer(m))
+    libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert libc.mprotect(ctypes.c_void_p(base + 2 * page), page, 0) == 0          # PROT_NONE guard page
+    rnd = random.Random(17)
+    out = ctypes.create_string_buffer(65536 + 64)
+    n = ctypes.c_uint32(0)
+    try:
+        for trial in range(600):
+            data = bytes(rnd.choice(b"ACGTN!#") for _ in range(rnd.choice([40, 900, 5000])))
+            p = bytearray(zlib.compress(data, 6)[2:-4])
+            mode = trial % 3
+            if mode == 1:
+                k = rnd.randrange(len(p)); p[k] ^= 1 << rnd.randrange(8)
+            elif mode == 2:
+                p = p[: rnd.randrange(1, len(p))]
+            start = 2 * page - 16 - len(p)
+            m[start:start + len(p)] = bytes(p)
+            m[2 * page - 16:2 * page] = bytes(rnd.randrange(256) for _ in range(16))
+            st = emu.emu_inflate(ctypes.c_void_p(base + start), len(p), out, 65536, ctypes.byref(n))
+            if mode == 0:
+                assert st == 0 and out.raw[:n.value] == data
+    finally:
+        libc.mprotect(ctypes.c_void_p(base + 2 * page), page, 3)
