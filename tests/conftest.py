@@ -18,7 +18,7 @@ def built():
     """Everything native is built once per session (a no-op when the .so files travelled with the snapshot)."""
     need = [os.path.join(ROOT, "regtools_amd", "libregtools_amd.so"), os.path.join(ROOT, "regtools_amd", "libregtools_synth.so"),
             os.path.join(ROOT, "oracle", "oracle_cli"), os.path.join(ROOT, "oracle", "liboracle.so"),
-            os.path.join(ROOT, "tests", "hostemu", "libhostemu.so")]
+            os.path.join(ROOT, "tests", "hostemu", "libhostemu.so"), os.path.join(ROOT, "bin", "regtools-amd")]
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__
         __graft_entry__.build()
