@@ -66,57 +66,115 @@ static std::string gtf_attr(const char *attrs, size_t alen, const char *key) {
     return "NA";
 }
 
+// value of `key` in a GTF attribute column as a view into the text (no allocation); found = false -> "NA" upstream
+static bool gtf_attr_view(const char *attrs, size_t alen, const char *key, size_t klen, const char *&v, size_t &vl) {
+    size_t i = 0;
+    while (i < alen) {
+        size_t j = i;
+        while (j < alen && attrs[j] != ';') ++j;
+        const char *p = attrs + i; size_t l = j - i;
+        if (l && p[0] == ' ') { ++p; --l; }
+        size_t a = 0; while (a < l && p[a] != ' ') ++a;
+        if (l > 0 && a == klen && !memcmp(p, key, klen)) {
+            size_t b = a < l ? a + 1 : l, c = b;
+            while (c < l && p[c] != ' ') ++c;
+            v = p + b; vl = c - b;
+            if (vl >= 1 && v[0] == '"' && v[vl - 1] == '"') { if (vl >= 2) { ++v; vl -= 2; } else vl = 0; }
+            return true;
+        }
+        if (j >= alen) break;
+        i = j + 1;
+    }
+    return false;
+}
+
+// atol on a field that is not NUL-terminated (leading blanks, optional sign, digits)
+static long field_atol(const char *s, size_t n) {
+    size_t i = 0;
+    while (i < n && (s[i] == ' ' || (s[i] >= 9 && s[i] <= 13))) ++i;
+    bool neg = false;
+    if (i < n && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; ++i; }
+    long v = 0;
+    while (i < n && s[i] >= '0' && s[i] <= '9') { v = v * 10 + (s[i] - '0'); ++i; }
+    return neg ? -v : v;
+}
+
 std::string GtfModel::load(const std::string &path) {
     std::string text;
     if (!slurp(path, text)) return "\nUnable to open GTF file.";
-    struct Tmp { std::string id, gene_name, gene_id; int32_t chrom; uint8_t strand; std::vector<uint32_t> s, e; };
+    struct Tmp { std::string id, gene_name, gene_id; int32_t chrom; uint8_t strand; uint32_t n = 0; };
     std::vector<Tmp> tmp;
-    std::unordered_map<std::string, uint32_t> by_id;
-    std::vector<std::pair<const char *, size_t>> f;
+    std::vector<uint32_t> ex_tx, ex_s, ex_e;                                       // exon lines in file order
+    const char *last_tv = nullptr; size_t last_tl = 0; uint32_t last_k = 0;        // exon lines of a transcript are usually adjacent
+    struct SvHash { size_t operator()(const std::pair<const char *, size_t> &k) const { uint64_t h = 1469598103934665603ull; for (size_t i = 0; i < k.second; ++i) h = (h ^ (uint8_t)k.first[i]) * 1099511628211ull; return (size_t)h; } };
+    struct SvEq { bool operator()(const std::pair<const char *, size_t> &a, const std::pair<const char *, size_t> &b) const { return a.second == b.second && !memcmp(a.first, b.first, a.second); } };
+    std::unordered_map<std::pair<const char *, size_t>, uint32_t, SvHash, SvEq> by_id;     // keys are views into `text`
+    by_id.reserve(1 << 16);
     size_t pos = 0;
     while (pos < text.size()) {
-        size_t e = text.find('\n', pos); if (e == std::string::npos) e = text.size();
+        const char *nl = (const char *)memchr(text.data() + pos, '\n', text.size() - pos);
+        const size_t e = nl ? (size_t)(nl - text.data()) : text.size();
         const char *line = text.data() + pos; const size_t ll = e - pos;
         pos = e + 1;
         if (ll == 0) return "basic_string::at";                                   // line.at(0) throws (gtf_parser.cc:230)
         if (line[0] == '#') continue;
-        tokenize(line, ll, '\t', f);
-        if (f.size() != 9) return "Expected 9 fields in GTF line.";               // gtf_parser.cc:67-70
-        if (!(f[2].second == 4 && !memcmp(f[2].first, "exon", 4))) continue;
-        std::string tid = gtf_attr(f[8].first, f[8].second, "transcript_id");
-        if (tid == "NA") continue;                                                // gtf_parser.cc:118
-        auto it = by_id.find(tid);
+        // Tokenize on tabs (std::getline semantics: no empty field after a trailing tab); exactly 9 fields or the run dies
+        const char *fb[10]; size_t fl[10]; size_t nf = 0;
+        for (size_t i = 0;;) {
+            const char *t = (const char *)memchr(line + i, '\t', ll - i);
+            const size_t j = t ? (size_t)(t - line) : ll;
+            if (nf < 10) { fb[nf] = line + i; fl[nf] = j - i; }
+            ++nf;
+            if (j >= ll) break;
+            i = j + 1;
+            if (i >= ll) break;
+        }
+        if (nf != 9) return "Expected 9 fields in GTF line.";                     // gtf_parser.cc:67-70
+        if (!(fl[2] == 4 && !memcmp(fb[2], "exon", 4))) continue;
+        const char *tv; size_t tl;
+        if (!gtf_attr_view(fb[8], fl[8], "transcript_id", 13, tv, tl) || (tl == 2 && !memcmp(tv, "NA", 2))) continue;   // gtf_parser.cc:118
         uint32_t k;
-        if (it == by_id.end()) {
-            k = (uint32_t)tmp.size(); by_id.emplace(tid, k);
-            Tmp t; t.id = tid;
-            t.gene_name = gtf_attr(f[8].first, f[8].second, "gene_name");         // first exon line seen wins (gtf_parser.cc:266-273)
-            t.gene_id = gtf_attr(f[8].first, f[8].second, "gene_id");
-            std::string cn(f[0].first, f[0].second);
+        if (last_tv && tl == last_tl && !memcmp(tv, last_tv, tl)) k = last_k;
+        else if (auto it = by_id.find({tv, tl}); it != by_id.end()) k = it->second;
+        else {
+            k = (uint32_t)tmp.size(); by_id.emplace(std::make_pair(tv, tl), k);
+            Tmp t; t.id.assign(tv, tl);
+            t.gene_name = gtf_attr(fb[8], fl[8], "gene_name");                    // first exon line seen wins (gtf_parser.cc:266-273)
+            t.gene_id = gtf_attr(fb[8], fl[8], "gene_id");
+            std::string cn(fb[0], fl[0]);
             auto ci = chrom_index.find(cn);
             if (ci == chrom_index.end()) { ci = chrom_index.emplace(cn, (int32_t)chroms.size()).first; chroms.push_back(cn); }
             t.chrom = ci->second;
-            t.strand = f[6].second == 1 ? (uint8_t)f[6].first[0] : (uint8_t)'?';
+            t.strand = fl[6] == 1 ? (uint8_t)fb[6][0] : (uint8_t)'?';
             tmp.push_back(std::move(t));
-        } else k = it->second;
-        tmp[k].s.push_back((uint32_t)atol(std::string(f[3].first, f[3].second).c_str()));
-        tmp[k].e.push_back((uint32_t)atol(std::string(f[4].first, f[4].second).c_str()));
+        }
+        last_tv = tv; last_tl = tl; last_k = k;
+        ++tmp[k].n;
+        ex_tx.push_back(k); ex_s.push_back((uint32_t)field_atol(fb[3], fl[3])); ex_e.push_back((uint32_t)field_atol(fb[4], fl[4]));
     }
+    // exons grouped by transcript, file order kept inside a group (one counting pass instead of 250 k small vectors)
+    std::vector<uint32_t> goff(tmp.size() + 1, 0), gs(ex_tx.size()), ge(ex_tx.size());
+    for (size_t k = 0; k < tmp.size(); ++k) goff[k + 1] = goff[k] + tmp[k].n;
+    { std::vector<uint32_t> fill(goff.begin(), goff.end() - 1);
+      for (size_t i = 0; i < ex_tx.size(); ++i) { const uint32_t q = fill[ex_tx[i]]++; gs[q] = ex_s[i]; ge[q] = ex_e[i]; } }
     std::vector<uint32_t> order(tmp.size());
     std::iota(order.begin(), order.end(), 0u);
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return tmp[a].id < tmp[b].id; });   // std::map<string,Transcript>
+    es.reserve(gs.size()); ee.reserve(gs.size());
+    std::vector<uint32_t> idx;
     for (uint32_t k : order) {
         Tmp &t = tmp[k];
         if (t.strand != '+' && t.strand != '-') return "Undefined strand for exon ";                          // gtf_parser.cc:193-197 exit(1)
-        std::vector<uint32_t> idx(t.s.size());
+        const uint32_t *ts = gs.data() + goff[k], *te = ge.data() + goff[k];
+        idx.resize(t.n);
         std::iota(idx.begin(), idx.end(), 0u);
-        // sort_exons_within_transcripts: '+' ascending start, '-' descending start
-        if (t.strand == '+') std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return t.s[a] < t.s[b]; });
-        else std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return t.s[a] > t.s[b]; });
+        // sort_exons_within_transcripts: '+' ascending start, '-' descending start (stable)
+        if (t.strand == '+') std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return ts[a] < ts[b]; });
+        else std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return ts[a] > ts[b]; });
         tx_id.push_back(t.id); tx_gene_name.push_back(t.gene_name); tx_gene_id.push_back(t.gene_id);
         tx_chrom.push_back(t.chrom); tx_strand.push_back(t.strand);
         tx_exon_off.push_back((uint32_t)es.size()); tx_n_exons.push_back((uint32_t)idx.size());
-        for (uint32_t i : idx) { es.push_back(t.s[i]); ee.push_back(t.e[i]); }
+        for (uint32_t i : idx) { es.push_back(ts[i]); ee.push_back(te[i]); }
         tx_bin.push_back(ucsc_bin(es[tx_exon_off.back()], ee.back()));                                         // gtf_parser.cc:154-160
     }
     // chr -> bin -> [transcript ids ascending]
