@@ -23,6 +23,10 @@ def batch(nb):
         return sub(s, "constexpr uint32_t kCopyBatch = 128;", "constexpr uint32_t kCopyBatch = %d;" % nb)
     return f
 
+def occ16(s):
+    return s
+occ16.kernels2 = [("constexpr uint32_t kHotSyms = 160;", "constexpr uint32_t kHotSyms = 96;"), ("amdgpu_waves_per_eu(3, 3)", "amdgpu_waves_per_eu(4, 4)")]
+
 def lds_bytes(nbytes):
     def f(s):
         return s
@@ -36,6 +40,7 @@ VARIANTS = {
     "nostore": [no_stores],
     "decode_only": [no_copy_loads, no_stores],
     "occ5": [lds_bytes(32768)],
+    "occ16": [occ16],
 }
 
 if __name__ == "__main__":
@@ -53,4 +58,6 @@ if __name__ == "__main__":
         for f in VARIANTS[v]:
             if hasattr(f, "kernels"):
                 k = sub(k, f.kernels[0], f.kernels[1])
+            for a, b in getattr(f, "kernels2", []):
+                k = sub(k, a, b)
         open(pk, "w").write(k)
