@@ -445,21 +445,24 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     HIP_TRY(hipEventRecord(c->ev[2], st));
     uint64_t *seg_start[2] = {nullptr, nullptr}, *seg_exit[2] = {nullptr, nullptr};
     uint32_t *seg_cnt[2] = {nullptr, nullptr}, *seg_base = nullptr;
+    uint16_t *seg_cp = nullptr;
     int cur = 0;
     if (n_seg) {
         const size_t per = (size_t)n_seg;
         HIP_TRY(b_seg.ensure(per * (8 + 8 + 4) * 2 + per * 4 + 64));
+        HIP_TRY(c->buf("seg_cp").ensure(per * kSegCpSlots * 2 + 64));
+        seg_cp = c->buf("seg_cp").as<uint16_t>();
         uint8_t *q = b_seg.as<uint8_t>();
         for (int k = 0; k < 2; ++k) { seg_start[k] = (uint64_t *)q; q += per * 8; seg_exit[k] = (uint64_t *)q; q += per * 8; }
         for (int k = 0; k < 2; ++k) { seg_cnt[k] = (uint32_t *)q; q += per * 4; }
         seg_base = (uint32_t *)q;
         HIP_TRY(b_tmp.ensure(scan_tmp_words(n_seg) * 4 + 64));
-        launch_seg_walk(arena, pos0, lim, n_seg, n_ref, seg_start[0], seg_exit[0], seg_cnt[0], st);
+        launch_seg_walk(arena, pos0, lim, n_seg, n_ref, seg_start[0], seg_exit[0], seg_cnt[0], seg_cp, st);
         // d_sc[10]: leftmost disagreeing segment, d_sc[11]: leftmost chain end, d_sc[3]: record total
         for (int iter = 0;; ++iter) {
             HIP_TRY(hipMemsetAsync(d_sc + 10, 0xff, 8, st));
             launch_seg_verify(arena, pos0, lim, n_seg, seg_start[cur], seg_exit[cur], seg_cnt[cur], seg_start[cur ^ 1], seg_exit[cur ^ 1],
-                              seg_cnt[cur ^ 1], d_sc + 10, st);
+                              seg_cnt[cur ^ 1], d_sc + 10, seg_cp, st);
             cur ^= 1;
             launch_scan_u32(seg_cnt[cur], seg_base, n_seg, d_sc + 3, b_tmp.as<uint32_t>(), st);
             HIP_TRY(hipMemcpyAsync(h_sc + 3, d_sc + 3, 4, hipMemcpyDeviceToHost, st));
@@ -498,7 +501,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         HIP_TRY(b_tmp.ensure(scan_tmp_words(n_rec) * 4 + 64));
         // per-segment outputs (no hot atomics): reuse the spare segment arrays as seg_iter / seg_long
         uint32_t *seg_iter = seg_cnt[cur ^ 1], *seg_long = (uint32_t *)seg_start[cur ^ 1], *seg_long_base = (uint32_t *)seg_exit[cur ^ 1];
-        launch_decode_seg(arena, pos0, lim, n_seg, seg_start[cur], seg_base, seg_cnt[cur], cfg, soa, seg_iter, seg_long, st);
+        launch_decode_seg(arena, pos0, lim, n_seg, seg_start[cur], seg_base, seg_cnt[cur], cfg, soa, seg_iter, seg_long, seg_cp, st);
         launch_scan_u32(soa.n_ev, ev_base, n_rec, d_sc + 4, b_tmp.as<uint32_t>(), st);
         launch_scan_u32(seg_iter, seg_iter, n_seg, d_sc + 8, b_tmp.as<uint32_t>(), st);
         launch_scan_u32(seg_long, seg_long_base, n_seg, d_sc + 5, b_tmp.as<uint32_t>(), st);

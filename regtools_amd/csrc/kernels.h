@@ -8,6 +8,7 @@
 namespace rgx {
 
 constexpr uint32_t kSegBytes = 16384;   // arena segment walked by one lane during record-boundary discovery
+constexpr uint32_t kSegCpSlots = 64;     // checkpoints per segment: offset of every 8th record (a segment starts at most 457 records)
 constexpr uint64_t kChainEnd = ~0ull;   // "the record chain ended before this point" (truncated/corrupt stream)
 
 // ---- a1: BGZF inflate (one lane per member) -----------------------------------------------------------
@@ -48,13 +49,13 @@ void launch_member_stop(const Member *members, uint32_t max_members, const uint3
 // (s==0) first record start >= segment begin; seg_exit[s] = first record start >= segment end reached by the
 // chain from seg_start[s]; seg_cnt[s] = records that start inside the segment.
 void launch_seg_walk(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, int32_t n_ref,
-                     uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, hipStream_t stream);
+                     uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, uint16_t *seg_cp /* n_seg * kSegCpSlots */, hipStream_t stream);
 // One verification sweep: segment s re-walks from seg_exit_in[s-1] when that differs from seg_start_in[s].
 // *changed is incremented when anything changed. Reads *_in, writes *_out (all segments).
 void launch_seg_verify(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg,
                        const uint64_t *seg_start_in, const uint64_t *seg_exit_in, const uint32_t *seg_cnt_in,
                        uint64_t *seg_start_out, uint64_t *seg_exit_out, uint32_t *seg_cnt_out,
-                       uint32_t *status /* [0] leftmost disagreeing segment, [1] leftmost chain end; both preset to ~0u */, hipStream_t stream);
+                       uint32_t *status /* [0] leftmost disagreeing segment, [1] leftmost chain end; both preset to ~0u */, uint16_t *seg_cp, hipStream_t stream);
 void launch_seg_truncate(uint64_t pos0, uint64_t lim, uint32_t n_seg, uint32_t last, uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, hipStream_t stream);
 
 // ---- a2/a3/a5/a6: SoA decode + per-read event count ---------------------------------------------------------
@@ -82,7 +83,7 @@ struct ExtractCfg {
 // one wave per framing segment, segment bytes staged through LDS (replaces launch_seg_fill + launch_decode on the hot path)
 // seg_iter[s] = records of segment s that pass the region filter; seg_long[s] = its reads for the wave-per-read kernel
 void launch_decode_seg(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, const uint64_t *seg_start, const uint32_t *seg_base,
-                       const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, hipStream_t stream);
+                       const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, const uint16_t *seg_cp, hipStream_t stream);
 void launch_long_fill(uint32_t n_seg, const uint32_t *seg_base, const uint32_t *seg_cnt, const uint32_t *seg_long_base, ExtractCfg cfg, ReadSoA soa,
                       uint32_t *long_list, hipStream_t stream);
 

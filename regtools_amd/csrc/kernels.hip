@@ -121,7 +121,10 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
 // =====================================================================================================
 // Walk the block_size chain from `o` until it leaves [.., seg_end). Returns the first record start >= seg_end
 // (or kChainEnd when the chain hits an unreadable record / the end of the stream) and counts the records started.
-__device__ __forceinline__ uint64_t walk_chain(const uint8_t *arena, uint64_t o, uint64_t seg_end, uint64_t lim, uint32_t &cnt) {
+// cp (optional): cp[j] = offset of record 8j from seg_begin -- k_decode_seg's lanes re-walk eight records each from there instead of
+// one lane re-walking all of them.
+__device__ __forceinline__ uint64_t walk_chain(const uint8_t *arena, uint64_t o, uint64_t seg_end, uint64_t lim, uint32_t &cnt, uint16_t *cp = nullptr,
+                                               uint64_t seg_begin = 0) {
     cnt = 0;
     while (o < seg_end) {
         if (o + 36 > lim) return kChainEnd;             // bam_read1: short read of the fixed part
@@ -129,6 +132,7 @@ __device__ __forceinline__ uint64_t walk_chain(const uint8_t *arena, uint64_t o,
         if (!rec_sane(h)) return kChainEnd;             // sam.c:421-423 -> iteration ends
         uint64_t nxt = o + 4 + (uint64_t)(uint32_t)h.block_len;
         if (nxt > lim) return kChainEnd;                // truncated record body
+        if (cp && (cnt & 7u) == 0) cp[cnt >> 3] = (uint16_t)(o - seg_begin);
         ++cnt;
         o = nxt;
     }
@@ -136,9 +140,10 @@ __device__ __forceinline__ uint64_t walk_chain(const uint8_t *arena, uint64_t o,
 }
 
 __global__ void k_seg_walk(const uint8_t *__restrict__ arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, int32_t n_ref,
-                           uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt) {
+                           uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, uint16_t *seg_cp) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seg) return;
+    uint16_t *cp = seg_cp + (size_t)s * kSegCpSlots;
     uint64_t a = pos0 + (uint64_t)s * kSegBytes, b = a + kSegBytes;
     if (b > lim) b = lim;
     uint64_t o = a, ex = kChainEnd;
@@ -184,12 +189,12 @@ __global__ void k_seg_walk(const uint8_t *__restrict__ arena, uint64_t pos0, uin
                 c += 16;
             }
             if (cand == kChainEnd) break;
-            ex = walk_chain(arena, cand, b, lim, cnt);
+            ex = walk_chain(arena, cand, b, lim, cnt, cp, a);
             if (ex != kChainEnd) { o = cand; break; }
             c = cand + 1;
         }
         if (o == kChainEnd) { ex = kChainEnd; o = b; cnt = 0; }      // nothing usable: verification will settle it
-    } else ex = walk_chain(arena, o, b, lim, cnt);
+    } else ex = walk_chain(arena, o, b, lim, cnt, cp, a);
     seg_start[s] = o; seg_exit[s] = ex; seg_cnt[s] = cnt;
 }
 
@@ -211,7 +216,7 @@ __device__ __forceinline__ bool seg_consistent(uint64_t pos0, uint64_t lim, uint
 // one segment per sweep.
 __global__ void k_seg_verify(const uint8_t *__restrict__ arena, uint64_t pos0, uint64_t lim, uint32_t n_seg,
                              const uint64_t *__restrict__ st_in, const uint64_t *__restrict__ ex_in, const uint32_t *__restrict__ cnt_in,
-                             uint64_t *st_out, uint64_t *ex_out, uint32_t *cnt_out, uint32_t *status) {
+                             uint64_t *st_out, uint64_t *ex_out, uint32_t *cnt_out, uint32_t *status, uint16_t *seg_cp) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seg) return;
     uint64_t st = st_in[s], ex = ex_in[s];
@@ -226,7 +231,7 @@ __global__ void k_seg_verify(const uint8_t *__restrict__ arena, uint64_t pos0, u
                 uint64_t b = pos0 + (uint64_t)s * kSegBytes + kSegBytes;
                 if (b > lim) b = lim;
                 if (expect >= b) { st = b; ex = expect; cnt = 0; }
-                else { st = expect; ex = walk_chain(arena, st, b, lim, cnt); }
+                else { st = expect; ex = walk_chain(arena, st, b, lim, cnt, seg_cp + (size_t)s * kSegCpSlots, pos0 + (uint64_t)s * kSegBytes); }
             }
         }
     }
@@ -243,16 +248,16 @@ __global__ void k_seg_truncate(uint64_t pos0, uint64_t lim, uint32_t n_seg, uint
 }
 
 void launch_seg_walk(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, int32_t n_ref, uint64_t *seg_start,
-                     uint64_t *seg_exit, uint32_t *seg_cnt, hipStream_t stream) {
+                     uint64_t *seg_exit, uint32_t *seg_cnt, uint16_t *seg_cp, hipStream_t stream) {
     if (!n_seg) return;
-    hipLaunchKernelGGL(k_seg_walk, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, pos0, lim, n_seg, n_ref, seg_start, seg_exit, seg_cnt);
+    hipLaunchKernelGGL(k_seg_walk, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, pos0, lim, n_seg, n_ref, seg_start, seg_exit, seg_cnt, seg_cp);
 }
 void launch_seg_verify(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, const uint64_t *seg_start_in,
                        const uint64_t *seg_exit_in, const uint32_t *seg_cnt_in, uint64_t *seg_start_out, uint64_t *seg_exit_out,
-                       uint32_t *seg_cnt_out, uint32_t *status, hipStream_t stream) {
+                       uint32_t *seg_cnt_out, uint32_t *status, uint16_t *seg_cp, hipStream_t stream) {
     if (!n_seg) return;
     hipLaunchKernelGGL(k_seg_verify, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, pos0, lim, n_seg, seg_start_in, seg_exit_in,
-                       seg_cnt_in, seg_start_out, seg_exit_out, seg_cnt_out, status);
+                       seg_cnt_in, seg_start_out, seg_exit_out, seg_cnt_out, status, seg_cp);
 }
 void launch_seg_truncate(uint64_t pos0, uint64_t lim, uint32_t n_seg, uint32_t last, uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, hipStream_t stream) {
     if (!n_seg) return;
@@ -271,7 +276,7 @@ constexpr uint32_t kSegMaxRecs = kSegBytes / 36 + 2;     // a record is at least
 __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ arena, uint64_t pos0, uint64_t lim, uint32_t n_seg,
                                                    const uint64_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_base,
                                                    const uint32_t *__restrict__ seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter,
-                                                   uint32_t *seg_long) {
+                                                   uint32_t *seg_long, const uint16_t *__restrict__ seg_cp) {
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[kSegBytes + kSegTail + 48];
     __shared__ uint32_t s_off[kSegMaxRecs];
     const uint32_t s = blockIdx.x, lane = threadIdx.x;
@@ -301,10 +306,12 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
     // unaligned 32-bit read from the LDS window: two aligned dword reads + a byte funnel shift (v_alignbyte_b32)
     const uint32_t *s_w = (const uint32_t *)s_buf;
     auto lds32 = [&](uint32_t off) -> uint32_t { return __builtin_amdgcn_alignbyte(s_w[(off >> 2) + 1], s_w[off >> 2], off & 3u); };
-    // lane 0: chain walk inside LDS
-    if (lane == 0) {
-        uint64_t o = seg_start[s];
-        for (uint32_t k = 0; k < cnt; ++k) {
+    // chain walk inside LDS: lane j re-walks records 8j .. 8j+7 from the checkpoint the framing left (a segment holds at most
+    // kSegMaxRecs = 457 records = 58 checkpoints)
+    if (lane * 8 < cnt) {
+        uint64_t o = a + seg_cp[(size_t)s * kSegCpSlots + lane];
+        const uint32_t k_end = min(cnt, lane * 8 + 8);
+        for (uint32_t k = lane * 8; k < k_end; ++k) {
             const uint32_t ro = (uint32_t)(o - w0);
             s_off[k] = ro;
             o += 4 + (uint64_t)((o + 4 <= w1) ? lds32(ro) : ld32(arena + o));
@@ -398,9 +405,9 @@ __global__ __launch_bounds__(64) void k_long_fill(uint32_t n_seg, const uint32_t
 }
 
 void launch_decode_seg(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, const uint64_t *seg_start, const uint32_t *seg_base,
-                       const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, hipStream_t stream) {
+                       const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, const uint16_t *seg_cp, hipStream_t stream) {
     if (!n_seg) return;
-    hipLaunchKernelGGL(k_decode_seg, dim3(n_seg), dim3(64), 0, stream, arena, pos0, lim, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long);
+    hipLaunchKernelGGL(k_decode_seg, dim3(n_seg), dim3(64), 0, stream, arena, pos0, lim, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
 }
 void launch_long_fill(uint32_t n_seg, const uint32_t *seg_base, const uint32_t *seg_cnt, const uint32_t *seg_long_base, ExtractCfg cfg, ReadSoA soa,
                       uint32_t *long_list, hipStream_t stream) {
