@@ -501,7 +501,8 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         HIP_TRY(b_tmp.ensure(scan_tmp_words(n_rec) * 4 + 64));
         // per-segment outputs (no hot atomics): reuse the spare segment arrays as seg_iter / seg_long
         uint32_t *seg_iter = seg_cnt[cur ^ 1], *seg_long = (uint32_t *)seg_start[cur ^ 1], *seg_long_base = (uint32_t *)seg_exit[cur ^ 1];
-        launch_decode_seg(arena, pos0, lim, n_seg, seg_start[cur], seg_base, seg_cnt[cur], cfg, soa, seg_iter, seg_long, seg_cp, st);
+        launch_decode_seg(arena, pos0, lim, n_seg, seg_start[cur], seg_base, seg_cnt[cur], cfg, soa, seg_iter, seg_long, seg_cp,
+                          /*staged=*/span / n_rec <= kSparseRecordBytes, st);
         launch_scan_u32(soa.n_ev, ev_base, n_rec, d_sc + 4, b_tmp.as<uint32_t>(), st);
         launch_scan_u32(seg_iter, seg_iter, n_seg, d_sc + 8, b_tmp.as<uint32_t>(), st);
         launch_scan_u32(seg_long, seg_long_base, n_seg, d_sc + 5, b_tmp.as<uint32_t>(), st);

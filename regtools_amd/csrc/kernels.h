@@ -8,6 +8,7 @@
 namespace rgx {
 
 constexpr uint32_t kSegBytes = 16384;   // arena segment walked by one lane during record-boundary discovery
+constexpr uint32_t kSparseRecordBytes = 2048;   // mean record size above which k_decode_seg reads records in place instead of staging segments
 constexpr uint32_t kSegCpSlots = 64;     // checkpoints per segment: offset of every 8th record (a segment starts at most 457 records)
 constexpr uint64_t kChainEnd = ~0ull;   // "the record chain ended before this point" (truncated/corrupt stream)
 
@@ -83,7 +84,8 @@ struct ExtractCfg {
 // one wave per framing segment, segment bytes staged through LDS (replaces launch_seg_fill + launch_decode on the hot path)
 // seg_iter[s] = records of segment s that pass the region filter; seg_long[s] = its reads for the wave-per-read kernel
 void launch_decode_seg(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, const uint64_t *seg_start, const uint32_t *seg_base,
-                       const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, const uint16_t *seg_cp, hipStream_t stream);
+                       const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, const uint16_t *seg_cp,
+                       bool staged /* segment bytes through LDS (short records) or read in place (long records) */, hipStream_t stream);
 void launch_long_fill(uint32_t n_seg, const uint32_t *seg_base, const uint32_t *seg_cnt, const uint32_t *seg_long_base, ExtractCfg cfg, ReadSoA soa,
                       uint32_t *long_list, hipStream_t stream);
 

@@ -273,11 +273,15 @@ void launch_seg_truncate(uint64_t pos0, uint64_t lim, uint32_t n_seg, uint32_t l
 // Scattered 4-byte global reads of the record heads (one 64 B HBM sector per field group) become a streaming read.
 constexpr uint32_t kSegTail = 1024;                      // bytes past the segment end kept in LDS (record bodies)
 constexpr uint32_t kSegMaxRecs = kSegBytes / 36 + 2;     // a record is at least 36 bytes
+// STAGED = false is the form for long records (kilobytes of sequence and quality per record, two or three records per segment):
+// nothing is staged, heads / CIGAR / aux are read where they lie, and the 95 % of the stream that is sequence and quality never
+// leaves HBM.  The host picks it when the mean record is longer than kSparseRecordBytes.
+template <bool STAGED>
 __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ arena, uint64_t pos0, uint64_t lim, uint32_t n_seg,
                                                    const uint64_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_base,
                                                    const uint32_t *__restrict__ seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter,
                                                    uint32_t *seg_long, const uint16_t *__restrict__ seg_cp) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_buf[kSegBytes + kSegTail + 48];
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_buf[];          // kSegBytes + kSegTail + 48 when STAGED, nothing otherwise
     __shared__ uint32_t s_off[kSegMaxRecs];
     const uint32_t s = blockIdx.x, lane = threadIdx.x;
     const uint32_t cnt = seg_cnt[s];
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
     const uint64_t w0 = a & ~15ull;
     uint64_t w1 = a + kSegBytes + kSegTail;
     if (w1 > lim) w1 = lim;
-    {
+    if constexpr (STAGED) {
         // all loads of the window in flight at once (18 x 1 KiB per wave), then the LDS stores: one HBM latency, not eighteen
         constexpr int kChunks = (kSegBytes + kSegTail + 16 + 1023) / 1024;
         u32x4 r[kChunks];
@@ -305,7 +309,10 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
     __syncthreads();
     // unaligned 32-bit read from the LDS window: two aligned dword reads + a byte funnel shift (v_alignbyte_b32)
     const uint32_t *s_w = (const uint32_t *)s_buf;
-    auto lds32 = [&](uint32_t off) -> uint32_t { return __builtin_amdgcn_alignbyte(s_w[(off >> 2) + 1], s_w[off >> 2], off & 3u); };
+    auto lds32 = [&](uint32_t off) -> uint32_t {
+        if constexpr (STAGED) return __builtin_amdgcn_alignbyte(s_w[(off >> 2) + 1], s_w[off >> 2], off & 3u);
+        else return ld32(arena + w0 + off);
+    };
     // chain walk inside LDS: lane j re-walks records 8j .. 8j+7 from the checkpoint the framing left (a segment holds at most
     // kSegMaxRecs = 457 records = 58 checkpoints)
     if (lane * 8 < cnt) {
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
         for (uint32_t k = lane * 8; k < k_end; ++k) {
             const uint32_t ro = (uint32_t)(o - w0);
             s_off[k] = ro;
-            o += 4 + (uint64_t)((o + 4 <= w1) ? lds32(ro) : ld32(arena + o));
+            o += 4 + (uint64_t)((STAGED && o + 4 <= w1) ? lds32(ro) : ld32(arena + o));
         }
     }
     __syncthreads();
@@ -327,12 +334,18 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
         RecHead h;
         {
             const uint32_t sh = ro & 3u, wi = ro >> 2;
-            uint32_t d[9];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) d[q] = s_w[wi + q];
             uint32_t x[8];
+            if constexpr (STAGED) {
+                uint32_t d[9];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) x[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh);
+                for (int q = 0; q < 9; ++q) d[q] = s_w[wi + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh);
+            } else {
+                (void)sh; (void)wi;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[q] = ld32(arena + o + 4 * q);
+            }
             h.block_len = (int32_t)x[0]; h.tid = (int32_t)x[1]; h.pos = (int32_t)x[2];
             h.l_qname = x[3] & 0xff; h.n_cigar = x[4] & 0xffff; h.flag = x[4] >> 16;
             h.l_qseq = (int32_t)x[5]; h.mtid = (int32_t)x[6];
@@ -340,7 +353,7 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
         }
         // body (CIGAR, aux) from the LDS window when the whole record is inside it, else straight from the arena
         const uint64_t rec_end = o + 4 + (uint64_t)(uint32_t)h.block_len;
-        const bool in_win = rec_end <= w1;
+        const bool in_win = STAGED && rec_end <= w1;
         const uint32_t cig_ro = ro + 36 + h.l_qname;
         const uint8_t *g_data = arena + o + 36;
         auto cigar_at = [&](uint32_t q) -> uint32_t { return in_win ? lds32(cig_ro + 4 * q) : ld32(g_data + h.l_qname + 4 * (size_t)q); };
@@ -405,9 +418,10 @@ __global__ __launch_bounds__(64) void k_long_fill(uint32_t n_seg, const uint32_t
 }
 
 void launch_decode_seg(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, const uint64_t *seg_start, const uint32_t *seg_base,
-                       const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, const uint16_t *seg_cp, hipStream_t stream) {
+                       const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, const uint16_t *seg_cp, bool staged, hipStream_t stream) {
     if (!n_seg) return;
-    hipLaunchKernelGGL(k_decode_seg, dim3(n_seg), dim3(64), 0, stream, arena, pos0, lim, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
+    if (staged) hipLaunchKernelGGL(k_decode_seg<true>, dim3(n_seg), dim3(64), kSegBytes + kSegTail + 48, stream, arena, pos0, lim, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
+    else hipLaunchKernelGGL(k_decode_seg<false>, dim3(n_seg), dim3(64), 0, stream, arena, pos0, lim, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
 }
 void launch_long_fill(uint32_t n_seg, const uint32_t *seg_base, const uint32_t *seg_cnt, const uint32_t *seg_long_base, ExtractCfg cfg, ReadSoA soa,
                       uint32_t *long_list, hipStream_t stream) {
