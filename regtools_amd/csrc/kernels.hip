@@ -811,15 +811,19 @@ __global__ void k_member_compact(const uint8_t *__restrict__ bam, const uint64_t
     isize_compact[r] = (isize[i] <= kBgzfMaxBlock) ? isize[i] : 0u;  // oversized/unusable members hold no bytes in the arena
 }
 
+// one block (the member count lives on the device; no host round trip): 256 threads x 8 consecutive members per trip
 __global__ __launch_bounds__(256) void k_member_upos(Member *members, const uint32_t *__restrict__ isz, const uint32_t *__restrict__ n_ptr, uint64_t *total) {
     __shared__ uint32_t s_wave[4];
     const uint32_t n = *n_ptr;
     uint64_t carry = 0;
-    for (uint32_t base = 0; base < n; base += 256) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < n ? isz[i] : 0u;
-        uint32_t tot; const uint32_t ex = block_excl_scan_256(v, s_wave, tot);   // 256 * 65536 < 2^32
-        if (i < n) members[i].upos = carry + ex;
+    for (uint32_t base = 0; base < n; base += 2048) {
+        const uint32_t i0 = base + threadIdx.x * 8;
+        uint32_t v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = i0 + k < n ? isz[i0 + k] : 0u; sum += v[k]; }     // 2048 * 65536 < 2^32
+        uint32_t tot; uint32_t ex = block_excl_scan_256(sum, s_wave, tot);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { if (i0 + k < n) members[i0 + k].upos = carry + ex; ex += v[k]; }
         carry += tot;
     }
     if (threadIdx.x == 0) *total = carry;
