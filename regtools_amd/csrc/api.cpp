@@ -548,10 +548,13 @@ struct HostRows {
     std::vector<uint32_t> group, start, end, ts, te, count, name_rank, first_seen, last_seen;
     std::vector<uint8_t> strand;
     size_t n = 0;
+    // the same rows as ten u32 columns of n entries in the context's pinned staging block (valid until the next call on the context);
+    // filled instead of the vectors when the caller asks for the view only
+    const uint32_t *cols = nullptr;
 };
 
 static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t group_bits, uint32_t ilen_bits, const uint32_t *rank_of_group_host,
-                         uint32_t n_groups, HostRows &R, char *err, size_t errlen) {
+                         uint32_t n_groups, HostRows &R, char *err, size_t errlen, bool view_only = false) {
     hipStream_t st = c->stream;
     uint32_t *d_sc = c->buf("scalars").as<uint32_t>();
     uint32_t *h_sc = (uint32_t *)c->pinned;
@@ -649,6 +652,8 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
         HIP_TRY(hipMemcpyAsync(c->pinned_rows, b_out.p, U * 40, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const uint32_t *hp = (const uint32_t *)c->pinned_rows;
+        R.cols = hp; R.n = U;
+        if (view_only) return RGX_OK;
         auto col = [&](size_t k, std::vector<uint32_t> &dst) { dst.assign(hp + k * U, hp + (k + 1) * U); };
         col(0, R.group); col(1, R.start); col(2, R.end); col(3, R.ts); col(4, R.te); col(5, R.count); col(6, R.name_rank); col(7, R.first_seen); col(8, R.last_seen);
         R.strand.resize(U);
@@ -683,17 +688,21 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     chrom_string_ranks(P.hdr, rank_of_tid);
     HostRows R;
     rc = reduce_events(c, P.ev, P.n_events, std::max<uint32_t>(1, bitlen((uint32_t)std::max(n_ref - 1, 0))), std::min<uint32_t>(32, bitlen(p->max_intron) + 2),
-                       rank_of_tid.data(), (uint32_t)std::max(n_ref, 1), R, err, errlen);
+                       rank_of_tid.data(), (uint32_t)std::max(n_ref, 1), R, err, errlen, /*view_only=*/true);
     if (rc != RGX_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev[6], st));
     rgx_junction_table *t = table_alloc(P.hdr, R.n);
-    for (size_t i = 0; i < R.n; ++i) {
-        t->tid[i] = (int32_t)R.group[i]; t->start[i] = R.start[i]; t->end[i] = R.end[i]; t->thick_start[i] = R.ts[i]; t->thick_end[i] = R.te[i];
-        t->read_count[i] = R.count[i]; t->name_index[i] = R.name_rank[i]; t->first_seen[i] = R.first_seen[i]; t->last_seen[i] = R.last_seen[i];
-        t->strand[i] = (char)R.strand[i];
-        // OR over reads of (start - thick_start >= a) == test on the minimum
-        t->left_ok[i] = (uint32_t)(t->start[i] - t->thick_start[i]) >= p->min_anchor;
-        t->right_ok[i] = (uint32_t)(t->thick_end[i] - t->end[i]) >= p->min_anchor;
+    {
+        const size_t U = R.n;
+        const uint32_t *hp = R.cols;     // columns: tid,start,end,ts,te,count,name_rank,first_seen,last_seen,strand
+        for (size_t i = 0; i < U; ++i) {
+            t->tid[i] = (int32_t)hp[i]; t->start[i] = hp[U + i]; t->end[i] = hp[2 * U + i]; t->thick_start[i] = hp[3 * U + i]; t->thick_end[i] = hp[4 * U + i];
+            t->read_count[i] = hp[5 * U + i]; t->name_index[i] = hp[6 * U + i]; t->first_seen[i] = hp[7 * U + i]; t->last_seen[i] = hp[8 * U + i];
+            t->strand[i] = (char)hp[9 * U + i];
+            // OR over reads of (start - thick_start >= a) == test on the minimum
+            t->left_ok[i] = (uint32_t)(t->start[i] - t->thick_start[i]) >= p->min_anchor;
+            t->right_ok[i] = (uint32_t)(t->thick_end[i] - t->end[i]) >= p->min_anchor;
+        }
     }
     if (R.n >= 100000000u) host_sort_rows(t);   // names wider than 8 digits compare as strings upstream
     t->n_records = P.n_iterated;
