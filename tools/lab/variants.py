@@ -27,6 +27,9 @@ def occ16(s):
     return s
 occ16.kernels2 = [("constexpr uint32_t kHotSyms = 160;", "constexpr uint32_t kHotSyms = 96;"), ("amdgpu_waves_per_eu(3, 3)", "amdgpu_waves_per_eu(4, 4)")]
 
+def cond_wait(s):       # the explicit vmcnt(0) only on trips that issued copy loads
+    return sub(s, "        __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0), expcnt/lgkmcnt untouched", "        if (copying) __builtin_amdgcn_s_waitcnt(0x0F70);")
+
 def lds_bytes(nbytes):
     def f(s):
         return s
@@ -40,6 +43,7 @@ VARIANTS = {
     "nostore": [no_stores],
     "decode_only": [no_copy_loads, no_stores],
     "occ5": [lds_bytes(32768)],
+    "condwait": [cond_wait],
     "occ16": [occ16],
 }
 
