@@ -7,3 +7,24 @@ extern "C" int emu_inflate(const uint8_t *in, uint32_t in_len, uint8_t *out, uin
     rgx::HostTab T;
     return rgx::inflate_raw(in, in_len, out, cap, out_len, T);
 }
+
+// ---- the per-alignment cores of bam_core.h / cse_core.h, as the kernels call them ---------------------------------------------
+#include "../../regtools_amd/csrc/bam_core.h"
+#include "../../regtools_amd/csrc/cse_core.h"
+
+struct emu_candidate { uint32_t start, end, thick_start, thick_end; };
+
+extern "C" int emu_cigar_walk(int32_t pos, const uint32_t *cigar, uint32_t n_cigar, emu_candidate *out, int max_out) {
+    int n = 0;
+    rgx::cigar_walk(pos, reinterpret_cast<const uint8_t *>(cigar), n_cigar, [&](uint32_t s, uint32_t e, uint32_t ts, uint32_t te) {
+        if (n < max_out) out[n] = emu_candidate{s, e, ts, te};
+        ++n;
+    });
+    return n;
+}
+extern "C" int emu_strand_from_flag(uint32_t flag, int strandness) { return rgx::strand_from_flag(flag, strandness); }
+extern "C" int emu_strand_from_tag(const uint8_t *aux, uint32_t len, uint8_t t0, uint8_t t1) { return rgx::strand_from_tag(aux, aux + len, t0, t1); }
+extern "C" uint32_t emu_ucsc_bin(uint32_t start, uint32_t end) { return rgx::ucsc_bin(start, end); }
+extern "C" int32_t emu_rec_endpos(const uint32_t *cigar, uint32_t n_cigar, uint32_t flag, int32_t pos) {
+    return rgx::rec_endpos(reinterpret_cast<const uint8_t *>(cigar), n_cigar, flag, pos);
+}
