@@ -216,6 +216,20 @@ int  rgx_annotate_junctions(rgx_ctx *ctx, const rgx_gtf *g, uint64_t n, const ch
                             const char *strand, rgx_junction_annot **out, char *err, size_t errlen);
 void rgx_junction_annot_free(rgx_junction_annot *a);
 
+/* a9: the window join on its own.  For every window w (contig name, 0-based half-open [beg, end) as sam_itr_querys leaves a region)
+ * the junction table that `junctions extract -r` over that window would produce with the parameters in p (p->region is ignored):
+ * only reads with pos < end && endpos > beg count, so read_count / thick bounds / names are window-restricted.  The BAM is inflated
+ * and scanned ONCE for all windows.  Rows come window-major in input order, inside a window in get_all_junctions order; name_index
+ * restarts at 1 in every window.  A contig that is not in the BAM header is an error (RGX_ERR_REGION), as upstream. */
+typedef struct {
+    uint64_t n;
+    uint32_t *window, *start, *end, *thick_start, *thick_end, *read_count, *name_index;
+    char *strand;
+} rgx_window_rows;
+int  rgx_window_join(rgx_ctx *ctx, const char *bam_path, const rgx_extract_params *p, uint64_t n_windows, const char *const *chrom,
+                     const int32_t *beg, const int32_t *end, rgx_window_rows **out, char *err, size_t errlen);
+void rgx_window_rows_free(rgx_window_rows *r);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,7 +42,7 @@ EXPORTS = ["rgx_extract_params_default", "rgx_ctx_create", "rgx_ctx_destroy", "r
            "rgx_table_format_bed12", "rgx_version", "rgx_k_inflate",
            "rgx_identify_params_default", "rgx_identify", "rgx_gtf_load", "rgx_gtf_free", "rgx_gtf_info", "rgx_gtf_transcript_bin",
            "rgx_gtf_transcript_id", "rgx_variant_windows", "rgx_variant_hits_free", "rgx_annotate_junctions", "rgx_junction_annot_free",
-           "rgx_associate", "rgx_variants_annotate", "rgx_junctions_annotate", "rgx_table_merge_device"]
+           "rgx_associate", "rgx_variants_annotate", "rgx_junctions_annotate", "rgx_table_merge_device", "rgx_window_join", "rgx_window_rows_free"]
 
 
 class IdentifyParams(C.Structure):
@@ -62,6 +62,11 @@ class IdentifyStats(C.Structure):
 class VariantHits(C.Structure):
     _fields_ = [("n", C.c_uint64), ("cis_start", C.POINTER(C.c_uint32)), ("cis_end", C.POINTER(C.c_uint32)), ("hit_off", C.POINTER(C.c_uint32)),
                 ("hit_transcript", C.POINTER(C.c_uint32)), ("hit_annotation", C.POINTER(C.c_uint32)), ("hit_distance", C.POINTER(C.c_uint32))]
+
+
+class WindowRows(C.Structure):
+    _fields_ = [("n", C.c_uint64)] + [(k, C.POINTER(C.c_uint32)) for k in ("window", "start", "end", "thick_start", "thick_end", "read_count", "name_index")] + \
+               [("strand", C.POINTER(C.c_char))]
 
 
 class JunctionAnnot(C.Structure):
@@ -132,6 +137,8 @@ def lib():
         L.rgx_annotate_junctions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_char_p), P(C.c_uint32), P(C.c_uint32), C.c_char_p,
                                              P(P(JunctionAnnot)), C.c_char_p, C.c_size_t]
         L.rgx_junction_annot_free.argtypes = [P(JunctionAnnot)]
+        L.rgx_window_join.argtypes = [C.c_void_p, C.c_char_p, P(ExtractParams), C.c_uint64, P(C.c_char_p), P(C.c_int32), P(C.c_int32), P(P(WindowRows)), C.c_char_p, C.c_size_t]
+        L.rgx_window_rows_free.argtypes = [P(WindowRows)]
         _lib = L
     return _lib
 

@@ -122,3 +122,52 @@ def test_cli_identify_and_errors(gpu_ctx, work):
     assert run(q["vcf"], q["bam"], q["fasta"], q["gtf"]) == 1                        # no -s
     assert run("-s", "XS", "nope.vcf", q["bam"], q["fasta"], q["gtf"]) == 1         # file_qc
     assert run("-s", "bogus", q["vcf"], q["bam"], q["fasta"], q["gtf"]) == 1
+
+
+def test_window_join_equals_one_extraction_per_window(gpu_ctx, work):
+    """rgx_window_join (row a9 on its own): for each window the rows equal what `junctions extract -r chr:beg-end` prints for it
+    (window-restricted counts, thick bounds and names), while the BAM is inflated and scanned once for all windows."""
+    import random
+    from regtools_amd import _ffi, synth
+    from conftest import run_oracle
+    L = _ffi.lib()
+    for shape, n, seed, contigs in (("short", 150000, 31, [("chr1", 248956422), ("chr7", 159345973), ("chrX", 156040895)]),
+                                    ("fuzz", 60000, 32, [("1", 600000), ("10", 300000), ("2", 500000), ("MT", 16569)])):
+        bam = os.path.join(str(work), "wj_%s.bam" % shape)
+        synth.write(bam, n, shape=shape, seed=seed)
+        rnd = random.Random(seed)
+        wins = []
+        for k in range(14):
+            name, ln = rnd.choice(contigs)
+            beg = rnd.randrange(0, ln - 10)
+            span = rnd.choice([500, 20000, 2000000, ln])
+            wins.append((name, beg, min(ln, beg + span)))
+        wins.append((contigs[0][0], 0, contigs[0][1]))
+        wins.append(wins[3])                                        # the same window twice: two independent result groups
+        p = _ffi.ExtractParams(); L.rgx_extract_params_default(C.byref(p)); p.strandness = 0
+        W = len(wins)
+        chrom = (C.c_char_p * W)(*[w[0].encode() for w in wins])
+        beg = (C.c_int32 * W)(*[w[1] for w in wins]); end = (C.c_int32 * W)(*[w[2] for w in wins])
+        out = C.POINTER(_ffi.WindowRows)(); err = C.create_string_buffer(512)
+        rc = L.rgx_window_join(gpu_ctx._h, bam.encode(), C.byref(p), W, chrom, beg, end, C.byref(out), err, len(err))
+        assert rc == 0, err.value
+        r = out.contents
+        got = {w: [] for w in range(W)}
+        for i in range(r.n):
+            s, e, ts, te = r.start[i], r.end[i], r.thick_start[i], r.thick_end[i]
+            if s - ts >= 8 and te - e >= 8:                         # print_all_junctions keeps anchored rows only
+                got[r.window[i]].append("%s\t%d\t%d\tJUNC%08d\t%d\t%s\t%d\t%d\t255,0,0\t2\t%d,%d\t0,%d\n" % (
+                    wins[r.window[i]][0], ts, te, r.name_index[i], r.read_count[i], r.strand[i].decode(), ts, te, s - ts, te - e, e - ts))
+        nonempty = 0
+        for w, (name, b0, e0) in enumerate(wins):
+            rc, exp, _ = run_oracle(["-s", "XS", "-r", "%s:%d-%d" % (name, b0 + 1, e0), bam])
+            assert rc == 0
+            assert "".join(got[w]).encode() == exp, (shape, w, wins[w])
+            nonempty += bool(exp)
+        assert nonempty >= 4
+        L.rgx_window_rows_free(out)
+    # an unknown contig is the reference's region error
+    chrom = (C.c_char_p * 1)(b"chrNope"); beg = (C.c_int32 * 1)(0); end = (C.c_int32 * 1)(10)
+    out = C.POINTER(_ffi.WindowRows)()
+    assert L.rgx_window_join(gpu_ctx._h, bam.encode(), C.byref(p), 1, chrom, beg, end, C.byref(out), err, len(err)) != 0
+    assert b"Unable to iterate to region" in err.value
