@@ -733,8 +733,8 @@ extern "C" int rgx_extract_mem(rgx_ctx *ctx, const void *bam, size_t bam_len, co
 
 extern "C" int rgx_extract(rgx_ctx *ctx, const char *bam_path, const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen) {
     if (!ctx || !bam_path || !out) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
-    std::vector<uint8_t> bam, bai;
-    if (!read_file(bam_path, bam)) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
+    FileBytes bam; std::vector<uint8_t> bai;
+    if (!bam.open(bam_path)) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
     std::string idx;
     int r = find_index(bam_path, idx);
     if (r != 0 || !read_file(idx, bai)) return fail(err, errlen, RGX_ERR_INDEX, "%s", kMsgIndex);

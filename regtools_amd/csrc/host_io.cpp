@@ -1,6 +1,11 @@
 // host_io.cpp -- see host_io.h.
 #include "host_io.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <ctype.h>
 #include <limits.h>
 #include <stdio.h>
@@ -116,6 +121,27 @@ bool read_file(const std::string &path, std::vector<uint8_t> &out) {
     bool ok = n == 0 || fread(out.data(), 1, (size_t)n, f) == (size_t)n;
     fclose(f);
     return ok;
+}
+
+FileBytes::~FileBytes() { if (mapped && p && n) munmap(const_cast<uint8_t *>(p), n); }
+
+bool FileBytes::open(const std::string &path) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            ::close(fd);
+            (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+            p = static_cast<const uint8_t *>(m); n = (size_t)st.st_size; mapped = true;
+            return true;
+        }
+    }
+    ::close(fd);
+    if (!read_file(path, own)) return false;
+    p = own.data(); n = own.size();
+    return true;
 }
 
 int parse_bam_header(const uint8_t *d, uint64_t have, BamHeader &h, uint64_t &need) {

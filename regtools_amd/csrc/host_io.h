@@ -36,6 +36,21 @@ int find_index(const std::string &bam_path, std::string &out);
 
 bool read_file(const std::string &path, std::vector<uint8_t> &out);
 
+// The bytes of a (large) input file without a private copy: a read-only mapping for regular files -- the upload to the device reads
+// straight from the page cache -- and a plain read for everything else (pipes, /dev/stdin).
+struct FileBytes {
+    const uint8_t *p = nullptr; size_t n = 0;
+    bool mapped = false;
+    std::vector<uint8_t> own;
+    FileBytes() = default;
+    FileBytes(const FileBytes &) = delete;
+    FileBytes &operator=(const FileBytes &) = delete;
+    ~FileBytes();
+    bool open(const std::string &path);
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+};
+
 // sam.c:114-223 bam_hdr_read on the first bytes of the inflated stream.
 // returns 0 ok, 1 need more bytes (need set), 2 bad magic
 struct BamHeader { std::vector<std::string> names; std::vector<uint32_t> lens; uint64_t end = 0; };
