@@ -1,5 +1,6 @@
 // cse_host.cpp -- see cse_host.h.  Citations relative to /root/reference/src.
 #include "cse_host.h"
+#include "host_io.h"
 
 #include <ctype.h>
 #include <stdio.h>
@@ -11,6 +12,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <thread>
 #include <numeric>
 
 #include "cse_core.h"
@@ -100,57 +102,93 @@ static long field_atol(const char *s, size_t n) {
 }
 
 std::string GtfModel::load(const std::string &path) {
-    std::string text;
-    if (!slurp(path, text)) return "\nUnable to open GTF file.";
+    FileBytes file;
+    if (!file.open(path, /*populate=*/true)) return "\nUnable to open GTF file.";
+    const char *text = (const char *)file.data();
+    const size_t text_len = file.size();
+    // ---- pass 1 (threads): every line -> at most one exon record; the pieces are views into the mapped text ---------------------
+    struct Rec { const char *tid; const char *attrs; const char *chrom; uint32_t tid_len, attrs_len, chrom_len, s, e; uint8_t strand; };
+    struct Part { std::vector<Rec> recs; size_t err_pos = SIZE_MAX; const char *err = nullptr; };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_parts = text_len < (1u << 22) ? 1 : std::min<size_t>(hw ? hw : 4, 16);
+    std::vector<size_t> cut(n_parts + 1, text_len);
+    cut[0] = 0;
+    for (size_t k = 1; k < n_parts; ++k) {                                   // cut points just after a newline
+        size_t q = text_len * k / n_parts;
+        const char *nl = (const char *)memchr(text + q, '\n', text_len - q);
+        cut[k] = nl ? (size_t)(nl - text) + 1 : text_len;
+    }
+    std::vector<Part> parts(n_parts);
+    auto scan = [&](size_t k) {
+        Part &P = parts[k];
+        size_t pos = cut[k];
+        const size_t lim = cut[k + 1];
+        while (pos < lim) {
+            const char *nl = (const char *)memchr(text + pos, '\n', lim - pos);
+            const size_t e = nl ? (size_t)(nl - text) : lim;
+            const char *line = text + pos; const size_t ll = e - pos;
+            const size_t line_pos = pos;
+            pos = e + 1;
+            if (ll == 0) { P.err_pos = line_pos; P.err = "basic_string::at"; return; }          // line.at(0) throws (gtf_parser.cc:230)
+            if (line[0] == '#') continue;
+            // Tokenize on tabs (std::getline semantics: no empty field after a trailing tab); exactly 9 fields or the run dies
+            const char *fb[10]; size_t fl[10]; size_t nf = 0;
+            for (size_t i = 0;;) {
+                const char *t = (const char *)memchr(line + i, '\t', ll - i);
+                const size_t j = t ? (size_t)(t - line) : ll;
+                if (nf < 10) { fb[nf] = line + i; fl[nf] = j - i; }
+                ++nf;
+                if (j >= ll) break;
+                i = j + 1;
+                if (i >= ll) break;
+            }
+            if (nf != 9) { P.err_pos = line_pos; P.err = "Expected 9 fields in GTF line."; return; }   // gtf_parser.cc:67-70
+            if (!(fl[2] == 4 && !memcmp(fb[2], "exon", 4))) continue;
+            const char *tv; size_t tl;
+            if (!gtf_attr_view(fb[8], fl[8], "transcript_id", 13, tv, tl) || (tl == 2 && !memcmp(tv, "NA", 2))) continue;   // gtf_parser.cc:118
+            P.recs.push_back(Rec{tv, fb[8], fb[0], (uint32_t)tl, (uint32_t)fl[8], (uint32_t)fl[0], (uint32_t)field_atol(fb[3], fl[3]), (uint32_t)field_atol(fb[4], fl[4]),
+                                 fl[6] == 1 ? (uint8_t)fb[6][0] : (uint8_t)'?'});
+        }
+    };
+    if (n_parts == 1) scan(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < n_parts; ++k) th.emplace_back(scan, k);
+        for (auto &t : th) t.join();
+    }
+    // ---- pass 2 (serial, file order): group exon records by transcript; the first bad line in file order ends the run, as upstream ---
     struct Tmp { std::string id, gene_name, gene_id; int32_t chrom; uint8_t strand; uint32_t n = 0; };
     std::vector<Tmp> tmp;
     std::vector<uint32_t> ex_tx, ex_s, ex_e;                                       // exon lines in file order
     const char *last_tv = nullptr; size_t last_tl = 0; uint32_t last_k = 0;        // exon lines of a transcript are usually adjacent
     struct SvHash { size_t operator()(const std::pair<const char *, size_t> &k) const { uint64_t h = 1469598103934665603ull; for (size_t i = 0; i < k.second; ++i) h = (h ^ (uint8_t)k.first[i]) * 1099511628211ull; return (size_t)h; } };
     struct SvEq { bool operator()(const std::pair<const char *, size_t> &a, const std::pair<const char *, size_t> &b) const { return a.second == b.second && !memcmp(a.first, b.first, a.second); } };
-    std::unordered_map<std::pair<const char *, size_t>, uint32_t, SvHash, SvEq> by_id;     // keys are views into `text`
+    std::unordered_map<std::pair<const char *, size_t>, uint32_t, SvHash, SvEq> by_id;     // keys are views into the mapped text
     by_id.reserve(1 << 16);
-    size_t pos = 0;
-    while (pos < text.size()) {
-        const char *nl = (const char *)memchr(text.data() + pos, '\n', text.size() - pos);
-        const size_t e = nl ? (size_t)(nl - text.data()) : text.size();
-        const char *line = text.data() + pos; const size_t ll = e - pos;
-        pos = e + 1;
-        if (ll == 0) return "basic_string::at";                                   // line.at(0) throws (gtf_parser.cc:230)
-        if (line[0] == '#') continue;
-        // Tokenize on tabs (std::getline semantics: no empty field after a trailing tab); exactly 9 fields or the run dies
-        const char *fb[10]; size_t fl[10]; size_t nf = 0;
-        for (size_t i = 0;;) {
-            const char *t = (const char *)memchr(line + i, '\t', ll - i);
-            const size_t j = t ? (size_t)(t - line) : ll;
-            if (nf < 10) { fb[nf] = line + i; fl[nf] = j - i; }
-            ++nf;
-            if (j >= ll) break;
-            i = j + 1;
-            if (i >= ll) break;
+    { size_t total = 0; for (auto &P : parts) total += P.recs.size(); ex_tx.reserve(total); ex_s.reserve(total); ex_e.reserve(total); }
+    for (size_t k = 0; k < n_parts; ++k) {
+        const Part &P = parts[k];
+        for (const Rec &r : P.recs) {
+            uint32_t t;
+            if (last_tv && r.tid_len == last_tl && !memcmp(r.tid, last_tv, last_tl)) t = last_k;
+            else if (auto it = by_id.find({r.tid, r.tid_len}); it != by_id.end()) t = it->second;
+            else {
+                t = (uint32_t)tmp.size(); by_id.emplace(std::make_pair(r.tid, (size_t)r.tid_len), t);
+                Tmp x; x.id.assign(r.tid, r.tid_len);
+                x.gene_name = gtf_attr(r.attrs, r.attrs_len, "gene_name");          // first exon line seen wins (gtf_parser.cc:266-273)
+                x.gene_id = gtf_attr(r.attrs, r.attrs_len, "gene_id");
+                std::string cn(r.chrom, r.chrom_len);
+                auto ci = chrom_index.find(cn);
+                if (ci == chrom_index.end()) { ci = chrom_index.emplace(cn, (int32_t)chroms.size()).first; chroms.push_back(cn); }
+                x.chrom = ci->second;
+                x.strand = r.strand;
+                tmp.push_back(std::move(x));
+            }
+            last_tv = r.tid; last_tl = r.tid_len; last_k = t;
+            ++tmp[t].n;
+            ex_tx.push_back(t); ex_s.push_back(r.s); ex_e.push_back(r.e);
         }
-        if (nf != 9) return "Expected 9 fields in GTF line.";                     // gtf_parser.cc:67-70
-        if (!(fl[2] == 4 && !memcmp(fb[2], "exon", 4))) continue;
-        const char *tv; size_t tl;
-        if (!gtf_attr_view(fb[8], fl[8], "transcript_id", 13, tv, tl) || (tl == 2 && !memcmp(tv, "NA", 2))) continue;   // gtf_parser.cc:118
-        uint32_t k;
-        if (last_tv && tl == last_tl && !memcmp(tv, last_tv, tl)) k = last_k;
-        else if (auto it = by_id.find({tv, tl}); it != by_id.end()) k = it->second;
-        else {
-            k = (uint32_t)tmp.size(); by_id.emplace(std::make_pair(tv, tl), k);
-            Tmp t; t.id.assign(tv, tl);
-            t.gene_name = gtf_attr(fb[8], fl[8], "gene_name");                    // first exon line seen wins (gtf_parser.cc:266-273)
-            t.gene_id = gtf_attr(fb[8], fl[8], "gene_id");
-            std::string cn(fb[0], fl[0]);
-            auto ci = chrom_index.find(cn);
-            if (ci == chrom_index.end()) { ci = chrom_index.emplace(cn, (int32_t)chroms.size()).first; chroms.push_back(cn); }
-            t.chrom = ci->second;
-            t.strand = fl[6] == 1 ? (uint8_t)fb[6][0] : (uint8_t)'?';
-            tmp.push_back(std::move(t));
-        }
-        last_tv = tv; last_tl = tl; last_k = k;
-        ++tmp[k].n;
-        ex_tx.push_back(k); ex_s.push_back((uint32_t)field_atol(fb[3], fl[3])); ex_e.push_back((uint32_t)field_atol(fb[4], fl[4]));
+        if (P.err) return P.err;                                                   // everything before it was consumed, nothing after it matters
     }
     // exons grouped by transcript, file order kept inside a group (one counting pass instead of 250 k small vectors)
     std::vector<uint32_t> goff(tmp.size() + 1, 0), gs(ex_tx.size()), ge(ex_tx.size());

@@ -125,12 +125,12 @@ bool read_file(const std::string &path, std::vector<uint8_t> &out) {
 
 FileBytes::~FileBytes() { if (mapped && p && n) munmap(const_cast<uint8_t *>(p), n); }
 
-bool FileBytes::open(const std::string &path) {
+bool FileBytes::open(const std::string &path, bool populate) {
     const int fd = ::open(path.c_str(), O_RDONLY);
     if (fd < 0) return false;
     struct stat st;
     if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
-        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | (populate ? MAP_POPULATE : 0), fd, 0);
         if (m != MAP_FAILED) {
             ::close(fd);
             (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
