@@ -34,3 +34,24 @@ def quartet(seed, n_genes, tmp, oracle_cli):
 
 def read(path):
     return open(path, "rb").read()
+
+
+def malformed_gtfs(tmp):
+    """(path, exit status of the reference, header-only?) -- verified against the real reference (oracle/_ref) in the dev container.  An empty line
+    makes the reference die with an uncaught std::out_of_range (status 134); here that is an ordinary error (status 1)."""
+    g = read(os.path.join(REF, "test_ensemble_chr22.gtf")).decode().splitlines()
+    first_exon = next(i for i, l in enumerate(g) if "\texon\t" in l)
+    out = []
+
+    def put(name, lines, rc):
+        p = os.path.join(str(tmp), name)
+        open(p, "w").write("\n".join(lines) + "\n")
+        out.append((p, rc))
+    put("empty_line.gtf", g[:20] + [""] + g[20:], 1)
+    put("eight_fields.gtf", g[:20] + ["\t".join(g[20].split("\t")[:8])] + g[21:], 1)
+    put("comment_inside.gtf", g[:20] + ["#comment"] + g[20:], 0)
+    f = g[first_exon].split("\t"); f[6] = "."
+    put("no_strand_first_exon.gtf", g[:first_exon] + ["\t".join(f)] + g[first_exon + 1:], 1)
+    f = g[first_exon + 1].split("\t"); f[6] = "."
+    put("no_strand_later_exon.gtf", g[:first_exon + 1] + ["\t".join(f)] + g[first_exon + 2:], 0)
+    return out

@@ -107,3 +107,14 @@ def test_bed_reader_quirks_and_cli(gpu_ctx, work):
     assert r.returncode == 0 and ac.read(pre + ".tsv") == ac.read(os.path.join(ac.CSE_REF, "expected-cis-splice-effects-identify-default-annotatedjunctions.out"))
     for sub in (["junctions", "annotate", "-h"], ["variants", "annotate", "-h"], ["cis-splice-effects", "associate", "-h"]):
         assert subprocess.run([exe] + sub, stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode == 0
+
+
+def test_malformed_gtf_exit_codes(gpu_ctx, work):
+    import regtools_amd
+    bed, fa = os.path.join(ac.REF, "test_hcc1395_junctions.bed"), os.path.join(ac.CSE_REF, "test_chr22.fa")
+    for path, rc in ac.malformed_gtfs(work):
+        out = os.path.join(str(work), "mg.out")
+        got, msg = run_mirror(regtools_amd.JunctionsAnnotator(ctx=gpu_ctx), ["-o", out, bed, fa, path], "annotate")
+        assert got == rc, (path, msg)
+        if rc == 0:
+            assert ac.read(out) == ac.read(os.path.join(ac.REF, "expected-annotate.out")), path

@@ -77,3 +77,12 @@ def test_bed_reader_quirks(work, oracle_cli):
     assert annotate(rows[:5] + [""] + rows[5:]) == (0, exp[:6])
     rc, got = annotate(rows[:2] + ["\t".join(rows[2].split("\t")[:6])] + rows[3:])
     assert rc == 1 and got == exp[:3]
+
+
+def test_malformed_gtf_exit_codes(work, oracle_cli):
+    bed, fa = os.path.join(ac.REF, "test_hcc1395_junctions.bed"), os.path.join(ac.CSE_REF, "test_chr22.fa")
+    for path, rc in ac.malformed_gtfs(work):
+        out = os.path.join(str(work), "mg.out")
+        assert run([oracle_cli, "junctions-annotate", "-o", out, bed, fa, path]) == rc, path
+        if rc == 0:
+            assert ac.read(out) == ac.read(os.path.join(ac.REF, "expected-annotate.out")), path
