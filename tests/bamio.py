@@ -75,7 +75,9 @@ def write_bam(path, contigs, records, block=0xff00, level=6, extra_members_after
     """records: list of bytes (already serialised, coordinate-sorted). Members are cut every `block` bytes of the
     record stream (records may straddle members), plus optional explicit extra members (e.g. an empty one)."""
     out = bytearray()
-    out += bgzf_member(header_bytes(contigs), level)
+    hdr = header_bytes(contigs)
+    for k in range(0, len(hdr), 0xff00):                 # a header with thousands of contigs spans several members
+        out += bgzf_member(hdr[k:k + 0xff00], level)
     for m in extra_members_after_header:
         out += m
     stream = b"".join(records)

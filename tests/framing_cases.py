@@ -18,7 +18,26 @@ CONTIGS = [("chrA", 5000000), ("chrB", 3000000)]
 MAGIC = 123456789
 
 
+def build_big_header(path, seed=9):
+    """6,000 contigs: the BAM header alone spans five BGZF members, tids need 13 bits, output order is by contig NAME string."""
+    rnd = random.Random(seed)
+    contigs = [("s%d" % i, 200000 + 7 * i) for i in range(6000)]
+    recs = []
+    for tid in (3, 17, 170, 1700, 4000, 5999):
+        pos = 100
+        for k in range(60):
+            pos += rnd.randint(1, 400)
+            cigar = "%dM%dN%dM" % (rnd.randint(8, 60), rnd.choice([90, 500, 1200]), rnd.randint(8, 60)) if k % 3 else "50M"
+            recs.append(bamio.record(tid, pos, cigar, flag=rnd.choice([0, 16]), qname="h%d_%d" % (tid, k), aux=bamio.tagA("XS", "+-"[k & 1])))
+    from regtools_amd import synth
+    bamio.write_bam(path, contigs, recs)
+    synth.index(path)
+    return path
+
+
 def build(variant, path, seed=5, n_records=4000):
+    if variant == "big_header":
+        return build_big_header(path)
     rnd = random.Random(seed)
     first = 100000000 if variant == "huge" else MAGIC
     decoy = struct.pack("<iiiIIiiii", first, 0, 5, 1, 0, 0, -1, -1, 0) + b"\0"

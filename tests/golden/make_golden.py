@@ -144,6 +144,11 @@ def main():
             p = framing_cases.build(variant, os.path.join(td, "framing_%s.bam" % variant))
             add_case("framing_%s.XS" % variant, ["-s", "XS"], framing=variant, tmp_bam=p)
             add_case("framing_%s.RF.a20" % variant, ["-s", "RF", "-a", "20"], framing=variant, tmp_bam=p)
+        # (vi) a header of 6,000 contigs (five BGZF members of header before the first record)
+        p = framing_cases.build("big_header", os.path.join(td, "framing_big_header.bam"))
+        add_case("big_header.XS", ["-s", "XS"], framing="big_header", tmp_bam=p)
+        add_case("big_header.XS.r_s1700", ["-s", "XS", "-r", "s1700"], framing="big_header", tmp_bam=p)
+        add_case("big_header.XS.r_s5999_1-20000", ["-s", "XS", "-r", "s5999:1-20000"], framing="big_header", tmp_bam=p)
 
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(cases, f, indent=1)
