@@ -10,7 +10,8 @@ namespace rgx {
 constexpr uint32_t kSegBytes = 16384;   // arena segment walked by one lane during record-boundary discovery
 constexpr uint32_t kSparseRecordBytes = 2048;   // mean record size above which k_decode_seg reads records in place instead of staging segments
 constexpr uint32_t kSegCpSlots = 64;     // checkpoints per segment: offset of every 8th record (a segment starts at most 457 records)
-constexpr uint64_t kChainEnd = ~0ull;   // "the record chain ended before this point" (truncated/corrupt stream)
+constexpr uint64_t kChainEnd = ~0ull;
+constexpr uint64_t kChainUnknown = ~0ull - 1;   // exit of a segment in which the guess found nothing: no claim at all (not "the chain ended")   // "the record chain ended before this point" (truncated/corrupt stream)
 
 // ---- a1: BGZF inflate (one lane per member) -----------------------------------------------------------
 // member m writes its bytes at arena + (members[m].upos - upos_bias)

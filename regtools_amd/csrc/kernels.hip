@@ -193,7 +193,7 @@ __global__ void k_seg_walk(const uint8_t *__restrict__ arena, uint64_t pos0, uin
             if (ex != kChainEnd) { o = cand; break; }
             c = cand + 1;
         }
-        if (o == kChainEnd) { ex = kChainEnd; o = b; cnt = 0; }      // nothing usable: verification will settle it
+        if (o == kChainEnd) { ex = kChainUnknown; o = b; cnt = 0; }  // nothing usable: a placeholder that claims nothing (see k_seg_verify)
     } else ex = walk_chain(arena, o, b, lim, cnt, cp, a);
     seg_start[s] = o; seg_exit[s] = ex; seg_cnt[s] = cnt;
 }
@@ -205,15 +205,17 @@ __device__ __forceinline__ bool seg_consistent(uint64_t pos0, uint64_t lim, uint
     return expect >= b ? (st == b && ex == expect && cnt == 0) : st == expect;   // expect >= b (incl. kChainEnd): no record starts here
 }
 
-// One sweep.  A segment that disagrees with its left neighbour's exit is re-walked from that exit -- but only once the
-// neighbour itself agrees with ITS neighbour: a wrong exit (a speculative guess that landed on a false chain which never
-// re-joins the true one) is then repaired where it happened instead of being copied one segment to the right per sweep with the
-// repair trailing it to the end of the file.  Sweeps needed = longest run of consecutive disagreeing segments (+1 to see
-// "no change").  `changed` counts every disagreement, repaired or waiting, so the loop ends only when the whole chain agrees
-// -- which, segment 0 being exact, means it is exact.  status[0] = leftmost disagreeing segment (everything left of it is exact),
-// status[1] = leftmost segment whose chain ends (kChainEnd): when that one lies in the exact prefix the stream really ends
-// there (truncated / unreadable record, sam.c:421-423) and the host empties everything to its right in one launch instead of
-// one segment per sweep.
+// One sweep.  Segment states: a GUESS (start/exit from a walk that left the segment through readable records), or a PLACEHOLDER
+// (the search found nothing; exit = kChainUnknown: typical for the segments inside a record that is longer than a segment).
+//  * a placeholder adopts its left neighbour's exit as soon as that exit is a real value -- it has no opinion to defend, and runs of
+//    placeholders (long reads) resolve left to right, all runs of the file in parallel;
+//  * a guess that disagrees with its left neighbour's exit is re-walked from that exit only once the neighbour itself agrees with
+//    ITS neighbour: a wrong exit (a guess that landed on a false chain which never re-joins the true one) is then repaired where it
+//    happened instead of being copied one segment to the right per sweep with the repair trailing it to the end of the file.
+// Sweeps needed = longest run of consecutive placeholders / disagreeing guesses (+1 to see "no change").  status[0] = leftmost segment
+// that is not final yet, so the loop ends only when the whole chain agrees -- which, segment 0 being exact, means it is exact.
+// status[1] = leftmost segment whose chain ends (kChainEnd): when that one lies in the exact prefix the stream really ends there
+// (truncated / unreadable record, sam.c:421-423) and the host empties everything to its right in one launch.
 __global__ void k_seg_verify(const uint8_t *__restrict__ arena, uint64_t pos0, uint64_t lim, uint32_t n_seg,
                              const uint64_t *__restrict__ st_in, const uint64_t *__restrict__ ex_in, const uint32_t *__restrict__ cnt_in,
                              uint64_t *st_out, uint64_t *ex_out, uint32_t *cnt_out, uint32_t *status, uint16_t *seg_cp) {
@@ -224,10 +226,13 @@ __global__ void k_seg_verify(const uint8_t *__restrict__ arena, uint64_t pos0, u
     if (ex == kChainEnd && (s == 0 || ex_in[s - 1] != kChainEnd)) atomicMin(status + 1, s);
     if (s > 0) {
         const uint64_t expect = ex_in[s - 1];
-        if (!seg_consistent(pos0, lim, s, expect, st, ex, cnt)) {
+        if (expect == kChainUnknown) atomicMin(status, s);                      // the left neighbour knows nothing yet: wait
+        else if (!seg_consistent(pos0, lim, s, expect, st, ex, cnt)) {
             atomicMin(status, s);
-            const bool left_settled = s == 1 || seg_consistent(pos0, lim, s - 1, ex_in[s - 2], st_in[s - 1], expect, cnt_in[s - 1]);
-            if (left_settled) {
+            const bool placeholder = ex == kChainUnknown;
+            const bool left_settled = s == 1 || (ex_in[s - 2] != kChainUnknown &&
+                                                 seg_consistent(pos0, lim, s - 1, ex_in[s - 2], st_in[s - 1], expect, cnt_in[s - 1]));
+            if (placeholder || left_settled) {
                 uint64_t b = pos0 + (uint64_t)s * kSegBytes + kSegBytes;
                 if (b > lim) b = lim;
                 if (expect >= b) { st = b; ex = expect; cnt = 0; }

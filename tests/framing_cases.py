@@ -35,9 +35,36 @@ def build_big_header(path, seed=9):
     return path
 
 
+def build_ultralong(path, seed=13):
+    """Reads of 60-250 kb (records of up to 375 KB: dozens of 16 KiB framing segments in which no record starts) between ordinary ones."""
+    rnd = random.Random(seed)
+    contigs = [("chrL", 40000000)]
+    recs, pos = [], 1000
+    for k in range(90):
+        pos += rnd.randint(50, 3000)
+        if k % 3 == 0:
+            blocks = rnd.randint(3, 9)
+            ops = []
+            for b in range(blocks):
+                ops.append((rnd.randint(8000, 30000), 0))
+                if b + 1 < blocks:
+                    ops.append((rnd.choice([120, 900, 15000]), 3))
+            if rnd.random() < 0.5:
+                ops.insert(1, (rnd.randint(1, 40), 1))
+            recs.append(bamio.record(0, pos, ops, flag=rnd.choice([0, 16]), qname="ul%d" % k, aux=bamio.tagA("XS", "+-"[k & 1])))
+        else:
+            recs.append(bamio.record(0, pos, "%dM%dN%dM" % (rnd.randint(8, 70), rnd.choice([100, 2000]), rnd.randint(8, 70)), qname="s%d" % k, aux=bamio.tagA("XS", "+-"[k & 1])))
+    from regtools_amd import synth
+    bamio.write_bam(path, contigs, recs)
+    synth.index(path)
+    return path
+
+
 def build(variant, path, seed=5, n_records=4000):
     if variant == "big_header":
         return build_big_header(path)
+    if variant == "ultralong":
+        return build_ultralong(path)
     rnd = random.Random(seed)
     first = 100000000 if variant == "huge" else MAGIC
     decoy = struct.pack("<iiiIIiiii", first, 0, 5, 1, 0, 0, -1, -1, 0) + b"\0"

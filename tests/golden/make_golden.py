@@ -149,6 +149,11 @@ def main():
         add_case("big_header.XS", ["-s", "XS"], framing="big_header", tmp_bam=p)
         add_case("big_header.XS.r_s1700", ["-s", "XS", "-r", "s1700"], framing="big_header", tmp_bam=p)
         add_case("big_header.XS.r_s5999_1-20000", ["-s", "XS", "-r", "s5999:1-20000"], framing="big_header", tmp_bam=p)
+        # (vii) reads of up to 250 kb: records far longer than a BGZF member or a framing segment
+        p = framing_cases.build("ultralong", os.path.join(td, "framing_ultralong.bam"))
+        add_case("ultralong.XS", ["-s", "XS"], framing="ultralong", tmp_bam=p)
+        add_case("ultralong.RF.a0.M100000", ["-s", "RF", "-a", "0", "-M", "100000"], framing="ultralong", tmp_bam=p)
+        add_case("ultralong.XS.r_chrL_100000-150000", ["-s", "XS", "-r", "chrL:100000-150000"], framing="ultralong", tmp_bam=p)
 
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(cases, f, indent=1)

@@ -244,3 +244,12 @@ def test_rccl_gather_and_device_merge_single_rank(gpu_ctx, synth_dir):
         assert merged.bed12() == single and merged.n == je.table.contents.n
     finally:
         dist.destroy_process_group()
+
+
+def test_record_framing_runs_of_startless_segments_resolve_in_parallel(gpu_ctx, synth_dir):
+    """Thirty reads of up to 250 kb: each spans up to 23 framing segments in which no record starts.  The runs must resolve side by
+    side (sweeps ~ longest run), not one after the other (sweeps ~ sum of the runs = 280 here)."""
+    case = [c for c in cases.MANIFEST if c["name"] == "ultralong.XS"][0]
+    rc, out, je = gpu_extract(gpu_ctx, cases.case_bam(case, synth_dir), case["args"])
+    assert rc == 0 and out == cases.expected(case)
+    assert 1 <= je.stats["framing_sweeps"] <= 40, je.stats
