@@ -54,6 +54,14 @@ def build_ultralong(path, seed=13):
             recs.append(bamio.record(0, pos, ops, flag=rnd.choice([0, 16]), qname="ul%d" % k, aux=bamio.tagA("XS", "+-"[k & 1])))
         else:
             recs.append(bamio.record(0, pos, "%dM%dN%dM" % (rnd.randint(8, 70), rnd.choice([100, 2000]), rnd.randint(8, 70)), qname="s%d" % k, aux=bamio.tagA("XS", "+-"[k & 1])))
+    # one read with 12,001 CIGAR operations (6,000 introns): the wave-per-read emitter walks it in LDS-sized pieces
+    ops = []
+    for i in range(6000):
+        ops += [(rnd.randint(9, 30), 0), (rnd.choice([80, 100, 700]), 3)]
+    ops.append((25, 0))
+    pos += 5000
+    recs.append(bamio.record(0, pos, ops, flag=16, qname="manyops", aux=bamio.tagA("XS", "-")))
+    recs.append(bamio.record(0, pos + 10, "30M100N30M", qname="after", aux=bamio.tagA("XS", "-")))
     from regtools_amd import synth
     bamio.write_bam(path, contigs, recs)
     synth.index(path)

@@ -247,9 +247,10 @@ def test_rccl_gather_and_device_merge_single_rank(gpu_ctx, synth_dir):
 
 
 def test_record_framing_runs_of_startless_segments_resolve_in_parallel(gpu_ctx, synth_dir):
-    """Thirty reads of up to 250 kb: each spans up to 23 framing segments in which no record starts.  The runs must resolve side by
-    side (sweeps ~ longest run), not one after the other (sweeps ~ sum of the runs = 280 here)."""
+    """Thirty reads of up to 250 kb (up to 23 framing segments in which no record starts) and one read with 12,001 CIGAR operations.
+    The runs of start-less segments must resolve side by side (sweeps ~ longest run), not one after the other (sweeps ~ their sum,
+    about 300 here)."""
     case = [c for c in cases.MANIFEST if c["name"] == "ultralong.XS"][0]
     rc, out, je = gpu_extract(gpu_ctx, cases.case_bam(case, synth_dir), case["args"])
     assert rc == 0 and out == cases.expected(case)
-    assert 1 <= je.stats["framing_sweeps"] <= 40, je.stats
+    assert 1 <= je.stats["framing_sweeps"] <= 48, je.stats
