@@ -254,3 +254,63 @@ def test_record_framing_runs_of_startless_segments_resolve_in_parallel(gpu_ctx, 
     rc, out, je = gpu_extract(gpu_ctx, cases.case_bam(case, synth_dir), case["args"])
     assert rc == 0 and out == cases.expected(case)
     assert 1 <= je.stats["framing_sweeps"] <= 48, je.stats
+
+
+def test_inflate_kernel_on_adversarial_members(gpu_ctx):
+    """The DEFLATE kernel alone on members built to hit its corners: runs (distance 1..15 with distance doubling), maximum-length matches,
+    incompressible bytes (stored blocks), fixed-Huffman blocks, several blocks per member (Z_FULL_FLUSH), one-byte and empty-ish members,
+    every zlib level and strategy, and 64 lanes of a wave that each see a different kind of stream.  Compared with zlib byte for byte;
+    the arena is checked beyond every member's end (nothing may be written there)."""
+    import random
+    import torch
+    from regtools_amd import _ffi
+    rnd = random.Random(99)
+    datas = []
+    for k in range(260):
+        kind = k % 13
+        n = rnd.choice([1, 2, 15, 16, 17, 255, 256, 4000, 30000, 65280])
+        if kind == 0: d = bytes([rnd.randrange(256)]) * n
+        elif kind == 1: d = (bytes(rnd.randrange(256) for _ in range(rnd.randint(2, 15))) * (n // 2 + 1))[:n]
+        elif kind == 2: d = bytes(rnd.randrange(256) for _ in range(n))
+        elif kind == 3: d = bytes(rnd.choice(b"ACGT") for _ in range(n))
+        elif kind == 4: d = (bytes(rnd.randrange(256) for _ in range(300)) * (n // 300 + 1))[:n]
+        elif kind == 5: d = b"".join(bytes([rnd.randrange(256)]) * rnd.randint(1, 600) for _ in range(n // 100 + 1))[:n]
+        elif kind == 6: d = bytes((i * 7 + (i >> 8)) & 0xff for i in range(n))
+        elif kind == 7: d = (b"\x11" * 51 + b"\xff" * 101 + bytes(rnd.randrange(256) for _ in range(12))) * (n // 164 + 1)
+        elif kind == 8: d = bytes(rnd.choice(b"ab") for _ in range(n))
+        elif kind == 9: d = b"\0" * n
+        elif kind == 10: d = bytes(rnd.randrange(4) for _ in range(n))
+        elif kind == 11: d = (bytes(rnd.randrange(256) for _ in range(16)) * (n // 16 + 1))[:n]
+        else: d = bytes(rnd.randrange(256) if rnd.random() < 0.1 else 65 for _ in range(n))
+        datas.append(d[:n] if len(d) >= n else d)
+    members, expect, blob, upos = [], [], bytearray(), 0
+    for k, d in enumerate(datas):
+        level = [0, 1, 6, 9][k % 4]
+        strategy = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED][k % 5]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        if k % 7 == 3 and len(d) > 10:
+            payload = c.compress(d[: len(d) // 3]) + c.flush(zlib.Z_FULL_FLUSH) + c.compress(d[len(d) // 3:]) + c.flush()
+        else:
+            payload = c.compress(d) + c.flush()
+        if len(payload) > 65000:
+            continue
+        members.append((len(blob), upos, len(payload), len(d)))
+        blob += payload + bytes(rnd.randrange(256) for _ in range(rnd.randint(8, 40)))     # footer-like bytes between payloads
+        expect.append(d)
+        upos += len(d) + (k % 3) * 5                                                             # gaps: bytes no member owns
+    total = upos + 64
+    arr = (_ffi.Member * len(members))(*[_ffi.Member(*m) for m in members])
+    d_comp = torch.zeros(len(blob) + 64, dtype=torch.uint8, device="cuda")
+    d_comp[: len(blob)].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+    d_mem = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    d_arena = torch.full((total + 256,), 0xA5, dtype=torch.uint8, device="cuda")
+    d_status = torch.tensor([0xffffffff, 0], dtype=torch.int64).to(torch.uint32).cuda()
+    torch.cuda.synchronize()
+    rc = _ffi.lib().rgx_k_inflate(d_comp.data_ptr(), d_mem.data_ptr(), len(members), d_arena.data_ptr(), d_status.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rc == 0 and d_status.cpu().tolist()[0] == 0xffffffff
+    got = d_arena.cpu().numpy().tobytes()
+    want = bytearray(b"\xa5" * (total + 256))
+    for (cpos, up, clen, isz), d in zip(members, expect):
+        want[up: up + isz] = d
+    assert got == bytes(want)
