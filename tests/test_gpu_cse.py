@@ -171,3 +171,15 @@ def test_window_join_equals_one_extraction_per_window(gpu_ctx, work):
     out = C.POINTER(_ffi.WindowRows)()
     assert L.rgx_window_join(gpu_ctx._h, bam.encode(), C.byref(p), 1, chrom, beg, end, C.byref(out), err, len(err)) != 0
     assert b"Unable to iterate to region" in err.value
+
+
+def test_window_join_batches_give_the_same_files(gpu_ctx, work):
+    """The (window, event) pairs are materialised in batches of whole windows (REGTOOLS_AMD_PAIR_BATCH pairs per batch, 2^26 by default);
+    with a batch of 200 pairs every case below runs through dozens of batches and must still write the reference's three files."""
+    import sys
+    env = dict(os.environ, REGTOOLS_AMD_PAIR_BATCH="200")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_cse as t, pytest; "
+            "sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', '-k', 'test_equals_reference and (s1_00 or s2_03 or s3_07 or s1_11)', t.__file__]))"
+            % (ROOT, os.path.join(ROOT, "tests")))
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
