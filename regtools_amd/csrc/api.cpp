@@ -220,6 +220,11 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     auto mark = [&](const char *what) { if (trace) { double t = now_ms(); fprintf(stderr, "[rgx trace] %-28s +%8.3f ms  (at %8.3f)\n", what, t - t_last, t - t_begin); t_last = t; } };
 
     if (bam_len < 28) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
+    // -- index: ~1 ms of host parsing for a 5 MB .bai, done on a second host thread while this one feeds the device the member scan --
+    BaiInfo bi;
+    bool bai_ok = false;
+    std::thread bai_thread([&] { bai_ok = bai && parse_bai(bai, bai_len, bi, /*collect_anchors=*/false); });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } bai_joiner{bai_thread};
     // -- upload ----------------------------------------------------------------------------------------------------------
     const uint8_t *d_bam = d_bam_in;
     if (!d_bam) {
@@ -247,9 +252,31 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     launch_magic_count(d_bam, bam_len, n_tiles, tile_cnt, st);
     launch_scan_u32(tile_cnt, tile_cnt, n_tiles, d_sc + 16, tile_tmp, st);
     HIP_TRY(hipMemcpyAsync(h_sc + 16, d_sc + 16, 4, hipMemcpyDeviceToHost, st));
-    // -- index (host, ~1 ms for a 5 MB .bai): parsed while the device scans the file for BGZF members ------------------------------
-    BaiInfo bi;
-    if (!bai || !parse_bai(bai, bai_len, bi, /*collect_anchors=*/false)) return (void)hipStreamSynchronize(st), fail(err, errlen, RGX_ERR_INDEX, "%s", kMsgIndex);
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t n_cand = h_sc[16];
+    if (n_cand == 0) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
+    DevBuf &b_cand = c->buf("cand");
+    {
+        const size_t N = n_cand;
+        HIP_TRY(b_cand.ensure(N * 8 + N * 4 * 6 + scan_tmp_words(n_cand) * 4 + 256));
+        HIP_TRY(b_members.ensure((N + 1) * sizeof(Member)));
+    }
+    uint64_t *cand = b_cand.as<uint64_t>();
+    uint32_t *nx[2] = {(uint32_t *)(cand + n_cand), (uint32_t *)(cand + n_cand) + n_cand};
+    uint32_t *c_isize = nx[1] + n_cand, *c_reach = c_isize + n_cand, *c_rank = c_reach + n_cand, *c_isz2 = c_rank + n_cand, *c_tmp = c_isz2 + n_cand;
+    launch_magic_fill(d_bam, bam_len, n_tiles, tile_cnt, cand, st);
+    launch_member_link(d_bam, bam_len, cand, n_cand, nx[0], c_isize, c_reach, st);
+    {
+        int cur = 0;
+        for (uint32_t span = 1; span < n_cand; span <<= 1) { launch_member_jump(n_cand, nx[cur], nx[cur ^ 1], c_reach, st); cur ^= 1; }
+        launch_member_jump(n_cand, nx[cur], nx[cur ^ 1], c_reach, st);
+    }
+    launch_scan_u32(c_reach, c_rank, n_cand, d_sc + 17, c_tmp, st);
+    Member *d_members = b_members.as<Member>();
+    launch_member_compact(d_bam, cand, c_isize, c_reach, c_rank, n_cand, d_members, c_isz2, st);
+    launch_member_upos(d_members, c_isz2, d_sc + 17, (uint64_t *)(d_sc + 20), st);
+    bai_thread.join();
+    if (!bai_ok) return (void)hipStreamSynchronize(st), fail(err, errlen, RGX_ERR_INDEX, "%s", kMsgIndex);
     mark("parse_bai");
     const bool whole = !strcmp(p->region ? p->region : ".", ".");
     // where the record stream starts (hts.c:1721-1731 for ".")
@@ -275,29 +302,6 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         mark("shard cuts");
     }
 
-    HIP_TRY(hipStreamSynchronize(st));
-    const uint32_t n_cand = h_sc[16];
-    if (n_cand == 0) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
-    DevBuf &b_cand = c->buf("cand");
-    {
-        const size_t N = n_cand;
-        HIP_TRY(b_cand.ensure(N * 8 + N * 4 * 6 + scan_tmp_words(n_cand) * 4 + 256));
-        HIP_TRY(b_members.ensure((N + 1) * sizeof(Member)));
-    }
-    uint64_t *cand = b_cand.as<uint64_t>();
-    uint32_t *nx[2] = {(uint32_t *)(cand + n_cand), (uint32_t *)(cand + n_cand) + n_cand};
-    uint32_t *c_isize = nx[1] + n_cand, *c_reach = c_isize + n_cand, *c_rank = c_reach + n_cand, *c_isz2 = c_rank + n_cand, *c_tmp = c_isz2 + n_cand;
-    launch_magic_fill(d_bam, bam_len, n_tiles, tile_cnt, cand, st);
-    launch_member_link(d_bam, bam_len, cand, n_cand, nx[0], c_isize, c_reach, st);
-    {
-        int cur = 0;
-        for (uint32_t span = 1; span < n_cand; span <<= 1) { launch_member_jump(n_cand, nx[cur], nx[cur ^ 1], c_reach, st); cur ^= 1; }
-        launch_member_jump(n_cand, nx[cur], nx[cur ^ 1], c_reach, st);
-    }
-    launch_scan_u32(c_reach, c_rank, n_cand, d_sc + 17, c_tmp, st);
-    Member *d_members = b_members.as<Member>();
-    launch_member_compact(d_bam, cand, c_isize, c_reach, c_rank, n_cand, d_members, c_isz2, st);
-    launch_member_upos(d_members, c_isz2, d_sc + 17, (uint64_t *)(d_sc + 20), st);
     {
         uint64_t q[3] = {seek ? (seek_voff >> 16) : 0, cut_lo >> 16, cut_hi == UINT64_MAX ? UINT64_MAX - 64 : (cut_hi >> 16)};
         memcpy(h_sc + 40, q, sizeof q);
