@@ -113,6 +113,10 @@ int  rgx_table_merge(const rgx_junction_table *const *parts, int n_parts, uint32
 size_t rgx_table_pack(const rgx_junction_table *t, void *dst, size_t dst_cap); /* returns bytes needed */
 int    rgx_table_unpack(const void *src, size_t n_rows, const rgx_junction_table *names_from,
                         rgx_junction_table **out);
+/* rgx_table_pack without the host: t must be the result of the LAST rgx_extract / rgx_extract_mem / rgx_extract_device call on this
+ * context (its rows are then still in HBM; anything else is RGX_ERR_ARG and the caller packs on the host).  Writes t->n packed rows
+ * to device memory at d_dst -- the all-gather input of the multi-GPU path. */
+int    rgx_last_table_pack_device(rgx_ctx *ctx, const rgx_junction_table *t, void *d_dst, uint64_t cap_rows, char *err, size_t errlen);
 /* The same merge with the gathered rows STILL IN HBM (what an RCCL all-gather leaves there): shard g's packed rows start at
  * d_rows + g * stride_rows * 48 bytes and there are part_rows[g] of them.  Sort, reduce, naming and output order run on the
  * device; one copy of the final rows comes back.  first_seen/last_seen of the result are the merge's own order words. */

@@ -42,7 +42,7 @@ EXPORTS = ["rgx_extract_params_default", "rgx_ctx_create", "rgx_ctx_destroy", "r
            "rgx_table_format_bed12", "rgx_version", "rgx_k_inflate",
            "rgx_identify_params_default", "rgx_identify", "rgx_gtf_load", "rgx_gtf_free", "rgx_gtf_info", "rgx_gtf_transcript_bin",
            "rgx_gtf_transcript_id", "rgx_variant_windows", "rgx_variant_hits_free", "rgx_annotate_junctions", "rgx_junction_annot_free",
-           "rgx_associate", "rgx_variants_annotate", "rgx_junctions_annotate", "rgx_table_merge_device", "rgx_window_join", "rgx_window_rows_free"]
+           "rgx_associate", "rgx_variants_annotate", "rgx_junctions_annotate", "rgx_table_merge_device", "rgx_window_join", "rgx_window_rows_free", "rgx_last_table_pack_device"]
 
 
 class IdentifyParams(C.Structure):
@@ -116,6 +116,7 @@ def lib():
         L.rgx_table_pack.argtypes = [P(JunctionTable), C.c_void_p, C.c_size_t]
         L.rgx_table_pack.restype = C.c_size_t
         L.rgx_table_unpack.argtypes = [C.c_void_p, C.c_size_t, P(JunctionTable), P(P(JunctionTable))]
+        L.rgx_last_table_pack_device.argtypes = [C.c_void_p, P(JunctionTable), C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
         L.rgx_table_merge_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64), C.c_int, C.c_uint32, P(JunctionTable), P(P(JunctionTable)), C.c_char_p, C.c_size_t]
         L.rgx_table_format_bed12.argtypes = [P(JunctionTable), C.c_int, C.c_char_p, C.c_size_t]
         L.rgx_table_format_bed12.restype = C.c_size_t

@@ -69,7 +69,8 @@ struct rgx_ctx {
     hipEvent_t ev[8] = {};
     std::map<std::string, DevBuf> bufs;
     void *pinned = nullptr; size_t pinned_cap = 0;     // small pinned staging for scalar readbacks
-    void *pinned_rows = nullptr; size_t pinned_rows_cap = 0;   // grow-only pinned staging for whole result tables (device merge)
+    void *pinned_rows = nullptr; size_t pinned_rows_cap = 0;
+    uint64_t last_rows = 0, last_records = 0, last_events = 0, last_bytes = 0; bool last_rows_valid = false;      // rows of the last rgx_extract* call, still in the "rows_out" block in HBM   // grow-only pinned staging for whole result tables (device merge)
     std::string fasta_path;                            // FASTA currently resident in the "fasta" buffer
     rgx::Fasta *fasta = nullptr;
     DevBuf &buf(const char *name) { return bufs[name]; }
@@ -563,6 +564,7 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
     uint32_t *d_sc = c->buf("scalars").as<uint32_t>();
     uint32_t *h_sc = (uint32_t *)c->pinned;
     DevBuf &b_sort = c->buf("sort"), &b_uni = c->buf("unique");
+    c->last_rows_valid = false;            // the "rows_out" block is about to be overwritten
     uint32_t n_unique = 0;
     UniqueSoA u; memset(&u, 0, sizeof u);
     uint32_t *perm[2] = {nullptr, nullptr};
@@ -683,6 +685,7 @@ static void chrom_string_ranks(const BamHeader &hdr, std::vector<uint32_t> &rank
 static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_bam, size_t bam_len, const uint8_t *bai, size_t bai_len,
                         const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen) {
     *out = nullptr;
+    c->last_rows_valid = false;
     Prep P;
     int rc = prepare_events(c, d_bam_in, h_bam, bam_len, bai, bai_len, p, false, P, err, errlen);
     if (rc != RGX_OK) return rc;
@@ -694,6 +697,7 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     rc = reduce_events(c, P.ev, P.n_events, std::max<uint32_t>(1, bitlen((uint32_t)std::max(n_ref - 1, 0))), std::min<uint32_t>(32, bitlen(p->max_intron) + 2),
                        rank_of_tid.data(), (uint32_t)std::max(n_ref, 1), R, err, errlen, /*view_only=*/true);
     if (rc != RGX_OK) return rc;
+    c->last_rows = R.n; c->last_records = P.n_iterated; c->last_events = P.n_events; c->last_bytes = P.total; c->last_rows_valid = true;
     HIP_TRY(hipEventRecord(c->ev[6], st));
     rgx_junction_table *t = table_alloc(P.hdr, R.n);
     {
@@ -840,6 +844,19 @@ extern "C" int rgx_table_merge(const rgx_junction_table *const *parts, int n_par
         t->compressed_bytes = parts[g]->compressed_bytes; t->n_members += parts[g]->n_members;
     }
     *out = t;
+    return RGX_OK;
+}
+
+// the rows of the context's last extraction, packed for the all-gather without leaving HBM
+extern "C" int rgx_last_table_pack_device(rgx_ctx *c, const rgx_junction_table *t, void *d_dst, uint64_t cap_rows, char *err, size_t errlen) {
+    if (!c || !t) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
+    if (!c->last_rows_valid || t->n != c->last_rows || t->n_records != c->last_records || t->n_events != c->last_events || t->inflated_bytes != c->last_bytes)
+        return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: the table is not the result of the last extraction on this context\n");
+    if (!t->n) return RGX_OK;
+    if (!d_dst || cap_rows < t->n) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: destination holds %llu rows, %llu needed\n", (unsigned long long)cap_rows, (unsigned long long)t->n);
+    HIP_TRY(hipSetDevice(c->device));
+    launch_cols_to_packed(c->buf("rows_out").as<uint32_t>(), (uint32_t)t->n, (uint32_t *)d_dst, c->stream);
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return RGX_OK;
 }
 

@@ -159,6 +159,7 @@ void launch_pair_gather(EventSoA ev, const uint32_t *pair_ev, const uint32_t *pa
 struct MergeSoA { uint32_t *tid, *start, *end, *ts, *te, *count, *cls, *first, *shard; uint32_t *strand; };
 struct MergeUnique { uint32_t *tid, *start, *end, *ts, *te, *count, *first, *last_shard, *strand; };
 void launch_merge_unpack(const uint32_t *rows, uint32_t stride_rows, uint32_t n_parts, const uint32_t *part_rows, const uint32_t *part_base, MergeSoA m, hipStream_t st);
+void launch_cols_to_packed(const uint32_t *cols /* launch_rows_out block */, uint32_t n, uint32_t *out, hipStream_t st);
 void launch_merge_heads(MergeSoA m, const uint32_t *sorted, uint32_t n, uint32_t *head, hipStream_t st);
 void launch_merge_reduce(MergeSoA m, const uint32_t *sorted, const uint32_t *head, const uint32_t *seg_excl, uint32_t n, MergeUnique u /* ts preset to ~0, rest 0 */, hipStream_t st);
 void launch_merge_rank(const uint32_t *by_first, uint32_t n, uint32_t *name_rank, hipStream_t st);

@@ -22,6 +22,16 @@ __global__ void k_merge_unpack(const uint32_t *__restrict__ rows, uint32_t strid
     m.shard[o] = g;
 }
 
+// the ten-column block a pipeline run leaves in HBM (launch_rows_out) -> packed 48-byte rows, written straight into the all-gather input
+__global__ void k_cols_to_packed(const uint32_t *__restrict__ cols, uint32_t n, uint32_t *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = n;
+    uint32_t *w = out + (size_t)i * 12;
+    w[0] = cols[i]; w[1] = cols[N + i]; w[2] = cols[2 * N + i]; w[3] = cols[3 * N + i]; w[4] = cols[4 * N + i]; w[5] = cols[5 * N + i];
+    w[6] = cols[7 * N + i]; w[7] = 0; w[8] = cols[8 * N + i]; w[9] = 0; w[10] = cols[9 * N + i]; w[11] = cols[6 * N + i];
+}
+
 __device__ __forceinline__ bool merge_same(const MergeSoA &m, uint32_t a, uint32_t b) {
     return m.tid[a] == m.tid[b] && m.start[a] == m.start[b] && m.end[a] == m.end[b] && m.cls[a] == m.cls[b];
 }
@@ -75,6 +85,9 @@ void launch_merge_unpack(const uint32_t *rows, uint32_t stride_rows, uint32_t n_
     const uint64_t total = (uint64_t)stride_rows * n_parts;
     if (!total) return;
     hipLaunchKernelGGL(k_merge_unpack, grid_for((uint32_t)total), dim3(256), 0, st, rows, stride_rows, n_parts, part_rows, part_base, m);
+}
+void launch_cols_to_packed(const uint32_t *cols, uint32_t n, uint32_t *out, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_cols_to_packed, grid_for(n), dim3(256), 0, st, cols, n, out);
 }
 void launch_merge_heads(MergeSoA m, const uint32_t *sorted, uint32_t n, uint32_t *head, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_merge_heads, grid_for(n), dim3(256), 0, st, m, sorted, n, head);

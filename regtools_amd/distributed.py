@@ -124,13 +124,18 @@ def _gather_and_merge_device(table, ctx, min_anchor, group, world):
     sizes = [int(x) for x in sizes_t.tolist()]
     stride = max(1, max(sizes))
     cap = stride * ROW
-    host = _pinned.get("rows")
-    if host is None or host.numel() < cap:
-        host = _pinned["rows"] = torch.empty(cap + cap // 8, dtype=torch.uint8, pin_memory=True)
-    if n:
-        lib.rgx_table_pack(table, C.c_void_p(host.data_ptr()), n * ROW)
     local = torch.empty(cap, dtype=torch.uint8, device="cuda")
-    local[: n * ROW].copy_(host[: n * ROW], non_blocking=True)
+    # the rows of the extraction that produced `table` are still in HBM: pack them there (no host round trip) ...
+    err = C.create_string_buffer(256)
+    rc = lib.rgx_last_table_pack_device(ctx._h, table, C.c_void_p(local.data_ptr()), stride, err, len(err))
+    if rc != 0:
+        # ... unless the context has run something else since: then from the host copy
+        host = _pinned.get("rows")
+        if host is None or host.numel() < cap:
+            host = _pinned["rows"] = torch.empty(cap + cap // 8, dtype=torch.uint8, pin_memory=True)
+        if n:
+            lib.rgx_table_pack(table, C.c_void_p(host.data_ptr()), n * ROW)
+        local[: n * ROW].copy_(host[: n * ROW], non_blocking=True)
     big = torch.empty(cap * world, dtype=torch.uint8, device="cuda")
     dist.all_gather_into_tensor(big, local, group=group)      # the one data collective of the whole job; the rows stay in HBM
     torch.cuda.current_stream().synchronize()

@@ -314,3 +314,25 @@ def test_inflate_kernel_on_adversarial_members(gpu_ctx):
     for (cpos, up, clen, isz), d in zip(members, expect):
         want[up: up + isz] = d
     assert got == bytes(want)
+
+
+def test_device_side_row_packing_equals_host_packing(gpu_ctx, synth_dir):
+    """rgx_last_table_pack_device: the packed rows of the last extraction, written in HBM, are the bytes rgx_table_pack makes on the host;
+    a table that is not the context's last result is refused (the caller then packs on the host)."""
+    import torch
+    from regtools_amd import _ffi, synth, distributed
+    L = _ffi.lib()
+    p1 = os.path.join(str(synth_dir), "pack1.bam"); synth.write(p1, 120000, shape="short", seed=81)
+    p2 = os.path.join(str(synth_dir), "pack2.bam"); synth.write(p2, 50000, shape="fuzz", seed=82)
+    rc, _, je1 = gpu_extract(gpu_ctx, p1, ["-s", "XS"])
+    assert rc == 0
+    host_bytes, n = distributed.pack_table(je1.table)
+    dev = torch.zeros((n + 5) * distributed.ROW, dtype=torch.uint8, device="cuda")
+    err = C.create_string_buffer(256)
+    assert L.rgx_last_table_pack_device(gpu_ctx._h, je1.table, C.c_void_p(dev.data_ptr()), n + 5, err, len(err)) == 0, err.value
+    assert dev[: n * distributed.ROW].cpu().numpy().tobytes() == host_bytes and n > 1000
+    assert L.rgx_last_table_pack_device(gpu_ctx._h, je1.table, C.c_void_p(dev.data_ptr()), n - 1, err, len(err)) != 0      # too small
+    rc, _, je2 = gpu_extract(gpu_ctx, p2, ["-s", "XS"])
+    assert rc == 0
+    assert L.rgx_last_table_pack_device(gpu_ctx._h, je1.table, C.c_void_p(dev.data_ptr()), n + 5, err, len(err)) != 0      # stale table
+    assert b"not the result of the last extraction" in err.value
