@@ -43,6 +43,8 @@ VARIANTS = {
     "nostore": [no_stores],
     "decode_only": [no_copy_loads, no_stores],
     "occ5": [lds_bytes(32768)],
+    "batch64": [batch(64)],
+    "batch96": [batch(96)],
     "condwait": [cond_wait],
     "occ16": [occ16],
 }
