@@ -361,7 +361,7 @@ constexpr uint32_t kCopyBatch = 128;   // bytes moved per memory round trip (8 i
 // In a 64-lane wavefront every lane is at a different point of a different member; a lane in the middle of a long
 // match therefore no longer stalls the 63 others for a whole copy loop -- each trip costs one round trip for all.
 template <class Tab>
-RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len, Tab &T) {
+RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len, Tab &T, uint32_t *in_used = nullptr) {
     BitReader br; br.init(in, in_len);
     OutStage S; S.init(out, out_cap);
     uint32_t o = 0;
@@ -465,6 +465,7 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
         if (done && pend_len == 0) break;
     }
     S.flush_partial(o);                                             // the tail chunk (also on errors: what was produced is in memory)
+    if (in_used) *in_used = (uint32_t)(((uint64_t)(br.p - br.in) * 8 - br.cnt + 7) / 8);   // whole bytes of the stream that were consumed
     *out_len = o;
     return status;
 }

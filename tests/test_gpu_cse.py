@@ -183,3 +183,29 @@ def test_window_join_batches_give_the_same_files(gpu_ctx, work):
             % (ROOT, os.path.join(ROOT, "tests")))
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
+
+
+def test_compressed_vcf_inputs(gpu_ctx, work):
+    """hts_open takes gzip and bgzip VCFs (the reference's outputs for a .vcf.gz equal those for the plain file -- checked against
+    oracle/_ref); here the members are inflated with the product's own decoder compiled for the host."""
+    import gzip
+    import bamio
+    import regtools_amd
+    src = open(os.path.join(REF_GOLD, "test1.vcf"), "rb").read()
+    forms = {"gzip": gzip.compress(src, 6),
+             "bgzip": b"".join(bamio.bgzf_member(src[k:k + 700]) for k in range(0, len(src), 700)) + bamio.EOF_MARKER,
+             "two_members": gzip.compress(src[:1000]) + gzip.compress(src[1000:])}
+    for name, blob in forms.items():
+        vcf = os.path.join(str(work), "t1_%s.vcf.gz" % name)
+        open(vcf, "wb").write(blob)
+        q = dict(vcf=vcf, bam=os.path.join(REF_GOLD, "test_hcc1395.2.bam"), fasta=os.path.join(REF_GOLD, "test_chr22.fa"), gtf=os.path.join(REF_GOLD, "test_ensemble_chr22.2.gtf"))
+        rc, files, ci, msg = gpu_identify(gpu_ctx, ["-s", "XS"], q, os.path.join(str(work), "gz_" + name))
+        assert rc == 0, msg
+        for ext, gold in (("tsv", "annotatedjunctions"), ("vcf", "annotatedvariants"), ("bed", "junctions")):
+            assert open(files[ext], "rb").read() == open(os.path.join(REF_GOLD, "expected-cis-splice-effects-identify-default-%s.out" % gold), "rb").read(), (name, ext)
+    # a truncated gzip stream is an error, not a crash
+    bad = os.path.join(str(work), "bad.vcf.gz")
+    open(bad, "wb").write(forms["gzip"][: len(forms["gzip"]) // 2])
+    q["vcf"] = bad
+    rc, files, ci, msg = gpu_identify(gpu_ctx, ["-s", "XS"], q, os.path.join(str(work), "gz_bad"))
+    assert rc == 1
