@@ -83,11 +83,11 @@ int  rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errlen);
 void rgx_ctx_destroy(rgx_ctx *ctx);
 
 /* Replaces JunctionsExtractor::identify_junctions_from_BAM + get_all_junctions (cc:500-535, 238-246):
- * reads <bam_path> and its .bai from disk, uploads, runs the device pipeline, returns the table. */
+ * reads <bam_path> and its index (.csi before .bai, plain or BGZF-compressed: hts.c:2031-2042) from disk, uploads, runs the device pipeline, returns the table. */
 int  rgx_extract(rgx_ctx *ctx, const char *bam_path, const rgx_extract_params *p,
                  rgx_junction_table **out, char *err, size_t errlen);
 
-/* Same, input already in host memory (file bytes of the .bam and of its .bai). */
+/* Same, input already in host memory (file bytes of the .bam and of its .bai or .csi). */
 int  rgx_extract_mem(rgx_ctx *ctx, const void *bam, size_t bam_len, const void *bai, size_t bai_len,
                      const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen);
 

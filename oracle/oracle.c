@@ -140,26 +140,46 @@ static char *idx_name(const char *fn, const char *ext) {
     return NULL;
 }
 
+/* hts_idx_load (hts.c:2031-2042): .csi before .bai.  hts_idx_load_local (hts.c:1569-1618) reads either through bgzf_open, so a
+ * BGZF-compressed file (every .csi samtools writes) and a plain one both work; the magic decides the format.  CSI (hts.c:1516-1567
+ * with is_bai = 0, :1575-1591): min_shift, depth, l_aux + aux, then per bin an extra u64 loffset and no linear index; its pseudo-bin
+ * is n_bins + 1 for that depth (hts.c:1277, :1092). */
 static int bai_load(const char *bam, bai_info *bi) {
     memset(bi, 0, sizeof *bi);
     char *fn = idx_name(bam, ".csi");
-    if (fn) { free(fn); return -2; } /* CSI not restated (out of scope) */
-    fn = idx_name(bam, ".bai");
+    if (!fn) fn = idx_name(bam, ".bai");
     if (!fn) return -1;
     size_t len; uint8_t *d = orc_slurp(fn, &len); free(fn);
     if (!d) return -1;
-    if (len < 8 || memcmp(d, "BAI\1", 4)) { free(d); return -1; }
+    if (len >= 18 && bgzf_header_ok(d)) {         /* bgzf_read over the whole file */
+        bgzf_reader r; rdr_init(&r, d, len);
+        while (rdr_load(&r)) {}
+        uint8_t *plain = (uint8_t *)malloc(r.end - r.beg + 1);
+        memcpy(plain, r.buf + r.beg, r.end - r.beg);
+        len = r.end - r.beg;
+        free(r.buf); free(d); d = plain;
+    }
+    int csi = len >= 4 && !memcmp(d, "CSI\1", 4);
+    if (len < 8 || (!csi && memcmp(d, "BAI\1", 4))) { free(d); return -1; }
     size_t p = 4;
+    uint32_t meta_bin = 37450; /* ((1<<18)-1)/7 + 1 for min_shift 14, 5 levels */
+    if (csi) {
+        if (len < 20) { free(d); return -1; }
+        int32_t depth = (int32_t)rd32(d + 8), l_aux = (int32_t)rd32(d + 12);
+        if (depth < 0 || depth > 12 || l_aux < 0 || 16 + (size_t)l_aux + 4 > len) { free(d); return -1; }
+        meta_bin = (uint32_t)((((uint64_t)1 << (3 * depth + 3)) - 1) / 7 + 1);
+        p = 16 + (size_t)l_aux;
+    }
     bi->n_ref = (int32_t)rd32(d + p); p += 4;
-    const uint32_t meta_bin = 37450; /* ((1<<18)-1)/7 + 1 for min_shift 14, 5 levels */
     bi->start_voff = UINT64_MAX;
     for (int32_t r = 0; r < bi->n_ref; ++r) {
         if (p + 4 > len) { free(d); return -1; }
         int32_t n_bin = (int32_t)rd32(d + p); p += 4;
         for (int32_t b = 0; b < n_bin; ++b) {
-            if (p + 8 > len) { free(d); return -1; }
-            uint32_t bin = rd32(d + p); int32_t n_chunk = (int32_t)rd32(d + p + 4); p += 8;
-            if (p + (size_t)n_chunk * 16 > len) { free(d); return -1; }
+            size_t head = csi ? 16 : 8;
+            if (p + head > len) { free(d); return -1; }
+            uint32_t bin = rd32(d + p); int32_t n_chunk = (int32_t)rd32(d + p + head - 4); p += head;
+            if (n_chunk < 0 || p + (size_t)n_chunk * 16 > len) { free(d); return -1; }
             if (bin == meta_bin && n_chunk > 0) {
                 uint64_t u = rd64(d + p);
                 bi->have_start = 1;
@@ -167,6 +187,7 @@ static int bai_load(const char *bam, bai_info *bi) {
             }
             p += (size_t)n_chunk * 16;
         }
+        if (csi) continue;
         if (p + 4 > len) { free(d); return -1; }
         int32_t n_intv = (int32_t)rd32(d + p); p += 4;
         if (p + (size_t)n_intv * 8 > len) { free(d); return -1; }

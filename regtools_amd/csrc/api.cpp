@@ -224,7 +224,10 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // -- index: ~1 ms of host parsing for a 5 MB .bai, done on a second host thread while this one feeds the device the member scan --
     BaiInfo bi;
     bool bai_ok = false;
-    std::thread bai_thread([&] { bai_ok = bai && parse_bai(bai, bai_len, bi, /*collect_anchors=*/false); });
+    std::vector<uint8_t> index_image;                        // a .csi (or a compressed index) rewritten as a plain BAI image
+    std::thread bai_thread([&] {
+        bai_ok = bai && normalize_index(bai, bai_len, index_image, bai, bai_len) && parse_bai(bai, bai_len, bi, /*collect_anchors=*/false);
+    });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } bai_joiner{bai_thread};
     // -- upload ----------------------------------------------------------------------------------------------------------
     const uint8_t *d_bam = d_bam_in;
@@ -745,7 +748,7 @@ extern "C" int rgx_extract(rgx_ctx *ctx, const char *bam_path, const rgx_extract
     if (!bam.open(bam_path)) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
     std::string idx;
     int r = find_index(bam_path, idx);
-    if (r != 0 || !read_file(idx, bai)) return fail(err, errlen, RGX_ERR_INDEX, "%s", kMsgIndex);
+    if (r != 0 || !read_index(idx, bai)) return fail(err, errlen, RGX_ERR_INDEX, "%s", kMsgIndex);
     return run_pipeline(ctx, nullptr, bam.data(), bam.size(), bai.data(), bai.size(), p, out, err, errlen);
 }
 

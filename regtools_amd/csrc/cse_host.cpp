@@ -227,61 +227,12 @@ std::string GtfModel::load(const std::string &path) {
     return "";
 }
 
-// gzip / bgzip input (hts_open accepts both, hts.c:204-260): every member is inflated with the product's own decoder compiled for the
-// host (inflate_core.h; nothing here links zlib).  Members are limited to 4 GiB of output each; BCF is not handled.
-static std::string gunzip_all(const std::string &z, std::string &out) {
-    const uint8_t *d = (const uint8_t *)z.data();
-    const size_t n = z.size();
-    size_t off = 0;
-    out.clear();
-    while (off + 18 <= n && d[off] == 0x1f && d[off + 1] == 0x8b) {
-        if (d[off + 2] != 8) return "regtools_amd: unsupported compression method in gzip input\n\n";
-        const uint8_t flg = d[off + 3];
-        size_t q = off + 10;
-        size_t member_len = 0;                                   // known for BGZF members (BC subfield)
-        if (flg & 4) {
-            if (q + 2 > n) break;
-            const size_t xlen = d[q] | d[q + 1] << 8; q += 2;
-            for (size_t x = q; x + 4 <= q + xlen && x + 4 <= n;) {
-                const size_t sl = d[x + 2] | d[x + 3] << 8;
-                if (d[x] == 'B' && d[x + 1] == 'C' && sl == 2 && x + 6 <= n) member_len = (size_t)(d[x + 4] | d[x + 5] << 8) + 1;
-                x += 4 + sl;
-            }
-            q += xlen;
-        }
-        if (flg & 8) { while (q < n && d[q]) ++q; ++q; }        // FNAME
-        if (flg & 16) { while (q < n && d[q]) ++q; ++q; }       // FCOMMENT
-        if (flg & 2) q += 2;                                     // FHCRC
-        if (q + 8 > n) return "regtools_amd: truncated gzip input\n\n";
-        size_t in_len = member_len ? (off + member_len >= q + 8 && off + member_len <= n ? off + member_len - 8 - q : 0) : n - 8 - q;
-        if (member_len && !in_len && off + member_len != q + 8) return "regtools_amd: corrupt BGZF member in compressed input\n\n";
-        if (in_len > 0xfffffff0u) return "regtools_amd: gzip member too large for this path (use bgzip)\n\n";
-        size_t cap = member_len ? 65536 : std::max<size_t>(in_len * 4, 1 << 16);
-        uint32_t out_len = 0, used = 0;
-        for (;;) {
-            if (cap > 0xfffffff0u) return "regtools_amd: gzip member inflates to more than 4 GiB (use bgzip)\n\n";
-            const size_t base = out.size();
-            out.resize(base + cap + 64);
-            HostTab T;
-            std::vector<uint8_t> padded;                          // the decoder prefetches up to 16 bytes past the payload
-            const uint8_t *src = d + q;
-            if (q + in_len + 16 > n) { padded.assign(d + q, d + q + in_len); padded.resize(in_len + 32, 0); src = padded.data(); }
-            const int st = inflate_raw(src, (uint32_t)in_len, (uint8_t *)&out[base], (uint32_t)cap, &out_len, T, &used);
-            if (st == INF_OK) { out.resize(base + out_len); break; }
-            out.resize(base);
-            if (st == INF_OUT_OVERFLOW && !member_len) { cap *= 2; continue; }
-            return "regtools_amd: corrupt compressed input\n\n";
-        }
-        off = member_len ? off + member_len : q + used + 8;      // + CRC32, ISIZE
-    }
-    return "";
-}
-
+// gzip / bgzip input (hts_open accepts both, hts.c:204-260): host_io's gunzip_all, i.e. the product's own decoder compiled for the host
 std::string VcfText::load(const std::string &path) {
     if (!slurp(path, text)) return "Unable to open file.\n\n";
     if (text.size() >= 2 && (uint8_t)text[0] == 0x1f && (uint8_t)text[1] == 0x8b) {
         std::string plain;
-        std::string e = gunzip_all(text, plain);
+        std::string e = gunzip_all((const uint8_t *)text.data(), text.size(), plain);
         if (!e.empty()) return e;
         if (plain.size() >= 3 && !memcmp(plain.data(), "BCF", 3)) return "regtools_amd: BCF input is not supported on this path\n\n";
         text.swap(plain);

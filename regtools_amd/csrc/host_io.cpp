@@ -1,5 +1,6 @@
 // host_io.cpp -- see host_io.h.
 #include "host_io.h"
+#include "inflate_core.h"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -103,9 +104,8 @@ static bool idx_name(const std::string &fn, const char *ext, std::string &out) {
     return false;
 }
 
-int find_index(const std::string &bam_path, std::string &out) {
-    std::string tmp;
-    if (idx_name(bam_path, ".csi", tmp)) return 2;
+int find_index(const std::string &bam_path, std::string &out) {      // hts_idx_load: <fn>.csi, <stem>.csi, <fn>.bai, <stem>.bai (hts.c:2031-2042)
+    if (idx_name(bam_path, ".csi", out)) return 0;
     if (idx_name(bam_path, ".bai", out)) return 0;
     return 1;
 }
@@ -121,6 +121,110 @@ bool read_file(const std::string &path, std::vector<uint8_t> &out) {
     bool ok = n == 0 || fread(out.data(), 1, (size_t)n, f) == (size_t)n;
     fclose(f);
     return ok;
+}
+
+std::string gunzip_all(const uint8_t *d, size_t n, std::string &out) {
+    size_t off = 0;
+    out.clear();
+    while (off + 18 <= n && d[off] == 0x1f && d[off + 1] == 0x8b) {
+        if (d[off + 2] != 8) return "regtools_amd: unsupported compression method in gzip input\n\n";
+        const uint8_t flg = d[off + 3];
+        size_t q = off + 10;
+        size_t member_len = 0;                                   // known for BGZF members (BC subfield)
+        if (flg & 4) {
+            if (q + 2 > n) break;
+            const size_t xlen = d[q] | d[q + 1] << 8; q += 2;
+            for (size_t x = q; x + 4 <= q + xlen && x + 4 <= n;) {
+                const size_t sl = d[x + 2] | d[x + 3] << 8;
+                if (d[x] == 'B' && d[x + 1] == 'C' && sl == 2 && x + 6 <= n) member_len = (size_t)(d[x + 4] | d[x + 5] << 8) + 1;
+                x += 4 + sl;
+            }
+            q += xlen;
+        }
+        if (flg & 8) { while (q < n && d[q]) ++q; ++q; }        // FNAME
+        if (flg & 16) { while (q < n && d[q]) ++q; ++q; }       // FCOMMENT
+        if (flg & 2) q += 2;                                     // FHCRC
+        if (q + 8 > n) return "regtools_amd: truncated gzip input\n\n";
+        if (member_len && (off + member_len < q + 8 || off + member_len > n)) return "regtools_amd: corrupt BGZF member in compressed input\n\n";
+        const size_t in_len = member_len ? off + member_len - 8 - q : n - 8 - q;
+        if (in_len > 0xfffffff0u) return "regtools_amd: gzip member too large for this path (use bgzip)\n\n";
+        size_t cap = member_len ? 65536 : std::max<size_t>(in_len * 4, 1 << 16);
+        uint32_t out_len = 0, used = 0;
+        for (;;) {
+            if (cap > 0xfffffff0u) return "regtools_amd: gzip member inflates to more than 4 GiB (use bgzip)\n\n";
+            const size_t base = out.size();
+            out.resize(base + cap + 64);
+            HostTab T;
+            std::vector<uint8_t> padded;                          // the decoder prefetches up to 16 bytes past the payload
+            const uint8_t *src = d + q;
+            if (q + in_len + 16 > n) { padded.assign(d + q, d + q + in_len); padded.resize(in_len + 32, 0); src = padded.data(); }
+            const int st = inflate_raw(src, (uint32_t)in_len, (uint8_t *)&out[base], (uint32_t)cap, &out_len, T, &used);
+            if (st == INF_OK) { out.resize(base + out_len); break; }
+            out.resize(base);
+            if (st == INF_OUT_OVERFLOW && !member_len) { cap *= 2; continue; }
+            return "regtools_amd: corrupt compressed input\n\n";
+        }
+        off = member_len ? off + member_len : q + used + 8;      // + CRC32, ISIZE
+    }
+    return "";
+}
+
+bool normalize_index(const uint8_t *in, size_t n, std::vector<uint8_t> &storage, const uint8_t *&out, size_t &out_len) {
+    std::string plain;
+    const uint8_t *d = in; size_t len = n;
+    if (n >= 2 && in[0] == 0x1f && in[1] == 0x8b) {
+        if (!gunzip_all(in, n, plain).empty()) return false;
+        d = (const uint8_t *)plain.data(); len = plain.size();
+    }
+    if (len >= 8 && !memcmp(d, "BAI\1", 4)) {
+        if (d == in) { out = in; out_len = n; return true; }
+        storage.assign(d, d + len); out = storage.data(); out_len = storage.size();
+        return true;
+    }
+    if (len < 20 || memcmp(d, "CSI\1", 4)) return false;
+    const int32_t depth = (int32_t)h32(d + 8), l_aux = (int32_t)h32(d + 12);
+    if (depth < 0 || depth > 12 || l_aux < 0 || 16 + (size_t)l_aux + 4 > len) return false;
+    const uint32_t meta_bin = (uint32_t)((((uint64_t)1 << (3 * depth + 3)) - 1) / 7 + 1);   // META_BIN: n_bins + 1 (hts.c:1277)
+    size_t p = 16 + (size_t)l_aux;
+    const int32_t n_ref = (int32_t)h32(d + p); p += 4;
+    if (n_ref < 0) return false;
+    std::vector<uint8_t> &o = storage;
+    o.clear();
+    auto w32 = [&](uint32_t v) { for (int k = 0; k < 4; ++k) o.push_back((uint8_t)(v >> (8 * k))); };
+    auto w64 = [&](uint64_t v) { for (int k = 0; k < 8; ++k) o.push_back((uint8_t)(v >> (8 * k))); };
+    o.insert(o.end(), {'B', 'A', 'I', 1});
+    w32((uint32_t)n_ref);
+    for (int32_t r = 0; r < n_ref; ++r) {
+        if (p + 4 > len) return false;
+        const int32_t n_bin = (int32_t)h32(d + p); p += 4;
+        if (n_bin < 0) return false;
+        w32((uint32_t)n_bin);
+        std::vector<uint64_t> loffs;
+        for (int32_t b = 0; b < n_bin; ++b) {
+            if (p + 16 > len) return false;
+            const uint32_t bin = h32(d + p); const uint64_t loff = h64(d + p + 4); const int32_t n_chunk = (int32_t)h32(d + p + 12); p += 16;
+            if (n_chunk < 0 || p + (size_t)n_chunk * 16 > len) return false;
+            w32(bin == meta_bin ? 37450u : 1u);                                                // real bins: any id but the pseudo-bin's
+            w32((uint32_t)n_chunk);
+            o.insert(o.end(), d + p, d + p + (size_t)n_chunk * 16);
+            if (bin != meta_bin && loff) loffs.push_back(loff);
+            p += (size_t)n_chunk * 16;
+        }
+        w32((uint32_t)loffs.size());                                                           // "linear index": the bins' lower bounds
+        for (uint64_t v : loffs) w64(v);
+    }
+    w64(p + 8 <= len ? h64(d + p) : 0);
+    out = o.data(); out_len = o.size();
+    return true;
+}
+
+bool read_index(const std::string &path, std::vector<uint8_t> &out) {
+    std::vector<uint8_t> raw, image;
+    if (!read_file(path, raw)) return false;
+    const uint8_t *d; size_t n;
+    if (!normalize_index(raw.data(), raw.size(), image, d, n)) return false;
+    if (d == raw.data()) out.swap(raw); else out.swap(image);
+    return true;
 }
 
 FileBytes::~FileBytes() { if (mapped && p && n) munmap(const_cast<uint8_t *>(p), n); }

@@ -30,11 +30,22 @@ bool parse_bai(const uint8_t *bai, size_t len, BaiInfo &out, bool collect_anchor
 // (UINT64_MAX when none); one linear pass, no sorting.
 void bai_first_anchor_ge(const uint8_t *bai, size_t len, const uint64_t *targets, int n, uint64_t *out);
 
-// hts.c:2009-2042 index file name resolution ("<fn>.bai" then "<fn minus extension>.bai"); csi is detected, not read.
-// returns 0 found, 1 none, 2 only a .csi exists
+// hts.c:2009-2042 index file name resolution: "<fn>.csi", "<fn minus extension>.csi", then the same two for ".bai".
+// returns 0 found, 1 none
 int find_index(const std::string &bam_path, std::string &out);
 
 bool read_file(const std::string &path, std::vector<uint8_t> &out);
+
+// gzip / BGZF bytes -> plain bytes, with the product's own decoder compiled for the host (no zlib).  "" on success.
+std::string gunzip_all(const uint8_t *d, size_t n, std::string &out);
+
+// hts_idx_load_local (hts.c:1569-1618) reads an index through bgzf_open, so .bai and .csi may both be BGZF-compressed, and a .csi
+// (any min_shift / depth) is as good as a .bai.  This path only needs what parse_bai / bai_first_anchor_ge read -- the pseudo-bin with
+// the first offset, every chunk begin and lower bound (record starts), n_no_coor -- so a CSI is rewritten as an equivalent BAI image.
+// out/out_len point into `in` (already a plain BAI) or into `storage`.  false = not an index this path understands.
+// read_file + normalize_index: `out` holds a plain BAI image afterwards.
+bool read_index(const std::string &path, std::vector<uint8_t> &out);
+bool normalize_index(const uint8_t *in, size_t n, std::vector<uint8_t> &storage, const uint8_t *&out, size_t &out_len);
 
 // The bytes of a (large) input file without a private copy: a read-only mapping for regular files -- the upload to the device reads
 // straight from the page cache -- and a plain read for everything else (pipes, /dev/stdin).

@@ -28,3 +28,16 @@ extern "C" uint32_t emu_ucsc_bin(uint32_t start, uint32_t end) { return rgx::ucs
 extern "C" int32_t emu_rec_endpos(const uint32_t *cigar, uint32_t n_cigar, uint32_t flag, int32_t pos) {
     return rgx::rec_endpos(reinterpret_cast<const uint8_t *>(cigar), n_cigar, flag, pos);
 }
+
+// ---- index normalisation (host_io.cpp): BAI / CSI / BGZF-compressed -> what the pipeline reads from it ---------------------------------
+#include "../../regtools_amd/csrc/host_io.h"
+// out[0..4] = n_ref, have_start, start_voff, n_no_coor, n_anchors; got[k] = first listed record start >= targets[k].  0 = not an index
+extern "C" int emu_index_summary(const uint8_t *idx, size_t n, uint64_t *out, const uint64_t *targets, int nt, uint64_t *got) {
+    std::vector<uint8_t> image; const uint8_t *d; size_t len;
+    if (!rgx::normalize_index(idx, n, image, d, len)) return 0;
+    rgx::BaiInfo bi;
+    if (!rgx::parse_bai(d, len, bi, true)) return 0;
+    out[0] = (uint64_t)bi.n_ref; out[1] = bi.have_start; out[2] = bi.start_voff; out[3] = bi.n_no_coor; out[4] = bi.anchors.size();
+    if (nt) rgx::bai_first_anchor_ge(d, len, targets, nt, got);
+    return 1;
+}
