@@ -48,6 +48,10 @@ typedef struct {
      * byte is in.  0/1 = everything. */
     int32_t     shard;
     int32_t     n_shards;
+    /* -b (cc:82-84): also count, per junction, the cell barcodes of its supporting reads (set_junction_barcode, cc:362-374).
+     * Needs the whole file in one shard. */
+    int32_t     barcodes;      /* 0 */
+    char        barcode_tag[2];/* "CB" (h:192, h:204) */
 } rgx_extract_params;
 
 void rgx_extract_params_default(rgx_extract_params *p);
@@ -77,6 +81,15 @@ typedef struct {
     uint64_t  *first_seen;      /* event order of the first read of each row (shard-local) */
     uint64_t  *last_seen;       /* event order of the last read (its strand is the row's strand) */
     uint64_t   framing_sweeps;  /* statistics: verification sweeps of the speculative record framing (1 = every guess was right) */
+    /* -b: Junction::barcodes (junctions_extractor.h:58) of every row, flattened.  Row i owns entries [bc_row_begin[i], bc_row_begin[i+1]),
+     * listed in the order Junction::print_barcodes (h:99-111) writes them, i.e. the iteration order of the std::unordered_map the
+     * reference keeps; entry k is the string bc_text[bc_str_begin[k] .. bc_str_begin[k+1]) seen bc_count[k] times.  All NULL unless
+     * rgx_extract_params.barcodes was set. */
+    uint64_t  *bc_row_begin;    /* n + 1 */
+    uint32_t  *bc_count;
+    uint64_t  *bc_str_begin;    /* entries + 1 */
+    char      *bc_text;
+    double     ms_barcodes;     /* statistics: the barcode group-by (device + host ordering) */
 } rgx_junction_table;
 
 int  rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errlen);
@@ -128,6 +141,11 @@ int    rgx_table_merge_device(rgx_ctx *ctx, const void *d_rows, uint64_t stride_
  * only_anchored != 0 keeps rows with both anchors (the `junctions extract` output).  Returns the number
  * of bytes written, or the size needed when buf is NULL. */
 size_t rgx_table_format_bed12(const rgx_junction_table *t, int only_anchored, char *buf, size_t cap);
+
+/* Replaces Junction::print_barcodes as print_all_junctions calls it (h:99-111, cc:272-273): one line "<distinct>\t<bc>:<count>,...\n"
+ * per printed row.  Same buffer protocol as rgx_table_format_bed12.  A table without barcodes gives "0\t\n" lines (what
+ * `cis-splice-effects identify -b` writes: its extractor never collects any, identifier.cc:288, :239-241). */
+size_t rgx_table_format_barcodes(const rgx_junction_table *t, int only_anchored, char *buf, size_t cap);
 
 /* Library/build identification: "regtools_amd <version> gfx950". */
 const char *rgx_version(void);

@@ -93,15 +93,16 @@ int main(int argc, char **argv) {
     }
     int timing = !strcmp(argv[1], "time");
     orc_params p; orc_default_params(&p);
-    const char *outfile = NULL;
+    const char *outfile = NULL, *bcfile = NULL;
     int c;
     optind = 2;
-    while ((c = getopt(argc, argv, "a:m:M:o:r:t:s:")) != -1) {
+    while ((c = getopt(argc, argv, "a:m:M:o:r:t:s:b:")) != -1) {
         switch (c) {
             case 'a': p.min_anchor = (uint32_t)atoi(optarg); break;
             case 'm': p.min_intron = (uint32_t)atoi(optarg); break;
             case 'M': p.max_intron = (uint32_t)atoi(optarg); break;
             case 'o': outfile = optarg; break;
+            case 'b': bcfile = optarg; p.barcodes = 1; break;
             case 'r': p.region = optarg; break;
             case 't': p.strand_tag[0] = optarg[0]; p.strand_tag[1] = optarg[0] ? optarg[1] : 0; break;
             case 's':
@@ -131,6 +132,10 @@ int main(int argc, char **argv) {
         if (!out) { perror("open output"); return 1; }
         orc_print_bed12(t, out, 1);
         if (outfile) fclose(out);
+        if (bcfile) {
+            FILE *b = fopen(bcfile, "w");
+            if (b) { orc_print_barcodes(t, b, 1); fclose(b); }      /* an unopenable -b file is silently skipped (cc:255-256, :272) */
+        }
     }
     orc_table_free(t);
     return 0;

@@ -15,7 +15,8 @@ SYNTH_PATH = os.path.join(_HERE, "libregtools_synth.so")
 class ExtractParams(C.Structure):
     _fields_ = [("region", C.c_char_p), ("strandness", C.c_int32), ("strand_tag", C.c_char * 2),
                 ("min_anchor", C.c_uint32), ("min_intron", C.c_uint32), ("max_intron", C.c_uint32),
-                ("fasta_path", C.c_char_p), ("shard", C.c_int32), ("n_shards", C.c_int32)]
+                ("fasta_path", C.c_char_p), ("shard", C.c_int32), ("n_shards", C.c_int32),
+                ("barcodes", C.c_int32), ("barcode_tag", C.c_char * 2)]
 
 
 class JunctionTable(C.Structure):
@@ -29,7 +30,9 @@ class JunctionTable(C.Structure):
                 ("compressed_bytes", C.c_uint64), ("n_members", C.c_uint64),
                 ("ms_total", C.c_double), ("ms_inflate", C.c_double), ("ms_records", C.c_double),
                 ("ms_scan", C.c_double), ("ms_reduce", C.c_double),
-                ("first_seen", C.POINTER(C.c_uint64)), ("last_seen", C.POINTER(C.c_uint64)), ("framing_sweeps", C.c_uint64)]
+                ("first_seen", C.POINTER(C.c_uint64)), ("last_seen", C.POINTER(C.c_uint64)), ("framing_sweeps", C.c_uint64),
+                ("bc_row_begin", C.POINTER(C.c_uint64)), ("bc_count", C.POINTER(C.c_uint32)), ("bc_str_begin", C.POINTER(C.c_uint64)),
+                ("bc_text", C.POINTER(C.c_char)), ("ms_barcodes", C.c_double)]
 
 
 class Member(C.Structure):
@@ -39,7 +42,7 @@ class Member(C.Structure):
 # every symbol include/regtools_amd.h declares (tests check the library exports all of them)
 EXPORTS = ["rgx_extract_params_default", "rgx_ctx_create", "rgx_ctx_destroy", "rgx_extract", "rgx_extract_mem",
            "rgx_extract_device", "rgx_table_free", "rgx_table_merge", "rgx_table_pack", "rgx_table_unpack",
-           "rgx_table_format_bed12", "rgx_version", "rgx_k_inflate",
+           "rgx_table_format_bed12", "rgx_table_format_barcodes", "rgx_version", "rgx_k_inflate",
            "rgx_identify_params_default", "rgx_identify", "rgx_gtf_load", "rgx_gtf_free", "rgx_gtf_info", "rgx_gtf_transcript_bin",
            "rgx_gtf_transcript_id", "rgx_variant_windows", "rgx_variant_hits_free", "rgx_annotate_junctions", "rgx_junction_annot_free",
            "rgx_associate", "rgx_variants_annotate", "rgx_junctions_annotate", "rgx_table_merge_device", "rgx_window_join", "rgx_window_rows_free", "rgx_last_table_pack_device"]
@@ -120,6 +123,8 @@ def lib():
         L.rgx_table_merge_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64), C.c_int, C.c_uint32, P(JunctionTable), P(P(JunctionTable)), C.c_char_p, C.c_size_t]
         L.rgx_table_format_bed12.argtypes = [P(JunctionTable), C.c_int, C.c_char_p, C.c_size_t]
         L.rgx_table_format_bed12.restype = C.c_size_t
+        L.rgx_table_format_barcodes.argtypes = [P(JunctionTable), C.c_int, C.c_char_p, C.c_size_t]
+        L.rgx_table_format_barcodes.restype = C.c_size_t
         L.rgx_k_inflate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rgx_identify_params_default.argtypes = [P(IdentifyParams)]
         L.rgx_identify.argtypes = [C.c_void_p, P(IdentifyParams), P(IdentifyStats), C.c_char_p, C.c_size_t]

@@ -17,6 +17,7 @@
 #include <map>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "cse_host.h"
@@ -82,6 +83,7 @@ extern "C" void rgx_extract_params_default(rgx_extract_params *p) {
     memset(p, 0, sizeof *p);
     p->region = "."; p->strandness = -1; p->strand_tag[0] = 'X'; p->strand_tag[1] = 'S';
     p->min_anchor = 8; p->min_intron = 70; p->max_intron = 500000; p->fasta_path = nullptr; p->shard = 0; p->n_shards = 1;
+    p->barcodes = 0; p->barcode_tag[0] = 'C'; p->barcode_tag[1] = 'B';
 }
 
 extern "C" int rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errlen) {
@@ -140,6 +142,7 @@ extern "C" void rgx_table_free(rgx_junction_table *t) {
     free(t->ref_name); free(t->ref_len);
     free(t->tid); free(t->start); free(t->end); free(t->thick_start); free(t->thick_end); free(t->read_count);
     free(t->name_index); free(t->strand); free(t->left_ok); free(t->right_ok); free(t->first_seen); free(t->last_seen);
+    free(t->bc_row_begin); free(t->bc_count); free(t->bc_str_begin); free(t->bc_text);
     free(t);
 }
 
@@ -196,6 +199,24 @@ extern "C" size_t rgx_table_format_bed12(const rgx_junction_table *t, int only_a
     return need;
 }
 
+extern "C" size_t rgx_table_format_barcodes(const rgx_junction_table *t, int only_anchored, char *buf, size_t cap) {
+    size_t need = 0;
+    auto put = [&](const char *s, size_t n) { if (buf && need + n <= cap) memcpy(buf + need, s, n); need += n; };
+    char num[32];
+    for (uint64_t i = 0; i < t->n; ++i) {
+        if (only_anchored && !(t->left_ok[i] && t->right_ok[i])) continue;
+        const uint64_t b = t->bc_row_begin ? t->bc_row_begin[i] : 0, e = t->bc_row_begin ? t->bc_row_begin[i + 1] : 0;
+        put(num, (size_t)snprintf(num, sizeof num, "%llu\t", (unsigned long long)(e - b)));     // Junction::print_barcodes (h:103-110)
+        for (uint64_t k = b; k < e; ++k) {
+            if (k != b) put(",", 1);
+            put(t->bc_text + t->bc_str_begin[k], (size_t)(t->bc_str_begin[k + 1] - t->bc_str_begin[k]));
+            put(num, (size_t)snprintf(num, sizeof num, ":%u", t->bc_count[k]));
+        }
+        put("\n", 1);
+    }
+    return need;
+}
+
 // ---- the pipeline ------------------------------------------------------------------------------------------------
 // Everything the later stages need from the front half of the pipeline (file bytes -> junction events in file order).
 struct Prep {
@@ -213,6 +234,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
                           const rgx_extract_params *p, bool want_read_span, Prep &P, char *err, size_t errlen) {
     if (!p || p->strandness < 0 || p->strandness > 3) return fail(err, errlen, RGX_ERR_ARG, "Please supply strandness mode with '-s' option!\n\n");
     if (p->strandness == 3 && !p->fasta_path) return fail(err, errlen, RGX_ERR_ARG, "Strandness mode 'intron-motif' requires a fasta file!\n\n");
+    if (p->barcodes && p->n_shards > 1) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: barcode counts (-b) need the whole file in one shard\n");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const double t_begin = now_ms();
@@ -500,9 +522,10 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     uint64_t n_iterated = 0;
     if (n_rec) {
         const size_t R = n_rec;
-        HIP_TRY(b_soa.ensure(R * (4 + 4 + 4 + 8 + 1 + 4 + 4 + 4) + 256));
+        HIP_TRY(b_soa.ensure(R * (4 + 4 + 4 + 8 + 1 + 4 + 4 + 4 + (p->barcodes ? 8 : 0)) + 256));
         uint8_t *q = b_soa.as<uint8_t>();
         soa.cig_off = (uint64_t *)q; q += R * 8;
+        if (p->barcodes) { soa.rec_off = (uint64_t *)q; q += R * 8; }
         soa.tid = (int32_t *)q; q += R * 4; soa.pos = (int32_t *)q; q += R * 4; soa.flag_nc = (uint32_t *)q; q += R * 4;
         soa.n_ev = (uint32_t *)q; q += R * 4; ev_base = (uint32_t *)q; q += R * 4; long_list = (uint32_t *)q; q += R * 4;
         soa.strand = q;
@@ -528,11 +551,12 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     EventSoA ev; memset(&ev, 0, sizeof ev);
     if (n_events) {
         const size_t E = n_events;
-        HIP_TRY(b_ev.ensure(E * (4 * 7 + 1) + 256));
+        HIP_TRY(b_ev.ensure(E * (4 * 8 + 1) + 256));
         uint8_t *q = b_ev.as<uint8_t>();
         ev.tid = (uint32_t *)q; q += E * 4; ev.start = (uint32_t *)q; q += E * 4; ev.ilen_cls = (uint32_t *)q; q += E * 4;
         ev.ts = (uint32_t *)q; q += E * 4; ev.te = (uint32_t *)q; q += E * 4;
         if (want_read_span) { ev.rpos = (uint32_t *)q; q += E * 4; ev.rend = (uint32_t *)q; q += E * 4; }
+        if (p->barcodes) { ev.read = (uint32_t *)q; q += E * 4; }
         ev.strand = q;
         launch_emit_short(arena, n_rec, cfg, soa, ev_base, ev, st);
         launch_emit_long(arena, long_list, n_long, cfg, soa, ev_base, ev, st);
@@ -561,8 +585,11 @@ struct HostRows {
     const uint32_t *cols = nullptr;
 };
 
+// where each event ended up: its unique row, and each unique row's position in the output order (device arrays; the -b pass keys on them)
+struct RowMap { uint32_t *ev_urow = nullptr, *urow_pos = nullptr; };
+
 static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t group_bits, uint32_t ilen_bits, const uint32_t *rank_of_group_host,
-                         uint32_t n_groups, HostRows &R, char *err, size_t errlen, bool view_only = false) {
+                         uint32_t n_groups, HostRows &R, char *err, size_t errlen, bool view_only = false, RowMap *row_map = nullptr) {
     hipStream_t st = c->stream;
     uint32_t *d_sc = c->buf("scalars").as<uint32_t>();
     uint32_t *h_sc = (uint32_t *)c->pinned;
@@ -614,6 +641,12 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
         launch_fill_u32(u.ts_min, 0xffffffffu, U, st);
         launch_fill_u32(u.te_max, 0u, U, st);
         launch_reduce(ev, sorted, head, seg_excl, n_events, u, head_pos, st);
+        if (row_map) {
+            DevBuf &b_map = c->buf("row_map");
+            HIP_TRY(b_map.ensure((E + U) * 4 + 256));
+            row_map->ev_urow = b_map.as<uint32_t>(); row_map->urow_pos = row_map->ev_urow + E;
+            launch_event_urow(sorted, head, seg_excl, n_events, row_map->ev_urow, st);
+        }
         // first-seen naming (junctions_extractor.cc:152-157): rank of the key's first event among all keys
         uint32_t *first_flag = head;       // reuse: head/seg_excl are dead after launch_reduce
         HIP_TRY(hipMemsetAsync(first_flag, 0, E * 4, st));
@@ -642,6 +675,7 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
         usort(u.ts_min, 32);
         usort(chrom_rank_rows, std::max<uint32_t>(1, bitlen(rk)));
         final_perm = uperm[upc];
+        if (row_map) launch_inverse_perm(final_perm, n_unique, row_map->urow_pos, st);
         HIP_TRY(hipStreamSynchronize(st));   // the host rank table must outlive the async copy
     }
 
@@ -672,6 +706,112 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
     return RGX_OK;
 }
 
+// ---- -b: barcode counts per junction ---------------------------------------------------------------------------------------------
+// Second group-by, on (output row, barcode of the supporting read) -- barcode_kernels.hip.  The device returns one entry per distinct
+// (junction, barcode) with its count and first event; the host puts each junction's distinct barcodes, in first-seen order, into the
+// container the reference keeps them in (std::unordered_map<std::string,int>, junctions_extractor.h:58) and reads back its iteration
+// order -- the order print_barcodes (h:99-111) writes.  Copies of that map (cc:202, :208, :214, :235) keep node order, bucket count and
+// rehash state, so one map fed in first-seen order walks through the same states as the reference's per-read copies.
+static int barcode_rows(rgx_ctx *c, const Prep &P, const RowMap &rm, const rgx_extract_params *p, rgx_junction_table *t, char *err, size_t errlen) {
+    hipStream_t st = c->stream;
+    const double t0 = now_ms();
+    const size_t E = P.n_events, U = t->n;
+    t->bc_row_begin = (uint64_t *)calloc(U + 1, 8);
+    if (!E) { t->bc_count = (uint32_t *)calloc(1, 4); t->bc_str_begin = (uint64_t *)calloc(1, 8); t->bc_text = (char *)calloc(1, 1); return RGX_OK; }
+    uint32_t *d_sc = c->buf("scalars").as<uint32_t>();
+    uint32_t *h_sc = (uint32_t *)c->pinned;
+    DevBuf &b_bc = c->buf("barcodes");
+    const size_t rtmp = radix_tmp_words((uint32_t)E) + scan_tmp_words((uint32_t)E) + 64;
+    HIP_TRY(b_bc.ensure(E * (8 + 4 * 4 + 4 * 4 + 8 + 4 * 5) + rtmp * 4 + 512));
+    uint8_t *q = b_bc.as<uint8_t>();
+    BarcodeEv b;
+    b.off = (uint64_t *)q; q += E * 8;
+    uint64_t *pair_off = (uint64_t *)q; q += E * 8;
+    b.len = (uint32_t *)q; q += E * 4; b.h_lo = (uint32_t *)q; q += E * 4; b.h_hi = (uint32_t *)q; q += E * 4; b.row = (uint32_t *)q; q += E * 4;
+    uint32_t *perm[2]; perm[0] = (uint32_t *)q; q += E * 4; perm[1] = (uint32_t *)q; q += E * 4;
+    uint32_t *head = (uint32_t *)q; q += E * 4; uint32_t *seg_excl = (uint32_t *)q; q += E * 4;
+    uint32_t *pair_row = (uint32_t *)q; q += E * 4; uint32_t *pair_first = (uint32_t *)q; q += E * 4; uint32_t *pair_pos = (uint32_t *)q; q += E * 4;
+    uint32_t *pair_len = (uint32_t *)q; q += E * 4; uint32_t *pair_count = (uint32_t *)q; q += E * 4;
+    uint32_t *tmp = (uint32_t *)q;
+    uint32_t *flags = d_sc + 72;
+    HIP_TRY(hipMemsetAsync(flags, 0, 8, st));
+    launch_bc_event_keys(P.arena, (uint32_t)E, P.ev.read, P.soa.rec_off, rm.ev_urow, rm.urow_pos, (uint8_t)p->barcode_tag[0], (uint8_t)p->barcode_tag[1], b, flags, st);
+    int pc = -1;
+    auto sort_word = [&](const uint32_t *word, uint32_t nbits) {
+        for (uint32_t sh = 0; sh < nbits; sh += 8) {
+            const int nxt = pc < 0 ? 0 : pc ^ 1;
+            launch_radix_pass(word, sh, std::min<uint32_t>(8, nbits - sh), pc < 0 ? nullptr : perm[pc], perm[nxt], (uint32_t)E, tmp, st);
+            pc = nxt;
+        }
+    };
+    sort_word(b.h_lo, 32); sort_word(b.h_hi, 32);
+    sort_word(b.row, std::max<uint32_t>(1, bitlen((uint32_t)std::max<size_t>(U, 1) - 1)));
+    const uint32_t *sorted = perm[pc];
+    launch_bc_heads(P.arena, b, sorted, (uint32_t)E, head, flags, st);
+    launch_scan_u32(head, seg_excl, (uint32_t)E, d_sc + 74, tmp, st);
+    HIP_TRY(hipMemcpyAsync(h_sc + 72, d_sc + 72, 12, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h_sc[72]) return fail(err, errlen, RGX_ERR_FORMAT, "regtools_amd: the %c%c tag of an alignment is not a string (the reference dies on such input)\n\n", p->barcode_tag[0], p->barcode_tag[1]);
+    if (h_sc[73]) return fail(err, errlen, RGX_ERR_DEVICE, "regtools_amd: two different barcodes of one junction share a 64-bit hash; not handled\n\n");
+    const uint32_t n_pairs = h_sc[74];
+    launch_bc_pairs(b, sorted, head, seg_excl, (uint32_t)E, pair_row, pair_first, pair_pos, pair_off, pair_len, st);
+    launch_bc_counts(n_pairs, (uint32_t)E, pair_pos, pair_count, st);
+    uint32_t *str_begin = head;                       // head / seg_excl are dead after launch_bc_pairs
+    launch_scan_u32(pair_len, str_begin, n_pairs, d_sc + 75, tmp, st);
+    HIP_TRY(hipMemcpyAsync(h_sc + 75, d_sc + 75, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const size_t text_len = h_sc[75];
+    DevBuf &b_txt = c->buf("barcode_text");
+    HIP_TRY(b_txt.ensure(text_len + 256));
+    launch_bc_gather(P.arena, n_pairs, pair_off, pair_len, str_begin, b_txt.as<uint8_t>(), st);
+    std::vector<uint32_t> h_row(n_pairs), h_first(n_pairs), h_count(n_pairs), h_begin(n_pairs), h_len(n_pairs);
+    std::vector<char> h_text(text_len + 1);
+    HIP_TRY(hipMemcpyAsync(h_row.data(), pair_row, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_first.data(), pair_first, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_count.data(), pair_count, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_begin.data(), str_begin, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_len.data(), pair_len, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+    if (text_len) HIP_TRY(hipMemcpyAsync(h_text.data(), b_txt.p, text_len, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+
+    // host: container order per junction.  Entries arrive sorted by row (then hash): each row's run is contiguous.
+    t->bc_count = (uint32_t *)calloc((size_t)n_pairs + 1, 4);
+    t->bc_str_begin = (uint64_t *)calloc((size_t)n_pairs + 1, 8);
+    t->bc_text = (char *)malloc(text_len + 1);
+    std::vector<uint32_t> run_begin(U + 1, 0);
+    for (uint32_t k = 0; k < n_pairs; ++k) run_begin[h_row[k] + 1]++;
+    for (size_t r = 0; r < U; ++r) run_begin[r + 1] += run_begin[r];
+    for (size_t r = 0; r <= U; ++r) t->bc_row_begin[r] = run_begin[r];
+    const unsigned n_thr = (unsigned)std::max<size_t>(1, std::min<size_t>(16, U / 256));
+    std::vector<std::thread> pool;
+    auto work = [&](size_t r0, size_t r1) {
+        std::vector<uint32_t> idx;
+        for (size_t r = r0; r < r1; ++r) {
+            const uint32_t k0 = run_begin[r], k1 = run_begin[r + 1];
+            idx.resize(k1 - k0);
+            for (uint32_t k = k0; k < k1; ++k) idx[k - k0] = k;
+            std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return h_first[x] < h_first[y]; });      // first-seen order
+            std::unordered_map<std::string, int> m;                                                               // the reference's container
+            for (uint32_t k : idx) m.insert(std::pair<std::string, int>(std::string(h_text.data() + h_begin[k], h_len[k]), (int)k));
+            uint32_t o = k0;
+            for (auto it = m.begin(); it != m.end(); ++it, ++o) { t->bc_count[o] = h_count[(uint32_t)it->second]; t->bc_str_begin[o] = (uint64_t)it->second; /* entry id for now */ }
+        }
+    };
+    for (unsigned w = 0; w < n_thr; ++w) pool.emplace_back(work, U * w / n_thr, U * (w + 1) / n_thr);
+    for (auto &th : pool) th.join();
+    // lay the strings out in output order
+    uint64_t pos = 0;
+    for (uint32_t o = 0; o < n_pairs; ++o) {
+        const uint32_t k = (uint32_t)t->bc_str_begin[o];
+        t->bc_str_begin[o] = pos;
+        memcpy(t->bc_text + pos, h_text.data() + h_begin[k], h_len[k]);
+        pos += h_len[k];
+    }
+    t->bc_str_begin[n_pairs] = pos;
+    t->ms_barcodes = now_ms() - t0;
+    return RGX_OK;
+}
+
 static void chrom_string_ranks(const BamHeader &hdr, std::vector<uint32_t> &rank_of_tid) {
     const size_t n = hdr.names.size();
     std::vector<uint32_t> order(n);
@@ -697,8 +837,9 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     std::vector<uint32_t> rank_of_tid;
     chrom_string_ranks(P.hdr, rank_of_tid);
     HostRows R;
+    RowMap rm;
     rc = reduce_events(c, P.ev, P.n_events, std::max<uint32_t>(1, bitlen((uint32_t)std::max(n_ref - 1, 0))), std::min<uint32_t>(32, bitlen(p->max_intron) + 2),
-                       rank_of_tid.data(), (uint32_t)std::max(n_ref, 1), R, err, errlen, /*view_only=*/true);
+                       rank_of_tid.data(), (uint32_t)std::max(n_ref, 1), R, err, errlen, /*view_only=*/true, p->barcodes ? &rm : nullptr);
     if (rc != RGX_OK) return rc;
     c->last_rows = R.n; c->last_records = P.n_iterated; c->last_events = P.n_events; c->last_bytes = P.total; c->last_rows_valid = true;
     HIP_TRY(hipEventRecord(c->ev[6], st));
@@ -716,6 +857,11 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
         }
     }
     if (R.n >= 100000000u) host_sort_rows(t);   // names wider than 8 digits compare as strings upstream
+    if (p->barcodes) {
+        if (R.n >= 100000000u) { rgx_table_free(t); return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: -b with 10^8 or more junctions is not supported\n"); }
+        rc = barcode_rows(c, P, rm, p, t, err, errlen);
+        if (rc != RGX_OK) { rgx_table_free(t); return rc; }
+    }
     t->n_records = P.n_iterated;
     t->n_events = P.n_events; t->inflated_bytes = P.total; t->compressed_bytes = bam_len; t->n_members = P.n_range; t->framing_sweeps = P.framing_sweeps;
     float ms = 0;

@@ -86,6 +86,55 @@ RGX_HD char strand_from_tag(const uint8_t *aux, const uint8_t *end, uint8_t t0, 
     return '?';
 }
 
+// junctions_extractor.cc:362-374 set_junction_barcode: bam_aux_get(tag) (sam.c:1254-1266) + bam_aux2Z (sam.c:1309-1315).
+// 1 = found, the value is aux[*val, *val + *len) (its NUL excluded); 0 = no such tag (the barcode is then "?"); -1 = the tag is there
+// but is not a Z/H string (upstream builds a std::string from NULL there and dies).
+RGX_HD int aux_find_string(const uint8_t *aux, const uint8_t *end, uint8_t t0, uint8_t t1, uint32_t *val, uint32_t *len) {
+    const uint8_t *s = aux;
+    while (s + 3 <= end) {
+        const bool hit = s[0] == t0 && s[1] == t1;
+        s += 2;
+        const uint8_t t = *s++;
+        if (hit) {
+            if (t != 'Z' && t != 'H') return -1;
+            const uint8_t *e = s;
+            while (e < end && *e) ++e;
+            *val = (uint32_t)(s - aux); *len = (uint32_t)(e - s);
+            return 1;
+        }
+        uint32_t sz;
+        switch (t) {
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            case 'd': sz = 8; break;
+            case 'Z': case 'H': { while (s < end && *s) ++s; sz = 1; break; }
+            case 'B': {
+                if (s + 5 > end) return 0;
+                uint8_t st = *s++; uint32_t n = (uint32_t)s[0] | (uint32_t)s[1] << 8 | (uint32_t)s[2] << 16 | (uint32_t)s[3] << 24; s += 4;
+                uint32_t es = (st == 'c' || st == 'C' || st == 'A') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : (st == 'd') ? 8 : 0;
+                if ((uint64_t)es * n > (uint64_t)(end - s)) return 0;
+                sz = es * n; break;
+            }
+            default: return 0;
+        }
+        s += sz;
+    }
+    return 0;
+}
+// grouping key of a barcode string: 64 bits, two independently seeded 32-bit lanes; equal strings are CHECKED byte for byte afterwards
+// (k_bc_heads), the hash only brings them together
+RGX_HD void barcode_hash(const uint8_t *s, uint32_t len, uint32_t *lo, uint32_t *hi) {
+    uint32_t a = 0x811c9dc5u ^ len, b = 0x9747b28cu + len * 0x85ebca6bu;
+    for (uint32_t i = 0; i < len; ++i) {
+        a = (a ^ s[i]) * 0x01000193u;
+        b = (b + s[i]) * 0xcc9e2d51u; b = (b << 15 | b >> 17) * 0x1b873593u;
+    }
+    a ^= a >> 16; a *= 0x7feb352du; a ^= a >> 15;
+    b ^= b >> 13; b *= 0xc2b2ae35u; b ^= b >> 16;
+    *lo = a; *hi = b;
+}
+
 // ---- intron-motif strand rule (junctions_extractor.cc:325-342, :564-584; faidx.c:341-413) --------------------------------
 // FASTA file bytes live in HBM; one descriptor per BAM contig (matched by name on the host).
 struct FaContig { int64_t offset, len; int32_t line_blen, line_len; int32_t present; int32_t pad; };

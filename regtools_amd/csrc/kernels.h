@@ -67,6 +67,7 @@ struct ReadSoA {
     uint64_t *cig_off;     // arena offset of the CIGAR array
     uint8_t  *strand;      // per-read strand char from the tag (XS mode) or the flag rule (RF/FR)
     uint32_t *n_ev;        // junction events this read contributes (after region filter and junction_qc)
+    uint64_t *rec_off;     // optional (may be null): arena offset of the record's block_size word (-b barcodes re-read the aux block)
 };
 struct ExtractCfg {
     int32_t  n_ref;
@@ -96,6 +97,7 @@ struct EventSoA {
     uint32_t *ts, *te;                  // thick_start / thick_end of this read's instance
     uint32_t *rpos, *rend;              // optional (may be null): the supporting read's pos / bam_endpos (window join of `identify`)
     uint8_t  *strand;
+    uint32_t *read;                     // optional (may be null): index of the supporting read (-b barcodes)
 };
 void launch_emit_short(const uint8_t *arena, uint32_t n_rec, ExtractCfg cfg, ReadSoA soa, const uint32_t *ev_base,
                        EventSoA ev, hipStream_t stream);
@@ -132,6 +134,25 @@ void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t stream);
 // ten u32 columns of n rows each, in `order`: tid,start,end,ts,te,count,name_rank,first_seen,last_seen,strand
 void launch_rows_out(UniqueSoA u, const uint32_t *order, uint32_t n, uint32_t *out, hipStream_t stream);
 
+
+// ---- -b: barcode counts per junction (junctions_extractor.cc:362-374, :204-217; barcode_kernels.hip) -------------------------------
+// per event: where its read's barcode string lies in the arena (off = ~0 -> the literal "?"), the 64-bit grouping hash, the junction's output row
+struct BarcodeEv { uint64_t *off; uint32_t *len, *h_lo, *h_hi, *row; };
+// ev_urow[e] = unique row of event e (from the group-by's sorted order); must run before head / seg_excl are reused
+void launch_event_urow(const uint32_t *sorted, const uint32_t *head, const uint32_t *seg_excl, uint32_t n, uint32_t *ev_urow, hipStream_t stream);
+void launch_inverse_perm(const uint32_t *perm, uint32_t n, uint32_t *inv, hipStream_t stream);
+// flags[0] = 1 when some read's tag is present but not a string
+void launch_bc_event_keys(const uint8_t *arena, uint32_t n_events, const uint32_t *ev_read, const uint64_t *rec_off, const uint32_t *ev_urow,
+                          const uint32_t *urow_pos, uint8_t t0, uint8_t t1, BarcodeEv b, uint32_t *flags, hipStream_t stream);
+// head[i] = sorted position i starts a new (row, barcode); equal hashes with different bytes set flags[1]
+void launch_bc_heads(const uint8_t *arena, BarcodeEv b, const uint32_t *perm, uint32_t n, uint32_t *head, uint32_t *flags, hipStream_t stream);
+// one output row per head: pair_row, pair_first (earliest event), pair_pos (sorted position of the head), pair_off / pair_len (the string)
+void launch_bc_pairs(BarcodeEv b, const uint32_t *perm, const uint32_t *head, const uint32_t *seg_excl, uint32_t n, uint32_t *pair_row,
+                     uint32_t *pair_first, uint32_t *pair_pos, uint64_t *pair_off, uint32_t *pair_len, hipStream_t stream);
+void launch_bc_counts(uint32_t n_pairs, uint32_t n, const uint32_t *pair_pos, uint32_t *pair_count, hipStream_t stream);
+// text[str_begin[k] .. +pair_len[k]) = the k-th pair's barcode
+void launch_bc_gather(const uint8_t *arena, uint32_t n_pairs, const uint64_t *pair_off, const uint32_t *pair_len, const uint32_t *str_begin,
+                      uint8_t *text, hipStream_t stream);
 
 // ---- a9-a11: `cis-splice-effects identify` interval kernels (cse_kernels.hip; logic in cse_core.h) --------------------------
 struct GtfView;

@@ -366,6 +366,7 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
         soa.tid[i] = h.tid; soa.pos[i] = h.pos;
         soa.flag_nc[i] = h.flag << 16 | h.n_cigar;
         soa.cig_off[i] = o + 36 + h.l_qname;
+        if (soa.rec_off) soa.rec_off[i] = o;
         bool in_region = true;
         if (cfg.region_tid != -2) {
             in_region = h.tid == cfg.region_tid && h.pos < cfg.region_end;
@@ -438,7 +439,8 @@ void launch_long_fill(uint32_t n_seg, const uint32_t *seg_base, const uint32_t *
 // a4. CIGAR scan + junction emit
 // =====================================================================================================
 __device__ __forceinline__ void put_event(const EventSoA &ev, uint32_t slot, int32_t tid, uint32_t start, uint32_t end, uint32_t ts,
-                                          uint32_t te, char strand, uint32_t rpos, uint32_t rend) {
+                                          uint32_t te, char strand, uint32_t rpos, uint32_t rend, uint32_t read) {
+    if (ev.read) ev.read[slot] = read;
     ev.tid[slot] = (uint32_t)tid; ev.start[slot] = start;
     ev.ilen_cls[slot] = (end - start) << 2 | strand_class(strand);
     ev.ts[slot] = ts; ev.te[slot] = te; ev.strand[slot] = (uint8_t)strand;
@@ -471,7 +473,7 @@ __global__ void k_emit_short(const uint8_t *__restrict__ arena, uint32_t n_rec, 
             else { const char m = strand_from_motif(cfg.fa_data, fc, s, e, carried); if (m != '?') st = m; }
             carried = st;
         }
-        if (intron_ok(s, e, cfg.min_intron, cfg.max_intron)) put_event(ev, slot++, tid, s, e, ts, te, st, (uint32_t)pos, rend);
+        if (intron_ok(s, e, cfg.min_intron, cfg.max_intron)) put_event(ev, slot++, tid, s, e, ts, te, st, (uint32_t)pos, rend, i);
     });
 }
 
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(256) void k_emit_long(const uint8_t *__restrict__ a
             if (pend && B) {
                 const uint32_t nb = (uint32_t)__ffsll((unsigned long long)B) - 1;
                 const uint32_t te = s_R[wave][nb];
-                if (lane == 0 && intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) put_event(ev, slot, tid, p_start, p_end, p_ts, te, p_strand, rpos, rend);
+                if (lane == 0 && intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) put_event(ev, slot, tid, p_start, p_end, p_ts, te, p_strand, rpos, rend, i);
                 if (intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) ++slot;
                 pend = false;
             }
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(256) void k_emit_long(const uint8_t *__restrict__ a
             }
             // events keep CIGAR order: rank among the qc-passing N lanes that close inside this tile
             const uint64_t emit_mask = __ballot(ok && closed);
-            if (ok && closed) put_event(ev, slot + (uint32_t)__popcll(emit_mask & lanemask_lt()), tid, R_before, R_after, ts, te, my_strand, rpos, rend);
+            if (ok && closed) put_event(ev, slot + (uint32_t)__popcll(emit_mask & lanemask_lt()), tid, R_before, R_after, ts, te, my_strand, rpos, rend, i);
             slot += (uint32_t)__popcll(emit_mask);
             // the last breaker of the tile: if it is an N it stays open into the next tile
             if (B) {
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(256) void k_emit_long(const uint8_t *__restrict__ a
             refpos = __shfl(R_after, 63, 64);
             __builtin_amdgcn_wave_barrier();
         }
-        if (pend && lane == 0 && intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) put_event(ev, slot, tid, p_start, p_end, p_ts, refpos, p_strand, rpos, rend);
+        if (pend && lane == 0 && intron_ok(p_start, p_end, cfg.min_intron, cfg.max_intron)) put_event(ev, slot, tid, p_start, p_end, p_ts, refpos, p_strand, rpos, rend, i);
     }
 }
 

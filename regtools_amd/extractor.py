@@ -60,11 +60,12 @@ class JunctionsExtractor(object):
 
     def __init__(self, bam="NA", region=".", strandness=-1, strand_tag="XS", min_anchor_length=8,
                  min_intron_length=70, max_intron_length=500000, ref="NA", ctx=None, device=0,
-                 shard=0, n_shards=1):
+                 shard=0, n_shards=1, output_barcodes_file="NA", barcode_tag="CB"):
         self.bam_, self.region_, self.strandness_, self.strand_tag_ = bam, region, strandness, strand_tag
         self.min_anchor_length_, self.min_intron_length_, self.max_intron_length_ = min_anchor_length, min_intron_length, max_intron_length
         self.ref_ = ref
         self.shard, self.n_shards = shard, n_shards
+        self.output_barcodes_file_, self.barcode_tag_ = output_barcodes_file, barcode_tag      # junctions_extractor.h:174, :182
         self._ctx, self._device = ctx, device
         self._table = None
         self.stats = {}
@@ -90,8 +91,7 @@ class JunctionsExtractor(object):
                 if v not in STRANDNESS:
                     raise RegtoolsError(1, "Unrecognized strandness argument!\n\n")
                 self.strandness_ = STRANDNESS[v]
-            elif k == "-b":
-                raise RegtoolsError(1, "regtools_amd: -b (single-cell barcodes) is outside the accelerated path\n\n")
+            elif k == "-b": self.output_barcodes_file_ = v
         if len(args) >= 1: self.bam_ = args[0]
         if len(args) >= 2: self.ref_ = args[1]
         if len(args) > 2 or self.bam_ == "NA":
@@ -117,6 +117,8 @@ class JunctionsExtractor(object):
         self._fa_b = None if self.ref_ == "NA" else self.ref_.encode()
         p.fasta_path = self._fa_b
         p.shard, p.n_shards = self.shard, self.n_shards
+        p.barcodes = 0 if self.output_barcodes_file_ == "NA" else 1
+        p.barcode_tag = (self.barcode_tag_.encode() + b"\0\0")[:2]
         return p
 
     # -- identify_junctions_from_BAM (junctions_extractor.cc:500-535) -------------------------------------------------
@@ -141,7 +143,8 @@ class JunctionsExtractor(object):
         t = tab.contents
         self.stats = dict(n_records=t.n_records, n_events=t.n_events, n_junctions=t.n, inflated_bytes=t.inflated_bytes,
                           compressed_bytes=t.compressed_bytes, n_members=t.n_members, ms_total=t.ms_total, ms_inflate=t.ms_inflate,
-                          ms_records=t.ms_records, ms_scan=t.ms_scan, ms_reduce=t.ms_reduce, framing_sweeps=t.framing_sweeps)
+                          ms_records=t.ms_records, ms_scan=t.ms_scan, ms_reduce=t.ms_reduce, framing_sweeps=t.framing_sweeps,
+                          ms_barcodes=t.ms_barcodes)
         return 0
 
     def _free(self):
@@ -178,8 +181,31 @@ class JunctionsExtractor(object):
         lib.rgx_table_format_bed12(self._table, 1 if only_anchored else 0, buf, n)
         return buf.raw[:n]
 
+    # -- Junction::print_barcodes per printed row (junctions_extractor.h:99-111, cc:272-273) ---------------------------------
+    def barcodes_text(self, only_anchored=True):
+        lib = _ffi.lib()
+        n = lib.rgx_table_format_barcodes(self._table, 1 if only_anchored else 0, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib.rgx_table_format_barcodes(self._table, 1 if only_anchored else 0, buf, n)
+        return buf.raw[:n]
+
+    def get_barcodes(self):
+        """Per row (get_all_junctions order): [(barcode, count), ...] in the order print_barcodes writes them."""
+        t = self._table.contents
+        if not t.bc_row_begin:
+            return [[] for _ in range(t.n)]
+        text = C.string_at(t.bc_text, t.bc_str_begin[t.bc_row_begin[t.n]]) if t.n else b""
+        return [[(text[t.bc_str_begin[k]:t.bc_str_begin[k + 1]], t.bc_count[k]) for k in range(t.bc_row_begin[i], t.bc_row_begin[i + 1])]
+                for i in range(t.n)]
+
     def print_all_junctions(self, out=None):
         data = self.bed12(True)
+        if self.output_barcodes_file_ != "NA":
+            try:
+                with open(self.output_barcodes_file_, "wb") as f:      # an unopenable file is silently skipped upstream (cc:255-256, :272)
+                    f.write(self.barcodes_text(True))
+            except OSError:
+                pass
         target = getattr(self, "output_file_", "NA")
         if target != "NA":
             with open(target, "wb") as f:

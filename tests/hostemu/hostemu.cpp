@@ -41,3 +41,21 @@ extern "C" int emu_index_summary(const uint8_t *idx, size_t n, uint64_t *out, co
     if (nt) rgx::bai_first_anchor_ge(d, len, targets, nt, got);
     return 1;
 }
+
+// ---- the REAL std::unordered_map<std::string,int> of this image's libstdc++: what oracle.c's restated container is pinned against -----
+#include <string>
+#include <unordered_map>
+// insert keys[0..n) the way Junction::barcodes receives them (a repeated key increments); order[k] = index of the first occurrence of the
+// k-th key in iteration order, counts[k] its count, buckets = final bucket_count; returns the number of distinct keys
+extern "C" size_t emu_umap_order(const char *const *keys, size_t n, size_t *order, int *counts, size_t *buckets) {
+    std::unordered_map<std::string, int> m, first;
+    for (size_t i = 0; i < n; ++i) {
+        auto it = m.find(keys[i]);
+        if (it != m.end()) { std::unordered_map<std::string, int> c = m; c[it->first]++; m = c; }      // the reference's copy-then-bump (cc:207-210)
+        else { std::unordered_map<std::string, int> c = m; c.insert(std::pair<std::string, int>(keys[i], 1)); m = c; first[keys[i]] = (int)i; }
+    }
+    size_t k = 0;
+    for (auto it = m.begin(); it != m.end(); ++it, ++k) { order[k] = (size_t)first[it->first]; counts[k] = it->second; }
+    *buckets = m.bucket_count();
+    return k;
+}
