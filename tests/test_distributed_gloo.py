@@ -34,7 +34,7 @@ dist.barrier(); dist.destroy_process_group()
 class OrcJunction(C.Structure):
     _fields_ = [("tid", C.c_int32), ("start", C.c_uint32), ("end", C.c_uint32), ("thick_start", C.c_uint32), ("thick_end", C.c_uint32),
                 ("read_count", C.c_uint32), ("name_index", C.c_uint64), ("strand", C.c_char), ("left_ok", C.c_uint8), ("right_ok", C.c_uint8),
-                ("first_seen", C.c_uint64), ("last_seen", C.c_uint64)]
+                ("first_seen", C.c_uint64), ("last_seen", C.c_uint64), ("barcodes", C.c_void_p)]
 
 
 class OrcTable(C.Structure):
@@ -45,7 +45,7 @@ class OrcTable(C.Structure):
 
 class OrcParams(C.Structure):
     _fields_ = [("bam", C.c_char_p), ("region", C.c_char_p), ("strandness", C.c_int), ("strand_tag", C.c_char * 2), ("min_anchor", C.c_uint32),
-                ("min_intron", C.c_uint32), ("max_intron", C.c_uint32), ("fasta", C.c_char_p)]
+                ("min_intron", C.c_uint32), ("max_intron", C.c_uint32), ("fasta", C.c_char_p), ("barcodes", C.c_int)]
 
 
 def oracle_partial_table(bam_path, strand):
