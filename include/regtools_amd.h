@@ -89,6 +89,8 @@ typedef struct {
     uint32_t  *bc_count;
     uint64_t  *bc_str_begin;    /* entries + 1 */
     char      *bc_text;
+    uint32_t  *bc_insert_rank;  /* entry k was the bc_insert_rank[k]-th distinct barcode its junction saw (0-based): a binding that refills a
+                                 * Junction::barcodes inserts a row's entries in THIS order and the container iterates them in the listed order */
     double     ms_barcodes;     /* statistics: the barcode group-by (device + host ordering) */
 } rgx_junction_table;
 

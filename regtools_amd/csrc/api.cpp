@@ -178,7 +178,7 @@ extern "C" void rgx_table_free(rgx_junction_table *t) {
     if (t->ref_name) for (int32_t i = 0; i < t->n_ref; ++i) free(t->ref_name[i]);
     free(t->ref_name); free(t->ref_len);
     block_give(box->block, box->block_cap);
-    free(t->bc_row_begin); free(t->bc_count); free(t->bc_str_begin); free(t->bc_text);
+    free(t->bc_row_begin); free(t->bc_count); free(t->bc_str_begin); free(t->bc_text); free(t->bc_insert_rank);
     free(box);
 }
 
@@ -753,7 +753,7 @@ static int barcode_rows(rgx_ctx *c, const Prep &P, const RowMap &rm, const rgx_e
     const double t0 = now_ms();
     const size_t E = P.n_events, U = t->n;
     t->bc_row_begin = (uint64_t *)calloc(U + 1, 8);
-    if (!E) { t->bc_count = (uint32_t *)calloc(1, 4); t->bc_str_begin = (uint64_t *)calloc(1, 8); t->bc_text = (char *)calloc(1, 1); return RGX_OK; }
+    if (!E) { t->bc_count = (uint32_t *)calloc(1, 4); t->bc_str_begin = (uint64_t *)calloc(1, 8); t->bc_text = (char *)calloc(1, 1); t->bc_insert_rank = (uint32_t *)calloc(1, 4); return RGX_OK; }
     uint32_t *d_sc = c->buf("scalars").as<uint32_t>();
     uint32_t *h_sc = (uint32_t *)c->pinned;
     DevBuf &b_bc = c->buf("barcodes");
@@ -814,6 +814,8 @@ static int barcode_rows(rgx_ctx *c, const Prep &P, const RowMap &rm, const rgx_e
     t->bc_count = (uint32_t *)calloc((size_t)n_pairs + 1, 4);
     t->bc_str_begin = (uint64_t *)calloc((size_t)n_pairs + 1, 8);
     t->bc_text = (char *)malloc(text_len + 1);
+    t->bc_insert_rank = (uint32_t *)calloc((size_t)n_pairs + 1, 4);
+    std::vector<uint32_t> rank_of(n_pairs);
     std::vector<uint32_t> run_begin(U + 1, 0);
     for (uint32_t k = 0; k < n_pairs; ++k) run_begin[h_row[k] + 1]++;
     for (size_t r = 0; r < U; ++r) run_begin[r + 1] += run_begin[r];
@@ -827,10 +829,11 @@ static int barcode_rows(rgx_ctx *c, const Prep &P, const RowMap &rm, const rgx_e
             idx.resize(k1 - k0);
             for (uint32_t k = k0; k < k1; ++k) idx[k - k0] = k;
             std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return h_first[x] < h_first[y]; });      // first-seen order
+            for (uint32_t q = 0; q < idx.size(); ++q) rank_of[idx[q]] = q;
             std::unordered_map<std::string, int> m;                                                               // the reference's container
             for (uint32_t k : idx) m.insert(std::pair<std::string, int>(std::string(h_text.data() + h_begin[k], h_len[k]), (int)k));
             uint32_t o = k0;
-            for (auto it = m.begin(); it != m.end(); ++it, ++o) { t->bc_count[o] = h_count[(uint32_t)it->second]; t->bc_str_begin[o] = (uint64_t)it->second; /* entry id for now */ }
+            for (auto it = m.begin(); it != m.end(); ++it, ++o) { t->bc_count[o] = h_count[(uint32_t)it->second]; t->bc_str_begin[o] = (uint64_t)it->second; /* entry id for now */ t->bc_insert_rank[o] = rank_of[(uint32_t)it->second]; }
         }
     };
     for (unsigned w = 0; w < n_thr; ++w) pool.emplace_back(work, U * w / n_thr, U * (w + 1) / n_thr);

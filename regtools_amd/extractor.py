@@ -189,11 +189,22 @@ class JunctionsExtractor(object):
         lib.rgx_table_format_barcodes(self._table, 1 if only_anchored else 0, buf, n)
         return buf.raw[:n]
 
-    def get_barcodes(self):
-        """Per row (get_all_junctions order): [(barcode, count), ...] in the order print_barcodes writes them."""
+    def get_barcodes(self, insertion_order=False):
+        """Per row (get_all_junctions order): [(barcode, count), ...] in the order print_barcodes writes them, or (insertion_order) in the
+        order the junction first saw them -- the order to refill a Junction::barcodes map in."""
         t = self._table.contents
         if not t.bc_row_begin:
             return [[] for _ in range(t.n)]
+        if insertion_order:
+            listed = self.get_barcodes()
+            out, k = [], 0
+            for m in listed:
+                o = [None] * len(m)
+                for e in m:
+                    o[t.bc_insert_rank[k]] = e
+                    k += 1
+                out.append(o)
+            return out
         text = C.string_at(t.bc_text, t.bc_str_begin[t.bc_row_begin[t.n]]) if t.n else b""
         return [[(text[t.bc_str_begin[k]:t.bc_str_begin[k + 1]], t.bc_count[k]) for k in range(t.bc_row_begin[i], t.bc_row_begin[i + 1])]
                 for i in range(t.n)]

@@ -100,6 +100,17 @@ def test_product_equals_reference_outputs(gpu_ctx, tmp_path, name, args):
     assert len(rows) == len(maps)
     for j, m in zip(rows, maps):
         assert sum(c for _, c in m) == j.read_count and len({b for b, _ in m}) == len(m)
+    # a binding refills Junction::barcodes in first-seen order (bc_insert_rank): the REAL container must then iterate in the listed order
+    emu = ctypes.CDLL(os.path.join(ROOT, "tests", "hostemu", "libhostemu.so"))
+    emu.emu_umap_order.restype = ctypes.c_size_t
+    for listed, ins in zip(maps, je.get_barcodes(insertion_order=True)):
+        if len(listed) < 2 or b"" in [b for b, _ in ins]:
+            continue
+        n = len(ins)
+        arr = (ctypes.c_char_p * n)(*[b for b, _ in ins])
+        order, counts, nb = (ctypes.c_size_t * n)(), (ctypes.c_int * n)(), ctypes.c_size_t()
+        assert emu.emu_umap_order(arr, ctypes.c_size_t(n), order, counts, ctypes.byref(nb)) == n
+        assert [ins[order[k]][0] for k in range(n)] == [b for b, _ in listed]
 
 
 @pytest.mark.gpu
