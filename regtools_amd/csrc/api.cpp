@@ -124,35 +124,41 @@ extern "C" void rgx_ctx_destroy(rgx_ctx *c) {
 // Result tables: all row columns of a table live in ONE block, and released blocks are kept (a few, bounded) for the next table.  A
 // pipeline that runs step after step -- bench.py, a multi-GPU job merging every step -- then writes its rows into pages that are already
 // mapped instead of paying mmap + first-touch faults + munmap for ~50 bytes per row each time (measured: 9 of 14 ms of an 8-shard merge).
-struct TableBox { rgx_junction_table t; void *block; size_t block_cap; };
+struct TableBox { rgx_junction_table t; void *block; size_t block_cap; bool pinned; };
+struct CachedBlock { void *p; size_t cap; bool pinned; };
 static std::mutex g_block_mu;
-static std::vector<std::pair<void *, size_t>> g_blocks;          // released blocks, at most kBlockCacheEntries / kBlockCacheBytes
-static const size_t kBlockCacheEntries = 4, kBlockCacheBytes = (size_t)1 << 30;
+static std::vector<CachedBlock> g_blocks;                        // released blocks, at most kBlockCacheEntries / kBlockCacheBytes
+static const size_t kBlockCacheEntries = 6, kBlockCacheBytes = (size_t)1 << 30;
 
-static void *block_take(size_t need, size_t &cap) {
+// pinned = page-locked (hipHostMalloc): the device pipelines copy the finished columns straight into the block
+static void *block_take(size_t need, size_t &cap, bool pinned) {
     {
         std::lock_guard<std::mutex> lk(g_block_mu);
         size_t best = g_blocks.size();
         for (size_t i = 0; i < g_blocks.size(); ++i)
-            if (g_blocks[i].second >= need && g_blocks[i].second <= need * 2 + (1 << 20) && (best == g_blocks.size() || g_blocks[i].second < g_blocks[best].second)) best = i;
-        if (best != g_blocks.size()) { void *p = g_blocks[best].first; cap = g_blocks[best].second; g_blocks.erase(g_blocks.begin() + (long)best); return p; }
+            if (g_blocks[i].pinned == pinned && g_blocks[i].cap >= need && g_blocks[i].cap <= need * 2 + (1 << 20) &&
+                (best == g_blocks.size() || g_blocks[i].cap < g_blocks[best].cap)) best = i;
+        if (best != g_blocks.size()) { void *p = g_blocks[best].p; cap = g_blocks[best].cap; g_blocks.erase(g_blocks.begin() + (long)best); return p; }
     }
     cap = need;
-    return malloc(need);
+    if (!pinned) return malloc(need);
+    void *p = nullptr;
+    if (hipHostMalloc(&p, need, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
 }
-static void block_give(void *p, size_t cap) {
+static void block_give(void *p, size_t cap, bool pinned) {
     if (!p) return;
     {
         std::lock_guard<std::mutex> lk(g_block_mu);
         size_t held = 0;
-        for (auto &b : g_blocks) held += b.second;
-        if (cap >= (1 << 16) && g_blocks.size() < kBlockCacheEntries && held + cap <= kBlockCacheBytes) { g_blocks.emplace_back(p, cap); return; }
+        for (auto &b : g_blocks) held += b.cap;
+        if (cap >= (1 << 16) && g_blocks.size() < kBlockCacheEntries && held + cap <= kBlockCacheBytes) { g_blocks.push_back(CachedBlock{p, cap, pinned}); return; }
     }
-    free(p);
+    if (pinned) (void)hipHostFree(p); else free(p);
 }
 
 // zero = the caller does not write every column of every row
-static rgx_junction_table *table_alloc(const BamHeader &h, uint64_t n, bool zero = true) {
+static rgx_junction_table *table_alloc(const BamHeader &h, uint64_t n, bool zero = true, bool pinned = false) {
     TableBox *box = (TableBox *)calloc(1, sizeof *box);
     rgx_junction_table *t = &box->t;
     t->n_ref = (int32_t)h.names.size();
@@ -160,9 +166,11 @@ static rgx_junction_table *table_alloc(const BamHeader &h, uint64_t n, bool zero
     t->ref_len = (uint32_t *)calloc(h.names.size() + 1, sizeof(uint32_t));
     for (size_t i = 0; i < h.names.size(); ++i) { t->ref_name[i] = strdup(h.names[i].c_str()); t->ref_len[i] = h.lens[i]; }
     t->n = n;
-    const size_t m = ((size_t)n + 1 + 15) & ~(size_t)15;          // every column starts 16-byte aligned
-    const size_t need = m * (8 * 3 + 4 * 6 + 3);
-    box->block = block_take(need, box->block_cap);
+    const size_t m = table_block_rows(n);                         // every column starts 16-byte aligned; the layout launch_rows_table writes
+    const size_t need = table_block_bytes(n);
+    box->pinned = pinned;
+    box->block = block_take(need, box->block_cap, pinned);
+    if (!box->block && pinned) { box->pinned = false; box->block = block_take(need, box->block_cap, false); }
     if (zero) memset(box->block, 0, need);
     uint8_t *q = (uint8_t *)box->block;
     t->name_index = (uint64_t *)q; q += m * 8; t->first_seen = (uint64_t *)q; q += m * 8; t->last_seen = (uint64_t *)q; q += m * 8;
@@ -177,7 +185,7 @@ extern "C" void rgx_table_free(rgx_junction_table *t) {
     TableBox *box = (TableBox *)t;                                   // t is the first member
     if (t->ref_name) for (int32_t i = 0; i < t->n_ref; ++i) free(t->ref_name[i]);
     free(t->ref_name); free(t->ref_len);
-    block_give(box->block, box->block_cap);
+    block_give(box->block, box->block_cap, box->pinned);
     free(t->bc_row_begin); free(t->bc_count); free(t->bc_str_begin); free(t->bc_text); free(t->bc_insert_rank);
     free(box);
 }
@@ -623,9 +631,11 @@ struct HostRows {
 
 // where each event ended up: its unique row, and each unique row's position in the output order (device arrays; the -b pass keys on them)
 struct RowMap { uint32_t *ev_urow = nullptr, *urow_pos = nullptr; };
+// ask reduce_events for the finished result table: columns written on the device in the host block's layout, one copy, no host loop
+struct TableSink { const BamHeader *hdr = nullptr; uint32_t min_anchor = 0; rgx_junction_table *table = nullptr; };
 
 static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t group_bits, uint32_t ilen_bits, const uint32_t *rank_of_group_host,
-                         uint32_t n_groups, HostRows &R, char *err, size_t errlen, bool view_only = false, RowMap *row_map = nullptr) {
+                         uint32_t n_groups, HostRows &R, char *err, size_t errlen, bool view_only = false, RowMap *row_map = nullptr, TableSink *sink = nullptr) {
     hipStream_t st = c->stream;
     uint32_t *d_sc = c->buf("scalars").as<uint32_t>();
     uint32_t *h_sc = (uint32_t *)c->pinned;
@@ -721,6 +731,17 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
         DevBuf &b_out = c->buf("rows_out");
         HIP_TRY(b_out.ensure(U * 40 + 256));
         launch_rows_out(u, final_perm, n_unique, b_out.as<uint32_t>(), st);
+        if (sink) {
+            rgx_junction_table *t = table_alloc(*sink->hdr, U, /*zero=*/false, /*pinned=*/true);
+            DevBuf &b_tab = c->buf("table_dev");
+            const size_t bytes = table_block_bytes(U);
+            HIP_TRY(b_tab.ensure(bytes + 256));
+            launch_rows_table(u, final_perm, n_unique, sink->min_anchor, b_tab.as<uint8_t>(), st);
+            HIP_TRY(hipMemcpyAsync(((TableBox *)t)->block, b_tab.p, bytes, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            sink->table = t; R.n = U;
+            return RGX_OK;
+        }
         if (U * 40 > c->pinned_rows_cap) {
             if (c->pinned_rows) (void)hipHostFree(c->pinned_rows);
             c->pinned_rows = nullptr; c->pinned_rows_cap = 0;
@@ -877,24 +898,13 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     chrom_string_ranks(P.hdr, rank_of_tid);
     HostRows R;
     RowMap rm;
+    TableSink sink; sink.hdr = &P.hdr; sink.min_anchor = p->min_anchor;
     rc = reduce_events(c, P.ev, P.n_events, std::max<uint32_t>(1, bitlen((uint32_t)std::max(n_ref - 1, 0))), std::min<uint32_t>(32, bitlen(p->max_intron) + 2),
-                       rank_of_tid.data(), (uint32_t)std::max(n_ref, 1), R, err, errlen, /*view_only=*/true, p->barcodes ? &rm : nullptr);
+                       rank_of_tid.data(), (uint32_t)std::max(n_ref, 1), R, err, errlen, /*view_only=*/true, p->barcodes ? &rm : nullptr, &sink);
     if (rc != RGX_OK) return rc;
     c->last_rows = R.n; c->last_records = P.n_iterated; c->last_events = P.n_events; c->last_bytes = P.total; c->last_rows_valid = true;
     HIP_TRY(hipEventRecord(c->ev[6], st));
-    rgx_junction_table *t = table_alloc(P.hdr, R.n, /*zero=*/false);
-    {
-        const size_t U = R.n;
-        const uint32_t *hp = R.cols;     // columns: tid,start,end,ts,te,count,name_rank,first_seen,last_seen,strand
-        for (size_t i = 0; i < U; ++i) {
-            t->tid[i] = (int32_t)hp[i]; t->start[i] = hp[U + i]; t->end[i] = hp[2 * U + i]; t->thick_start[i] = hp[3 * U + i]; t->thick_end[i] = hp[4 * U + i];
-            t->read_count[i] = hp[5 * U + i]; t->name_index[i] = hp[6 * U + i]; t->first_seen[i] = hp[7 * U + i]; t->last_seen[i] = hp[8 * U + i];
-            t->strand[i] = (char)hp[9 * U + i];
-            // OR over reads of (start - thick_start >= a) == test on the minimum
-            t->left_ok[i] = (uint32_t)(t->start[i] - t->thick_start[i]) >= p->min_anchor;
-            t->right_ok[i] = (uint32_t)(t->thick_end[i] - t->end[i]) >= p->min_anchor;
-        }
-    }
+    rgx_junction_table *t = sink.table ? sink.table : table_alloc(P.hdr, 0);
     if (R.n >= 100000000u) host_sort_rows(t);   // names wider than 8 digits compare as strings upstream
     if (p->barcodes) {
         if (R.n >= 100000000u) { rgx_table_free(t); return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: -b with 10^8 or more junctions is not supported\n"); }
@@ -1077,7 +1087,7 @@ extern "C" int rgx_table_merge_device(rgx_ctx *c, const void *d_rows, uint64_t s
     HIP_TRY(sc.ensure(512));
     const size_t Nn = N, P = (size_t)n_parts, R = rank_of_tid.size();
     const size_t tmp_words = radix_tmp_words(N) + scan_tmp_words(N) + 64;
-    HIP_TRY(b.ensure((Nn * (10 + 2 + 2 + 9 + 4 + 12) + 2 * P + R + tmp_words) * 4 + 1024));
+    HIP_TRY(b.ensure((Nn * (10 + 2 + 2 + 9 + 4 + 13) + 64 + 2 * P + R + tmp_words) * 4 + 1024));
     uint32_t *w = b.as<uint32_t>();
     MergeSoA m; m.tid = w; w += Nn; m.start = w; w += Nn; m.end = w; w += Nn; m.ts = w; w += Nn; m.te = w; w += Nn; m.count = w; w += Nn;
     m.cls = w; w += Nn; m.first = w; w += Nn; m.shard = w; w += Nn; m.strand = w; w += Nn;
@@ -1086,7 +1096,7 @@ extern "C" int rgx_table_merge_device(rgx_ctx *c, const void *d_rows, uint64_t s
     MergeUnique u; u.tid = w; w += Nn; u.start = w; w += Nn; u.end = w; w += Nn; u.ts = w; w += Nn; u.te = w; w += Nn; u.count = w; w += Nn;
     u.first = w; w += Nn; u.last_shard = w; w += Nn; u.strand = w; w += Nn;
     uint32_t *name_rank = w; w += Nn; uint32_t *crank = w; w += Nn; uint32_t *uperm[2] = {w, w + Nn}; w += 2 * Nn;
-    uint32_t *packed = w; w += Nn * 12;
+    uint32_t *packed = w; w += Nn * 13 + 64;          // the merged table's device image (51 bytes per row + padding)
     uint32_t *d_rows_n = w; w += P; uint32_t *d_base = w; w += P; uint32_t *d_rank = w; w += R;
     uint32_t *tmp = w;
     uint32_t *d_total = sc.as<uint32_t>() + 70;
@@ -1129,38 +1139,12 @@ extern "C" int rgx_table_merge_device(rgx_ctx *c, const void *d_rows, uint64_t s
     sort_word(u.te, 32, U, uperm, upc);
     sort_word(u.ts, 32, U, uperm, upc);
     sort_word(crank, std::max<uint32_t>(1, bitlen(rk)), U, uperm, upc);
-    launch_merge_pack(u, uperm[upc], name_rank, U, packed, st);
+    rgx_junction_table *t = table_alloc(h, U, /*zero=*/false, /*pinned=*/true);
+    launch_merge_table(u, uperm[upc], name_rank, U, min_anchor, (uint8_t *)packed, st);      // the packed area doubles as the table's device image
     mark("reduce + name + order");
-    if ((size_t)U * 48 > c->pinned_rows_cap) {
-        if (c->pinned_rows) (void)hipHostFree(c->pinned_rows);
-        c->pinned_rows = nullptr; c->pinned_rows_cap = 0;
-        const size_t want = (size_t)U * 48 + (size_t)U * 6 + 4096;
-        HIP_TRY(hipHostMalloc(&c->pinned_rows, want, hipHostMallocDefault));
-        c->pinned_rows_cap = want;
-    }
-    const uint32_t *hp = (const uint32_t *)c->pinned_rows;
-    HIP_TRY(hipMemcpyAsync(c->pinned_rows, packed, (size_t)U * 48, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(((TableBox *)t)->block, packed, table_block_bytes(U), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    mark("rows to host");
-    rgx_junction_table *t = table_alloc(h, U, /*zero=*/false);
-    mark("table_alloc");
-    auto fill = [&](size_t lo, size_t hi) {
-        for (size_t i = lo; i < hi; ++i) {
-            const uint32_t *r = &hp[i * 12];
-            t->tid[i] = (int32_t)r[0]; t->start[i] = r[1]; t->end[i] = r[2]; t->thick_start[i] = r[3]; t->thick_end[i] = r[4]; t->read_count[i] = r[5];
-            t->first_seen[i] = r[6]; t->last_seen[i] = r[8]; t->strand[i] = (char)r[10]; t->name_index[i] = r[11];
-            t->left_ok[i] = (uint32_t)(r[1] - r[3]) >= min_anchor; t->right_ok[i] = (uint32_t)(r[4] - r[2]) >= min_anchor;
-        }
-    };
-    // the rows of a large merged table are spread over a few host threads (first-touch page faults of the fresh columns dominate)
-    const size_t n_thr = U < (1u << 17) ? 1 : 8;
-    if (n_thr == 1) fill(0, U);
-    else {
-        std::vector<std::thread> th;
-        for (size_t k = 0; k < n_thr; ++k) th.emplace_back(fill, (size_t)U * k / n_thr, (size_t)U * (k + 1) / n_thr);
-        for (auto &x : th) x.join();
-    }
-    mark("table fill");
+    mark("rows to host table");
     *out = t;
     return RGX_OK;
 }

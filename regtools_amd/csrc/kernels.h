@@ -133,6 +133,11 @@ void launch_gather_u32(uint32_t n, const uint32_t *table, const uint32_t *idx, u
 void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t stream);
 // ten u32 columns of n rows each, in `order`: tid,start,end,ts,te,count,name_rank,first_seen,last_seen,strand
 void launch_rows_out(UniqueSoA u, const uint32_t *order, uint32_t n, uint32_t *out, hipStream_t stream);
+// The result table's host block, written on the device so that ONE copy fills every column (api.cpp table_alloc): m = padded row count;
+// u64 name_index[m], first_seen[m], last_seen[m]; u32 tid[m], start[m], end[m], thick_start[m], thick_end[m], read_count[m]; u8 strand[m], left_ok[m], right_ok[m]
+RGX_HD size_t table_block_rows(uint64_t n) { return ((size_t)n + 1 + 15) & ~(size_t)15; }
+RGX_HD size_t table_block_bytes(uint64_t n) { return table_block_rows(n) * (8 * 3 + 4 * 6 + 3); }
+void launch_rows_table(UniqueSoA u, const uint32_t *order, uint32_t n, uint32_t min_anchor, uint8_t *out, hipStream_t stream);
 
 
 // ---- -b: barcode counts per junction (junctions_extractor.cc:362-374, :204-217; barcode_kernels.hip) -------------------------------
@@ -185,5 +190,7 @@ void launch_merge_heads(MergeSoA m, const uint32_t *sorted, uint32_t n, uint32_t
 void launch_merge_reduce(MergeSoA m, const uint32_t *sorted, const uint32_t *head, const uint32_t *seg_excl, uint32_t n, MergeUnique u /* ts preset to ~0, rest 0 */, hipStream_t st);
 void launch_merge_rank(const uint32_t *by_first, uint32_t n, uint32_t *name_rank, hipStream_t st);
 void launch_merge_pack(MergeUnique u, const uint32_t *order, const uint32_t *name_rank, uint32_t n, uint32_t *out, hipStream_t st);
+// the merged rows in the result table's host block layout (see launch_rows_table)
+void launch_merge_table(MergeUnique u, const uint32_t *order, const uint32_t *name_rank, uint32_t n, uint32_t min_anchor, uint8_t *out, hipStream_t st);
 
 }  // namespace rgx

@@ -964,6 +964,25 @@ __global__ void k_rows_out(UniqueSoA u, const uint32_t *__restrict__ order, uint
     out[9 * N + i] = u.strand[s];
 }
 
+// one row of the host table block (layout: kernels.h table_block_rows)
+__device__ __forceinline__ void table_row(uint8_t *out, size_t m, uint32_t i, uint32_t tid, uint32_t start, uint32_t end, uint32_t ts, uint32_t te, uint32_t count,
+                                          uint64_t name_index, uint64_t first, uint64_t last, uint32_t strand, uint32_t min_anchor) {
+    uint64_t *q8 = (uint64_t *)out;
+    q8[i] = name_index; q8[m + i] = first; q8[2 * m + i] = last;
+    uint32_t *q4 = (uint32_t *)(out + m * 24);
+    q4[i] = tid; q4[m + i] = start; q4[2 * m + i] = end; q4[3 * m + i] = ts; q4[4 * m + i] = te; q4[5 * m + i] = count;
+    uint8_t *q1 = out + m * 48;
+    q1[i] = (uint8_t)strand;
+    q1[m + i] = (uint32_t)(start - ts) >= min_anchor;       // OR over reads of (start - thick_start >= a) == the test on the minimum
+    q1[2 * m + i] = (uint32_t)(te - end) >= min_anchor;
+}
+__global__ void k_rows_table(UniqueSoA u, const uint32_t *__restrict__ order, uint32_t n, uint32_t min_anchor, uint8_t *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = order[i];
+    table_row(out, table_block_rows(n), i, u.tid[s], u.start[s], u.end[s], u.ts_min[s], u.te_max[s], u.count[s], u.name_rank[s], u.first_seen[s], u.last_seen[s], u.strand[s], min_anchor);
+}
+
 __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -988,6 +1007,9 @@ void launch_gather_u32(uint32_t n, const uint32_t *table, const uint32_t *idx, u
 }
 void launch_rows_out(UniqueSoA u, const uint32_t *order, uint32_t n, uint32_t *out, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(k_rows_out, dim3((n + 255) / 256), dim3(256), 0, stream, u, order, n, out);
+}
+void launch_rows_table(UniqueSoA u, const uint32_t *order, uint32_t n, uint32_t min_anchor, uint8_t *out, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_rows_table, dim3((n + 255) / 256), dim3(256), 0, stream, u, order, n, min_anchor, out);
 }
 void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, v, n);

@@ -79,6 +79,21 @@ __global__ void k_merge_pack(MergeUnique u, const uint32_t *__restrict__ order, 
     w[6] = u.first[s]; w[7] = 0; w[8] = u.last_shard[s]; w[9] = 0; w[10] = u.strand[s]; w[11] = name_rank[s] + 1u;
 }
 
+// the same rows in the result table's host block layout (kernels.h table_block_rows), so that one copy fills the host table
+__global__ void k_merge_table(MergeUnique u, const uint32_t *__restrict__ order, const uint32_t *__restrict__ name_rank, uint32_t n, uint32_t min_anchor, uint8_t *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = order[i];
+    const size_t m = table_block_rows(n);
+    const uint32_t start = u.start[s], end = u.end[s], ts = u.ts[s], te = u.te[s];
+    uint64_t *q8 = (uint64_t *)out;
+    q8[i] = (uint64_t)name_rank[s] + 1u; q8[m + i] = u.first[s]; q8[2 * m + i] = u.last_shard[s];
+    uint32_t *q4 = (uint32_t *)(out + m * 24);
+    q4[i] = u.tid[s]; q4[m + i] = start; q4[2 * m + i] = end; q4[3 * m + i] = ts; q4[4 * m + i] = te; q4[5 * m + i] = u.count[s];
+    uint8_t *q1 = out + m * 48;
+    q1[i] = (uint8_t)u.strand[s]; q1[m + i] = (uint32_t)(start - ts) >= min_anchor; q1[2 * m + i] = (uint32_t)(te - end) >= min_anchor;
+}
+
 static inline dim3 grid_for(uint32_t n) { return dim3((n + 255) / 256); }
 
 void launch_merge_unpack(const uint32_t *rows, uint32_t stride_rows, uint32_t n_parts, const uint32_t *part_rows, const uint32_t *part_base, MergeSoA m, hipStream_t st) {
@@ -102,6 +117,10 @@ void launch_merge_rank(const uint32_t *by_first, uint32_t n, uint32_t *name_rank
 }
 void launch_merge_pack(MergeUnique u, const uint32_t *order, const uint32_t *name_rank, uint32_t n, uint32_t *out, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_merge_pack, grid_for(n), dim3(256), 0, st, u, order, name_rank, n, out);
+}
+
+void launch_merge_table(MergeUnique u, const uint32_t *order, const uint32_t *name_rank, uint32_t n, uint32_t min_anchor, uint8_t *out, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_merge_table, grid_for(n), dim3(256), 0, st, u, order, name_rank, n, min_anchor, out);
 }
 
 }  // namespace rgx
