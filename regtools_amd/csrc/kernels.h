@@ -113,6 +113,10 @@ void launch_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *to
 size_t radix_tmp_words(uint32_t n);
 void launch_radix_pass(const uint32_t *word, uint32_t shift, uint32_t bits, const uint32_t *perm_in, uint32_t *perm_out,
                        uint32_t n, uint32_t *tmp, hipStream_t stream);
+// The same pass with the keys travelling along: position i's key is key_in[i] (streamed, no gather through the permutation), and
+// key_out receives the keys in the new order.  perm_in null = identity.  A multi-pass sort on one word gathers that word once.
+void launch_radix_pass_keyed(const uint32_t *key_in, uint32_t *key_out, uint32_t shift, uint32_t bits, const uint32_t *perm_in, uint32_t *perm_out,
+                             uint32_t n, uint32_t *tmp, hipStream_t stream);
 
 // ---- a7: segmented reduce ------------------------------------------------------------------------------------------
 struct UniqueSoA {

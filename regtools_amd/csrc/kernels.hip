@@ -680,6 +680,8 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
     return m;
 }
 
+// KEYED = the key of position i is word[i] itself (it travels with the permutation: launch_radix_pass_keyed) instead of word[perm_in[i]]
+template <bool KEYED>
 __global__ __launch_bounds__(64) void k_radix_hist(const uint32_t *__restrict__ word, uint32_t shift, uint32_t mask,
                                                    const uint32_t *__restrict__ perm_in, uint32_t n, uint32_t n_tiles, uint32_t *hist) {
     __shared__ uint32_t s_cnt[256];
@@ -688,15 +690,16 @@ __global__ __launch_bounds__(64) void k_radix_hist(const uint32_t *__restrict__ 
     const uint32_t base = blockIdx.x * kRadixTile;
     for (uint32_t r = 0; r < kRadixRows; ++r) {
         const uint32_t i = base + r * 64 + threadIdx.x;
-        if (i < n) { uint32_t src; atomicAdd(&s_cnt[radix_digit(word, perm_in, i, shift, mask, src)], 1u); }
+        if (i < n) { uint32_t src; atomicAdd(&s_cnt[KEYED ? ((word[i] >> shift) & mask) : radix_digit(word, perm_in, i, shift, mask, src)], 1u); }
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < 256; k += 64) hist[(size_t)k * n_tiles + blockIdx.x] = s_cnt[k];   // digit-major
 }
 
+template <bool KEYED>
 __global__ __launch_bounds__(64) void k_radix_scatter(const uint32_t *__restrict__ word, uint32_t shift, uint32_t mask,
                                                       const uint32_t *__restrict__ perm_in, uint32_t *perm_out, uint32_t n,
-                                                      uint32_t n_tiles, const uint32_t *__restrict__ hist_scan) {
+                                                      uint32_t n_tiles, const uint32_t *__restrict__ hist_scan, uint32_t *key_out) {
     __shared__ uint32_t s_base[256];
     for (uint32_t k = threadIdx.x; k < 256; k += 64) s_base[k] = hist_scan[(size_t)k * n_tiles + blockIdx.x];
     __syncthreads();
@@ -704,8 +707,10 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const uint32_t *__restrict
     for (uint32_t r = 0; r < kRadixRows; ++r) {
         const uint32_t i = base + r * 64 + threadIdx.x;
         const bool valid = i < n;
-        uint32_t src = 0;
-        const uint32_t d = valid ? radix_digit(word, perm_in, i, shift, mask, src) : 0u;
+        uint32_t src = 0, key = 0;
+        uint32_t d = 0;
+        if (KEYED) { if (valid) { key = word[i]; src = perm_in ? perm_in[i] : i; d = (key >> shift) & mask; } }
+        else d = valid ? radix_digit(word, perm_in, i, shift, mask, src) : 0u;
         const uint64_t m = match_digit(d, valid);
         if (valid) {
             const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt());
@@ -714,6 +719,7 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const uint32_t *__restrict
             if (lane_id() == leader) { b = s_base[d]; s_base[d] = b + (uint32_t)__popcll(m); }
             b = __shfl(b, leader, 64);
             perm_out[b + rank] = src;
+            if (KEYED) key_out[b + rank] = key;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -730,9 +736,19 @@ void launch_radix_pass(const uint32_t *word, uint32_t shift, uint32_t bits, cons
     const uint32_t tiles = (n + kRadixTile - 1) / kRadixTile;
     const uint32_t mask = (1u << bits) - 1u;
     uint32_t *hist = tmp, *scan_tmp = tmp + (size_t)256 * tiles;
-    hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(64), 0, stream, word, shift, mask, perm_in, n, tiles, hist);
+    hipLaunchKernelGGL(k_radix_hist<false>, dim3(tiles), dim3(64), 0, stream, word, shift, mask, perm_in, n, tiles, hist);
     launch_scan_u32(hist, hist, 256 * tiles, nullptr, scan_tmp, stream);
-    hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(64), 0, stream, word, shift, mask, perm_in, perm_out, n, tiles, hist);
+    hipLaunchKernelGGL(k_radix_scatter<false>, dim3(tiles), dim3(64), 0, stream, word, shift, mask, perm_in, perm_out, n, tiles, hist, (uint32_t *)nullptr);
+}
+void launch_radix_pass_keyed(const uint32_t *key_in, uint32_t *key_out, uint32_t shift, uint32_t bits, const uint32_t *perm_in, uint32_t *perm_out,
+                             uint32_t n, uint32_t *tmp, hipStream_t stream) {
+    if (!n) return;
+    const uint32_t tiles = (n + kRadixTile - 1) / kRadixTile;
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t *hist = tmp, *scan_tmp = tmp + (size_t)256 * tiles;
+    hipLaunchKernelGGL(k_radix_hist<true>, dim3(tiles), dim3(64), 0, stream, key_in, shift, mask, perm_in, n, tiles, hist);
+    launch_scan_u32(hist, hist, 256 * tiles, nullptr, scan_tmp, stream);
+    hipLaunchKernelGGL(k_radix_scatter<true>, dim3(tiles), dim3(64), 0, stream, key_in, shift, mask, perm_in, perm_out, n, tiles, hist, key_out);
 }
 
 
