@@ -336,3 +336,31 @@ def test_device_side_row_packing_equals_host_packing(gpu_ctx, synth_dir):
     assert rc == 0
     assert L.rgx_last_table_pack_device(gpu_ctx._h, je1.table, C.c_void_p(dev.data_ptr()), n + 5, err, len(err)) != 0      # stale table
     assert b"not the result of the last extraction" in err.value
+
+
+def test_full_size_properties(gpu_ctx):
+    """BASELINE configs[1] at its real size (50 M reads; the oracle would need minutes here, bench.py does that comparison against the
+    reference itself): properties that do not depend on the size -- determinism, conservation of events, output order, naming, and
+    independence of the shard count."""
+    from regtools_amd import synth, distributed
+    bam, bai, st = synth.generate(50_000_000, shape="short", seed=1)
+    import regtools_amd
+    def run(**kw):
+        je = regtools_amd.JunctionsExtractor(strandness=0, ctx=gpu_ctx, **kw)
+        je.identify_junctions_from_BAM(bam_bytes=bam, bai_bytes=bai)
+        return je
+    a, b = run(), run()
+    bed = a.bed12()
+    assert bed == b.bed12() and a.stats["n_records"] == st["n_reads"] == 50_000_000
+    rows = a.get_all_junctions()
+    assert sum(j.read_count for j in rows) == a.stats["n_events"] > 5_000_000
+    assert sorted(int(j.name[4:]) for j in rows) == list(range(1, len(rows) + 1))             # first-seen names: a permutation of 1..n
+    keys = [(j.chrom, j.thick_start, j.thick_end, j.name) for j in rows]
+    assert keys == sorted(keys)                                                               # compare_junctions (h:117-140)
+    assert len({(j.chrom, j.start, j.end, j.strand in "+-" and j.strand) for j in rows}) == len(rows)
+    parts, keep, recs = [], [], 0
+    for g in range(2):
+        je = run(shard=g, n_shards=2)
+        keep.append(je); parts.append(distributed.pack_table(je.table)); recs += je.stats["n_records"]
+    assert recs == 50_000_000
+    assert distributed.merge_packed(parts, keep[0].table, 8).bed12() == bed
