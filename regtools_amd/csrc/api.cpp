@@ -372,6 +372,25 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         mark("shard cuts");
     }
 
+    // region queries: the member range comes from the index, as the reference's iterator seeks (hts_itr_query, hts.c:1733-1800) -- the
+    // overlap predicate in k_decode_seg stays the judge, the span only spares inflating members no record of the region can be in.
+    // Needs the contig names before the launch: the header is inflated on the host from the head of the file.  Anything unusual
+    // (header not readable this way, a .csi, a region the parser rejects) leaves the range alone and the full path decides.
+    if (!whole && p->n_shards <= 1 && p->region && strcmp(p->region, "*")) {
+        const size_t head_len = std::min<size_t>(bam_len, (size_t)8 << 20);
+        std::vector<uint8_t> head_copy;
+        const uint8_t *head = h_bam;
+        if (!head) { head_copy.resize(head_len); HIP_TRY(hipMemcpy(head_copy.data(), d_bam, head_len, hipMemcpyDeviceToHost)); head = head_copy.data(); }
+        BamHeader hh;
+        int32_t tid = -1, beg = 0, end = 0;
+        uint64_t lo = 0, hi = 0; bool usable = false;
+        if (host_bam_header(head, head_len, hh) && parse_region(hh, p->region, tid, beg, end) && tid < bi.n_ref && end >= beg) {
+            if (bai_region_span(bai, bai_len, tid, beg, end, lo, hi, usable)) { cut_lo = lo; cut_hi = hi; }
+            else if (usable && bi.have_start && bi.start_voff) { cut_lo = cut_hi = bi.start_voff; }     // no bin of the region holds a record: nothing to inflate
+        }
+        mark("region span");
+    }
+
     {
         uint64_t q[3] = {seek ? (seek_voff >> 16) : 0, cut_lo >> 16, cut_hi == UINT64_MAX ? UINT64_MAX - 64 : (cut_hi >> 16)};
         memcpy(h_sc + 40, q, sizeof q);

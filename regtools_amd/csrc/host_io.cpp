@@ -91,6 +91,79 @@ void bai_first_anchor_ge(const uint8_t *d, size_t len, const uint64_t *targets, 
     }
 }
 
+bool bai_region_span(const uint8_t *d, size_t len, int32_t tid, int32_t beg, int32_t end, uint64_t &lo, uint64_t &hi, bool &usable) {
+    usable = false;
+    if (len < 8 || memcmp(d, "BAI\1", 4) || tid < 0) return false;
+    size_t p = 4;
+    const int32_t n_ref = (int32_t)h32(d + p); p += 4;
+    if (tid >= n_ref) return false;
+    if (beg < 0) beg = 0;
+    if (end <= beg) { usable = true; return false; }
+    int64_t e = end; if (e > (1ll << 29)) e = 1ll << 29;                  // reg2bins: min_shift 14, depth 5
+    const uint32_t b0 = (uint32_t)beg, e0 = (uint32_t)(e - 1);
+    auto in_region = [&](uint32_t bin) {
+        uint32_t t = 0;
+        for (int l = 0, s = 29; l <= 5; ++l, s -= 3) {
+            const uint32_t n_l = 1u << (3 * l);
+            if (bin < t + n_l) { const uint32_t k = bin - t; return k >= (b0 >> s) && k <= (e0 >> s); }
+            t += n_l;
+        }
+        return false;
+    };
+    for (int32_t r = 0; r < n_ref; ++r) {
+        if (p + 4 > len) return false;
+        const int32_t n_bin = (int32_t)h32(d + p); p += 4;
+        uint64_t cmin = UINT64_MAX, cmax = 0;
+        for (int32_t b = 0; b < n_bin; ++b) {
+            if (p + 8 > len) return false;
+            const uint32_t bin = h32(d + p); const int32_t n_chunk = (int32_t)h32(d + p + 4); p += 8;
+            if (n_chunk < 0 || p + (size_t)n_chunk * 16 > len) return false;
+            if (bin == kCsiBin) return false;
+            if (r == tid && bin != 37450 && in_region(bin))
+                for (int32_t c = 0; c < n_chunk; ++c) { cmin = std::min(cmin, h64(d + p + (size_t)c * 16)); cmax = std::max(cmax, h64(d + p + (size_t)c * 16 + 8)); }
+            p += (size_t)n_chunk * 16;
+        }
+        if (p + 4 > len) return false;
+        const int32_t n_intv = (int32_t)h32(d + p); p += 4;
+        if (n_intv < 0 || p + (size_t)n_intv * 8 > len) return false;
+        if (r == tid) {
+            usable = true;
+            if (cmin == UINT64_MAX) return false;
+            uint64_t lin = 0;                                             // entry of beg's window, zeros filled from the left (hts.c:1543-1547)
+            const int32_t w = std::min<int32_t>(beg >> 14, n_intv - 1);
+            for (int32_t i = w; i >= 0 && !lin; --i) lin = h64(d + p + (size_t)i * 8);
+            lo = std::max(cmin, lin); hi = cmax;
+            if (hi < lo) hi = lo;
+            return true;
+        }
+        p += (size_t)n_intv * 8;
+    }
+    return false;
+}
+
+bool host_bam_header(const uint8_t *d, size_t n, BamHeader &h) {
+    std::string plain;
+    size_t off = 0;
+    for (int members = 0; off + 18 <= n && members < 4096; ++members) {
+        if (d[off] != 31 || d[off + 1] != 139 || d[off + 2] != 8 || !(d[off + 3] & 4) || d[off + 10] != 6 || d[off + 11] != 0 || d[off + 12] != 'B' || d[off + 13] != 'C') return false;
+        const size_t bl = (size_t)h16(d + off + 16) + 1;
+        if (bl < 26 || off + bl + 16 > n) return false;                    // (the decoder may look 16 bytes past a payload)
+        const uint32_t isz = h32(d + off + bl - 4);
+        if (isz == 0 || isz > 65536) return false;                         // an empty member ends the header read upstream: let the device path judge
+        const size_t base = plain.size();
+        plain.resize(base + isz + 64);
+        HostTab T; uint32_t got = 0;
+        if (inflate_raw(d + off + 18, (uint32_t)(bl - 26), (uint8_t *)&plain[base], isz, &got, T) != INF_OK || got != isz) return false;
+        plain.resize(base + isz);
+        off += bl;
+        uint64_t need = 0;
+        const int r = parse_bam_header((const uint8_t *)plain.data(), plain.size(), h, need);
+        if (r == 0) return true;
+        if (r == 2) return false;
+    }
+    return false;
+}
+
 static bool readable(const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (!f) return false; fclose(f); return true; }
 
 static bool idx_name(const std::string &fn, const char *ext, std::string &out) {
@@ -204,7 +277,7 @@ bool normalize_index(const uint8_t *in, size_t n, std::vector<uint8_t> &storage,
             if (p + 16 > len) return false;
             const uint32_t bin = h32(d + p); const uint64_t loff = h64(d + p + 4); const int32_t n_chunk = (int32_t)h32(d + p + 12); p += 16;
             if (n_chunk < 0 || p + (size_t)n_chunk * 16 > len) return false;
-            w32(bin == meta_bin ? 37450u : 1u);                                                // real bins: any id but the pseudo-bin's
+            w32(bin == meta_bin ? 37450u : kCsiBin);                                           // real bins: an id no BAI has (a .csi's geometry is its own)
             w32((uint32_t)n_chunk);
             o.insert(o.end(), d + p, d + p + (size_t)n_chunk * 16);
             if (bin != meta_bin && loff) loffs.push_back(loff);

@@ -29,6 +29,17 @@ bool parse_bai(const uint8_t *bai, size_t len, BaiInfo &out, bool collect_anchor
 // for each target virtual offset: the smallest record-start offset listed in the index that is >= target
 // (UINT64_MAX when none); one linear pass, no sorting.
 void bai_first_anchor_ge(const uint8_t *bai, size_t len, const uint64_t *targets, int n, uint64_t *out);
+// Where the records that can overlap [beg, end) of reference tid lie in the file (hts_itr_query, hts.c:1733-1800, reg2bins :1668-1681): [lo, hi) in
+// virtual offsets, both record boundaries.  lo = the smallest chunk begin over the region's bins, raised to the linear index's entry for
+// beg's 16 KiB window (no record before that offset reaches the window, hts.c:1755-1768); hi = the largest chunk end.  A superset of
+// what the reference's iterator reads, so filtering [lo, hi) by overlap gives exactly its records.  false = nothing to read (no bin of
+// the region has a chunk) or an image whose bins are not BAI bins (converted from a .csi: kCsiBin).
+bool bai_region_span(const uint8_t *bai, size_t len, int32_t tid, int32_t beg, int32_t end, uint64_t &lo, uint64_t &hi, bool &usable);
+constexpr uint32_t kCsiBin = 0xfffffffeu;   // bin number normalize_index gives the real bins of a converted .csi
+// The BAM header from the head of the file, inflated on the host (the product's own decoder): region queries need the contig names
+// BEFORE the device launch to turn the region into a member range.  false = not available this way (the device path will say why).
+struct BamHeader;
+bool host_bam_header(const uint8_t *bam_head, size_t len, BamHeader &h);
 
 // hts.c:2009-2042 index file name resolution: "<fn>.csi", "<fn minus extension>.csi", then the same two for ".bai".
 // returns 0 found, 1 none

@@ -59,3 +59,19 @@ extern "C" size_t emu_umap_order(const char *const *keys, size_t n, size_t *orde
     *buckets = m.bucket_count();
     return k;
 }
+
+// region -> [lo, hi) virtual offsets from a BAI (host_io.cpp bai_region_span); returns 1 span, 0 nothing to read, -1 not usable
+extern "C" int emu_region_span(const uint8_t *bai, size_t n, int32_t tid, int32_t beg, int32_t end, uint64_t *lo, uint64_t *hi) {
+    std::vector<uint8_t> image; const uint8_t *d; size_t len;
+    if (!rgx::normalize_index(bai, n, image, d, len)) return -2;          // as prepare_events sees it: .bai, .csi or BGZF-compressed
+    bool usable = false;
+    if (rgx::bai_region_span(d, len, tid, beg, end, *lo, *hi, usable)) return 1;
+    return usable ? 0 : -1;
+}
+// the BAM header through the host decoder (host_io.cpp host_bam_header): number of contigs, or -1
+extern "C" int emu_host_header(const uint8_t *bam, size_t n, char *first_name, size_t cap) {
+    rgx::BamHeader h;
+    if (!rgx::host_bam_header(bam, n, h)) return -1;
+    if (!h.names.empty() && cap) { strncpy(first_name, h.names[0].c_str(), cap - 1); first_name[cap - 1] = 0; }
+    return (int)h.names.size();
+}

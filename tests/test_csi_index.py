@@ -161,3 +161,63 @@ def test_identify_with_a_csi_index(gpu_ctx, tmp_path):
     for ext, gold in (("tsv", "annotatedjunctions"), ("vcf", "annotatedvariants"), ("bed", "junctions")):
         exp = open(os.path.join(REF_GOLD, "expected-cis-splice-effects-identify-default-stranded-%s.out" % gold), "rb").read()
         assert open(files[ext], "rb").read() == exp, ext
+
+
+def test_region_span_covers_every_overlapping_record():
+    """bai_region_span (the member range of a -r query): every record that overlaps the region starts inside [lo, hi), both ends are
+    record boundaries, and a converted .csi image declines (its bins are not BAI bins)."""
+    import random
+    import struct
+    emu = ctypes.CDLL(os.path.join(ROOT, "tests", "hostemu", "libhostemu.so"))
+    emu.emu_region_span.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    emu.emu_host_header.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    rng = random.Random(3)
+    for shape, n in (("short", 60000), ("fuzz", 20000), ("long", 800)):
+        bam, bai, _ = synth.generate(n, shape=shape, seed=13)
+        name = ctypes.create_string_buffer(64)
+        n_ref = emu.emu_host_header(bam, len(bam), name, 64)
+        # records with their virtual offsets
+        recs, upos = [], 0
+        starts = []                                    # (inflated offset of member start, compressed offset)
+        for coff, payload, isz in bamio.bgzf_members(bam):
+            starts.append((upos, coff)); upos += isz
+        inflated = bamio.inflate_all(bam)
+        contigs, _ = bamio.split_records(inflated)
+        assert n_ref == len(contigs) and name.value.decode() == contigs[0][0]
+        q = 12 + struct.unpack_from("<i", inflated, 4)[0]
+        for _ in contigs:
+            q += 8 + struct.unpack_from("<i", inflated, q)[0]
+        import bisect
+        keys = [u for u, _ in starts]
+        def voff(u):
+            k = bisect.bisect_right(keys, u) - 1
+            return starts[k][1] << 16 | (u - starts[k][0])
+        while q + 4 <= len(inflated):
+            bl = struct.unpack_from("<i", inflated, q)[0]
+            tid, pos = struct.unpack_from("<ii", inflated, q + 4)
+            l_qname = inflated[q + 12]; n_cig = struct.unpack_from("<H", inflated, q + 16)[0]; flag = struct.unpack_from("<H", inflated, q + 18)[0]
+            ref = 0
+            for k in range(n_cig):
+                c = struct.unpack_from("<I", inflated, q + 36 + l_qname + 4 * k)[0]
+                if (c & 15) in (0, 2, 3, 7, 8): ref += c >> 4
+            endpos = pos + ref if (not flag & 4 and n_cig) else pos + 1
+            recs.append((tid, pos, endpos, voff(q)))
+            q += 4 + bl
+        boundaries = {r[3] for r in recs} | {voff(q)}
+        for _ in range(150):
+            tid = rng.randrange(len(contigs))
+            L = contigs[tid][1]
+            beg = rng.randrange(0, max(1, L)); end = beg + rng.choice([1, 50, 16384, 100000, 5_000_000, L])
+            lo, hi = ctypes.c_uint64(), ctypes.c_uint64()
+            r = emu.emu_region_span(bai, len(bai), tid, beg, end, ctypes.byref(lo), ctypes.byref(hi))
+            inside = [v for t, p0, p1, v in recs if t == tid and p0 < end and p1 > beg]
+            assert r >= 0
+            if r == 0:
+                assert not inside
+            else:
+                assert all(lo.value <= v < hi.value for v in inside), (shape, tid, beg, end)
+                assert lo.value in boundaries and (hi.value in boundaries or hi.value >= max(boundaries))
+        csi = csi_common.csi_bytes(bai)                  # a .csi has its own bin geometry: the span declines, the whole file is read
+        assert emu.emu_region_span(csi, len(csi), 0, 100, 5000, ctypes.byref(lo), ctypes.byref(hi)) == -1
+        gz = b"".join(bamio.bgzf_member(bai[i:i + 0xff00]) for i in range(0, len(bai), 0xff00)) + bamio.EOF_MARKER
+        assert emu.emu_region_span(gz, len(gz), 0, 100, 5000, ctypes.byref(lo), ctypes.byref(hi)) >= 0

@@ -364,3 +364,40 @@ def test_full_size_properties(gpu_ctx):
         keep.append(je); parts.append(distributed.pack_table(je.table)); recs += je.stats["n_records"]
     assert recs == 50_000_000
     assert distributed.merge_packed(parts, keep[0].table, 8).bed12() == bed
+
+
+def test_region_queries_read_only_the_members_the_index_names(gpu_ctx, synth_dir):
+    """-r: the member range comes from the index's bins + linear index (hts_itr_query, hts.c:1733-1800); the rows must be the oracle's
+    for any region, and a small region must not inflate the whole file."""
+    import random
+    from regtools_amd import synth
+    p = os.path.join(str(synth_dir), "region_idx.bam")
+    synth.write(p, 400000, shape="short", seed=77)
+    _, _, whole = gpu_extract(gpu_ctx, p, ["-s", "XS"])
+    rng = random.Random(5)
+    regions = ["chr1:1-50000", "chr1:100000-100001", "chr2:5000000-9000000", "chr7", "chrX:1-1000", "chr1:200000000-249000000", "chr22:1-60000000",
+               "chr3:16384-16385", "chr3:16383-32769", "chrY:10000000-10000100"]
+    for _ in range(12):
+        c = rng.choice(["chr1", "chr2", "chr5", "chr11", "chr19", "chrX"])
+        b = rng.randrange(1, 150_000_000); regions.append("%s:%d-%d" % (c, b, b + rng.choice([1, 100, 20000, 3_000_000, 80_000_000])))
+    small = 0
+    for reg in regions:
+        for args in (["-s", "XS", "-r", reg], ["-s", "RF", "-a", "5", "-r", reg]):
+            rc, out, je = gpu_extract(gpu_ctx, p, args)
+            orc, exp, _ = run_oracle(args + [p])
+            assert rc == orc and out == exp, (reg, args)
+        small += rc == 0 and je.stats["inflated_bytes"] * 4 < whole.stats["inflated_bytes"]
+    assert small >= 12, small
+    # the same through a .csi (no bin geometry this path reads: whole-file inflate, same rows) and with the file already in HBM
+    import shutil, csi_common, torch
+    q = os.path.join(str(synth_dir), "region_csi.bam")
+    shutil.copy(p, q); shutil.copy(p + ".bai", q + ".bai"); csi_common.bai_to_csi(q)
+    raw, bai = open(p, "rb").read(), open(p + ".bai", "rb").read()
+    d = torch.zeros(len(raw) + 64, dtype=torch.uint8, device="cuda"); d[:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8)); torch.cuda.synchronize()
+    import regtools_amd
+    for reg in regions[:6]:
+        exp = run_oracle(["-s", "XS", "-r", reg, p])[1]
+        assert gpu_extract(gpu_ctx, q, ["-s", "XS", "-r", reg])[1] == exp
+        je = regtools_amd.JunctionsExtractor(strandness=0, region=reg, ctx=gpu_ctx)
+        je.identify_junctions_from_BAM(bai_bytes=bai, device_ptr=d.data_ptr(), device_len=len(raw))
+        assert je.bed12() == exp
