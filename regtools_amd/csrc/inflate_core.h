@@ -81,7 +81,7 @@ RGX_HD int build_code(Tab &T, uint32_t w0, uint32_t n, int kind, Code &C) {
     offs_of[0] = 0;
 #pragma unroll
     for (int l = 1; l <= 15; ++l) {
-        left <<= 1; left -= (int)count[l];
+        left = left * 2 - (int)count[l];                 // (may go negative: over-subscribed, reported below)
         C.c[l - 1] = (code << (15 - l)) << 13 | (uint32_t)l << 9 | offs;   // lim[l-1] = first code of length l, left-justified to 15 bits
         offs_of[l] = offs;
         code += count[l]; offs += count[l];
@@ -288,7 +288,7 @@ RGX_HD int block_header(BitReader &br, Tab &T, Code &LL, Code &DD, const uint8_t
         cl_lim[0] = 0; cl_base[0] = 0; cl_off[0] = 0;
 #pragma unroll
         for (int l = 1; l <= 7; ++l) {
-            left <<= 1; left -= (int)cl_count[l];
+            left = left * 2 - (int)cl_count[l];
             cl_base[l] = (offs - code) & 0xff; cl_off[l] = offs;
             code += cl_count[l]; offs += cl_count[l];
             cl_lim[l] = code << (7 - l);
