@@ -1,5 +1,6 @@
 // cse_host.cpp -- see cse_host.h.  Citations relative to /root/reference/src.
 #include "cse_host.h"
+#include <limits.h>
 #include "host_io.h"
 
 #include <ctype.h>
@@ -97,9 +98,16 @@ static long field_atol(const char *s, size_t n) {
     while (i < n && (s[i] == ' ' || (s[i] >= 9 && s[i] <= 13))) ++i;
     bool neg = false;
     if (i < n && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; ++i; }
-    long v = 0;
-    while (i < n && s[i] >= '0' && s[i] <= '9') { v = v * 10 + (s[i] - '0'); ++i; }
-    return neg ? -v : v;
+    unsigned long v = 0;                                 // atol == strtol: saturates (stdlib), never overflows
+    const unsigned long lim = neg ? (unsigned long)LONG_MAX + 1ul : (unsigned long)LONG_MAX;
+    bool sat = false;
+    while (i < n && s[i] >= '0' && s[i] <= '9') {
+        const unsigned long d = (unsigned long)(s[i] - '0');
+        if (v > (lim - d) / 10) sat = true; else v = v * 10 + d;
+        ++i;
+    }
+    if (sat) return neg ? LONG_MIN : LONG_MAX;
+    return neg ? (long)(0ul - v) : (long)v;
 }
 
 std::string GtfModel::load(const std::string &path) {

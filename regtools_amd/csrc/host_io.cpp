@@ -234,7 +234,8 @@ std::string gunzip_all(const uint8_t *d, size_t n, std::string &out) {
             const int st = inflate_raw(src, (uint32_t)in_len, (uint8_t *)&out[base], (uint32_t)cap, &out_len, T, &used);
             if (st == INF_OK) { out.resize(base + out_len); break; }
             out.resize(base);
-            if (st == INF_OUT_OVERFLOW && !member_len) { cap *= 2; continue; }
+            // DEFLATE cannot expand more than 1032:1 (a 258-byte match per 2 bits): a stream that still overflows is corrupt, not big
+            if (st == INF_OUT_OVERFLOW && !member_len && cap < in_len * 1032 + 65536) { cap *= 2; continue; }
             return "regtools_amd: corrupt compressed input\n\n";
         }
         off = member_len ? off + member_len : q + used + 8;      // + CRC32, ISIZE
