@@ -770,7 +770,8 @@ int orc_extract(const orc_params *p, orc_table **out, char *err, size_t errlen) 
     } else {
         if (!strcmp(p->region, "*")) BAIL(itr_err); /* not restated */
         if (parse_region(t, p->region, &r_tid, &r_beg, &r_end) || r_tid >= bi.n_ref || r_end < r_beg) BAIL(itr_err);
-        /* sorted+indexed input: index-driven iteration == predicate filter in file order */
+        /* sorted+indexed input: index-driven iteration == predicate filter in file order.  (Not on a file that is damaged BEFORE the
+         * region: the reference seeks past the damage, this reads into it and stops.  The product seeks; see tools/fuzz.) */
     }
 
     fasta *fa = NULL;

@@ -275,7 +275,7 @@ struct Prep {
 };
 
 static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_bam, size_t bam_len, const uint8_t *bai, size_t bai_len,
-                          const rgx_extract_params *p, bool want_read_span, Prep &P, char *err, size_t errlen) {
+                          const rgx_extract_params *p, bool want_read_span, Prep &P, char *err, size_t errlen, const uint32_t *d_true_sizes = nullptr) {
     if (!p || p->strandness < 0 || p->strandness > 3) return fail(err, errlen, RGX_ERR_ARG, "Please supply strandness mode with '-s' option!\n\n");
     if (p->strandness == 3 && !p->fasta_path) return fail(err, errlen, RGX_ERR_ARG, "Strandness mode 'intron-motif' requires a fasta file!\n\n");
     if (p->barcodes && p->n_shards > 1) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: barcode counts (-b) need the whole file in one shard\n");
@@ -343,7 +343,8 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     }
     launch_scan_u32(c_reach, c_rank, n_cand, d_sc + 17, c_tmp, st);
     Member *d_members = b_members.as<Member>();
-    launch_member_compact(d_bam, cand, c_isize, c_reach, c_rank, n_cand, d_members, c_isz2, st);
+    launch_member_compact(d_bam, bam_len, cand, c_isize, c_reach, c_rank, n_cand, d_members, c_isz2, st);
+    if (d_true_sizes) launch_member_fix(d_members, c_isz2, n_cand, d_sc + 17, d_true_sizes, st);     // second run: lengths from the probe, not the footers
     launch_member_upos(d_members, c_isz2, d_sc + 17, (uint64_t *)(d_sc + 20), st);
     bai_thread.join();
     if (!bai_ok) return (void)hipStreamSynchronize(st), fail(err, errlen, RGX_ERR_INDEX, "%s", kMsgIndex);
@@ -439,6 +440,37 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st);
     HIP_TRY(hipEventRecord(c->ev[1], st));
     mark("launch inflate");
+
+    // -- files whose ISIZE footers lie ------------------------------------------------------------------------------------------
+    // The arena was laid out from the footers; the reference never reads them (inflate_block, bgzf.c:292-316: a block is as long as
+    // zlib says, at most 64 KiB).  When a member inflates to another length than its footer claims, or the member that ends the
+    // stream is not the plain empty block it claims to be, every member is inflated once into its own 64 KiB slot to learn the true
+    // lengths and the pipeline starts over with those.  Costs two extra inflate passes; only malformed files ever pay them.
+    if (!d_true_sizes && !getenv("REGTOOLS_AMD_NO_REPAIR")) {
+        HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        bool lies = h_sc[0] != 0xffffffffu && (h_sc[1] == 12u /* INF_SIZE_MISMATCH */ || h_sc[1] == 10u /* INF_OUT_OVERFLOW */);
+        if (!lies && stop < n_members_all) {
+            Member ms; uint8_t two[2] = {0, 0};
+            HIP_TRY(hipMemcpy(&ms, d_members + stop, sizeof ms, hipMemcpyDeviceToHost));
+            if (ms.isize == 0 && ms.clen >= 2) HIP_TRY(hipMemcpy(two, d_bam + ms.cpos, 2, hipMemcpyDeviceToHost));
+            // fine: an empty block (03 00, the EOF marker) or a member cut off by the end of the file
+            lies = !(ms.isize == 0 && two[0] == 3 && two[1] == 0) && ms.isize != 0xffffffffu;
+        }
+        if (lies) {
+            mark("footer mismatch: probing");
+            DevBuf &b_slots = c->buf("probe_slots"), &b_sizes = c->buf("probe_sizes");
+            HIP_TRY(b_slots.ensure((size_t)n_members_all * kBgzfMaxBlock + 256));
+            HIP_TRY(b_sizes.ensure((size_t)n_members_all * 4 + 64));
+            HIP_TRY(b_lens.ensure(inflate_scratch_bytes(std::max<uint32_t>(n_members_all, 64))));
+            launch_inflate_probe(d_bam, d_members, n_members_all, b_slots.as<uint8_t>(), b_lens.as<uint32_t>(), b_sizes.as<uint32_t>(), st);
+            HIP_TRY(hipStreamSynchronize(st));
+            b_slots.release();                                  // 64 KiB per member: not kept
+            const int rc2 = prepare_events(c, d_bam_in, h_bam, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, b_sizes.as<uint32_t>());
+            P.t_begin = t_begin;
+            return rc2;
+        }
+    }
 
     // -- header (sam.c:114-223): it sits at the start of the arena when the range starts at member 0; otherwise the head of
     //    the file is inflated into its own small arena -----------------------------------------------------------------------

@@ -34,7 +34,7 @@ void launch_member_link(const uint8_t *bam, uint64_t len, const uint64_t *cand, 
                         uint32_t *reach, hipStream_t stream);
 void launch_member_jump(uint32_t n, const uint32_t *next_in, uint32_t *next_out, uint32_t *reach, hipStream_t stream);
 // members[rank] for reachable candidates (rank = exclusive scan of reach); upos filled later by launch_member_upos
-void launch_member_compact(const uint8_t *bam, const uint64_t *cand, const uint32_t *isize, const uint32_t *reach, const uint32_t *rank,
+void launch_member_compact(const uint8_t *bam, uint64_t len, const uint64_t *cand, const uint32_t *isize, const uint32_t *reach, const uint32_t *rank,
                            uint32_t n, Member *members, uint32_t *isize_compact, hipStream_t stream);
 // 64-bit exclusive scan of isize over the compacted members (single workgroup; n is ~1e5) -> Member::upos, total
 void launch_member_upos(Member *members, const uint32_t *isize_compact, const uint32_t *n_members /*device*/, uint64_t *total, hipStream_t stream);
@@ -43,6 +43,13 @@ void launch_member_upos(Member *members, const uint32_t *isize_compact, const ui
 void launch_member_query(const Member *members, const uint32_t *n_members /*device*/, const uint64_t *q_coff, uint32_t n_q, uint32_t *q_index,
                          uint64_t *q_upos, hipStream_t stream);
 // *stop = min(*stop, first index >= *from whose ISIZE is 0 or > 65536)
+// repair of files whose ISIZE footers do not say what the members inflate to (the reference never reads ISIZE, bgzf.c:292-316):
+// launch_inflate_probe puts member m into slots + m * 64 KiB and its true length (~0 = does not inflate) into sizes[m];
+// launch_member_fix makes those lengths the members' sizes before the offsets are scanned.
+void launch_inflate_probe(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *slots, uint32_t *len_scratch, uint32_t *sizes,
+                          hipStream_t stream);
+void launch_member_fix(Member *members, uint32_t *isize_compact, uint32_t max_members, const uint32_t *n_members /*device*/, const uint32_t *fix,
+                       hipStream_t stream);
 void launch_member_stop(const Member *members, uint32_t max_members, const uint32_t *n_members /*device*/, const uint32_t *from /*device*/, uint32_t *stop,
                         hipStream_t stream);
 

@@ -85,6 +85,10 @@ struct LdsTab {
     __device__ __forceinline__ void clear_syms() {}
 };
 
+// PROBE = false: the pipeline's launch -- member m goes to its planned place arena + upos (planned from the ISIZE footers) and must
+// inflate to exactly ISIZE bytes.  PROBE = true: the repair launch for files whose footers lie (bgzf.c:292-316 never reads ISIZE: a
+// block is as long as zlib says): every member into its own 64 KiB slot, true length (or ~0 = does not inflate) to sizes[m].
+template <bool PROBE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_inflate(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
                                                 uint32_t n_members, uint8_t *__restrict__ arena, uint64_t upos_bias, uint32_t *len_scratch,
                                                 uint32_t *status) {
@@ -94,6 +98,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     Member mb = members[m];
     LdsTab T{lds + threadIdx.x, len_scratch + m, gridDim.x * 64};
     uint32_t out_len = 0;
+    if (PROBE) {
+        if (mb.isize == 0xffffffffu) { status[m] = 0xffffffffu; return; }   // k_member_link: BSIZE runs past the end of the file (or is < 26): the read fails upstream
+        const int st = inflate_raw(comp + mb.cpos, mb.clen, arena + (uint64_t)m * kBgzfMaxBlock, kBgzfMaxBlock, &out_len, T);
+        status[m] = st == INF_OK ? out_len : 0xffffffffu;
+        return;
+    }
     int st = inflate_raw(comp + mb.cpos, mb.clen, arena + (mb.upos - upos_bias), mb.isize, &out_len, T);
     if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
     if (st != INF_OK) {
@@ -109,11 +119,18 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
     if (!n_members) return;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+        (void)hipFuncSetAttribute((const void *)k_inflate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+        (void)hipFuncSetAttribute((const void *)k_inflate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
         attr_set = true;
     }
     uint32_t blocks = (n_members + 63) / 64;
-    hipLaunchKernelGGL(k_inflate, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status);
+    hipLaunchKernelGGL(k_inflate<false>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status);
+}
+void launch_inflate_probe(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *slots, uint32_t *len_scratch, uint32_t *sizes,
+                          hipStream_t stream) {
+    if (!n_members) return;
+    (void)hipFuncSetAttribute((const void *)k_inflate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+    hipLaunchKernelGGL(k_inflate<true>, dim3((n_members + 63) / 64), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes);
 }
 
 // =====================================================================================================
@@ -803,6 +820,7 @@ __global__ void k_member_link(const uint8_t *__restrict__ bam, uint64_t len, con
     uint32_t nx = n, isz = 0xffffffffu;                              // malformed member: chain ends, never inflated
     if (blen >= 26 && off + blen <= len) {
         isz = ld32(bam + off + blen - 4);
+        if (isz == 0xffffffffu) isz = 0xfffffffeu;                       // ~0 is the mark of an unusable member; as a footer value both just mean "too big"
         const uint64_t want = off + blen;
         uint32_t lo = i + 1, hi = n;                                 // candidates are sorted by offset
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cand[mid] < want) lo = mid + 1; else hi = mid; }
@@ -822,14 +840,19 @@ __global__ void k_member_jump(uint32_t n, const uint32_t *__restrict__ next_in, 
     } else next_out[i] = nx;
 }
 
-__global__ void k_member_compact(const uint8_t *__restrict__ bam, const uint64_t *__restrict__ cand, const uint32_t *__restrict__ isize,
+__global__ void k_member_compact(const uint8_t *__restrict__ bam, uint64_t len, const uint64_t *__restrict__ cand, const uint32_t *__restrict__ isize,
                                  const uint32_t *__restrict__ reach, const uint32_t *__restrict__ rank, uint32_t n, Member *members, uint32_t *isize_compact) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !reach[i]) return;
     const uint64_t off = cand[i];
     const uint32_t blen = (uint32_t)ld16(bam + off + 16) + 1;
     const uint32_t r = rank[i];
-    Member m; m.cpos = off + 18; m.upos = 0; m.clen = blen >= 26 ? blen - 26 : 0; m.isize = isize[i];
+    // inflate_block (bgzf.c:292-316) hands zlib block_length - 16 bytes from offset 18: the payload AND the footer (a stream that ends late
+    // eats CRC bytes instead of failing, e.g. when BSIZE is one short).  Here: everything up to the member's end, clipped so that the
+    // decoder's 16-byte look-ahead stays inside the documented bam_len + 8 readable bytes.
+    Member m; m.cpos = off + 18; m.upos = 0; m.isize = isize[i];
+    m.clen = blen >= 26 ? blen - 18 : 0;
+    if (m.cpos + m.clen + 8 > len) m.clen = len > m.cpos + 8 ? (uint32_t)(len - 8 - m.cpos) : 0;
     members[r] = m;
     isize_compact[r] = (isize[i] <= kBgzfMaxBlock) ? isize[i] : 0u;  // oversized/unusable members hold no bytes in the arena
 }
@@ -865,6 +888,14 @@ __global__ void k_member_query(const Member *__restrict__ members, const uint32_
     q_upos[k] = hit ? members[lo].upos : ~0ull;
 }
 
+// the true lengths a probe launch found replace the ISIZE footers (members and the compact copy the offsets are scanned from)
+__global__ void k_member_fix(Member *members, uint32_t *isize_compact, const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ fix) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_ptr) return;
+    const uint32_t sz = fix[i];
+    members[i].isize = sz;
+    isize_compact[i] = sz <= kBgzfMaxBlock ? sz : 0u;
+}
 __global__ void k_member_stop(const Member *__restrict__ members, const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ from_ptr, uint32_t *stop) {
     const uint32_t n = *n_ptr;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -885,9 +916,9 @@ void launch_member_link(const uint8_t *bam, uint64_t len, const uint64_t *cand, 
 void launch_member_jump(uint32_t n, const uint32_t *next_in, uint32_t *next_out, uint32_t *reach, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(k_member_jump, dim3((n + 255) / 256), dim3(256), 0, stream, n, next_in, next_out, reach);
 }
-void launch_member_compact(const uint8_t *bam, const uint64_t *cand, const uint32_t *isize, const uint32_t *reach, const uint32_t *rank, uint32_t n,
+void launch_member_compact(const uint8_t *bam, uint64_t len, const uint64_t *cand, const uint32_t *isize, const uint32_t *reach, const uint32_t *rank, uint32_t n,
                            Member *members, uint32_t *isize_compact, hipStream_t stream) {
-    if (n) hipLaunchKernelGGL(k_member_compact, dim3((n + 255) / 256), dim3(256), 0, stream, bam, cand, isize, reach, rank, n, members, isize_compact);
+    if (n) hipLaunchKernelGGL(k_member_compact, dim3((n + 255) / 256), dim3(256), 0, stream, bam, len, cand, isize, reach, rank, n, members, isize_compact);
 }
 void launch_member_upos(Member *members, const uint32_t *isize_compact, const uint32_t *n_members, uint64_t *total, hipStream_t stream) {
     hipLaunchKernelGGL(k_member_upos, dim3(1), dim3(256), 0, stream, members, isize_compact, n_members, total);
@@ -895,6 +926,9 @@ void launch_member_upos(Member *members, const uint32_t *isize_compact, const ui
 void launch_member_query(const Member *members, const uint32_t *n_members, const uint64_t *q_coff, uint32_t n_q, uint32_t *q_index, uint64_t *q_upos,
                          hipStream_t stream) {
     if (n_q) hipLaunchKernelGGL(k_member_query, dim3((n_q + 63) / 64), dim3(64), 0, stream, members, n_members, q_coff, n_q, q_index, q_upos);
+}
+void launch_member_fix(Member *members, uint32_t *isize_compact, uint32_t max_members, const uint32_t *n_members, const uint32_t *fix, hipStream_t stream) {
+    if (max_members) hipLaunchKernelGGL(k_member_fix, dim3((max_members + 255) / 256), dim3(256), 0, stream, members, isize_compact, n_members, fix);
 }
 void launch_member_stop(const Member *members, uint32_t max_members, const uint32_t *n_members, const uint32_t *from, uint32_t *stop, hipStream_t stream) {
     if (max_members) hipLaunchKernelGGL(k_member_stop, dim3((max_members + 255) / 256), dim3(256), 0, stream, members, n_members, from, stop);

@@ -1,0 +1,67 @@
+"""Whole-pipeline robustness on an MI355X: mutated BAM files (bit flips in compressed payloads, BSIZE / ISIZE / gzip header bytes, record
+fields inside re-compressed members, truncation) through the C-ABI, each compared with the oracle (exit status and BED12 bytes).
+Run under `timeout`; prints one line per disagreement."""
+import os, random, struct, subprocess, sys, tempfile, zlib
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bamio
+import regtools_amd
+from regtools_amd import synth
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctx = regtools_amd.Context(0)
+ORACLE = os.path.join(ROOT, "oracle", "oracle_cli")
+bad = 0
+with tempfile.TemporaryDirectory() as td:
+    bases = []
+    for shape, n, seed in (("short", 20000, 3), ("fuzz", 8000, 4), ("long", 150, 5)):
+        p = os.path.join(td, "base_%s.bam" % shape)
+        synth.write(p, n, shape=shape, seed=seed)
+        bases.append((open(p, "rb").read(), open(p + ".bai", "rb").read()))
+    for case in range(n_cases):
+        bam, bai = rng.choice(bases)
+        b = bytearray(bam)
+        members = list(bamio.bgzf_members(bam))
+        kind = rng.choice(["payload", "payload", "bsize", "isize", "magic", "truncate", "record", "crc", "dup_eof"])
+        mi = rng.randrange(1 if len(members) > 2 else 0, len(members))          # usually not the header member
+        coff, payload, isz = members[mi]
+        if kind == "payload":
+            for _ in range(rng.choice([1, 1, 4])):
+                b[coff + 18 + rng.randrange(max(1, len(payload)))] ^= 1 << rng.randrange(8)
+        elif kind == "bsize":
+            struct.pack_into("<H", b, coff + 16, rng.choice([0, 1, 25, 26, 27, rng.randrange(65536), struct.unpack_from("<H", b, coff + 16)[0] ^ 1]))
+        elif kind == "isize":
+            struct.pack_into("<I", b, coff + 18 + len(payload) + 4, rng.choice([0, 1, (isz - 1) & 0xffffffff, isz + 1, 65536, 65537, 0xffffffff]))
+        elif kind == "magic":
+            b[coff + rng.choice([0, 1, 2, 3, 10, 12, 13, 14])] ^= rng.choice([1, 0x80, 0xff])
+        elif kind == "truncate":
+            b = b[:rng.randrange(30, len(b))]
+        elif kind == "crc":
+            b[coff + 18 + len(payload) + rng.randrange(4)] ^= 0xff               # the reference never checks the CRC
+        elif kind == "dup_eof":
+            b[coff:coff] = bamio.EOF_MARKER                                      # an empty member in the middle ends the stream
+        elif kind == "record":
+            raw = bytearray(zlib.decompress(payload, -15))
+            if len(raw) > 64:
+                k = rng.randrange(len(raw) - 40)
+                raw[k:k + 4] = struct.pack("<I", rng.choice([0, 31, 32, 33, 1 << 27, (1 << 27) + 1, 0x7fffffff, 0xffffffff, rng.randrange(1 << 16)]))
+                newm = bamio.bgzf_member(bytes(raw))
+                bl = struct.unpack_from("<H", b, coff + 16)[0] + 1
+                b[coff:coff + bl] = newm
+        path = os.path.join(td, "case.bam")
+        open(path, "wb").write(bytes(b)); open(path + ".bai", "wb").write(bai)
+        args = rng.choice([["-s", "XS"], ["-s", "RF", "-a", "3"], ["-s", "XS", "-r", rng.choice(["chr1", "1", "chr2:1-90000000", "10:1000-200000"])]])
+        orc = subprocess.run([ORACLE, "extract"] + args + [path], capture_output=True)
+        je = regtools_amd.JunctionsExtractor(ctx=ctx)
+        try:
+            je.parse_options(args + [path]); je.identify_junctions_from_BAM(); rc, out = 0, je.bed12()
+        except regtools_amd.RegtoolsError as e:
+            rc, out = 1, b""
+        if (rc != 0) != (orc.returncode != 0) or (rc == 0 and out != orc.stdout):
+            bad += 1
+            keep = os.path.join(ROOT, "gpurun_out", "fuzz_case_%d.bam" % case)
+            os.makedirs(os.path.dirname(keep), exist_ok=True)
+            open(keep, "wb").write(bytes(b)); open(keep + ".bai", "wb").write(bai)
+            print("DISAGREE case %d kind %s member %d args %s: gpu rc %d rows %d, oracle rc %d rows %d" % (case, kind, mi, args, rc, out.count(b"\n"), orc.returncode, orc.stdout.count(b"\n")), flush=True)
+print("cases %d, disagreements %d" % (n_cases, bad))
