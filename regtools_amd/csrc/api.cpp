@@ -314,6 +314,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     HIP_TRY(hipMemsetAsync(d_sc, 0xff, 4, st));
     HIP_TRY(hipMemsetAsync(d_sc + 12, 0xff, 4, st));
     HIP_TRY(hipMemsetAsync(d_sc + 18, 0xff, 4, st));
+    HIP_TRY(hipMemsetAsync(d_sc + kStatusEarly, 0xff, 4, st));
 
     // -- BGZF member discovery on the device (replaces the serial BSIZE walk, bgzf.c:421-546) -------------------------------
     const uint32_t n_tiles = (uint32_t)((bam_len + kMagicTile - 1) / kMagicTile);
@@ -335,17 +336,19 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     uint32_t *nx[2] = {(uint32_t *)(cand + n_cand), (uint32_t *)(cand + n_cand) + n_cand};
     uint32_t *c_isize = nx[1] + n_cand, *c_reach = c_isize + n_cand, *c_rank = c_reach + n_cand, *c_isz2 = c_rank + n_cand, *c_tmp = c_isz2 + n_cand;
     launch_magic_fill(d_bam, bam_len, n_tiles, tile_cnt, cand, st);
-    launch_member_link(d_bam, bam_len, cand, n_cand, nx[0], c_isize, c_reach, st);
-    {
+    Member *d_members = b_members.as<Member>();
+    // the members = the candidates that chain up from offset 0 (and, second try below, from the offset a seek lands on)
+    auto chain = [&](uint64_t root2) {
+        launch_member_link(d_bam, bam_len, cand, n_cand, nx[0], c_isize, c_reach, root2, st);
         int cur = 0;
         for (uint32_t span = 1; span < n_cand; span <<= 1) { launch_member_jump(n_cand, nx[cur], nx[cur ^ 1], c_reach, st); cur ^= 1; }
         launch_member_jump(n_cand, nx[cur], nx[cur ^ 1], c_reach, st);
-    }
-    launch_scan_u32(c_reach, c_rank, n_cand, d_sc + 17, c_tmp, st);
-    Member *d_members = b_members.as<Member>();
-    launch_member_compact(d_bam, bam_len, cand, c_isize, c_reach, c_rank, n_cand, d_members, c_isz2, st);
-    if (d_true_sizes) launch_member_fix(d_members, c_isz2, n_cand, d_sc + 17, d_true_sizes, st);     // second run: lengths from the probe, not the footers
-    launch_member_upos(d_members, c_isz2, d_sc + 17, (uint64_t *)(d_sc + 20), st);
+        launch_scan_u32(c_reach, c_rank, n_cand, d_sc + 17, c_tmp, st);
+        launch_member_compact(d_bam, bam_len, cand, c_isize, c_reach, c_rank, n_cand, d_members, c_isz2, st);
+        if (d_true_sizes) launch_member_fix(d_members, c_isz2, n_cand, d_sc + 17, d_true_sizes, st);     // second run: lengths from the probe, not the footers
+        launch_member_upos(d_members, c_isz2, d_sc + 17, (uint64_t *)(d_sc + 20), st);
+    };
+    chain(UINT64_MAX);
     bai_thread.join();
     if (!bai_ok) return (void)hipStreamSynchronize(st), fail(err, errlen, RGX_ERR_INDEX, "%s", kMsgIndex);
     mark("parse_bai");
@@ -386,22 +389,35 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         int32_t tid = -1, beg = 0, end = 0;
         uint64_t lo = 0, hi = 0; bool usable = false;
         if (host_bam_header(head, head_len, hh) && parse_region(hh, p->region, tid, beg, end) && tid < bi.n_ref && end >= beg) {
-            if (bai_region_span(bai, bai_len, tid, beg, end, lo, hi, usable)) { cut_lo = lo; cut_hi = hi; }
-            else if (usable && bi.have_start && bi.start_voff) { cut_lo = cut_hi = bi.start_voff; }     // no bin of the region holds a record: nothing to inflate
+            // like the iterator's bgzf_seek: reading starts at lo whatever the state of the members in front of it
+            if (bai_region_span(bai, bai_len, tid, beg, end, lo, hi, usable)) { cut_lo = lo; cut_hi = hi; seek = true; seek_voff = lo; }
+            else if (usable && bi.have_start && bi.start_voff) { cut_lo = cut_hi = bi.start_voff; seek = true; seek_voff = cut_lo; }     // no bin of the region holds a record: nothing to inflate
         }
         mark("region span");
     }
 
-    {
+    auto query = [&]() -> hipError_t {
         uint64_t q[3] = {seek ? (seek_voff >> 16) : 0, cut_lo >> 16, cut_hi == UINT64_MAX ? UINT64_MAX - 64 : (cut_hi >> 16)};
         memcpy(h_sc + 40, q, sizeof q);
-        HIP_TRY(hipMemcpyAsync(d_sc + 40, h_sc + 40, sizeof q, hipMemcpyHostToDevice, st));
+        hipError_t e = hipMemcpyAsync(d_sc + 40, h_sc + 40, sizeof q, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(d_sc + 18, 0xff, 4, st);
+        if (e != hipSuccess) return e;
         launch_member_query(d_members, d_sc + 17, (const uint64_t *)(d_sc + 40), 3, d_sc + 24, (uint64_t *)(d_sc + 32), st);
         // the stream ends at the first empty (or oversized = corrupt) member at/after the first one read (bgzf.c:548-578)
         launch_member_stop(d_members, n_cand, d_sc + 17, d_sc + 24, d_sc + 18, st);
+        e = hipMemcpyAsync(h_sc, d_sc, 256, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return e;
+        return hipStreamSynchronize(st);
+    };
+    HIP_TRY(query());
+    if (seek && (seek_voff >> 16) != 0 && h_sc[24] >= h_sc[17]) {
+        // the seek target is no member of the chain from offset 0: something in front of it is broken.  bgzf_seek (hts_itr_next, hts.c:1935)
+        // goes there regardless -- take it as a second chain root.  (Only damaged files get here.)
+        chain(seek_voff >> 16);
+        HIP_TRY(query());
+        mark("second chain root");
     }
-    HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 256, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
     const uint32_t n_members_all = h_sc[17];
     if (n_members_all == 0) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);     // offset 0 is not a BGZF member
     uint64_t total_all; memcpy(&total_all, h_sc + 20, 8);
@@ -419,7 +435,6 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         m_hi = std::min(stop, (mh < n_members_all && (cut_hi & 0xffff)) ? mh + 1 : mh);
     }
     if (m_lo > m_hi) m_lo = m_hi;
-    (void)first_member;
     // arena offsets of the range ends
     auto upos_of = [&](uint32_t k, uint64_t &out_v) -> hipError_t {
         if (k >= n_members_all) { out_v = total_all; return hipSuccess; }
@@ -437,7 +452,9 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     HIP_TRY(hipEventRecord(c->ev[0], st));
     DevBuf &b_lens = c->buf("inflate_scratch");
     HIP_TRY(b_lens.ensure(inflate_scratch_bytes(std::max<uint32_t>(n_range, 64))));
-    launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st);
+    // with a seek, the members in front of its target are only inflated for the header's sake (same launch): their failures end nothing
+    const uint32_t ignore_below = (seek && first_member < n_members_all && first_member > m_lo) ? first_member - m_lo : 0;
+    launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below);
     HIP_TRY(hipEventRecord(c->ev[1], st));
     mark("launch inflate");
 
@@ -446,10 +463,12 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // zlib says, at most 64 KiB).  When a member inflates to another length than its footer claims, or the member that ends the
     // stream is not the plain empty block it claims to be, every member is inflated once into its own 64 KiB slot to learn the true
     // lengths and the pipeline starts over with those.  Costs two extra inflate passes; only malformed files ever pay them.
-    if (!d_true_sizes && !getenv("REGTOOLS_AMD_NO_REPAIR")) {
-        HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        bool lies = h_sc[0] != 0xffffffffu && (h_sc[1] == 12u /* INF_SIZE_MISMATCH */ || h_sc[1] == 10u /* INF_OUT_OVERFLOW */);
+    HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_sc + kStatusEarly, d_sc + kStatusEarly, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (!d_true_sizes) {
+        auto size_trouble = [&](uint32_t k) { return h_sc[k] != 0xffffffffu && (h_sc[k + 1] == 12u /* INF_SIZE_MISMATCH */ || h_sc[k + 1] == 10u /* INF_OUT_OVERFLOW */); };
+        bool lies = size_trouble(0) || size_trouble(kStatusEarly);
         if (!lies && stop < n_members_all) {
             Member ms; uint8_t two[2] = {0, 0};
             HIP_TRY(hipMemcpy(&ms, d_members + stop, sizeof ms, hipMemcpyDeviceToHost));
@@ -476,6 +495,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     //    the file is inflated into its own small arena -----------------------------------------------------------------------
     BamHeader hdr;
     {
+        const uint32_t h_early = h_sc[kStatusEarly];            // read back right after the launch finished (below the footer check)
         uint32_t n_h = std::min<uint32_t>(n_members_all, 4);
         for (;;) {
             const uint8_t *src; uint64_t have;
@@ -498,7 +518,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             HIP_TRY(hipMemcpyAsync(hbuf.data(), src, have, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 64, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            bad_h = (src == b_arena.as<uint8_t>()) ? h_sc[0] : h_sc[12];
+            bad_h = (src == b_arena.as<uint8_t>()) ? std::min(h_sc[0], h_early) : h_sc[12];     // (members in front of a seek target report apart)
             if (bad_h != 0xffffffffu && bad_h < used) have = hmem[bad_h].upos;          // a corrupt member ends the header read
             uint64_t need = 0;
             int r = parse_bam_header(hbuf.data(), have, hdr, need);

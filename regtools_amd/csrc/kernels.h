@@ -17,8 +17,9 @@ constexpr uint64_t kChainUnknown = ~0ull - 1;   // exit of a segment in which th
 // member m writes its bytes at arena + (members[m].upos - upos_bias)
 // len_scratch: inflate_scratch_bytes(n_members) bytes of device memory (code-length scratch of the block headers)
 size_t inflate_scratch_bytes(uint32_t n_members);
+constexpr uint32_t kStatusEarly = 76;   // status[kStatusEarly..+1]: the same pair for members below ignore_below (only written when that is > 0)
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
-                    uint32_t *status /* [0]=first bad member (min), [1]=its status */, hipStream_t stream);
+                    uint32_t *status /* [0]=first bad member (min), [1]=its status */, hipStream_t stream, uint32_t ignore_below = 0 /* failures of members below this index are not reported */);
 
 // ---- a1 (container): BGZF member discovery on the device --------------------------------------------------
 // The member chain (bgzf.c:525: next = this + BSIZE + 1) is serial on a CPU (one dependent cache miss per member).
@@ -31,7 +32,7 @@ void launch_magic_count(const uint8_t *bam, uint64_t len, uint32_t n_tiles, uint
 void launch_magic_fill(const uint8_t *bam, uint64_t len, uint32_t n_tiles, const uint32_t *tile_base, uint64_t *cand, hipStream_t stream);
 // next[i] = index of the candidate at cand[i] + BSIZE + 1, or n when the chain ends there; isize[i] = ISIZE footer
 void launch_member_link(const uint8_t *bam, uint64_t len, const uint64_t *cand, uint32_t n, uint32_t *next, uint32_t *isize,
-                        uint32_t *reach, hipStream_t stream);
+                        uint32_t *reach, uint64_t root2 /* second chain root: compressed offset of a seek target, ~0 = none */, hipStream_t stream);
 void launch_member_jump(uint32_t n, const uint32_t *next_in, uint32_t *next_out, uint32_t *reach, hipStream_t stream);
 // members[rank] for reachable candidates (rank = exclusive scan of reach); upos filled later by launch_member_upos
 void launch_member_compact(const uint8_t *bam, uint64_t len, const uint64_t *cand, const uint32_t *isize, const uint32_t *reach, const uint32_t *rank,

@@ -91,7 +91,7 @@ struct LdsTab {
 template <bool PROBE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_inflate(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
                                                 uint32_t n_members, uint8_t *__restrict__ arena, uint64_t upos_bias, uint32_t *len_scratch,
-                                                uint32_t *status) {
+                                                uint32_t *status, uint32_t ignore_below) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t m = blockIdx.x * 64 + threadIdx.x;
     if (m >= n_members) return;
@@ -107,15 +107,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     int st = inflate_raw(comp + mb.cpos, mb.clen, arena + (mb.upos - upos_bias), mb.isize, &out_len, T);
     if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
     if (st != INF_OK) {
-        uint32_t prev = atomicMin(&status[0], m);
-        if (m < prev) status[1] = (uint32_t)st;   // best effort: status of (one of) the earliest bad members
+        // members in front of a seek target are inflated for the header only: their failures do not end the record stream and are
+        // reported apart (the header read and the footer check still want to know)
+        uint32_t *slot = m >= ignore_below ? status : status + kStatusEarly;
+        uint32_t prev = atomicMin(&slot[0], m);
+        if (m < prev) slot[1] = (uint32_t)st;     // best effort: status of (one of) the earliest bad members
     }
 }
 
 size_t inflate_scratch_bytes(uint32_t n_members) { return (size_t)((n_members + 63) / 64) * 64 * kScratchWordsPerLane * 4; }
 
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
-                    uint32_t *status, hipStream_t stream) {
+                    uint32_t *status, hipStream_t stream, uint32_t ignore_below) {
     if (!n_members) return;
     static bool attr_set = false;
     if (!attr_set) {
@@ -124,13 +127,13 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
         attr_set = true;
     }
     uint32_t blocks = (n_members + 63) / 64;
-    hipLaunchKernelGGL(k_inflate<false>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status);
+    hipLaunchKernelGGL(k_inflate<false>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below);
 }
 void launch_inflate_probe(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *slots, uint32_t *len_scratch, uint32_t *sizes,
                           hipStream_t stream) {
     if (!n_members) return;
     (void)hipFuncSetAttribute((const void *)k_inflate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
-    hipLaunchKernelGGL(k_inflate<true>, dim3((n_members + 63) / 64), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes);
+    hipLaunchKernelGGL(k_inflate<true>, dim3((n_members + 63) / 64), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u);
 }
 
 // =====================================================================================================
@@ -812,7 +815,7 @@ __global__ __launch_bounds__(256) void k_magic_fill(const uint8_t *__restrict__ 
 }
 
 __global__ void k_member_link(const uint8_t *__restrict__ bam, uint64_t len, const uint64_t *__restrict__ cand, uint32_t n, uint32_t *next,
-                              uint32_t *isize, uint32_t *reach) {
+                              uint32_t *isize, uint32_t *reach, uint64_t root2) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t off = cand[i];
@@ -827,7 +830,9 @@ __global__ void k_member_link(const uint8_t *__restrict__ bam, uint64_t len, con
         if (lo < n && cand[lo] == want) nx = lo;
     } else nx = 0xffffffffu;                                         // marks "this candidate itself is unusable"
     next[i] = nx; isize[i] = isz;
-    reach[i] = (i == 0 && off == 0) ? 1u : 0u;
+    // chain roots: the start of the file, and (root2 != ~0) the compressed offset a seek lands on -- bgzf_seek does not care whether
+    // the members in front of it still chain up
+    reach[i] = ((i == 0 && off == 0) || off == root2) ? 1u : 0u;
 }
 
 __global__ void k_member_jump(uint32_t n, const uint32_t *__restrict__ next_in, uint32_t *next_out, uint32_t *reach) {
@@ -910,8 +915,8 @@ void launch_magic_fill(const uint8_t *bam, uint64_t len, uint32_t n_tiles, const
     if (n_tiles) hipLaunchKernelGGL(k_magic_fill, dim3(n_tiles), dim3(256), 0, stream, bam, len, tile_base, cand);
 }
 void launch_member_link(const uint8_t *bam, uint64_t len, const uint64_t *cand, uint32_t n, uint32_t *next, uint32_t *isize, uint32_t *reach,
-                        hipStream_t stream) {
-    if (n) hipLaunchKernelGGL(k_member_link, dim3((n + 255) / 256), dim3(256), 0, stream, bam, len, cand, n, next, isize, reach);
+                        uint64_t root2, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_member_link, dim3((n + 255) / 256), dim3(256), 0, stream, bam, len, cand, n, next, isize, reach, root2);
 }
 void launch_member_jump(uint32_t n, const uint32_t *next_in, uint32_t *next_out, uint32_t *reach, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(k_member_jump, dim3((n + 255) / 256), dim3(256), 0, stream, n, next_in, next_out, reach);
