@@ -256,7 +256,11 @@ bool normalize_index(const uint8_t *in, size_t n, std::vector<uint8_t> &storage,
         return true;
     }
     if (len < 20 || memcmp(d, "CSI\1", 4)) return false;
-    const int32_t depth = (int32_t)h32(d + 8), l_aux = (int32_t)h32(d + 12);
+    const int32_t min_shift = (int32_t)h32(d + 4), depth = (int32_t)h32(d + 8), l_aux = (int32_t)h32(d + 12);
+    // `samtools index -c` defaults (min_shift 14, depth 5) are the BAI's own geometry: the bins keep their numbers and the level-5 bins'
+    // lower bounds (the linear-index entry of their 16 KiB window, hts.c:1330-1350) stand in for the linear index, so region queries
+    // find their member range as with a .bai.  Any other geometry: the bins are renumbered kCsiBin and a region reads the whole file.
+    const bool bai_geometry = min_shift == 14 && depth == 5;
     if (depth < 0 || depth > 12 || l_aux < 0 || 16 + (size_t)l_aux + 4 > len) return false;
     const uint32_t meta_bin = (uint32_t)((((uint64_t)1 << (3 * depth + 3)) - 1) / 7 + 1);   // META_BIN: n_bins + 1 (hts.c:1277)
     size_t p = 16 + (size_t)l_aux;
@@ -274,14 +278,17 @@ bool normalize_index(const uint8_t *in, size_t n, std::vector<uint8_t> &storage,
         if (n_bin < 0) return false;
         w32((uint32_t)n_bin);
         std::vector<uint64_t> loffs;
+        if (bai_geometry) loffs.reserve(64);
         for (int32_t b = 0; b < n_bin; ++b) {
             if (p + 16 > len) return false;
             const uint32_t bin = h32(d + p); const uint64_t loff = h64(d + p + 4); const int32_t n_chunk = (int32_t)h32(d + p + 12); p += 16;
             if (n_chunk < 0 || p + (size_t)n_chunk * 16 > len) return false;
-            w32(bin == meta_bin ? 37450u : kCsiBin);                                           // real bins: an id no BAI has (a .csi's geometry is its own)
+            w32(bin == meta_bin ? 37450u : bai_geometry ? bin : kCsiBin);                      // other geometries: an id no BAI has
             w32((uint32_t)n_chunk);
             o.insert(o.end(), d + p, d + p + (size_t)n_chunk * 16);
-            if (bin != meta_bin && loff) loffs.push_back(loff);
+            if (bai_geometry) {
+                if (bin >= 4681 && bin < 37449 && loff) { const size_t w = bin - 4681; if (loffs.size() <= w) loffs.resize(w + 1, 0); loffs[w] = loff; }
+            } else if (bin != meta_bin && loff) loffs.push_back(loff);
             p += (size_t)n_chunk * 16;
         }
         w32((uint32_t)loffs.size());                                                           // "linear index": the bins' lower bounds

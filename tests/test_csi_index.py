@@ -217,7 +217,17 @@ def test_region_span_covers_every_overlapping_record():
             else:
                 assert all(lo.value <= v < hi.value for v in inside), (shape, tid, beg, end)
                 assert lo.value in boundaries and (hi.value in boundaries or hi.value >= max(boundaries))
-        csi = csi_common.csi_bytes(bai)                  # a .csi has its own bin geometry: the span declines, the whole file is read
-        assert emu.emu_region_span(csi, len(csi), 0, 100, 5000, ctypes.byref(lo), ctypes.byref(hi)) == -1
+        # a .csi in the default geometry (min_shift 14, depth 5 = the BAI's) gives the same kind of span; any other geometry declines
+        csi = csi_common.csi_bytes(bai)
+        for _ in range(60):
+            tid = rng.randrange(len(contigs)); L = contigs[tid][1]
+            beg = rng.randrange(0, max(1, L)); end = beg + rng.choice([1, 16384, 100000, L])
+            r = emu.emu_region_span(csi, len(csi), tid, beg, end, ctypes.byref(lo), ctypes.byref(hi))
+            inside = [v for t, p0, p1, v in recs if t == tid and p0 < end and p1 > beg]
+            assert r >= 0 and (r == 1 or not inside)
+            if r == 1:
+                assert all(lo.value <= v < hi.value for v in inside) and lo.value in boundaries
+        odd = bytearray(csi_common.csi_bytes(bai, compress=False)); struct.pack_into("<i", odd, 4, 15)     # min_shift 15: not the BAI's bins
+        assert emu.emu_region_span(bytes(odd), len(odd), 0, 100, 5000, ctypes.byref(lo), ctypes.byref(hi)) == -1
         gz = b"".join(bamio.bgzf_member(bai[i:i + 0xff00]) for i in range(0, len(bai), 0xff00)) + bamio.EOF_MARKER
         assert emu.emu_region_span(gz, len(gz), 0, 100, 5000, ctypes.byref(lo), ctypes.byref(hi)) >= 0
