@@ -67,6 +67,8 @@ typedef struct {
     uint8_t *buf; size_t cap, beg, end;   /* unconsumed inflated bytes are buf[beg,end) */
     int      eof;
     uint64_t inflated;      /* total bytes inflated (statistics) */
+    /* where the loaded members lie in buf, for bgzf_tell (bgzf.h:137: block_address << 16 | block_offset) */
+    struct { int64_t start; size_t ulen, coff; } *mk; size_t n_mk, cap_mk;       /* start may be negative: a member partly compacted away */
 } bgzf_reader;
 
 static void rdr_init(bgzf_reader *r, const uint8_t *file, size_t flen) {
@@ -81,9 +83,16 @@ static int rdr_load(bgzf_reader *r) {   /* returns 1 if a non-empty member was a
     if (r->flen - off < 18 || !bgzf_header_ok(r->file + off)) { r->eof = 1; return 0; }
     size_t blen = (size_t)rd16(r->file + off + 16) + 1;
     if (off + blen > r->flen || blen < 26) { r->eof = 1; return 0; }
-    if (r->beg && r->beg == r->end) r->beg = r->end = 0;
+    if (r->beg && r->beg == r->end) { r->beg = r->end = 0; r->n_mk = 0; }
     if (r->end + 65536 > r->cap) {
-        if (r->beg) { memmove(r->buf, r->buf + r->beg, r->end - r->beg); r->end -= r->beg; r->beg = 0; }
+        if (r->beg) {
+            size_t sh = r->beg, k = 0;
+            memmove(r->buf, r->buf + r->beg, r->end - r->beg); r->end -= r->beg; r->beg = 0;
+            for (size_t i = 0; i < r->n_mk; ++i) if (r->mk[i].start + (int64_t)r->mk[i].ulen > (int64_t)sh) {     /* keep the members still (partly) unread */
+                r->mk[k] = r->mk[i]; r->mk[k].start -= (int64_t)sh; ++k;
+            }
+            r->n_mk = k;
+        }
         if (r->end + 65536 > r->cap) { while (r->end + 65536 > r->cap) r->cap *= 2; r->buf = (uint8_t *)realloc(r->buf, r->cap); }
     }
     z_stream zs; memset(&zs, 0, sizeof zs);
@@ -97,8 +106,19 @@ static int rdr_load(bgzf_reader *r) {   /* returns 1 if a non-empty member was a
     if (zr != Z_STREAM_END) { r->eof = 1; return 0; }
     r->coff = off + blen;
     if (ulen == 0) { r->eof = 1; return 0; }
+    if (r->n_mk == r->cap_mk) { r->cap_mk = r->cap_mk ? r->cap_mk * 2 : 16; r->mk = realloc(r->mk, r->cap_mk * sizeof *r->mk); }
+    r->mk[r->n_mk].start = (int64_t)r->end; r->mk[r->n_mk].ulen = ulen; r->mk[r->n_mk].coff = off; r->n_mk++;
     r->end += ulen; r->inflated += ulen;
     return 1;
+}
+
+/* bgzf_tell (bgzf.h:137) after a read: inside a member its address << 16 | offset; at a member's very end the address of the NEXT one
+ * (bgzf_read normalises that way, bgzf.c:569-574) */
+static uint64_t rdr_tell(const bgzf_reader *r) {
+    for (size_t i = r->n_mk; i-- > 0;)
+        if (r->mk[i].start <= (int64_t)r->beg && (int64_t)r->beg < r->mk[i].start + (int64_t)r->mk[i].ulen)
+            return (uint64_t)r->mk[i].coff << 16 | (uint64_t)((int64_t)r->beg - r->mk[i].start);
+    return (uint64_t)r->coff << 16;
 }
 
 /* make n bytes available at buf+beg; returns 0 if the stream ends first */
@@ -109,7 +129,7 @@ static int rdr_need(bgzf_reader *r, size_t n) {
 
 /* bgzf_seek to a virtual offset: load that member, position inside it */
 static void rdr_seek(bgzf_reader *r, uint64_t voff) {
-    r->coff = (size_t)(voff >> 16); r->beg = r->end = 0; r->eof = 0;
+    r->coff = (size_t)(voff >> 16); r->beg = r->end = 0; r->eof = 0; r->n_mk = 0;
     if (rdr_load(r)) { size_t u = (size_t)(voff & 0xffff); r->beg = u <= r->end ? u : r->end; }
 }
 
@@ -122,6 +142,8 @@ typedef struct {
     int      have_start;    /* some reference has the pseudo-bin */
     uint64_t start_voff;    /* smallest pseudo-bin chunk[0].beg */
     uint64_t n_no_coor;
+    /* the plain index bytes, for region queries */
+    uint8_t *img; size_t img_len, refs_off; int csi, min_shift, depth;
 } bai_info;
 
 static int file_readable(const char *p) { FILE *f = fopen(p, "rb"); if (!f) return 0; fclose(f); return 1; }
@@ -169,8 +191,10 @@ static int bai_load(const char *bam, bai_info *bi) {
         if (depth < 0 || depth > 12 || l_aux < 0 || 16 + (size_t)l_aux + 4 > len) { free(d); return -1; }
         meta_bin = (uint32_t)((((uint64_t)1 << (3 * depth + 3)) - 1) / 7 + 1);
         p = 16 + (size_t)l_aux;
-    }
+        bi->min_shift = (int32_t)rd32(d + 4); bi->depth = depth;
+    } else { bi->min_shift = 14; bi->depth = 5; }
     bi->n_ref = (int32_t)rd32(d + p); p += 4;
+    bi->refs_off = p;
     bi->start_voff = UINT64_MAX;
     for (int32_t r = 0; r < bi->n_ref; ++r) {
         if (p + 4 > len) { free(d); return -1; }
@@ -194,8 +218,102 @@ static int bai_load(const char *bam, bai_info *bi) {
         p += (size_t)n_intv * 8;
     }
     bi->n_no_coor = (p + 8 <= len) ? rd64(d + p) : 0;
-    free(d);
+    bi->img = d; bi->img_len = len; bi->csi = csi;
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * hts_itr_query (hts.c:1733-1800) for one reference: the chunks an iterator over [beg, end) reads, in order.
+ * reg2bins :1668-1681; min_off from the lowest-level bin of beg or its nearest existing left sibling / ancestor (:1755-1768); each
+ * bin's loff is stored in a CSI and, for a BAI, derived at load time from the zero-filled linear index (update_loff :1330-1350,
+ * load :1543-1547); chunks ending at or before min_off are dropped, the rest sorted and merged (:1777-1797).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { uint64_t u, v; } chunk_t;
+static int cmp_chunk(const void *a, const void *b) {
+    const chunk_t *x = (const chunk_t *)a, *y = (const chunk_t *)b;
+    return x->u < y->u ? -1 : x->u > y->u ? 1 : x->v < y->v ? -1 : x->v > y->v;
+}
+static uint32_t bin_first(int l) { return (uint32_t)((((uint64_t)1 << (3 * l)) - 1) / 7); }
+/* returns the number of chunks (>= 0); *out malloc'ed when > 0 */
+static int itr_query(const bai_info *bi, int tid, int64_t beg, int64_t end, chunk_t **out) {
+    *out = NULL;
+    const uint8_t *d = bi->img; size_t len = bi->img_len, p = bi->refs_off;
+    const int n_lvls = bi->depth, min_shift = bi->min_shift;
+    const size_t head = bi->csi ? 16 : 8;
+    const uint32_t n_bins = (uint32_t)((((uint64_t)1 << (3 * n_lvls + 3)) - 1) / 7), meta = n_bins + 1;
+    for (int r = 0; r < tid; ++r) {             /* skip to the reference */
+        int32_t n_bin = (int32_t)rd32(d + p); p += 4;
+        for (int32_t b = 0; b < n_bin; ++b) { int32_t nc = (int32_t)rd32(d + p + head - 4); p += head + (size_t)nc * 16; }
+        if (!bi->csi) { int32_t n_intv = (int32_t)rd32(d + p); p += 4 + (size_t)n_intv * 8; }
+    }
+    (void)len;
+    int32_t n_bin = (int32_t)rd32(d + p); p += 4;
+    typedef struct { uint32_t bin; uint64_t loff; int32_t n; size_t at; } bin_t;
+    bin_t *bins = (bin_t *)calloc((size_t)(n_bin > 0 ? n_bin : 1), sizeof(bin_t));
+    for (int32_t b = 0; b < n_bin; ++b) {
+        bins[b].bin = rd32(d + p); bins[b].loff = bi->csi ? rd64(d + p + 4) : 0; bins[b].n = (int32_t)rd32(d + p + head - 4);
+        bins[b].at = p + head; p += head + (size_t)bins[b].n * 16;
+    }
+    if (!bi->csi) {                               /* loff of a BAI bin = linear[first window of the bin], zeros filled from the left */
+        int32_t n_intv = (int32_t)rd32(d + p); p += 4;
+        uint64_t *lin = (uint64_t *)calloc((size_t)(n_intv > 0 ? n_intv : 1), 8);
+        for (int32_t i = 0; i < n_intv; ++i) { lin[i] = rd64(d + p + (size_t)i * 8); if (i > 0 && lin[i] == 0) lin[i] = lin[i - 1]; }
+        for (int32_t b = 0; b < n_bin; ++b) {
+            if (bins[b].bin >= n_bins) { bins[b].loff = 0; continue; }
+            int l = 0; while (l < n_lvls && bins[b].bin >= bin_first(l + 1)) ++l;
+            uint64_t bot = (uint64_t)(bins[b].bin - bin_first(l)) << ((n_lvls - l) * 3);
+            bins[b].loff = bot < (uint64_t)n_intv ? lin[bot] : 0;
+        }
+        free(lin);
+    }
+#define FIND_BIN(id, idx) do { idx = -1; for (int32_t b_ = 0; b_ < n_bin; ++b_) if (bins[b_].bin == (id)) { idx = b_; break; } } while (0)
+    if (beg < 0) beg = 0;
+    /* min_off */
+    uint32_t bin = bin_first(n_lvls) + (uint32_t)(beg >> min_shift);
+    int k;
+    do {
+        FIND_BIN(bin, k);
+        if (k >= 0) break;
+        uint32_t parent = (bin - 1) >> 3, first = (parent << 3) + 1;
+        if (bin > first) --bin; else bin = parent;
+    } while (bin);
+    if (bin == 0) FIND_BIN(0u, k);
+    const uint64_t min_off = k >= 0 ? bins[k].loff : 0;
+    /* reg2bins + chunk collection */
+    int n_off = 0, cap = 16;
+    chunk_t *off = (chunk_t *)malloc((size_t)cap * sizeof *off);
+    int s_ = min_shift + 3 * n_lvls;
+    int64_t e = end;
+    if (beg < e) {
+        if (e >= (int64_t)1 << s_) e = (int64_t)1 << s_;
+        --e;
+        uint32_t t = 0;
+        for (int l = 0; l <= n_lvls; s_ -= 3, t += 1u << (3 * l), ++l) {
+            uint32_t b0 = t + (uint32_t)(beg >> s_), e0 = t + (uint32_t)(e >> s_);
+            for (uint32_t id = b0; id <= e0; ++id) {
+                if (id == meta) continue;
+                FIND_BIN(id, k);
+                if (k < 0) continue;
+                for (int32_t j = 0; j < bins[k].n; ++j) {
+                    chunk_t c = { rd64(d + bins[k].at + (size_t)j * 16), rd64(d + bins[k].at + (size_t)j * 16 + 8) };
+                    if (c.v > min_off) { if (n_off == cap) { cap *= 2; off = (chunk_t *)realloc(off, (size_t)cap * sizeof *off); } off[n_off++] = c; }
+                }
+            }
+        }
+    }
+#undef FIND_BIN
+    free(bins);
+    if (n_off == 0) { free(off); return 0; }
+    qsort(off, (size_t)n_off, sizeof *off, cmp_chunk);
+    int l = 0;
+    for (int i = 1; i < n_off; ++i) if (off[l].v < off[i].v) off[++l] = off[i];          /* completely contained chunks */
+    n_off = l + 1;
+    for (int i = 1; i < n_off; ++i) if (off[i - 1].v >= off[i].u) off[i - 1].v = off[i].u;  /* overlaps */
+    l = 0;
+    for (int i = 1; i < n_off; ++i) { if (off[l].v >> 16 == off[i].u >> 16) off[l].v = off[i].v; else off[++l] = off[i]; }   /* adjacent */
+    n_off = l + 1;
+    *out = off;
+    return n_off;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -755,12 +873,13 @@ int orc_extract(const orc_params *p, orc_table **out, char *err, size_t errlen) 
         }
     }
     const char *itr_err = "Unable to iterate to region within BAM.\n\n";
-#define BAIL(msg) do { free(rd.buf); free(file); orc_table_free(t); return fail(err, errlen, msg); } while (0)
+#define BAIL(msg) do { free(rd.buf); free(rd.mk); free(bi.img); free(file); orc_table_free(t); return fail(err, errlen, msg); } while (0)
     if (!hdr_ok) BAIL(itr_err);
 
     /* iterator set-up */
     int whole = !strcmp(p->region, ".");
     int r_tid = -1, r_beg = 0, r_end = 0;
+    chunk_t *off = NULL; int n_off = 0, ci = -1; uint64_t curr_off = 0;     /* hts_itr_next state (hts.c:1924-1965) */
     if (whole) {
         uint64_t v;
         if (bi.have_start) v = bi.start_voff;
@@ -770,8 +889,7 @@ int orc_extract(const orc_params *p, orc_table **out, char *err, size_t errlen) 
     } else {
         if (!strcmp(p->region, "*")) BAIL(itr_err); /* not restated */
         if (parse_region(t, p->region, &r_tid, &r_beg, &r_end) || r_tid >= bi.n_ref || r_end < r_beg) BAIL(itr_err);
-        /* sorted+indexed input: index-driven iteration == predicate filter in file order.  (Not on a file that is damaged BEFORE the
-         * region: the reference seeks past the damage, this reads into it and stops.  The product seeks; see tools/fuzz.) */
+        n_off = itr_query(&bi, r_tid, r_beg, r_end, &off);       /* 0 chunks: an iterator that returns nothing */
     }
 
     fasta *fa = NULL;
@@ -786,6 +904,15 @@ int orc_extract(const orc_params *p, orc_table **out, char *err, size_t errlen) 
 
     int rc = 0;
     for (;;) {
+        if (!whole) {
+            /* hts_itr_next :1935-1946: past the current chunk (or before the first) -> the next one, seeking unless it is adjacent */
+            if (n_off == 0) break;
+            if (curr_off == 0 || curr_off >= off[ci].v) {
+                if (ci == n_off - 1) break;
+                if (ci < 0 || off[ci].v != off[ci + 1].u) { rdr_seek(&rd, off[ci + 1].u); curr_off = rdr_tell(&rd); }
+                ++ci;
+            }
+        }
         /* bam_read1 sam.c:399-433 */
         if (!rdr_need(&rd, 4)) break;
         int32_t block_len = (int32_t)rd32(rd.buf + rd.beg);
@@ -807,7 +934,8 @@ int orc_extract(const orc_params *p, orc_table **out, char *err, size_t errlen) 
 
         if (!whole) {
             /* hts_itr_next hts.c:1946-1957 with bam_endpos sam.c:336-342 */
-            if (tid != r_tid || pos >= r_end) continue; /* sorted input: == the reference's early stop */
+            curr_off = rdr_tell(&rd);
+            if (tid != r_tid || pos >= r_end) break;     /* "no need to proceed" */
             int32_t endpos;
             if (!(flag & 4) && n_cigar > 0) {
                 int32_t l = 0;
@@ -835,6 +963,7 @@ int orc_extract(const orc_params *p, orc_table **out, char *err, size_t errlen) 
         if (ec.fa_error) { rc = fail(err, errlen, "Unable to extract FASTA sequence for position\n\n"); break; }
     }
     t->inflated_bytes = rd.inflated;
+    free(off); free(bi.img); free(rd.mk);
     free(rd.buf); free(file);
     fasta_free(fa);
     free(m.slot);

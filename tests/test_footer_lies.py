@@ -71,3 +71,60 @@ def test_product_equals_oracle_on_lying_footers(gpu_ctx, tmp_path):
         if name == "isize_all":
             whole = out
     assert whole and whole.count(b"\n") > 100                  # nothing was lost although no footer was right
+
+
+# ---- damage in front of a region: the iterator seeks past it (hts_itr_next -> bgzf_seek, hts.c:1935-1946) ---------------------------------------
+REGIONS = ["10:1000-200000", "2:1-400000", "MT", "1:1-100000", "10:250000-260000"]
+
+
+def damaged(tmp_path):
+    """(name, path): one synthetic BAM (contigs 1, 10, 2, MT in file order) damaged in members that hold contig 1; index untouched and valid."""
+    src = str(tmp_path / "dsrc.bam")
+    synth.write(src, 30000, shape="fuzz", seed=21)
+    bam, bai = open(src, "rb").read(), open(src + ".bai", "rb").read()
+    members = list(bamio.bgzf_members(bam))
+    out = []
+
+    def emit(name, b):
+        p = str(tmp_path / (name + ".bam"))
+        open(p, "wb").write(bytes(b)); open(p + ".bai", "wb").write(bai)
+        out.append((name, p))
+    for name, mi, fn in (("payload_bit", 2, lambda b, c, pl: b.__setitem__(c + 18 + len(pl) // 2, b[c + 18 + len(pl) // 2] ^ 0x10)),
+                         ("magic", 2, lambda b, c, pl: b.__setitem__(c + 1, 0)),
+                         ("bsize_big", 3, lambda b, c, pl: struct.pack_into("<H", b, c + 16, struct.unpack_from("<H", b, c + 16)[0] + 300)),
+                         ("bsize_small", 1, lambda b, c, pl: struct.pack_into("<H", b, c + 16, 40)),
+                         ("isize_and_payload", 2, lambda b, c, pl: (struct.pack_into("<I", b, c + 18 + len(pl) + 4, 5), b.__setitem__(c + 30, b[c + 30] ^ 0xff)))):
+        coff, payload, isz = members[mi]
+        b = bytearray(bam); fn(b, coff, payload); emit(name, b)
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the real reference is only built where /root/reference exists")
+def test_oracle_seeks_like_the_reference_on_damaged_files(tmp_path):
+    n_rows = 0
+    for name, p in damaged(tmp_path):
+        for reg in REGIONS + [None]:
+            args = ["-s", "XS"] + (["-r", reg] if reg else [])
+            r = subprocess.run([REF, "junctions", "extract"] + args + ["-o", str(tmp_path / "r.bed"), p], capture_output=True)
+            if r.returncode not in (0, 1):
+                continue                                  # the reference itself died on this input
+            rc, out, _ = run_oracle(args + [p])
+            assert (r.returncode != 0) == (rc != 0), (name, reg)
+            if rc == 0:
+                assert open(tmp_path / "r.bed", "rb").read() == out, (name, reg)
+                n_rows += out.count(b"\n")
+    assert n_rows > 200                                    # the regions behind the damage were really read
+
+
+@pytest.mark.gpu
+def test_product_seeks_like_the_oracle_on_damaged_files(gpu_ctx, tmp_path):
+    from test_gpu_parity import gpu_extract
+    n_rows = 0
+    for name, p in damaged(tmp_path):
+        for reg in REGIONS + [None]:
+            args = ["-s", "XS"] + (["-r", reg] if reg else [])
+            rc, out, _ = gpu_extract(gpu_ctx, p, args)
+            orc, exp, _ = run_oracle(args + [p])
+            assert rc == orc and out == exp, (name, reg)
+            n_rows += out.count(b"\n")
+    assert n_rows > 200
