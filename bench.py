@@ -188,7 +188,7 @@ def main():
             "junction_rows": s["n_junctions"],
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "input_generation_s": round(t_gen, 2),
-            "roofline": {"bound": "hbm", "kernel": "rgx::k_inflate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "rgx::k_inflate<false>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_note": traffic_note, "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
                          "note": "DEFLATE is a serial bit stream per member: one lane per member, bound by per-lane dependent ALU/LDS chains plus one memory round trip per symbol trip, far below the HBM line (SURVEY 8d; DESIGN.md 5)",
                          "pipeline_frac": aln_per_s / world * (alg_bytes / n_reads) / (HBM_PEAK_GBS * 1e9)},
