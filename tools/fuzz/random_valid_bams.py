@@ -19,6 +19,8 @@ with tempfile.TemporaryDirectory() as td:
     for case in range(n_cases):
         contigs = [(n, rng.choice([5000, 200000, 3000000])) for n in rng.sample(["chr1", "chr10", "chr2", "1", "X", "MT", "chrUn_1", "b", "a"], rng.randrange(1, 5))]
         recs = []
+        with_bc = rng.random() < 0.35                      # -b: cell barcodes (junctions_extractor.cc:362-374)
+        bcs = ["".join(rng.choice("ACGT") for _ in range(rng.choice([1, 8, 16]))) + "-1" for _ in range(rng.choice([1, 3, 40]))] + ["?", ""]
         for tid, (name, L) in enumerate(contigs):
             pos = 0
             for k in range(rng.randrange(0, 120)):
@@ -40,6 +42,7 @@ with tempfile.TemporaryDirectory() as td:
                 elif r < 0.75: aux += b"XSA\x00"
                 if rng.random() < 0.3: aux = bamio.tagZ("RG", "g1") + aux + b"NMi" + struct.pack("<i", 3)
                 if rng.random() < 0.2: aux += bamio.tagA("ZS", rng.choice("+-"))
+                if with_bc and rng.random() < 0.85: aux += bamio.tagZ("CB", rng.choice(bcs))
                 try:
                     recs.append(bamio.record(tid, pos, cig if cig != "*" else "", flag=flag, qname="r%d" % len(recs), aux=aux))
                 except Exception:
@@ -59,20 +62,26 @@ with tempfile.TemporaryDirectory() as td:
         if rng.random() < 0.4: args += ["-M", str(rng.choice([1, 69, 500000, 3000000]))]
         if rng.random() < 0.2: args += ["-t", "ZS"]
         if rng.random() < 0.4: args += ["-r", rng.choice([name0, "%s:%d-%d" % (name0, rng.randrange(1, 3000), rng.randrange(1, 9000)), "%s:100" % name0, "nope", name0 + ":5-2"])]
-        o = subprocess.run([ORC, "extract"] + args + ["-o", os.path.join(td, "o.bed"), p], capture_output=True)
+        bc_o, bc_r = os.path.join(td, "o.bc"), os.path.join(td, "r.bc")
+        for f in (bc_o, bc_r):
+            if os.path.exists(f): os.remove(f)
+        o = subprocess.run([ORC, "extract"] + args + (["-b", bc_o] if with_bc else []) + ["-o", os.path.join(td, "o.bed"), p], capture_output=True)
         if GPU:
             je = regtools_amd.JunctionsExtractor(ctx=ctx)
             try:
-                je.parse_options(args + [p]); je.identify_junctions_from_BAM(); rc, out = 0, je.bed12()
+                je.parse_options(args + (["-b", bc_r] if with_bc else []) + [p]); je.identify_junctions_from_BAM(); rc, out = 0, je.bed12()
+                if with_bc: open(bc_r, "wb").write(je.barcodes_text(True))
             except regtools_amd.RegtoolsError:
                 rc, out = 1, b""
             open(os.path.join(td, "r.bed"), "wb").write(out)
             r = subprocess.CompletedProcess([], rc)
         else:
-            r = subprocess.run([REF, "junctions", "extract"] + args + ["-o", os.path.join(td, "r.bed"), p], capture_output=True)
+            r = subprocess.run([REF, "junctions", "extract"] + args + (["-b", bc_r] if with_bc else []) + ["-o", os.path.join(td, "r.bed"), p], capture_output=True)
             if r.returncode not in (0, 1):
                 continue
         same = (r.returncode != 0) == (o.returncode != 0) and (r.returncode != 0 or open(os.path.join(td, "r.bed"), "rb").read() == open(os.path.join(td, "o.bed"), "rb").read())
+        if same and with_bc and o.returncode == 0:
+            same = open(bc_o, "rb").read() == open(bc_r, "rb").read()
         if o.returncode == 0:
             k = sum(1 for _ in open(os.path.join(td, "o.bed"))); rows_total += k; nonempty += k > 0
         if not same:
