@@ -396,6 +396,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         mark("region span");
     }
 
+    bool empty_stream = false;
     auto query = [&]() -> hipError_t {
         uint64_t q[3] = {seek ? (seek_voff >> 16) : 0, cut_lo >> 16, cut_hi == UINT64_MAX ? UINT64_MAX - 64 : (cut_hi >> 16)};
         memcpy(h_sc + 40, q, sizeof q);
@@ -417,6 +418,13 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         chain(seek_voff >> 16);
         HIP_TRY(query());
         mark("second chain root");
+        if (h_sc[24] >= h_sc[17]) {
+            // there is no BGZF member at the seek target at all (a truncated file, an index that belongs to another file): the
+            // reference's read after bgzf_seek fails and the iterator returns nothing.  Keep the head of the file for the header only.
+            chain(UINT64_MAX);
+            seek = false; cut_lo = 0; cut_hi = 1; empty_stream = true;
+            HIP_TRY(query());
+        }
     }
     const uint32_t n_members_all = h_sc[17];
     if (n_members_all == 0) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);     // offset 0 is not a BGZF member
@@ -547,6 +555,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     else pos0 = hdr.end;                 // no seek: records start right after the header (range starts at member 0)
     if (cut_hi != UINT64_MAX) lim = std::min(lim, arena_of(cut_hi, h_sc[26], q_upos[2]));
     if (pos0 > lim) pos0 = lim;
+    if (empty_stream) lim = pos0;            // the seek target does not exist: no record is read
 
     ExtractCfg cfg;
     memset(&cfg, 0, sizeof cfg);

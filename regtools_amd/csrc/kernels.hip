@@ -104,8 +104,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         status[m] = st == INF_OK ? out_len : 0xffffffffu;
         return;
     }
-    int st = inflate_raw(comp + mb.cpos, mb.clen, arena + (mb.upos - upos_bias), mb.isize, &out_len, T);
-    if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
+    // a member whose claimed size is no BGZF block size owns no bytes of the arena (k_member_compact): it must not write any, whatever
+    // range the host asked for.  ~0 = the member runs past the end of the file (k_member_link).
+    int st;
+    if (mb.isize > kBgzfMaxBlock) st = mb.isize == 0xffffffffu ? INF_IN_OVERRUN : INF_OUT_OVERFLOW;
+    else {
+        st = inflate_raw(comp + mb.cpos, mb.clen, arena + (mb.upos - upos_bias), mb.isize, &out_len, T);
+        if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
+    }
     if (st != INF_OK) {
         // members in front of a seek target are inflated for the header only: their failures do not end the record stream and are
         // reported apart (the header read and the footer check still want to know)

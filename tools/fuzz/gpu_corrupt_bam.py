@@ -53,6 +53,11 @@ with tempfile.TemporaryDirectory() as td:
         open(path, "wb").write(bytes(b)); open(path + ".bai", "wb").write(bai)
         args = rng.choice([["-s", "XS"], ["-s", "RF", "-a", "3"], ["-s", "XS", "-r", rng.choice(["chr1", "1", "chr2:1-90000000", "10:1000-200000"])]])
         orc = subprocess.run([ORACLE, "extract"] + args + [path], capture_output=True)
+        if os.environ.get("FUZZ_VERBOSE"):                                  # a crash of the process must leave its input behind
+            keep = os.path.join(ROOT, "gpurun_out", "last_case.bam")
+            os.makedirs(os.path.dirname(keep), exist_ok=True)
+            open(keep, "wb").write(bytes(b)); open(keep + ".bai", "wb").write(bai)
+            open(os.path.join(ROOT, "gpurun_out", "last_case.txt"), "w").write("case %d kind %s member %d args %s\n" % (case, kind, mi, args))
         je = regtools_amd.JunctionsExtractor(ctx=ctx)
         try:
             je.parse_options(args + [path]); je.identify_junctions_from_BAM(); rc, out = 0, je.bed12()
