@@ -92,6 +92,10 @@ typedef struct {
     uint32_t  *bc_insert_rank;  /* entry k was the bc_insert_rank[k]-th distinct barcode its junction saw (0-based): a binding that refills a
                                  * Junction::barcodes inserts a row's entries in THIS order and the container iterates them in the listed order */
     double     ms_barcodes;     /* statistics: the barcode group-by (device + host ordering) */
+    /* per-shard tables: nonzero when the record stream stopped inside this shard for a reason that ends iteration upstream (a member
+     * that does not inflate, an empty member, an unreadable record) instead of reaching the shard's upper cut.  The merges ignore the
+     * shards behind such a one: a later shard is a seek past the damage, a sequential reader never gets there. */
+    uint64_t   stream_ended;
 } rgx_junction_table;
 
 int  rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errlen);

@@ -271,6 +271,7 @@ struct Prep {
     uint32_t n_rec = 0, n_events = 0, n_range = 0;
     uint64_t n_iterated = 0, total = 0;
     uint32_t framing_sweeps = 0;
+    bool stream_ended = false;     // the record stream stopped for a reason that ends iteration upstream (not: it reached this shard's upper cut)
     double t_begin = 0;
 };
 
@@ -553,7 +554,18 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     uint64_t pos0;
     if (cut_lo) pos0 = arena_of(cut_lo, h_sc[25], q_upos[1]);
     else pos0 = hdr.end;                 // no seek: records start right after the header (range starts at member 0)
-    if (cut_hi != UINT64_MAX) lim = std::min(lim, arena_of(cut_hi, h_sc[26], q_upos[2]));
+    // Did the stream stop for a reason that ends iteration upstream, rather than at this shard's upper cut?  (A later shard is a seek past
+    // that point; the merge drops the shards behind one that ended, so that a damaged file gives the same table whatever the shard count.)
+    bool chain_ended = false;
+    P.stream_ended = empty_stream;
+    if (cut_hi != UINT64_MAX) {
+        const uint64_t cut_lim = arena_of(cut_hi, h_sc[26], q_upos[2]);
+        const uint32_t mh = h_sc[26];
+        const uint32_t hi_wanted = (mh < n_members_all && (cut_hi & 0xffff)) ? mh + 1 : mh;
+        if (h_sc[0] != 0xffffffffu && lim < cut_lim) P.stream_ended = true;        // a member in front of the cut does not inflate
+        if (stop < std::min(hi_wanted, n_members_all)) P.stream_ended = true;      // an empty / unusable member in front of the cut (bgzf.c:548-578)
+        lim = std::min(lim, cut_lim);
+    } else if (h_sc[0] != 0xffffffffu) P.stream_ended = true;
     if (pos0 > lim) pos0 = lim;
     if (empty_stream) lim = pos0;            // the seek target does not exist: no record is read
 
@@ -623,6 +635,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             HIP_TRY(hipMemcpyAsync(h_sc + 10, d_sc + 10, 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             ++P.framing_sweeps;
+            if (h_sc[11] != 0xffffffffu) chain_ended = true;     // some segment's chain ends: an unreadable / cut-off record (sam.c:421-423)
             if (h_sc[10] == 0xffffffffu) break;
             if (h_sc[11] < h_sc[10]) {     // the chain ends inside the exact prefix: nothing starts after that segment
                 launch_seg_truncate(pos0, lim, n_seg, h_sc[11], seg_start[cur], seg_exit[cur], seg_cnt[cur], st);
@@ -635,6 +648,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         }
         n_rec = h_sc[3];
     }
+    if (chain_ended) P.stream_ended = true;
     HIP_TRY(hipEventRecord(c->ev[3], st));
     mark("framing (sync)");
 
@@ -999,7 +1013,7 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
         if (rc != RGX_OK) { rgx_table_free(t); return rc; }
     }
     t->n_records = P.n_iterated;
-    t->n_events = P.n_events; t->inflated_bytes = P.total; t->compressed_bytes = bam_len; t->n_members = P.n_range; t->framing_sweeps = P.framing_sweeps;
+    t->n_events = P.n_events; t->inflated_bytes = P.total; t->compressed_bytes = bam_len; t->n_members = P.n_range; t->framing_sweeps = P.framing_sweeps; t->stream_ended = P.stream_ended ? 1 : 0;
     float ms = 0;
     HIP_TRY(hipEventSynchronize(c->ev[6]));
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); t->ms_inflate = ms;
@@ -1089,6 +1103,7 @@ extern "C" int rgx_table_merge(const rgx_junction_table *const *parts, int n_par
         for (uint64_t i = 0; i < t->n; ++i)
             rows.push_back({t->tid[i], t->start[i], t->end[i], t->thick_start[i], t->thick_end[i], t->read_count[i],
                             (uint64_t)g << 40 | t->first_seen[i], (uint64_t)g << 40 | t->last_seen[i], t->strand[i]});
+        if (t->stream_ended) break;          // the record stream ended inside this shard: upstream reads nothing behind that point
     }
     mark("collect");
     std::stable_sort(rows.begin(), rows.end(), [&](const Row &a, const Row &b) {

@@ -48,14 +48,17 @@ def pack_table(table_ptr):
     return bytes(buf)[: n * ROW], n
 
 
-def merge_packed(parts, names_from, min_anchor):
-    """parts: list of (bytes, n_rows) in shard order; names_from: any JunctionTable* carrying the contig table."""
+def merge_packed(parts, names_from, min_anchor, ended=None):
+    """parts: list of (bytes, n_rows) in shard order; names_from: any JunctionTable* carrying the contig table; ended: per shard, the
+    table's stream_ended flag (the shards behind the first one that ended are ignored, as a sequential reader never gets there)."""
     lib = _ffi.lib()
     ptrs = (C.POINTER(_ffi.JunctionTable) * len(parts))()
     for i, (b, n) in enumerate(parts):
         t = C.POINTER(_ffi.JunctionTable)()
         raw = (C.c_uint8 * max(1, len(b))).from_buffer_copy(b if len(b) else b"\0")
         lib.rgx_table_unpack(raw, n, names_from, C.byref(t))
+        if ended is not None and ended[i]:
+            t.contents.stream_ended = 1
         ptrs[i] = t
     out = C.POINTER(_ffi.JunctionTable)()
     err = C.create_string_buffer(256)
@@ -93,9 +96,10 @@ def gather_and_merge(je_or_table, min_anchor=8, group=None, ctx=None):
     if dev == "cuda" and ctx is not None:
         return _gather_and_merge_device(table, ctx, min_anchor, group, world)
     payload, n = pack_table(table)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
-    sizes = [int(s.item()) for s in sizes]
+    sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([n, int(table.contents.stream_ended)], dtype=torch.int64, device=dev), group=group)
+    ended = [bool(int(s[1].item())) for s in sizes]
+    sizes = [int(s[0].item()) for s in sizes]
     cap = max(1, max(sizes)) * ROW
     local = torch.zeros(cap, dtype=torch.uint8, device=dev)
     if n:
@@ -106,7 +110,7 @@ def gather_and_merge(je_or_table, min_anchor=8, group=None, ctx=None):
     for r in range(world):
         raw = gathered[r][: sizes[r] * ROW].cpu().numpy().tobytes()
         parts.append((raw, sizes[r]))
-    return merge_packed(parts, table, min_anchor)
+    return merge_packed(parts, table, min_anchor, ended)
 
 
 _pinned = {}
@@ -119,9 +123,15 @@ def _gather_and_merge_device(table, ctx, min_anchor, group, world):
 
     lib = _ffi.lib()
     n = int(table.contents.n)
-    sizes_t = torch.zeros(world, dtype=torch.int64, device="cuda")
-    dist.all_gather_into_tensor(sizes_t, torch.tensor([n], dtype=torch.int64, device="cuda"), group=group)
-    sizes = [int(x) for x in sizes_t.tolist()]
+    sizes_t = torch.zeros(2 * world, dtype=torch.int64, device="cuda")
+    dist.all_gather_into_tensor(sizes_t, torch.tensor([n, int(table.contents.stream_ended)], dtype=torch.int64, device="cuda"), group=group)
+    flat = [int(x) for x in sizes_t.tolist()]
+    sizes = flat[0::2]
+    merge_sizes = list(sizes)
+    for r in range(world):                       # the shards behind one whose record stream ended contribute nothing
+        if flat[2 * r + 1]:
+            merge_sizes[r + 1:] = [0] * (world - r - 1)
+            break
     stride = max(1, max(sizes))
     cap = stride * ROW
     local = torch.empty(cap, dtype=torch.uint8, device="cuda")
@@ -139,4 +149,4 @@ def _gather_and_merge_device(table, ctx, min_anchor, group, world):
     big = torch.empty(cap * world, dtype=torch.uint8, device="cuda")
     dist.all_gather_into_tensor(big, local, group=group)      # the one data collective of the whole job; the rows stay in HBM
     torch.cuda.current_stream().synchronize()
-    return merge_device(ctx, big.data_ptr(), stride, sizes, table, min_anchor)
+    return merge_device(ctx, big.data_ptr(), stride, merge_sizes, table, min_anchor)

@@ -175,3 +175,27 @@ def test_product_survives_truncated_files_with_regions(gpu_ctx, tmp_path):
         for g in range(3):                                   # and cut into shards (each shard a seek)
             rc, _, _ = gpu_extract(gpu_ctx, p, ["-s", "XS"], shard=g, n_shards=3)
             assert rc in (0, 1)
+
+
+@pytest.mark.gpu
+def test_shards_of_a_damaged_file_merge_to_the_single_pass(gpu_ctx, tmp_path):
+    """A later shard is a seek past the damage; a sequential reader never gets there.  Every shard reports whether its record stream ended
+    (stream_ended) and the merge ignores the shards behind the first that did: same table whatever the shard count."""
+    from test_gpu_parity import gpu_extract
+    from regtools_amd import distributed
+    n = 0
+    for name, p in damaged(tmp_path) + truncated(tmp_path)[:3]:
+        rc, single, _ = gpu_extract(gpu_ctx, p, ["-s", "XS"])
+        if rc != 0:
+            continue
+        assert single == run_oracle(["-s", "XS", p])[1], name
+        for G in (2, 3, 7):
+            parts, keep = [], []
+            for g in range(G):
+                rc, _, je = gpu_extract(gpu_ctx, p, ["-s", "XS"], shard=g, n_shards=G)
+                assert rc == 0, (name, G, g)
+                keep.append(je); parts.append(distributed.pack_table(je.table))
+            merged = distributed.merge_packed(parts, keep[0].table, 8, [k.stats["stream_ended"] for k in keep])
+            assert merged.bed12() == single, (name, G)
+            n += 1
+    assert n >= 15
