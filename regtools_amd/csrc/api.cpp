@@ -49,17 +49,21 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 uint32_t bitlen(uint32_t v) { uint32_t b = 0; while (v) { ++b; v >>= 1; } return b; }
 
 // growable device buffer that survives across calls (workspace reuse: no hipMalloc in steady state)
+// Every buffer starts kFront bytes into its allocation: k_inflate_ring's far copies load their source from up to 15 bytes in front of it
+// (inflate_ring.h, kArenaFrontPad), and for the first member of an arena that is in front of the buffer.
 struct DevBuf {
+    static constexpr size_t kFront = 256;
     void *p = nullptr; size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        release();
         size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
+        void *raw = nullptr;
+        hipError_t e = hipMalloc(&raw, want + kFront);
+        if (e == hipSuccess) { p = (uint8_t *)raw + kFront; cap = want; }
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)hipFree((uint8_t *)p - kFront); p = nullptr; cap = 0; }
     template <class T> T *as() const { return (T *)p; }
 };
 

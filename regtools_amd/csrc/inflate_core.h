@@ -219,38 +219,10 @@ struct OutStage {
     }
 };
 
-// ---- block header ------------------------------------------------------------------------------------------------
-// Parses one DEFLATE block header.  Dynamic/fixed blocks: builds the two canonical codes (returns 1 = symbols follow).
-// Stored blocks: copies the raw bytes and returns 0 (= another header follows, or the stream ends if *last).
+// The tables of a fixed (btype 1) or dynamic (btype 2) block, bit reader positioned right after the 3 header bits.
+// Returns 1 = symbols follow, 0 = status says why not.
 template <class Tab>
-RGX_HD int block_header(BitReader &br, Tab &T, Code &LL, Code &DD, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t &o,
-                        uint32_t out_cap, uint32_t &last, int &status, OutStage &S) {
-    if (br.overran()) { status = INF_IN_OVERRUN; return 0; }     // a run of empty stored blocks must not walk off the input
-    br.ensure(32);
-    last = br.bits(1);
-    const uint32_t btype = br.bits(2);
-    if (btype == 0) {
-        // stored: skip to byte boundary, LEN, NLEN, raw bytes
-        br.drop(br.cnt & 7);
-        br.ensure(32);
-        uint32_t len = br.bits(16);
-        const uint32_t nlen = br.bits(16);
-        if ((len ^ 0xffff) != nlen) { status = INF_BAD_STORED; return 0; }
-        if (o + len > out_cap) { status = INF_OUT_OVERFLOW; return 0; }
-        S.flush_partial(o);                                    // raw bytes go straight to memory; the stage is picked up again below
-        while (len && br.cnt >= 8) { out[o++] = (uint8_t)br.bits(8); --len; }     // bytes still in the bit buffer
-        if (len) {
-            const uint8_t *src = br.byte_ptr();   // cnt == 0 here: the prefetched word starts at the next payload byte
-            if ((uint64_t)(src - in) + len > in_len) { status = INF_IN_OVERRUN; return 0; }
-            uint32_t k = 0;
-            for (; k + 16 <= len; k += 16) st128(out + o + k, ld128(src + k));
-            for (; k < len; ++k) out[o + k] = src[k];
-            o += len; br.restart_at(src + len);
-        }
-        S.resync(o);
-        return 0;
-    }
-    if (btype == 3) { status = INF_BAD_BTYPE; return 0; }
+RGX_HD int build_block_codes(BitReader &br, Tab &T, Code &LL, Code &DD, uint32_t btype, int &status) {
     T.clear_syms();
     if (btype == 1) {
         // fixed code (RFC 1951 3.2.6): lengths 8 x144, 9 x112, 7 x24, 8 x8; 32 distance codes of length 5 (30,31 rejected at decode)
@@ -347,6 +319,41 @@ RGX_HD int block_header(BitReader &br, Tab &T, Code &LL, Code &DD, const uint8_t
     if (status != INF_OK) return 0;
     status = build_code(T, kLenWordsLL, hdist, 1, DD);
     return status == INF_OK ? 1 : 0;
+}
+
+// ---- block header ------------------------------------------------------------------------------------------------
+// Parses one DEFLATE block header.  Dynamic/fixed blocks: builds the two canonical codes (returns 1 = symbols follow).
+// Stored blocks: copies the raw bytes and returns 0 (= another header follows, or the stream ends if *last).
+template <class Tab>
+RGX_HD int block_header(BitReader &br, Tab &T, Code &LL, Code &DD, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t &o,
+                        uint32_t out_cap, uint32_t &last, int &status, OutStage &S) {
+    if (br.overran()) { status = INF_IN_OVERRUN; return 0; }     // a run of empty stored blocks must not walk off the input
+    br.ensure(32);
+    last = br.bits(1);
+    const uint32_t btype = br.bits(2);
+    if (btype == 0) {
+        // stored: skip to byte boundary, LEN, NLEN, raw bytes
+        br.drop(br.cnt & 7);
+        br.ensure(32);
+        uint32_t len = br.bits(16);
+        const uint32_t nlen = br.bits(16);
+        if ((len ^ 0xffff) != nlen) { status = INF_BAD_STORED; return 0; }
+        if (o + len > out_cap) { status = INF_OUT_OVERFLOW; return 0; }
+        S.flush_partial(o);                                    // raw bytes go straight to memory; the stage is picked up again below
+        while (len && br.cnt >= 8) { out[o++] = (uint8_t)br.bits(8); --len; }     // bytes still in the bit buffer
+        if (len) {
+            const uint8_t *src = br.byte_ptr();   // cnt == 0 here: the prefetched word starts at the next payload byte
+            if ((uint64_t)(src - in) + len > in_len) { status = INF_IN_OVERRUN; return 0; }
+            uint32_t k = 0;
+            for (; k + 16 <= len; k += 16) st128(out + o + k, ld128(src + k));
+            for (; k < len; ++k) out[o + k] = src[k];
+            o += len; br.restart_at(src + len);
+        }
+        S.resync(o);
+        return 0;
+    }
+    if (btype == 3) { status = INF_BAD_BTYPE; return 0; }
+    return build_block_codes(br, T, LL, DD, btype, status);
 }
 
 constexpr uint32_t kCopyBatch = 128;   // bytes moved per memory round trip (8 independent 16-byte loads in flight)

@@ -6,6 +6,7 @@
 
 #include "bam_core.h"
 #include "inflate_core.h"
+#include "inflate_ring.h"
 
 namespace rgx {
 
@@ -121,25 +122,152 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     }
 }
 
+// ---- round 2: the same decoder with its output in LDS (inflate_ring.h) --------------------------------------------------------------
+// LDS of one wave (= one workgroup): [symbol lists, kLdsDwordsPerLane x 64 dwords][rings, kRingLaneDw x 64 dwords][flush work list, 128 x 4].
+// Everything is dword-interleaved across the lanes (dword d of lane L at d * 64 + L), so a lane only ever touches bank L % 32 and
+// consecutive dwords of a lane are one ds_read2st64_b32 / ds_write2st64_b32 apart.  159 dwords per lane = 40 704 B per wave: four waves per CU.
+constexpr uint32_t kRingLdsDwords = (kLdsDwordsPerLane + kRingLaneDw + 8) * 64;      // (flush list: 128 items of 4 dwords)
+constexpr uint32_t kRingLdsBytes = kRingLdsDwords * 4;
+
+struct LdsRing {
+    uint32_t *base;       // LDS, already offset by lane
+    __device__ __forceinline__ uint32_t rd(uint32_t dw) const { return base[dw * 64]; }
+    __device__ __forceinline__ void rd4(uint32_t dw, uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d) const {
+        const uint32_t *q = base + dw * 64;
+        a = q[0]; b = q[64]; c = q[128]; d = q[192];
+    }
+    __device__ __forceinline__ void wr4(uint32_t dw, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+        uint32_t *q = base + dw * 64;
+        q[0] = a; q[64] = b; q[128] = c; q[192] = d;
+    }
+    __device__ __forceinline__ void wr8(uint32_t byte_pos, uint32_t b) { ((uint8_t *)(base + (byte_pos >> 2) * 64))[byte_pos & 3u] = (uint8_t)b; }
+};
+
+// The wave as a flushing machine.  A flush round: every lane with complete lines appends one 16-byte work item per line {line base
+// address, position, ring line, member} to a list in LDS (slots from ballots: no atomics); then lane j stores piece j & 7 (16 bytes) of
+// item 8 * step + (j >> 3): one store instruction = eight whole, aligned 128-byte lines, and only as many instructions as there are lines.
+// Four steps are read before the first is stored, so a round waits on LDS twice, not per line.  (A member's ring lives in ONE bank, so
+// the eight lanes of a line take turns on it: 32 LDS cycles per eight lines -- LDS time well spent: what HBM sees is each output byte
+// once, in full lines.)
+struct WaveCoop {
+    uint32_t *ring_wave;  // LDS: dword d of lane L's ring at ring_wave[d * 64 + L]
+    uint32_t *list;       // LDS: 128 work items of 4 dwords
+    uint32_t lane;
+    __device__ __forceinline__ bool any(bool b) const { return __builtin_amdgcn_ballot_w64(b) != 0; }
+    __device__ __forceinline__ void flush_lines(const LdsRing &R, RingOut &O) const {
+        if (O.fl & 127u) {                                        // the partial line in front of the member's first boundary: this lane alone
+            const uint32_t c = (O.fl + 127u) & ~127u;
+            if (O.hd >= c) { O.slow_flush(R, O.fl, c); O.fl = c; }
+        }
+        const uint32_t nl = (O.fl & 127u) ? 0u : (O.hd - O.fl) >> 7;            // 0..2 (head - flushed <= kRingFill)
+        const uint64_t m0 = __builtin_amdgcn_ballot_w64(nl > 0), m1 = __builtin_amdgcn_ballot_w64(nl > 1);
+        const uint32_t c0 = (uint32_t)__popcll(m0), total = c0 + (uint32_t)__popcll(m1);
+        if (!total) return;
+        const uint64_t lt = (1ull << lane) - 1ull;
+        {
+            const uint64_t a = (uint64_t)(uintptr_t)O.lbase;
+            uint32_t line = (O.fl % kRingBytes) >> 7;
+            if (nl > 0) { const u32x4 e = {(uint32_t)a, (uint32_t)(a >> 32), O.fl, line << 8 | lane}; *(u32x4 *)(list + 4 * (uint32_t)__popcll(m0 & lt)) = e; }
+            if (nl > 1) {
+                if (++line >= 3) line = 0;
+                const u32x4 e = {(uint32_t)a, (uint32_t)(a >> 32), O.fl + 128, line << 8 | lane}; *(u32x4 *)(list + 4 * (c0 + (uint32_t)__popcll(m1 & lt))) = e;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t piece = lane & 7u, sub = lane >> 3;
+        for (uint32_t base = 0; base < total; base += 32) {
+            u32x4 e[4], v[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const uint32_t k = base + 8 * s4 + sub;
+                e[s4] = *(const u32x4 *)(list + 4 * (k < total ? k : total - 1));
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const uint32_t *q = ring_wave + ((e[s4][3] >> 8) * 32 + piece * 4) * 64 + (e[s4][3] & 0xffu);
+                v[s4] = u32x4{q[0], q[64], q[128], q[192]};
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if (base + 8 * s4 + sub < total) {
+                    uint8_t *dst = (uint8_t *)(uintptr_t)((uint64_t)e[s4][0] | (uint64_t)e[s4][1] << 32) + e[s4][2] + 16 * piece;
+                    *(u32x4 *)dst = v[s4];
+                }
+            }
+        }
+        O.fl += 128 * nl;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();                             // (the list is rewritten by the next round)
+    }
+};
+
+template <bool PROBE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_inflate_ring(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
+                                                uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
+                                                uint32_t *status, uint32_t ignore_below) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t m = blockIdx.x * 64 + lane;
+    const bool have = m < n_members;
+    Member mb = members[have ? m : n_members - 1];
+    LdsTab T{lds + lane, len_scratch + (have ? m : 0), gridDim.x * 64};
+    LdsRing R{lds + kLdsDwordsPerLane * 64 + lane};
+    WaveCoop C{lds + kLdsDwordsPerLane * 64, lds + (kLdsDwordsPerLane + kRingLaneDw) * 64, lane};
+    uint32_t out_len = 0;
+    if (PROBE) {
+        const bool run = have && mb.isize != 0xffffffffu;         // ~0: BSIZE runs past the end of the file (or is < 26): the read fails upstream
+        const int st = inflate_ring(comp + mb.cpos, mb.clen, arena + (uint64_t)(have ? m : 0) * kBgzfMaxBlock, kBgzfMaxBlock, &out_len, T, R, C, run);
+        if (have) status[m] = run && st == INF_OK ? out_len : 0xffffffffu;
+        return;
+    }
+    // a member whose claimed size is no BGZF block size owns no bytes of the arena (k_member_compact): it must not write any, whatever
+    // range the host asked for.  ~0 = the member runs past the end of the file (k_member_link).
+    const bool run = have && mb.isize <= kBgzfMaxBlock;
+    int st = inflate_ring(comp + mb.cpos, mb.clen, arena + (run ? mb.upos - upos_bias : 0), run ? mb.isize : 0, &out_len, T, R, C, run);
+    if (!have) return;
+    if (!run) st = mb.isize == 0xffffffffu ? INF_IN_OVERRUN : INF_OUT_OVERFLOW;
+    else if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
+    if (st != INF_OK) {
+        uint32_t *slot = m >= ignore_below ? status : status + kStatusEarly;
+        uint32_t prev = atomicMin(&slot[0], m);
+        if (m < prev) slot[1] = (uint32_t)st;
+    }
+}
+
 size_t inflate_scratch_bytes(uint32_t n_members) { return (size_t)((n_members + 63) / 64) * 64 * kScratchWordsPerLane * 4; }
 
+// Two forms of the decoder: k_inflate (round 1: output straight to HBM, 12 waves per CU) is what the pipeline runs; k_inflate_ring
+// (inflate_ring.h: output through a per-lane LDS window, whole lines to HBM, 4 waves per CU) moves 0.3x the HBM bytes but its symbol loop
+// has one wave per SIMD to hide its LDS round trips behind and measures 1.9x slower.  REGTOOLS_AMD_INFLATE=ring selects it.
+static bool inflate_ring_selected() {
+    static const bool ring = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE"); return e && !strcmp(e, "ring"); }();
+    return ring;
+}
+static void inflate_attrs() {
+    static bool done = false;
+    if (done) return;
+    (void)hipFuncSetAttribute((const void *)k_inflate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+    (void)hipFuncSetAttribute((const void *)k_inflate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+    (void)hipFuncSetAttribute((const void *)k_inflate_ring<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRingLdsBytes);
+    (void)hipFuncSetAttribute((const void *)k_inflate_ring<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRingLdsBytes);
+    done = true;
+}
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
                     uint32_t *status, hipStream_t stream, uint32_t ignore_below) {
     if (!n_members) return;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_inflate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
-        (void)hipFuncSetAttribute((const void *)k_inflate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
-        attr_set = true;
-    }
+    inflate_attrs();
     uint32_t blocks = (n_members + 63) / 64;
-    hipLaunchKernelGGL(k_inflate<false>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below);
+    if (!inflate_ring_selected()) { hipLaunchKernelGGL(k_inflate<false>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below); return; }
+    hipLaunchKernelGGL(k_inflate_ring<false>, dim3(blocks), dim3(64), kRingLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below);
 }
 void launch_inflate_probe(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *slots, uint32_t *len_scratch, uint32_t *sizes,
                           hipStream_t stream) {
     if (!n_members) return;
-    (void)hipFuncSetAttribute((const void *)k_inflate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
-    hipLaunchKernelGGL(k_inflate<true>, dim3((n_members + 63) / 64), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u);
+    inflate_attrs();
+    if (!inflate_ring_selected()) { hipLaunchKernelGGL(k_inflate<true>, dim3((n_members + 63) / 64), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u); return; }
+    hipLaunchKernelGGL(k_inflate_ring<true>, dim3((n_members + 63) / 64), dim3(64), kRingLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u);
 }
 
 // =====================================================================================================

@@ -8,6 +8,25 @@ extern "C" int emu_inflate(const uint8_t *in, uint32_t in_len, uint8_t *out, uin
     return rgx::inflate_raw(in, in_len, out, cap, out_len, T);
 }
 
+// the round-2 decoder (inflate_ring.h: per-lane LDS window, cooperative line flush) with a one-lane wave.  The member is inflated into
+// a private buffer at destination phase `phase` (address % 128) with guard bytes around it: returns -100 / -101 if a byte in front of /
+// behind the member's [0, cap) was written.
+#include "../../regtools_amd/csrc/inflate_ring.h"
+#include <vector>
+extern "C" int emu_inflate_ring(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t cap, uint32_t *out_len, uint32_t phase) {
+    std::vector<uint8_t> ibuf((size_t)in_len + 64 + 32, 0);
+    memcpy(ibuf.data() + 32, in, in_len);
+    std::vector<uint8_t> obuf((size_t)cap + 1024, 0xA5);
+    uint8_t *dst = (uint8_t *)(((uintptr_t)obuf.data() + 127) & ~(uintptr_t)127) + 256 + (phase & 127u);
+    rgx::HostTab T; rgx::HostRing R; rgx::HostCoop C;
+    memset(&R, 0xCC, sizeof R);
+    const int st = rgx::inflate_ring(ibuf.data() + 32, in_len, dst, cap, out_len, T, R, C, true);
+    for (uint8_t *q = obuf.data(); q < dst; ++q) if (*q != 0xA5) return -100;
+    for (uint8_t *q = dst + cap; q < obuf.data() + obuf.size(); ++q) if (*q != 0xA5) return -101;
+    memcpy(out, dst, *out_len <= cap ? *out_len : cap);
+    return st;
+}
+
 // ---- the per-alignment cores of bam_core.h / cse_core.h, as the kernels call them ---------------------------------------------
 #include "../../regtools_amd/csrc/bam_core.h"
 #include "../../regtools_amd/csrc/cse_core.h"

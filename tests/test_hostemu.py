@@ -17,12 +17,26 @@ def emu(built):
     return ctypes.CDLL(os.path.join(ROOT, "tests", "hostemu", "libhostemu.so"))
 
 
+_phase = [0]
+
+
 def inflate(emu, payload, cap=65536):
+    """Both decoders on the same payload: round 1's lane decoder (inflate_core.h) and the LDS-window decoder (inflate_ring.h, one-lane
+    wave, destination phase cycling through all 128 line offsets); they must agree, and the common answer is returned."""
     out = ctypes.create_string_buffer(cap + 64)
     n = ctypes.c_uint32(0)
     buf = ctypes.create_string_buffer(payload + b"\0" * 16, len(payload) + 16)
     st = emu.emu_inflate(buf, len(payload), out, cap, ctypes.byref(n))
-    return st, out.raw[:n.value]
+    got = out.raw[:n.value]
+    out2 = ctypes.create_string_buffer(cap + 64)
+    n2 = ctypes.c_uint32(0)
+    _phase[0] = (_phase[0] + 37) % 128
+    st2 = emu.emu_inflate_ring(buf, len(payload), out2, cap, ctypes.byref(n2), _phase[0])
+    assert st2 not in (-100, -101), "the ring decoder wrote outside its member (phase %d)" % _phase[0]
+    assert (st2 == 0) == (st == 0), (st, st2, _phase[0])
+    if st == 0:
+        assert out2.raw[:n2.value] == got, "ring decoder differs at phase %d" % _phase[0]
+    return st, got
 
 
 def test_members_of_synthetic_bams(emu, tmp_path):
@@ -163,3 +177,20 @@ def test_reads_stay_within_16_bytes_of_the_payload_even_on_corrupt_streams(emu):
                 assert st == 0 and out.raw[:n.value] == data
     finally:
         libc.mprotect(ctypes.c_void_p(base + 2 * page), page, 3)
+
+
+def test_ring_decoder_every_destination_phase_and_window_edge(emu):
+    """inflate_ring.h: matches at the distances around the ring's near limit (352) and its size (384), lengths around the 128-byte batch,
+    at every destination phase of a 128-byte line; guard bytes around the member must stay untouched (emu_inflate_ring checks them)."""
+    rnd = random.Random(23)
+    for dist in (1, 3, 4, 5, 15, 16, 17, 127, 128, 129, 220, 228, 351, 352, 353, 367, 368, 369, 383, 384, 385, 400, 1000, 32768):
+        seed = bytes(rnd.randrange(256) for _ in range(dist))
+        for total in (dist + 3, dist + 130, dist + 258, dist + 700):
+            data = (seed * (total // dist + 2))[:total]
+            c = zlib.compressobj(9, zlib.DEFLATED, -15, 9)
+            p = c.compress(data) + c.flush()
+            for phase in (0, 1, 15, 16, 17, 63, 64, 100, 127, rnd.randrange(128)):
+                out = ctypes.create_string_buffer(len(data) + 64)
+                n = ctypes.c_uint32(0)
+                st = emu.emu_inflate_ring(p, len(p), out, len(data), ctypes.byref(n), phase)
+                assert st == 0 and out.raw[:n.value] == data, (dist, total, phase, st)
