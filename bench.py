@@ -2,8 +2,9 @@
 """bench.py -- `junctions extract` hot path on N MI355X GPUs (one process per GPU).
 
 A "step" is one complete pass of the hot path over one synthetic BAM (SURVEY.md 8d, config 2 shape):
-BGZF members already resident in HBM -> inflate -> record framing -> SoA decode -> CIGAR scan/emit ->
-radix sort + segmented reduce -> sorted junction table on the host.  N > 1 is weak scaling: every rank
+BGZF file bytes in page-locked host memory -> chunked upload, overlapped with -> inflate -> record framing -> SoA
+decode -> CIGAR scan/emit -> radix sort + segmented reduce -> sorted junction table on the host.  (`value` is timed
+on that region; `value_device_resident` is the same pass with the file already in HBM, reported beside it.)  N > 1 is weak scaling: every rank
 holds its own coordinate slice (same read count) of one big coordinate-sorted BAM, the per-rank tables are
 exchanged with one RCCL all-gather of packed rows and merged.
 
@@ -80,6 +81,7 @@ def main():
     ap.add_argument("--shape", default="short", choices=["short", "long"])
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-only", action="store_true", help="(profiling) only the timed host-bytes pass; the roofline line then quotes the overlapped launches")
     ap.add_argument("--realistic", action="store_true", help="random bases + binned qualities instead of the named constant payload")
     args = ap.parse_args()
 
@@ -109,15 +111,14 @@ def main():
                                   slice_index=rank, n_slices=world)
     t_gen = time.time() - t_gen
     n_reads = st["n_reads"]
-    d_bam = torch.zeros(len(bam) + 64, dtype=torch.uint8, device="cuda")
-    d_bam[: len(bam)].copy_(torch.frombuffer(bytearray(bam), dtype=torch.uint8))
-    torch.cuda.synchronize()
-
     ctx = regtools_amd.Context(local_rank)
     je = regtools_amd.JunctionsExtractor(strandness=0, ctx=ctx)
+    # The timed region: file bytes in page-locked HOST memory -> sorted junction table in host memory.  The upload is part of
+    # every step (chunked over a copy stream, the members of the chunks that have arrived inflate meanwhile: rgx_extract_mem).
+    pin = regtools_amd.PinnedBuffer(bam)
 
     def step():
-        je.identify_junctions_from_BAM(bai_bytes=bai, device_ptr=d_bam.data_ptr(), device_len=len(bam))
+        je.identify_junctions_from_BAM(bai_bytes=bai, host_ptr=pin.ptr, host_len=len(bam))
         if world > 1:
             return rdist.gather_and_merge(je, min_anchor=8)
         return je.table
@@ -130,26 +131,50 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    inflate_ms, stage_ms = [], dict(inflate=0.0, records=0.0, scan=0.0, reduce=0.0, total=0.0)
     fence()
     t0 = time.time()
     for _ in range(args.steps):
         step()
+    fence()
+    dt = time.time() - t0
+    n_events = je.stats["n_events"]
+    bed_host_path = je.bed12() if world == 1 else None
+
+    # Second, untimed-for-the-headline pass with the file ALREADY RESIDENT in HBM: one k_inflate launch over the whole file, which is what
+    # the roofline of the dominant kernel is quoted on (HIP events on the pipeline's stream), and the per-stage times.
+    d_bam = torch.zeros(len(bam) + 64, dtype=torch.uint8, device="cuda")
+    d_bam[: len(bam)].copy_(torch.frombuffer(bytearray(bam), dtype=torch.uint8))
+    torch.cuda.synchronize()
+
+    def step_resident():
+        je.identify_junctions_from_BAM(bai_bytes=bai, device_ptr=d_bam.data_ptr(), device_len=len(bam))
+        if world > 1:
+            return rdist.gather_and_merge(je, min_anchor=8)
+        return je.table
+
+    if args.host_only:
+        step_resident = step
+    step_resident()
+    inflate_ms, stage_ms = [], dict(inflate=0.0, records=0.0, scan=0.0, reduce=0.0, total=0.0)
+    fence()
+    t1 = time.time()
+    for _ in range(1 if args.host_only else args.steps):
+        step_resident()
         s = je.stats
         inflate_ms.append(s["ms_inflate"])
         for k in stage_ms:
-            stage_ms[k] += s["ms_" + k] / args.steps
+            stage_ms[k] += s["ms_" + k] / (1 if args.host_only else args.steps)
     fence()
-    dt = time.time() - t0
+    dt_res = (time.time() - t1) * (args.steps if args.host_only else 1)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt, dt_res], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        cnt = torch.tensor([float(n_reads), float(je.stats["n_events"])], dtype=torch.float64, device="cuda")
+        dt, dt_res = float(tt[0].item()), float(tt[1].item())
+        cnt = torch.tensor([float(n_reads), float(n_events)], dtype=torch.float64, device="cuda")
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         total_reads, total_events = cnt[0].item(), cnt[1].item()
     else:
-        total_reads, total_events = float(n_reads), float(je.stats["n_events"])
+        total_reads, total_events = float(n_reads), float(n_events)
 
     if rank == 0:
         s = je.stats
@@ -185,6 +210,8 @@ def main():
                        "bgzf_members": s["n_members"], "compressed_bytes_per_gpu": s["compressed_bytes"], "inflated_bytes_per_gpu": s["inflated_bytes"],
                        "bytes_per_alignment": {"compressed": s["compressed_bytes"] / n_reads, "inflated": s["inflated_bytes"] / n_reads}},
             "junction_events_per_s": total_events * args.steps / dt,
+            "timed_region": "file bytes in page-locked host memory -> sorted junction table in host memory (SURVEY.md 8d): chunked H2D upload inside every step, overlapped with the inflate",
+            "value_device_resident": total_reads * args.steps / dt_res, "ms_per_step_device_resident": 1e3 * dt_res / args.steps,
             "junction_rows": s["n_junctions"],
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "input_generation_s": round(t_gen, 2),
@@ -203,7 +230,8 @@ def main():
                 cb, bed = cpu_baseline(path, n_reads, s["n_events"])
                 # while we are here: the GPU table must equal the CPU one on the full-size workload
                 with open(bed, "rb") as f:
-                    cb["bed12_identical_to_gpu"] = f.read() == je.bed12()
+                    ref_bed = f.read()
+                    cb["bed12_identical_to_gpu"] = ref_bed == je.bed12() and ref_bed == bed_host_path
                 line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
     if world > 1:

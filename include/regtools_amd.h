@@ -106,7 +106,13 @@ void rgx_ctx_destroy(rgx_ctx *ctx);
 int  rgx_extract(rgx_ctx *ctx, const char *bam_path, const rgx_extract_params *p,
                  rgx_junction_table **out, char *err, size_t errlen);
 
-/* Same, input already in host memory (file bytes of the .bam and of its .bai or .csi). */
+/* Same, input already in host memory (file bytes of the .bam and of its .bai or .csi) -- the configuration SURVEY.md 8(d) times:
+ * "file bytes in host memory" -> "sorted junction table in host memory".  The file is uploaded in chunks on a copy stream while the
+ * BGZF members of the chunks that have arrived are already being inflated; for that overlap the bytes should sit in page-locked memory
+ * (rgx_host_alloc, or any hipHostMalloc / pinned allocation) -- pageable memory works, the copies then go through the driver's staging
+ * buffer at a fraction of the link rate.  Replaces the file read of junctions_extractor.cc:503-525 (hts_open / sam_itr_querys). */
+void *rgx_host_alloc(size_t bytes);      /* page-locked host memory (NULL when there is none to be had) */
+void  rgx_host_free(void *p);
 int  rgx_extract_mem(rgx_ctx *ctx, const void *bam, size_t bam_len, const void *bai, size_t bai_len,
                      const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen);
 
@@ -160,7 +166,7 @@ const char *rgx_version(void);
  * dominant kernel in isolation; all asynchronous on `stream`, a hipStream_t passed as void*). */
 typedef struct { uint64_t cpos, upos; uint32_t clen, isize; } rgx_member;   /* == rgx::Member */
 int  rgx_k_inflate(const void *d_comp, const rgx_member *d_members, uint32_t n_members,
-                   void *d_arena, uint32_t *d_status, void *stream);
+                   void *d_arena, uint32_t *d_status, void *stream);   /* with REGTOOLS_AMD_INFLATE=ring: 16 readable bytes in front of d_arena */
 
 /* =====================================================================================================
  * `cis-splice-effects identify`.

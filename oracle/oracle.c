@@ -142,6 +142,8 @@ typedef struct {
     int      have_start;    /* some reference has the pseudo-bin */
     uint64_t start_voff;    /* smallest pseudo-bin chunk[0].beg */
     uint64_t n_no_coor;
+    int      have_nocoor;   /* the LAST reference has the pseudo-bin: "*" starts at its chunk[0].end (hts.c:1733-1741) */
+    uint64_t nocoor_voff;
     /* the plain index bytes, for region queries */
     uint8_t *img; size_t img_len, refs_off; int csi, min_shift, depth;
 } bai_info;
@@ -208,6 +210,7 @@ static int bai_load(const char *bam, bai_info *bi) {
                 uint64_t u = rd64(d + p);
                 bi->have_start = 1;
                 if (u < bi->start_voff) bi->start_voff = u;
+                if (r == bi->n_ref - 1) { bi->have_nocoor = 1; bi->nocoor_voff = rd64(d + p + 8); }
             }
             p += (size_t)n_chunk * 16;
         }
@@ -877,17 +880,18 @@ int orc_extract(const orc_params *p, orc_table **out, char *err, size_t errlen) 
     if (!hdr_ok) BAIL(itr_err);
 
     /* iterator set-up */
-    int whole = !strcmp(p->region, ".");
+    int rest = !strcmp(p->region, "*");            /* HTS_IDX_NOCOOR (hts.c:1903-1904, :1733-1741): read_rest from behind the last reference */
+    int whole = rest || !strcmp(p->region, ".");
     int r_tid = -1, r_beg = 0, r_end = 0;
     chunk_t *off = NULL; int n_off = 0, ci = -1; uint64_t curr_off = 0;     /* hts_itr_next state (hts.c:1924-1965) */
     if (whole) {
         uint64_t v;
-        if (bi.have_start) v = bi.start_voff;
+        if (rest) { if (bi.have_nocoor) v = bi.nocoor_voff; else if (bi.n_no_coor) v = 0; else BAIL(itr_err); }
+        else if (bi.have_start) v = bi.start_voff;
         else if (bi.n_no_coor) v = 0;
         else BAIL(itr_err);
         if (v != 0) rdr_seek(&rd, v);   /* curr_off == 0 means "do not seek": continue right after the header */
     } else {
-        if (!strcmp(p->region, "*")) BAIL(itr_err); /* not restated */
         if (parse_region(t, p->region, &r_tid, &r_beg, &r_end) || r_tid >= bi.n_ref || r_end < r_beg) BAIL(itr_err);
         n_off = itr_query(&bi, r_tid, r_beg, r_end, &off);       /* 0 chunks: an iterator that returns nothing */
     }

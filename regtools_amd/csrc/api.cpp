@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -72,9 +73,15 @@ struct DevBuf {
 struct rgx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // host input (rgx_extract_mem / rgx_extract): the file goes up in chunks on its own stream while the members that have arrived are
+    // being inflated on the side streams (prepare_events)
+    hipStream_t copy_stream = nullptr, side[2] = {};
+    std::vector<hipEvent_t> chunk_ev;
+    hipEvent_t ev_ready = nullptr, ev_side[2] = {};
     hipEvent_t ev[8] = {};
     std::map<std::string, DevBuf> bufs;
     void *pinned = nullptr; size_t pinned_cap = 0;     // small pinned staging for scalar readbacks
+    void *pinned_members = nullptr; size_t pinned_members_cap = 0;      // the host scan's member list: kernels read it in place (grow-only)
     void *pinned_rows = nullptr; size_t pinned_rows_cap = 0;
     uint64_t last_rows = 0, last_records = 0, last_events = 0, last_bytes = 0; bool last_rows_valid = false;      // rows of the last rgx_extract* call, still in the "rows_out" block in HBM   // grow-only pinned staging for whole result tables (device merge)
     std::string fasta_path;                            // FASTA currently resident in the "fasta" buffer
@@ -105,6 +112,10 @@ extern "C" int rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errle
     rgx_ctx *c = new rgx_ctx();
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (auto &q : c->side) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    for (auto &e : c->ev_side) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
     c->pinned_cap = 4096;
@@ -117,9 +128,15 @@ extern "C" void rgx_ctx_destroy(rgx_ctx *c) {
     (void)hipSetDevice(c->device);
     for (auto &kv : c->bufs) kv.second.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->chunk_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_side) if (e) (void)hipEventDestroy(e);
+    if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+    for (auto &q : c->side) if (q) (void)hipStreamDestroy(q);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c->fasta;
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned_rows) (void)hipHostFree(c->pinned_rows);
+    if (c->pinned_members) (void)hipHostFree(c->pinned_members);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -175,6 +192,11 @@ static rgx_junction_table *table_alloc(const BamHeader &h, uint64_t n, bool zero
     box->pinned = pinned;
     box->block = block_take(need, box->block_cap, pinned);
     if (!box->block && pinned) { box->pinned = false; box->block = block_take(need, box->block_cap, false); }
+    if (!box->block) {                                           // no memory for the rows: no table (callers report RGX_ERR_DEVICE / RGX_ERR_ARG)
+        for (int32_t i = 0; i < t->n_ref; ++i) free(t->ref_name[i]);
+        free(t->ref_name); free(t->ref_len); free(box);
+        return nullptr;
+    }
     if (zero) memset(box->block, 0, need);
     uint8_t *q = (uint8_t *)box->block;
     t->name_index = (uint64_t *)q; q += m * 8; t->first_seen = (uint64_t *)q; q += m * 8; t->last_seen = (uint64_t *)q; q += m * 8;
@@ -233,16 +255,18 @@ static void host_sort_rows(rgx_junction_table *t) {
 
 extern "C" size_t rgx_table_format_bed12(const rgx_junction_table *t, int only_anchored, char *buf, size_t cap) {
     size_t need = 0;
-    char line[512];
+    char tail[256];                                        // everything behind the contig name: ten bounded numeric fields
     for (uint64_t i = 0; i < t->n; ++i) {
         if (only_anchored && !(t->left_ok[i] && t->right_ok[i])) continue;
-        // Junction::print (junctions_extractor.h:90-98)
-        int n = snprintf(line, sizeof line, "%s\t%u\t%u\tJUNC%08llu\t%u\t%c\t%u\t%u\t255,0,0\t2\t%u,%u\t0,%u\n", t->ref_name[t->tid[i]],
-                         t->thick_start[i], t->thick_end[i], (unsigned long long)t->name_index[i], t->read_count[i], t->strand[i],
-                         t->thick_start[i], t->thick_end[i], (uint32_t)(t->start[i] - t->thick_start[i]),
-                         (uint32_t)(t->thick_end[i] - t->end[i]), (uint32_t)(t->end[i] - t->thick_start[i]));
-        if (buf && need + (size_t)n <= cap) memcpy(buf + need, line, (size_t)n);
-        need += (size_t)n;
+        // Junction::print (junctions_extractor.h:90-98).  The name is copied as it is: the BAM header puts no limit on its length.
+        const char *name = t->ref_name[t->tid[i]];
+        const size_t ln = strlen(name);
+        const int n = snprintf(tail, sizeof tail, "\t%u\t%u\tJUNC%08llu\t%u\t%c\t%u\t%u\t255,0,0\t2\t%u,%u\t0,%u\n",
+                               t->thick_start[i], t->thick_end[i], (unsigned long long)t->name_index[i], t->read_count[i], t->strand[i],
+                               t->thick_start[i], t->thick_end[i], (uint32_t)(t->start[i] - t->thick_start[i]),
+                               (uint32_t)(t->thick_end[i] - t->end[i]), (uint32_t)(t->end[i] - t->thick_start[i]));
+        if (buf && need + ln + (size_t)n <= cap) { memcpy(buf + need, name, ln); memcpy(buf + need + ln, tail, (size_t)n); }
+        need += ln + (size_t)n;
     }
     return need;
 }
@@ -280,7 +304,8 @@ struct Prep {
 };
 
 static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_bam, size_t bam_len, const uint8_t *bai, size_t bai_len,
-                          const rgx_extract_params *p, bool want_read_span, Prep &P, char *err, size_t errlen, const uint32_t *d_true_sizes = nullptr) {
+                          const rgx_extract_params *p, bool want_read_span, Prep &P, char *err, size_t errlen, const uint32_t *d_true_sizes = nullptr,
+                          bool allow_overlap = true) {
     if (!p || p->strandness < 0 || p->strandness > 3) return fail(err, errlen, RGX_ERR_ARG, "Please supply strandness mode with '-s' option!\n\n");
     if (p->strandness == 3 && !p->fasta_path) return fail(err, errlen, RGX_ERR_ARG, "Strandness mode 'intron-motif' requires a fasta file!\n\n");
     if (p->barcodes && p->n_shards > 1) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: barcode counts (-b) need the whole file in one shard\n");
@@ -301,12 +326,49 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } bai_joiner{bai_thread};
     // -- upload ----------------------------------------------------------------------------------------------------------
+    // Host input: the file goes up in chunks on the copy stream from a helper thread (a pageable source makes hipMemcpyAsync block), while
+    // this thread finds the members on the host (scan_members_parallel) -- the inflate of chunk k's members then runs while chunk k+1 is
+    // still on the bus (SURVEY 8d times the path from file bytes in host memory).  A file the host scan does not vouch for waits for the
+    // whole upload and takes the device's member discovery, as does device input.
     const uint8_t *d_bam = d_bam_in;
+    struct Upload {
+        std::thread th; std::atomic<uint32_t> recorded{0}; std::atomic<int> err{0};
+        std::vector<size_t> end;                            // end[j] = bytes resident once chunk event j has fired
+        ~Upload() { if (th.joinable()) th.join(); }
+    } up;
+    bool overlap = false;
+    std::vector<Member> hm;                                  // the host scan's member list (overlap only)
+    uint64_t hm_total = 0;
     if (!d_bam) {
         DevBuf &b = c->buf("bam");
         HIP_TRY(b.ensure(bam_len + 64));
-        HIP_TRY(hipMemcpyAsync(b.p, h_bam, bam_len, hipMemcpyHostToDevice, st));
         d_bam = b.as<uint8_t>();
+        static const bool no_overlap = getenv("REGTOOLS_AMD_NO_OVERLAP") != nullptr;
+        if (allow_overlap && !d_true_sizes && !no_overlap && bam_len >= ((size_t)8 << 20)) {
+            // three pieces, one per side stream: every piece is its own launch, a launch takes ~8 ms however small (one lane per member), and the
+            // runtime maps streams onto four hardware queues -- more pieces would queue behind each other, not overlap (profiles/r02_overlap_timeline.txt)
+            const size_t chunk = std::max<size_t>((size_t)4 << 20, ((bam_len + 2) / 3 + 4095) & ~(size_t)4095);
+            for (size_t o = 0; o < bam_len; o += chunk) up.end.push_back(std::min(bam_len, o + chunk));
+            while (c->chunk_ev.size() < up.end.size()) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->chunk_ev.push_back(e); }
+            uint8_t *dst = b.as<uint8_t>();
+            up.th = std::thread([c, dst, h_bam, &up] {
+                if (hipSetDevice(c->device) != hipSuccess) { up.err = 1; up.recorded = (uint32_t)up.end.size(); return; }
+                size_t o = 0;
+                for (size_t j = 0; j < up.end.size(); ++j) {
+                    if (hipMemcpyAsync(dst + o, h_bam + o, up.end[j] - o, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
+                        hipEventRecord(c->chunk_ev[j], c->copy_stream) != hipSuccess) up.err = 1;
+                    o = up.end[j];
+                    up.recorded.store((uint32_t)j + 1, std::memory_order_release);
+                }
+            });
+            overlap = scan_members_parallel(h_bam, bam_len, (int)std::min<unsigned>(24, std::max(2u, std::thread::hardware_concurrency()) - 1), hm, hm_total);
+            mark("host member scan");
+            if (!overlap) {       // not a file the host vouches for: everything on the device, after the last chunk
+                up.th.join();
+                if (up.err) return fail(err, errlen, RGX_ERR_DEVICE, "regtools_amd: upload failed\n");
+                HIP_TRY(hipStreamWaitEvent(st, c->chunk_ev[up.end.size() - 1], 0));
+            }
+        } else HIP_TRY(hipMemcpyAsync(b.p, h_bam, bam_len, hipMemcpyHostToDevice, st));
     }
     DevBuf &b_arena = c->buf("arena"), &b_members = c->buf("members"), &b_scalars = c->buf("scalars"), &b_hdr = c->buf("hdr_arena"), &b_disc = c->buf("discover");
     HIP_TRY(b_scalars.ensure(512));
@@ -322,6 +384,26 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     HIP_TRY(hipMemsetAsync(d_sc + kStatusEarly, 0xff, 4, st));
 
     // -- BGZF member discovery on the device (replaces the serial BSIZE walk, bgzf.c:421-546) -------------------------------
+    uint32_t n_cand = 0;
+    uint64_t *cand = nullptr;
+    uint32_t *nx[2] = {nullptr, nullptr}, *c_isize = nullptr, *c_reach = nullptr, *c_rank = nullptr, *c_isz2 = nullptr, *c_tmp = nullptr;
+    if (overlap) {
+        // the member list came from the host scan: what the discovery kernels would have left in HBM
+        // (in page-locked host memory, read in place by the kernels -- 24 bytes per member, once: an upload would queue behind the file's
+        // chunks on the copy engine, measured 4 ms)
+        n_cand = (uint32_t)hm.size();
+        const size_t need = ((size_t)n_cand + 1) * sizeof(Member);
+        if (need > c->pinned_members_cap) {
+            if (c->pinned_members) (void)hipHostFree(c->pinned_members);
+            c->pinned_members = nullptr; c->pinned_members_cap = 0;
+            HIP_TRY(hipHostMalloc(&c->pinned_members, need + need / 4, hipHostMallocDefault));
+            c->pinned_members_cap = need + need / 4;
+        }
+        memcpy(c->pinned_members, hm.data(), (size_t)n_cand * sizeof(Member));
+        h_sc[17] = n_cand; memcpy(h_sc + 20, &hm_total, 8);
+        HIP_TRY(hipMemcpyAsync(d_sc + 17, h_sc + 17, 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_sc + 20, h_sc + 20, 8, hipMemcpyHostToDevice, st));
+    } else {
     const uint32_t n_tiles = (uint32_t)((bam_len + kMagicTile - 1) / kMagicTile);
     HIP_TRY(b_disc.ensure((size_t)n_tiles * 4 + scan_tmp_words(n_tiles) * 4 + 256));
     uint32_t *tile_cnt = b_disc.as<uint32_t>(), *tile_tmp = tile_cnt + n_tiles;
@@ -329,7 +411,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     launch_scan_u32(tile_cnt, tile_cnt, n_tiles, d_sc + 16, tile_tmp, st);
     HIP_TRY(hipMemcpyAsync(h_sc + 16, d_sc + 16, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    const uint32_t n_cand = h_sc[16];
+    n_cand = h_sc[16];
     if (n_cand == 0) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
     DevBuf &b_cand = c->buf("cand");
     {
@@ -337,11 +419,13 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         HIP_TRY(b_cand.ensure(N * 8 + N * 4 * 6 + scan_tmp_words(n_cand) * 4 + 256));
         HIP_TRY(b_members.ensure((N + 1) * sizeof(Member)));
     }
-    uint64_t *cand = b_cand.as<uint64_t>();
-    uint32_t *nx[2] = {(uint32_t *)(cand + n_cand), (uint32_t *)(cand + n_cand) + n_cand};
-    uint32_t *c_isize = nx[1] + n_cand, *c_reach = c_isize + n_cand, *c_rank = c_reach + n_cand, *c_isz2 = c_rank + n_cand, *c_tmp = c_isz2 + n_cand;
+    cand = b_cand.as<uint64_t>();
+    nx[0] = (uint32_t *)(cand + n_cand); nx[1] = (uint32_t *)(cand + n_cand) + n_cand;
+    c_isize = nx[1] + n_cand; c_reach = c_isize + n_cand; c_rank = c_reach + n_cand; c_isz2 = c_rank + n_cand; c_tmp = c_isz2 + n_cand;
     launch_magic_fill(d_bam, bam_len, n_tiles, tile_cnt, cand, st);
-    Member *d_members = b_members.as<Member>();
+    }
+    Member *d_members = overlap ? (Member *)c->pinned_members : b_members.as<Member>();
+    const hipMemcpyKind from_members = overlap ? hipMemcpyHostToHost : hipMemcpyDeviceToHost;
     // the members = the candidates that chain up from offset 0 (and, second try below, from the offset a seek lands on)
     auto chain = [&](uint64_t root2) {
         launch_member_link(d_bam, bam_len, cand, n_cand, nx[0], c_isize, c_reach, root2, st);
@@ -353,14 +437,20 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         if (d_true_sizes) launch_member_fix(d_members, c_isz2, n_cand, d_sc + 17, d_true_sizes, st);     // second run: lengths from the probe, not the footers
         launch_member_upos(d_members, c_isz2, d_sc + 17, (uint64_t *)(d_sc + 20), st);
     };
-    chain(UINT64_MAX);
+    if (!overlap) chain(UINT64_MAX);
     bai_thread.join();
     if (!bai_ok) return (void)hipStreamSynchronize(st), fail(err, errlen, RGX_ERR_INDEX, "%s", kMsgIndex);
     mark("parse_bai");
-    const bool whole = !strcmp(p->region ? p->region : ".", ".");
-    // where the record stream starts (hts.c:1721-1731 for ".")
+    // "." = every record from the first one on; "*" = every record behind the last reference's reads (hts_itr_querys, hts.c:1901-1904:
+    // HTS_IDX_START / HTS_IDX_NOCOOR; both read to the end of the file without a predicate)
+    const bool rest = p->region && !strcmp(p->region, "*");
+    const bool whole = rest || !strcmp(p->region ? p->region : ".", ".");
+    // where the record stream starts (hts.c:1721-1741)
     bool seek = false; uint64_t seek_voff = 0;
-    if (whole) {
+    if (rest) {
+        if (bi.have_nocoor) { seek_voff = bi.nocoor_voff; seek = seek_voff != 0; }
+        else if (!bi.n_no_coor) return (void)hipStreamSynchronize(st), fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion);
+    } else if (whole) {
         if (bi.have_start) { seek_voff = bi.start_voff; seek = seek_voff != 0; }
         else if (!bi.n_no_coor) return (void)hipStreamSynchronize(st), fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion);
     }
@@ -385,7 +475,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // overlap predicate in k_decode_seg stays the judge, the span only spares inflating members no record of the region can be in.
     // Needs the contig names before the launch: the header is inflated on the host from the head of the file.  Anything unusual
     // (header not readable this way, a .csi, a region the parser rejects) leaves the range alone and the full path decides.
-    if (!whole && p->n_shards <= 1 && p->region && strcmp(p->region, "*")) {
+    if (!whole && p->n_shards <= 1 && p->region) {
         const size_t head_len = std::min<size_t>(bam_len, (size_t)8 << 20);
         std::vector<uint8_t> head_copy;
         const uint8_t *head = h_bam;
@@ -417,6 +507,15 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         return hipStreamSynchronize(st);
     };
     HIP_TRY(query());
+    if (overlap && seek && (seek_voff >> 16) != 0 && h_sc[24] >= h_sc[17]) {
+        // the index points at something that is no member of this (well-formed) file: the device's discovery decides what that means
+        up.th.join();
+        HIP_TRY(hipStreamSynchronize(c->copy_stream));
+        HIP_TRY(hipStreamSynchronize(st));
+        const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, nullptr, false);
+        P.t_begin = t_begin;
+        return rc2;
+    }
     if (seek && (seek_voff >> 16) != 0 && h_sc[24] >= h_sc[17]) {
         // the seek target is no member of the chain from offset 0: something in front of it is broken.  bgzf_seek (hts_itr_next, hts.c:1935)
         // goes there regardless -- take it as a second chain root.  (Only damaged files get here.)
@@ -452,7 +551,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     auto upos_of = [&](uint32_t k, uint64_t &out_v) -> hipError_t {
         if (k >= n_members_all) { out_v = total_all; return hipSuccess; }
         Member m;
-        hipError_t e = hipMemcpy(&m, d_members + k, sizeof m, hipMemcpyDeviceToHost);
+        hipError_t e = hipMemcpy(&m, d_members + k, sizeof m, from_members);
         out_v = m.upos;
         return e;
     };
@@ -467,7 +566,39 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     HIP_TRY(b_lens.ensure(inflate_scratch_bytes(std::max<uint32_t>(n_range, 64))));
     // with a seek, the members in front of its target are only inflated for the header's sake (same launch): their failures end nothing
     const uint32_t ignore_below = (seek && first_member < n_members_all && first_member > m_lo) ? first_member - m_lo : 0;
-    launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below);
+    if (!overlap) launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below);
+    else {
+        // one launch per upload chunk, on the side streams: the members whose bytes (plus the decoder's 16-byte look-ahead) have arrived with
+        // chunk j start as soon as its event fires, next to the launches of the chunks before it
+        HIP_TRY(b_lens.ensure(inflate_scratch_bytes(std::max<uint32_t>(n_range, 64)) + up.end.size() * inflate_scratch_bytes(64)));
+        HIP_TRY(hipEventRecord(c->ev_ready, st));
+        for (auto &q : c->side) HIP_TRY(hipStreamWaitEvent(q, c->ev_ready, 0));
+        uint32_t g_lo = m_lo; size_t scratch_off = 0; unsigned used_side = 0;
+        for (size_t j = 0; j < up.end.size() && g_lo < m_hi; ++j) {
+            uint32_t g_hi = m_hi;
+            if (up.end[j] < bam_len) {       // first member of [g_lo, m_hi) that needs bytes beyond this chunk
+                const uint64_t lim_b = up.end[j];
+                uint32_t lo = g_lo, hi = m_hi;
+                while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (hm[mid].cpos + hm[mid].clen + 16 <= lim_b) lo = mid + 1; else hi = mid; }
+                g_hi = lo;
+            }
+            if (g_hi == g_lo) continue;
+            while (up.recorded.load(std::memory_order_acquire) <= j) std::this_thread::yield();      // (an event must have been recorded before a stream can wait on it)
+            if (up.err) return fail(err, errlen, RGX_ERR_DEVICE, "regtools_amd: upload failed\n");
+            // the pipeline's own stream is idle until the inflate is done: it takes every third piece (the runtime maps streams onto four
+            // hardware queues round-robin; a third side stream would share its queue with the second: profiles/r02_overlap_timeline.txt)
+            hipStream_t q = (j % 3 == 2) ? st : c->side[j % 3];
+            if (j % 3 != 2) used_side |= 1u << (j % 3);
+            HIP_TRY(hipStreamWaitEvent(q, c->chunk_ev[j], 0));
+            launch_inflate(d_bam, d_members + g_lo, g_hi - g_lo, b_arena.as<uint8_t>(), upos_lo, (uint32_t *)(b_lens.as<uint8_t>() + scratch_off), d_sc, q, ignore_below, g_lo - m_lo);
+            scratch_off += inflate_scratch_bytes(g_hi - g_lo);
+            g_lo = g_hi;
+        }
+        up.th.join();
+        if (up.err) return fail(err, errlen, RGX_ERR_DEVICE, "regtools_amd: upload failed\n");
+        for (unsigned k = 0; k < 2; ++k) if (used_side >> k & 1) { HIP_TRY(hipEventRecord(c->ev_side[k], c->side[k])); HIP_TRY(hipStreamWaitEvent(st, c->ev_side[k], 0)); }
+        HIP_TRY(hipStreamWaitEvent(st, c->chunk_ev[up.end.size() - 1], 0));      // (later stages read the file too: barcodes, header)
+    }
     HIP_TRY(hipEventRecord(c->ev[1], st));
     mark("launch inflate");
 
@@ -484,7 +615,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         bool lies = size_trouble(0) || size_trouble(kStatusEarly);
         if (!lies && stop < n_members_all) {
             Member ms; uint8_t two[2] = {0, 0};
-            HIP_TRY(hipMemcpy(&ms, d_members + stop, sizeof ms, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&ms, d_members + stop, sizeof ms, from_members));
             if (ms.isize == 0 && ms.clen >= 2) HIP_TRY(hipMemcpy(two, d_bam + ms.cpos, 2, hipMemcpyDeviceToHost));
             // fine: an empty block (03 00, the EOF marker) or a member cut off by the end of the file
             lies = !(ms.isize == 0 && two[0] == 3 && two[1] == 0) && ms.isize != 0xffffffffu;
@@ -514,7 +645,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             const uint8_t *src; uint64_t have;
             uint32_t bad_h = 0xffffffffu;
             std::vector<Member> hmem(n_h);
-            HIP_TRY(hipMemcpyAsync(hmem.data(), d_members, (size_t)n_h * sizeof(Member), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(hmem.data(), d_members, (size_t)n_h * sizeof(Member), from_members, st));
             HIP_TRY(hipStreamSynchronize(st));
             uint32_t used = 0;
             for (; used < n_h; ++used) if (hmem[used].isize == 0 || hmem[used].isize > kBgzfMaxBlock) break;   // the header read stops there
@@ -580,7 +711,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     cfg.region_tid = -2; cfg.long_threshold = 16;
     if (!whole) {
         int32_t tid, beg, end;
-        if (!strcmp(p->region, "*") || !parse_region(hdr, p->region, tid, beg, end) || tid >= bi.n_ref || end < beg)
+        if (!parse_region(hdr, p->region, tid, beg, end) || tid >= bi.n_ref || end < beg)
             return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion);
         cfg.region_tid = tid; cfg.region_beg = beg; cfg.region_end = end;
     }
@@ -599,7 +730,15 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         memset(tab.data(), 0, tab.size() * sizeof(FaContig));
         for (int32_t t = 0; t < n_ref; ++t)
             for (const Fasta::Seq &s : c->fasta->seqs)
-                if (s.name == hdr.names[(size_t)t]) { tab[(size_t)t].offset = s.offset; tab[(size_t)t].len = s.len; tab[(size_t)t].line_blen = s.line_blen; tab[(size_t)t].line_len = s.line_len; tab[(size_t)t].present = 1; }
+                if (s.name == hdr.names[(size_t)t]) {
+                    // the kernels index fa[offset + p / line_blen * line_len + p % line_blen] without a bounds check: a descriptor that does
+                    // not fit the file (stale or damaged .fai) makes the contig absent -- a junction there then fails the call like a contig
+                    // the FASTA does not have (junctions_extractor.cc:553), instead of reading HBM out of bounds
+                    const bool sane = s.offset >= 0 && s.len >= 0 && s.line_blen > 0 && s.line_len >= s.line_blen &&
+                                      (s.len == 0 || (uint64_t)s.offset + (uint64_t)((s.len - 1) / s.line_blen) * (uint64_t)s.line_len + (uint64_t)((s.len - 1) % s.line_blen) < (uint64_t)c->fasta->size);
+                    if (!sane) continue;
+                    tab[(size_t)t].offset = s.offset; tab[(size_t)t].len = s.len; tab[(size_t)t].line_blen = s.line_blen; tab[(size_t)t].line_len = s.line_len; tab[(size_t)t].present = 1;
+                }
         DevBuf &bt = c->buf("fasta_tab");
         HIP_TRY(bt.ensure(tab.size() * sizeof(FaContig) + 64));
         HIP_TRY(hipMemcpy(bt.p, tab.data(), tab.size() * sizeof(FaContig), hipMemcpyHostToDevice));
@@ -837,18 +976,21 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
         HIP_TRY(b_out.ensure(U * 40 + 256));
         launch_rows_out(u, final_perm, n_unique, b_out.as<uint32_t>(), st);
         if (sink) {
-            rgx_junction_table *t = table_alloc(*sink->hdr, U, /*zero=*/false, /*pinned=*/true);
             DevBuf &b_tab = c->buf("table_dev");
             const size_t bytes = table_block_bytes(U);
             HIP_TRY(b_tab.ensure(bytes + 256));
             launch_rows_table(u, final_perm, n_unique, sink->min_anchor, b_tab.as<uint8_t>(), st);
-            HIP_TRY(hipMemcpyAsync(((TableBox *)t)->block, b_tab.p, bytes, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            rgx_junction_table *t = table_alloc(*sink->hdr, U, /*zero=*/false, /*pinned=*/true);
+            if (!t) { (void)hipStreamSynchronize(st); return fail(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no memory for the result table\n"); }
+            hipError_t e_ = hipMemcpyAsync(((TableBox *)t)->block, b_tab.p, bytes, hipMemcpyDeviceToHost, st);
+            if (e_ == hipSuccess) e_ = hipStreamSynchronize(st);
+            if (e_ != hipSuccess) { rgx_table_free(t); return fail(err, errlen, RGX_ERR_DEVICE, "HIP error %s copying the result table\n", hipGetErrorString(e_)); }
             sink->table = t; R.n = U;
             return RGX_OK;
         }
         if (U * 40 > c->pinned_rows_cap) {
             if (c->pinned_rows) (void)hipHostFree(c->pinned_rows);
+    if (c->pinned_members) (void)hipHostFree(c->pinned_members);
             c->pinned_rows = nullptr; c->pinned_rows_cap = 0;
             const size_t want = U * 40 + U * 5 + 4096;
             HIP_TRY(hipHostMalloc(&c->pinned_rows, want, hipHostMallocDefault));
@@ -1010,6 +1152,7 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     c->last_rows = R.n; c->last_records = P.n_iterated; c->last_events = P.n_events; c->last_bytes = P.total; c->last_rows_valid = true;
     HIP_TRY(hipEventRecord(c->ev[6], st));
     rgx_junction_table *t = sink.table ? sink.table : table_alloc(P.hdr, 0);
+    if (!t) return fail(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no memory for the result table\n");
     if (R.n >= 100000000u) host_sort_rows(t);   // names wider than 8 digits compare as strings upstream
     if (p->barcodes) {
         if (R.n >= 100000000u) { rgx_table_free(t); return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: -b with 10^8 or more junctions is not supported\n"); }
@@ -1041,6 +1184,12 @@ extern "C" int rgx_extract_mem(rgx_ctx *ctx, const void *bam, size_t bam_len, co
     if (!ctx || !bam || !out) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
     return run_pipeline(ctx, nullptr, (const uint8_t *)bam, bam_len, (const uint8_t *)bai, bai_len, p, out, err, errlen);
 }
+
+extern "C" void *rgx_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+extern "C" void rgx_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 extern "C" int rgx_extract(rgx_ctx *ctx, const char *bam_path, const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen) {
     if (!ctx || !bam_path || !out) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
@@ -1084,6 +1233,7 @@ extern "C" int rgx_table_unpack(const void *src, size_t n_rows, const rgx_juncti
     BamHeader h;
     for (int32_t i = 0; i < names_from->n_ref; ++i) { h.names.push_back(names_from->ref_name[i]); h.lens.push_back(names_from->ref_len[i]); }
     rgx_junction_table *t = table_alloc(h, n_rows);
+    if (!t) return RGX_ERR_ARG;
     const uint8_t *q = (const uint8_t *)src;
     for (size_t i = 0; i < n_rows; ++i, q += RGX_PACKED_ROW_BYTES) {
         uint32_t w[12]; memcpy(w, q, sizeof w);
@@ -1133,6 +1283,7 @@ extern "C" int rgx_table_merge(const rgx_junction_table *const *parts, int n_par
     BamHeader h;
     for (int32_t i = 0; i < parts[0]->n_ref; ++i) { h.names.push_back(parts[0]->ref_name[i]); h.lens.push_back(parts[0]->ref_len[i]); }
     rgx_junction_table *t = table_alloc(h, uq.size());
+    if (!t) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: no memory for the result table\n");
     for (size_t k = 0; k < by_first.size(); ++k) {
         const Row &r = uq[by_first[k]];
         const size_t i = by_first[k];
@@ -1184,7 +1335,7 @@ extern "C" int rgx_table_merge_device(rgx_ctx *c, const void *d_rows, uint64_t s
     BamHeader h;
     for (int32_t i = 0; i < names_from->n_ref; ++i) { h.names.push_back(names_from->ref_name[i]); h.lens.push_back(names_from->ref_len[i]); }
     const uint32_t N = (uint32_t)total;
-    if (!N) { *out = table_alloc(h, 0); return RGX_OK; }
+    if (!N) { *out = table_alloc(h, 0); return *out ? RGX_OK : RGX_ERR_DEVICE; }
     std::vector<uint32_t> rank_of_tid;
     chrom_string_ranks(h, rank_of_tid);
     uint32_t rk = 0; for (uint32_t r : rank_of_tid) rk = std::max(rk, r);
@@ -1245,11 +1396,15 @@ extern "C" int rgx_table_merge_device(rgx_ctx *c, const void *d_rows, uint64_t s
     sort_word(u.te, 32, U, uperm, upc);
     sort_word(u.ts, 32, U, uperm, upc);
     sort_word(crank, std::max<uint32_t>(1, bitlen(rk)), U, uperm, upc);
-    rgx_junction_table *t = table_alloc(h, U, /*zero=*/false, /*pinned=*/true);
     launch_merge_table(u, uperm[upc], name_rank, U, min_anchor, (uint8_t *)packed, st);      // the packed area doubles as the table's device image
     mark("reduce + name + order");
-    HIP_TRY(hipMemcpyAsync(((TableBox *)t)->block, packed, table_block_bytes(U), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    rgx_junction_table *t = table_alloc(h, U, /*zero=*/false, /*pinned=*/true);
+    if (!t) { (void)hipStreamSynchronize(st); return fail(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no memory for the result table\n"); }
+    {
+        hipError_t e_ = hipMemcpyAsync(((TableBox *)t)->block, packed, table_block_bytes(U), hipMemcpyDeviceToHost, st);
+        if (e_ == hipSuccess) e_ = hipStreamSynchronize(st);
+        if (e_ != hipSuccess) { rgx_table_free(t); return fail(err, errlen, RGX_ERR_DEVICE, "HIP error %s copying the merged table\n", hipGetErrorString(e_)); }
+    }
     mark("rows to host table");
     *out = t;
     return RGX_OK;

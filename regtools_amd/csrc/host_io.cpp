@@ -1,5 +1,7 @@
 // host_io.cpp -- see host_io.h.
 #include "host_io.h"
+
+#include <thread>
 #include "inflate_core.h"
 
 #include <fcntl.h>
@@ -35,6 +37,63 @@ void walk_members(const uint8_t *bam, size_t len, std::vector<HostMember> &out) 
     }
 }
 
+static inline bool host_magic_at(const uint8_t *h) {
+    return h[0] == 31 && h[1] == 139 && h[2] == 8 && (h[3] & 4) && h16(h + 10) == 6 && h[12] == 'B' && h[13] == 'C' && h16(h + 14) == 2;
+}
+
+bool scan_members_parallel(const uint8_t *bam, size_t len, int threads, std::vector<Member> &out, uint64_t &total_inflated) {
+    out.clear(); total_inflated = 0;
+    if (len < 28 || !host_magic_at(bam)) return false;
+    int T = threads < 1 ? 1 : threads;
+    if ((size_t)T > len / (1u << 20) + 1) T = (int)(len / (1u << 20) + 1);          // not worth a thread per few members
+    std::vector<size_t> start((size_t)T + 1, len);
+    start[0] = 0;
+    for (int t = 1; t < T; ++t) {
+        size_t p = std::max(start[(size_t)t - 1] + 1, (size_t)((double)len * t / T));
+        size_t found = len;
+        while (p + 18 <= len) {
+            const uint8_t *q = (const uint8_t *)memchr(bam + p, 31, len - 18 - p + 1);
+            if (!q) break;
+            if (host_magic_at(q)) { found = (size_t)(q - bam); break; }
+            p = (size_t)(q - bam) + 1;
+        }
+        start[(size_t)t] = found;
+    }
+    std::vector<std::vector<Member>> part((size_t)T);
+    std::vector<char> ok((size_t)T, 0);
+    auto walk = [&](int t) {
+        size_t off = start[(size_t)t];
+        const size_t end = start[(size_t)t + 1];
+        std::vector<Member> &v = part[(size_t)t];
+        v.reserve((end - off) / 2048 + 16);
+        while (off < end) {
+            if (len - off < 18 || !host_magic_at(bam + off)) return;
+            const size_t blen = (size_t)h16(bam + off + 16) + 1;
+            if (blen < 26 || off + blen > len) return;
+            Member m; m.cpos = off + 18; m.upos = 0; m.isize = h32(bam + off + blen - 4);
+            if (m.isize > kBgzfMaxBlock) return;
+            m.clen = (uint32_t)(blen - 18);
+            if (m.cpos + m.clen + 8 > len) m.clen = len > m.cpos + 8 ? (uint32_t)(len - 8 - m.cpos) : 0;      // as k_member_compact
+            v.push_back(m);
+            off += blen;
+        }
+        ok[(size_t)t] = off == end;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; ++t) pool.emplace_back(walk, t);
+    walk(0);
+    for (auto &th : pool) th.join();
+    size_t n = 0;
+    for (int t = 0; t < T; ++t) { if (!ok[(size_t)t]) return false; n += part[(size_t)t].size(); }
+    if (n == 0 || n >= 0xfffffff0u) return false;
+    out.reserve(n + 1);
+    uint64_t up = 0;
+    for (int t = 0; t < T; ++t)
+        for (Member m : part[(size_t)t]) { m.upos = up; up += m.isize; out.push_back(m); }
+    total_inflated = up;
+    return true;
+}
+
 bool parse_bai(const uint8_t *d, size_t len, BaiInfo &bi, bool collect_anchors) {
     bi = BaiInfo();
     if (len < 8 || memcmp(d, "BAI\1", 4)) return false;
@@ -50,6 +109,7 @@ bool parse_bai(const uint8_t *d, size_t len, BaiInfo &bi, bool collect_anchors) 
             if (n_chunk < 0 || p + (size_t)n_chunk * 16 > len) return false;
             if (bin == 37450) {                                  // pseudo-bin: chunk 0 = (first offset, last offset)
                 if (n_chunk > 0) { uint64_t u = h64(d + p); bi.have_start = true; if (u < bi.start_voff) bi.start_voff = u; }
+                if (n_chunk > 0 && r == bi.n_ref - 1) { bi.have_nocoor = true; bi.nocoor_voff = h64(d + p + 8); }
             } else if (collect_anchors) {
                 for (int32_t c = 0; c < n_chunk; ++c) bi.anchors.push_back(h64(d + p + (size_t)c * 16));
             }

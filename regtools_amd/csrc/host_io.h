@@ -17,12 +17,21 @@ struct HostMember { uint64_t coff; uint32_t blen; uint32_t isize; };
 // malformed member (the reference would fail to read that block, ending iteration).
 void walk_members(const uint8_t *bam, size_t len, std::vector<HostMember> &out);
 
+// The member list of a WELL-FORMED file, found by several host threads at once (the upload of the file to the device runs meanwhile):
+// thread t starts at the first BGZF header at or after byte t * len / T and walks the BSIZE chain (bgzf.c:525); every walk must end
+// exactly where the next one started and the last one at the end of the file, every member must carry the header of bgzf.c:348-355, a
+// BSIZE of at least 26 and an ISIZE of at most 64 KiB.  Anything else -- false = the caller falls back to the device's member discovery,
+// which knows what the reference does with damaged files.  Members come out as the device kernels build them (k_member_compact).
+bool scan_members_parallel(const uint8_t *bam, size_t len, int threads, std::vector<Member> &out, uint64_t &total_inflated);
+
 // hts.c:1517-1567 (BAI loader), :1092 META_BIN, :1721-1731 HTS_IDX_START
 struct BaiInfo {
     int32_t  n_ref = 0;
     bool     have_start = false;
     uint64_t start_voff = 0;
     uint64_t n_no_coor = 0;
+    bool     have_nocoor = false;    // the LAST reference has the pseudo-bin: region "*" starts at its end offset (hts.c:1733-1741)
+    uint64_t nocoor_voff = 0;
     std::vector<uint64_t> anchors;   // sorted unique virtual offsets that are record starts (linear index + chunk begins)
 };
 bool parse_bai(const uint8_t *bai, size_t len, BaiInfo &out, bool collect_anchors = true);

@@ -92,7 +92,7 @@ struct LdsTab {
 template <bool PROBE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_inflate(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
                                                 uint32_t n_members, uint8_t *__restrict__ arena, uint64_t upos_bias, uint32_t *len_scratch,
-                                                uint32_t *status, uint32_t ignore_below) {
+                                                uint32_t *status, uint32_t ignore_below, uint32_t index_bias) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t m = blockIdx.x * 64 + threadIdx.x;
     if (m >= n_members) return;
@@ -116,9 +116,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (st != INF_OK) {
         // members in front of a seek target are inflated for the header only: their failures do not end the record stream and are
         // reported apart (the header read and the footer check still want to know)
-        uint32_t *slot = m >= ignore_below ? status : status + kStatusEarly;
-        uint32_t prev = atomicMin(&slot[0], m);
-        if (m < prev) slot[1] = (uint32_t)st;     // best effort: status of (one of) the earliest bad members
+        const uint32_t mi = m + index_bias;       // (index in the caller's member range: a range may be launched in several pieces)
+        uint32_t *slot = mi >= ignore_below ? status : status + kStatusEarly;
+        uint32_t prev = atomicMin(&slot[0], mi);
+        if (mi < prev) slot[1] = (uint32_t)st;    // best effort: status of (one of) the earliest bad members
     }
 }
 
@@ -206,7 +207,7 @@ struct WaveCoop {
 template <bool PROBE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_inflate_ring(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
                                                 uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
-                                                uint32_t *status, uint32_t ignore_below) {
+                                                uint32_t *status, uint32_t ignore_below, uint32_t index_bias) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
     const uint32_t m = blockIdx.x * 64 + lane;
@@ -230,9 +231,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (!run) st = mb.isize == 0xffffffffu ? INF_IN_OVERRUN : INF_OUT_OVERFLOW;
     else if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
     if (st != INF_OK) {
-        uint32_t *slot = m >= ignore_below ? status : status + kStatusEarly;
-        uint32_t prev = atomicMin(&slot[0], m);
-        if (m < prev) slot[1] = (uint32_t)st;
+        const uint32_t mi = m + index_bias;
+        uint32_t *slot = mi >= ignore_below ? status : status + kStatusEarly;
+        uint32_t prev = atomicMin(&slot[0], mi);
+        if (mi < prev) slot[1] = (uint32_t)st;
     }
 }
 
@@ -255,19 +257,19 @@ static void inflate_attrs() {
     done = true;
 }
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
-                    uint32_t *status, hipStream_t stream, uint32_t ignore_below) {
+                    uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias) {
     if (!n_members) return;
     inflate_attrs();
     uint32_t blocks = (n_members + 63) / 64;
-    if (!inflate_ring_selected()) { hipLaunchKernelGGL(k_inflate<false>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below); return; }
-    hipLaunchKernelGGL(k_inflate_ring<false>, dim3(blocks), dim3(64), kRingLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below);
+    if (!inflate_ring_selected()) { hipLaunchKernelGGL(k_inflate<false>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias); return; }
+    hipLaunchKernelGGL(k_inflate_ring<false>, dim3(blocks), dim3(64), kRingLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias);
 }
 void launch_inflate_probe(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *slots, uint32_t *len_scratch, uint32_t *sizes,
                           hipStream_t stream) {
     if (!n_members) return;
     inflate_attrs();
-    if (!inflate_ring_selected()) { hipLaunchKernelGGL(k_inflate<true>, dim3((n_members + 63) / 64), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u); return; }
-    hipLaunchKernelGGL(k_inflate_ring<true>, dim3((n_members + 63) / 64), dim3(64), kRingLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u);
+    if (!inflate_ring_selected()) { hipLaunchKernelGGL(k_inflate<true>, dim3((n_members + 63) / 64), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u); return; }
+    hipLaunchKernelGGL(k_inflate_ring<true>, dim3((n_members + 63) / 64), dim3(64), kRingLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u);
 }
 
 // =====================================================================================================

@@ -32,6 +32,13 @@ class Junction(object):
             (self.thick_end - self.end) & 0xffffffff, (self.end - self.thick_start) & 0xffffffff)
 
 
+def _atoi(s):
+    """atoi as junctions_extractor.cc:62-70 uses it: leading white space, an optional sign, the digits that follow; anything else is 0."""
+    import re
+    m = re.match(r"\s*([+-]?\d+)", s)
+    return int(m.group(1)) if m else 0
+
+
 class Context(object):
     """One HIP device context (stream + reusable HBM workspace)."""
 
@@ -47,6 +54,30 @@ class Context(object):
         if self._h:
             self._lib.rgx_ctx_destroy(self._h)
             self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PinnedBuffer(object):
+    """File bytes in page-locked host memory (rgx_host_alloc): the input form under which rgx_extract_mem's chunked upload overlaps the
+    inflate of the chunks that have already arrived."""
+
+    def __init__(self, data):
+        self._lib = _ffi.lib()
+        self.size = len(data)
+        self.ptr = self._lib.rgx_host_alloc(self.size + 64)
+        if not self.ptr:
+            raise RegtoolsError(1, "regtools_amd: no page-locked memory for %d bytes\n" % self.size)
+        C.memmove(self.ptr, data if isinstance(data, bytes) else bytes(data), self.size)
+
+    def close(self):
+        if self.ptr:
+            self._lib.rgx_host_free(self.ptr)
+            self.ptr = None
 
     def __del__(self):
         try:
@@ -81,9 +112,9 @@ class JunctionsExtractor(object):
         for k, v in opts:
             if k == "-h":
                 raise RegtoolsError(0, "help")
-            elif k == "-a": self.min_anchor_length_ = int(v)
-            elif k == "-m": self.min_intron_length_ = int(v)
-            elif k == "-M": self.max_intron_length_ = int(v)
+            elif k == "-a": self.min_anchor_length_ = _atoi(v)
+            elif k == "-m": self.min_intron_length_ = _atoi(v)
+            elif k == "-M": self.max_intron_length_ = _atoi(v)
             elif k == "-o": self.output_file_ = v
             elif k == "-r": self.region_ = v
             elif k == "-t": self.strand_tag_ = v
@@ -122,14 +153,18 @@ class JunctionsExtractor(object):
         return p
 
     # -- identify_junctions_from_BAM (junctions_extractor.cc:500-535) -------------------------------------------------
-    def identify_junctions_from_BAM(self, bam_bytes=None, bai_bytes=None, device_ptr=None, device_len=0):
+    def identify_junctions_from_BAM(self, bam_bytes=None, bai_bytes=None, device_ptr=None, device_len=0, host_ptr=None, host_len=0):
+        """bam_bytes: the file as a bytes object; host_ptr/host_len: the file at a host address (page-locked memory from
+        regtools_amd.PinnedBuffer lets the upload overlap the inflate, rgx_extract_mem); device_ptr/device_len: the file already in HBM."""
         lib = _ffi.lib()
         if self._ctx is None:
             self._ctx = Context(self._device)
         p = self._params()
         tab = C.POINTER(_ffi.JunctionTable)()
         err = C.create_string_buffer(512)
-        if bam_bytes is None and device_ptr is None:
+        if host_ptr is not None:
+            rc = lib.rgx_extract_mem(self._ctx._h, C.c_void_p(host_ptr), host_len, bai_bytes, len(bai_bytes), C.byref(p), C.byref(tab), err, len(err))
+        elif bam_bytes is None and device_ptr is None:
             rc = lib.rgx_extract(self._ctx._h, self.bam_.encode(), C.byref(p), C.byref(tab), err, len(err))
         elif device_ptr is None:
             rc = lib.rgx_extract_mem(self._ctx._h, bam_bytes, len(bam_bytes), bai_bytes, len(bai_bytes), C.byref(p), C.byref(tab), err, len(err))

@@ -22,6 +22,12 @@ def case_bam(case, tmpdir):
     """Path of the case's BAM: a committed fixture, or a deterministic synthetic file generated on demand."""
     if case["bam"]:
         return os.path.join(GOLD, case["bam"])
+    if case.get("cse"):
+        import cse_synth
+        key = ("cse", case["cse"]["seed"], case["cse"]["n_genes"])
+        if key not in _synth_cache:
+            _synth_cache[key] = cse_synth.build(os.path.join(str(tmpdir), "cse_q%d_%d" % key[1:]), seed=key[1], n_genes=key[2])
+        return _synth_cache[key]["bam"]
     if case.get("framing"):
         import framing_cases
         key = ("framing", case["framing"])
@@ -36,6 +42,15 @@ def case_bam(case, tmpdir):
         synth.write(p, s["n_reads"], shape=s["shape"], seed=s["seed"])
         _synth_cache[key] = p
     return _synth_cache[key]
+
+
+def case_argv(case, tmpdir):
+    """The full argument list of the case: options, the BAM, then whatever follows it (the FASTA of a `cse` quartet)."""
+    bam = case_bam(case, tmpdir)
+    after = []
+    for a in case.get("after", []):
+        after.append(_synth_cache[("cse", case["cse"]["seed"], case["cse"]["n_genes"])]["fasta"] if a == "<fasta>" else a)
+    return list(case["args"]) + [bam] + after
 
 
 def expected(case):

@@ -23,18 +23,24 @@ REF = os.path.join(ROOT, "oracle", "_ref", "regtools_ref")
 cases = []
 
 
-def run_ref(bam, args):
-    r = subprocess.run([REF, "junctions", "extract"] + args + [bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+def run_ref(bam, args, after=()):
+    r = subprocess.run([REF, "junctions", "extract"] + args + [bam] + list(after), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     return r.returncode, r.stdout
 
 
-def add_case(name, args, bam=None, synth_spec=None, tmp_bam=None, framing=None):
+def add_case(name, args, bam=None, synth_spec=None, tmp_bam=None, framing=None, cse=None, after=()):
+    """cse: the BAM (and the FASTA named by the "<fasta>" placeholder in `after`) of a deterministic tests/cse_synth.py quartet."""
     path = tmp_bam if tmp_bam else os.path.join(HERE, bam)
-    rc, out = run_ref(path, args)
+    rc, out = run_ref(path, args, [cse["_fasta"] if a == "<fasta>" else a for a in after])
     exp = "%s.expected" % name
     with open(os.path.join(HERE, "expected", exp), "wb") as f:
         f.write(out)
-    cases.append(dict(name=name, args=args, bam=bam, synth=synth_spec, framing=framing, expected=exp, rc=rc, rows=out.count(b"\n")))
+    c = dict(name=name, args=args, bam=bam, synth=synth_spec, framing=framing, expected=exp, rc=rc, rows=out.count(b"\n"))
+    if cse:
+        c["cse"] = {k: v for k, v in cse.items() if not k.startswith("_")}
+    if after:
+        c["after"] = list(after)
+    cases.append(c)
     print("%-44s rc=%d rows=%d" % (name, rc, out.count(b"\n")))
 
 
@@ -154,6 +160,30 @@ def main():
         add_case("ultralong.XS", ["-s", "XS"], framing="ultralong", tmp_bam=p)
         add_case("ultralong.RF.a0.M100000", ["-s", "RF", "-a", "0", "-M", "100000"], framing="ultralong", tmp_bam=p)
         add_case("ultralong.XS.r_chrL_100000-150000", ["-s", "XS", "-r", "chrL:100000-150000"], framing="ultralong", tmp_bam=p)
+
+    # (viii) region "*" (hts_itr_querys -> HTS_IDX_NOCOOR, hts.c:1903-1904, :1733-1741): the records behind the last reference's reads;
+    #        an index whose last reference has no pseudo-bin and no unplaced count gives no iterator (exit 1)
+    add_case("contigs.XS.r_star", ["-s", "XS", "-r", "*"], bam="contigs.bam")
+    add_case("strand.XS.r_star", ["-s", "XS", "-r", "*"], bam="strand.bam")
+    add_case("hcc1395.XS.r_star", ["-s", "XS", "-r", "*"], bam="test_hcc1395.bam")
+
+    # (ix) a contig name of 1,000 characters (the BAM header puts no limit on l_name; Junction::print writes it through a std::string)
+    long_name = "contig_" + "N" * 993
+    recs = [bamio.record(0, 1000 + 37 * k, "%dM%dN%dM" % (20 + k % 5, 100 + 7 * (k % 3), 25), qname="l%02d" % k, aux=xs_plus) for k in range(12)]
+    bamio.write_bam(os.path.join(HERE, "longname.bam"), [(long_name, 500000), ("short", 1000)], recs)
+    synth.index(os.path.join(HERE, "longname.bam"))
+    add_case("longname.XS", ["-s", "XS"], bam="longname.bam")
+    add_case("longname.XS.a30", ["-s", "XS", "-a", "30"], bam="longname.bam")
+
+    # (x) `junctions extract ... <bam> <fasta>`: the intron-motif strand rule with its carried-over state (junctions_extractor.cc:325-359,
+    #     :564-584), on the deterministic quartets of tests/cse_synth.py (genes on both strands, reads across several junctions)
+    import cse_synth
+    with tempfile.TemporaryDirectory() as td:
+        for seed, n_genes in ((5, 14), (8, 10)):
+            q = cse_synth.build(os.path.join(td, "q%d" % seed), seed=seed, n_genes=n_genes)
+            spec = dict(seed=seed, n_genes=n_genes, _fasta=q["fasta"])
+            for a in (["-s", "intron-motif"], ["-s", "XS"], ["-s", "RF", "-a", "3"], ["-s", "FR", "-m", "200"]):
+                add_case("motif_q%d.%s" % (seed, "_".join(x.strip("-") for x in a)), a, cse=spec, tmp_bam=q["bam"], after=["<fasta>"])
 
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(cases, f, indent=1)

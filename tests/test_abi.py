@@ -107,3 +107,29 @@ def test_pack_unpack_roundtrip_and_merge_semantics(built):
     assert len(m.bed12(only_anchored=True).decode().splitlines()) == 3
     for t in (t0, t1):
         L.rgx_table_free(t)
+
+
+def test_bed12_rows_carry_contig_names_of_any_length(built):
+    """The BAM header puts no limit on l_name; Junction::print (junctions_extractor.h:90-98) writes the name through a std::string.
+    A fixed line buffer here once truncated / over-read rows of contigs with names beyond ~370 characters."""
+    from regtools_amd import _ffi
+    L = _ffi.lib()
+    names = ("c" * 5000, "x" * 511, "y" * 512, "z" * 513)
+    rows = [(k, 100 + k, 300 + k, 90, 330 + k, 2 + k, k, k, "+-?."[k]) for k in range(4)]
+    t = _table_from_rows(rows, names=names)
+    n = L.rgx_table_format_bed12(t, 0, None, 0)
+    buf = C.create_string_buffer(n + 1)
+    assert L.rgx_table_format_bed12(t, 0, buf, n) == n
+    # _table_from_rows leaves name_index 0 and the anchor flags unset: the row text is what this checks
+    exp = "".join("%s\t90\t%d\tJUNC00000000\t%d\t%s\t90\t%d\t255,0,0\t2\t%d,30\t0,%d\n" % (names[k], 330 + k, 2 + k, "+-?."[k], 330 + k, 10 + k, 210 + k) for k in range(4))
+    got = buf.raw[:n].decode()
+    assert sorted(got.splitlines()) == sorted(exp.splitlines())
+    L.rgx_table_free(t)
+
+
+def test_python_mirror_reads_numbers_like_atoi(built):
+    """junctions_extractor.cc:62-70 reads -a / -m / -M with atoi: "12x" is 12, "foo" is 0, never an exception."""
+    import regtools_amd
+    je = regtools_amd.JunctionsExtractor()
+    je.parse_options(["-a", "12x", "-m", "foo", "-M", " 77", "-s", "XS", "in.bam"])
+    assert (je.min_anchor_length_, je.min_intron_length_, je.max_intron_length_) == (12, 0, 77)

@@ -21,12 +21,12 @@ def synth_dir(tmp_path_factory):
     return tmp_path_factory.mktemp("synth")
 
 
-def gpu_extract(ctx, bam, args, **kw):
-    """(rc, bed12 bytes) the way `regtools junctions extract <args> bam` would produce them."""
+def gpu_extract(ctx, bam, args, after=(), **kw):
+    """(rc, bed12 bytes) the way `regtools junctions extract <args> bam [after]` would produce them."""
     import regtools_amd
     je = regtools_amd.JunctionsExtractor(ctx=ctx, **kw)
     try:
-        je.parse_options(list(args) + [bam])
+        je.parse_options(list(args) + [bam] + list(after))
         je.identify_junctions_from_BAM()
     except regtools_amd.RegtoolsError as e:
         return (0 if e.code == 0 else 1), b"", je
@@ -42,7 +42,8 @@ def test_reference_integration_goldens(gpu_ctx, args, golden):
 
 @pytest.mark.parametrize("case", cases.MANIFEST, ids=[c["name"] for c in cases.MANIFEST])
 def test_equals_reference_outputs(gpu_ctx, case, synth_dir):
-    rc, out, _ = gpu_extract(gpu_ctx, cases.case_bam(case, synth_dir), case["args"])
+    argv = cases.case_argv(case, synth_dir)
+    rc, out, _ = gpu_extract(gpu_ctx, argv[len(case["args"])], case["args"], after=argv[len(case["args"]) + 1:])
     assert rc == case["rc"]
     assert out == cases.expected(case)
 
@@ -174,7 +175,7 @@ def test_inflate_kernel_against_zlib(gpu_ctx):
     assert bytes(d_arena[:upos].cpu().numpy().tobytes()) == b"".join(expect)
 
 
-def test_full_size_properties(gpu_ctx, synth_dir):
+def test_multi_million_read_properties(gpu_ctx, synth_dir):
     """Size-independent properties at a multi-million-read scale (the 50M-read identity check lives in bench.py)."""
     from regtools_amd import synth
     n = 5_000_000
@@ -401,3 +402,40 @@ def test_region_queries_read_only_the_members_the_index_names(gpu_ctx, synth_dir
         je = regtools_amd.JunctionsExtractor(strandness=0, region=reg, ctx=gpu_ctx)
         je.identify_junctions_from_BAM(bai_bytes=bai, device_ptr=d.data_ptr(), device_len=len(raw))
         assert je.bed12() == exp
+
+
+def test_host_bytes_overlapped_upload_equals_device_resident_path(gpu_ctx):
+    """rgx_extract_mem on a file large enough for the chunked upload (SURVEY 8d's timed region: host bytes -> table): members found by the
+    host scan, one inflate launch per upload chunk on the side streams.  Same bytes as with the file resident in HBM (device member
+    discovery, one launch), from page-locked and from pageable memory, whole file / region / shards; a file the host scan does not vouch
+    for (cut inside a member) takes the device discovery after the upload and still equals the device-resident run."""
+    import torch
+    import regtools_amd
+    from regtools_amd import synth, distributed
+    bam, bai, st = synth.generate(3_000_000, shape="short", seed=11)
+    assert len(bam) > (24 << 20)                                                    # at least two upload chunks
+    d = torch.zeros(len(bam) + 64, dtype=torch.uint8, device="cuda"); d[:len(bam)].copy_(torch.frombuffer(bytearray(bam), dtype=torch.uint8)); torch.cuda.synchronize()
+    pin = regtools_amd.PinnedBuffer(bam)
+
+    def run(how, n=len(bam), **kw):
+        je = regtools_amd.JunctionsExtractor(strandness=0, ctx=gpu_ctx, **kw)
+        if how == "device": je.identify_junctions_from_BAM(bai_bytes=bai, device_ptr=d.data_ptr(), device_len=n)
+        elif how == "pinned": je.identify_junctions_from_BAM(bai_bytes=bai, host_ptr=pin.ptr, host_len=n)
+        else: je.identify_junctions_from_BAM(bam_bytes=bam[:n], bai_bytes=bai)
+        return je
+    ref = run("device")
+    assert ref.stats["n_records"] == 3_000_000 and ref.stats["n_events"] == st["n_spliced"]
+    for how in ("pinned", "pageable", "pinned"):
+        je = run(how)
+        assert je.bed12() == ref.bed12() and je.stats["n_records"] == 3_000_000 and je.stats["inflated_bytes"] == ref.stats["inflated_bytes"], how
+    for reg in ("chr2", "chr1:1000000-90000000", "chrX:1-500"):
+        assert run("pinned", region=reg).bed12() == run("device", region=reg).bed12(), reg
+    parts, keep = [], []
+    for g in range(3):
+        je = run("pinned", shard=g, n_shards=3)
+        keep.append(je); parts.append(distributed.pack_table(je.table))
+    assert distributed.merge_packed(parts, keep[0].table, 8).bed12() == ref.bed12()
+    cut = len(bam) - 70000                                                          # inside a member: the record stream ends early (bgzf.c:421-546)
+    a, b = run("device", n=cut), run("pinned", n=cut)
+    assert a.bed12() == b.bed12() and a.stats["n_records"] == b.stats["n_records"] < 3_000_000
+    pin.close()

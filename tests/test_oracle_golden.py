@@ -26,7 +26,7 @@ def test_reference_integration_goldens(args, golden):
 
 @pytest.mark.parametrize("case", cases.MANIFEST, ids=[c["name"] for c in cases.MANIFEST])
 def test_oracle_equals_reference_outputs(case, synth_dir):
-    rc, out, _ = run_oracle(case["args"] + [cases.case_bam(case, synth_dir)])
+    rc, out, _ = run_oracle(cases.case_argv(case, synth_dir))
     assert rc == case["rc"]
     assert out == cases.expected(case)
 
