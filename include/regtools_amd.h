@@ -124,6 +124,18 @@ int  rgx_extract_device(rgx_ctx *ctx, const void *d_bam, size_t bam_len,
                         const void *bai, size_t bai_len, const rgx_extract_params *p,
                         rgx_junction_table **out, char *err, size_t errlen);
 
+/* The same over several GPUs of one node from ONE host process: shard g of n_devices -- a contiguous BGZF member range
+ * cut at record starts the index lists -- runs the whole pipeline on devices[g] from its own host thread; the shards' unique rows
+ * (48 bytes each, still in HBM) are exchanged with one ncclAllGather (RCCL over xGMI; librccl.so.1 is loaded at run time) and merged on
+ * devices[0] (rgx_table_merge_device).  Shard order is file order: the table is the single-GPU table whatever n_devices is.  A device
+ * may be listed more than once: those shards take turns on it and the exchange is a device copy (how a one-GPU box tests this path).
+ * Replaces the call junctions_extract() makes into JunctionsExtractor (junctions_main.cc:45-59) on a multi-GPU node.  -b is refused for
+ * n_devices > 1 (a junction's barcodes would have to travel in first-seen order). */
+int  rgx_extract_multi(const int *devices, int n_devices, const char *bam_path, const rgx_extract_params *p,
+                       rgx_junction_table **out, char *err, size_t errlen);
+int  rgx_extract_multi_mem(const int *devices, int n_devices, const void *bam, size_t bam_len, const void *bai, size_t bai_len,
+                           const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen);
+
 void rgx_table_free(rgx_junction_table *t);
 
 /* Merge per-shard tables (shard order = file order) into the final table: sum counts, min/max thick

@@ -1,0 +1,204 @@
+// multi.cpp -- `junctions extract` over several GPUs of one node from ONE host process (BASELINE.json north_star:
+// "BAMs shard by BGZF block / coordinate window across the GPUs of one node with a final RCCL reduce of per-junction counts").
+//
+// Replaces, for a multi-GPU node, the single call junctions_extract() makes into JunctionsExtractor::identify_junctions_from_BAM
+// (/root/reference/src/junctions/junctions_main.cc:45-59).  One host thread, one context and one stream per device:
+//   thread g:  shard g of n (contiguous BGZF member range cut at record starts the index lists, api.cpp prepare_events) ->
+//              the whole single-GPU pipeline on device g -> its unique rows packed in HBM (48 bytes per row)
+//   exchange:  ONE ncclAllGather of the padded row blocks over xGMI (RCCL, loaded at run time: librccl.so.1 is the only thing this
+//              library needs from it, and a process that also runs PyTorch must not end up with two RCCL copies bound at link time)
+//   merge:     on the first device, rgx_table_merge_device: radix sort by key, sum / min / max, first-seen naming by (shard, rank),
+//              strand of the last shard that saw the key, output order.  Shard order = file order, so the table is the single-GPU table.
+// The same device may be listed more than once (the shards then run one after the other on it and the exchange is a device copy): that
+// is how a one-GPU box exercises every line here except the collective itself.
+#include "../../include/regtools_amd.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <set>
+#include <thread>
+#include <vector>
+
+#include "host_io.h"
+
+using namespace rgx;
+
+namespace {
+
+int failm(char *err, size_t errlen, int code, const char *fmt, ...) {
+    if (err && errlen) { va_list ap; va_start(ap, fmt); vsnprintf(err, errlen, fmt, ap); va_end(ap); }
+    return code;
+}
+
+// ---- RCCL, bound at run time ------------------------------------------------------------------------------------------------------
+// (rccl.h: ncclResult_t is an int with ncclSuccess == 0; ncclComm_t an opaque pointer; ncclUint8 == 1 in ncclDataType_t)
+typedef void *nccl_comm;
+struct Rccl {
+    void *so = nullptr;
+    int (*CommInitAll)(nccl_comm *, int, const int *) = nullptr;
+    int (*CommDestroy)(nccl_comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, nccl_comm, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool load(char *err, size_t errlen) {
+        if (so) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so"}) { so = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (so) break; }
+        if (!so) { failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: cannot load RCCL (librccl.so.1): %s\n", dlerror()); return false; }
+        CommInitAll = (decltype(CommInitAll))dlsym(so, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(so, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(so, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(so, "ncclGroupEnd");
+        AllGather = (decltype(AllGather))dlsym(so, "ncclAllGather");
+        GetErrorString = (decltype(GetErrorString))dlsym(so, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !AllGather) {
+            failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: librccl.so.1 lacks a symbol this path needs\n");
+            return false;
+        }
+        return true;
+    }
+};
+Rccl g_rccl;
+const int kNcclUint8 = 1;
+
+struct Shard {
+    int device = 0;
+    rgx_ctx *ctx = nullptr;
+    rgx_junction_table *table = nullptr;
+    void *d_send = nullptr, *d_recv = nullptr;
+    hipStream_t stream = nullptr;
+    nccl_comm comm = nullptr;
+    int rc = RGX_OK;
+    char err[512] = {0};
+};
+
+void release(std::vector<Shard> &S) {
+    for (Shard &s : S) {
+        (void)hipSetDevice(s.device);
+        if (s.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s.comm);
+        if (s.d_send) (void)hipFree(s.d_send);
+        if (s.d_recv) (void)hipFree(s.d_recv);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        if (s.table) rgx_table_free(s.table);
+        if (s.ctx) rgx_ctx_destroy(s.ctx);
+    }
+}
+
+}  // namespace
+
+extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const void *bam, size_t bam_len, const void *bai, size_t bai_len,
+                                     const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen) {
+    if (!devices || n_devices <= 0 || n_devices > 255 || !bam || !out || !p) return failm(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
+    if (p->n_shards > 1) return failm(err, errlen, RGX_ERR_ARG, "regtools_amd: rgx_extract_multi shards the file itself\n");
+    if (p->barcodes && n_devices > 1) return failm(err, errlen, RGX_ERR_ARG, "regtools_amd: barcode counts (-b) need the whole file in one shard\n");
+    *out = nullptr;
+    const int n = n_devices;
+    std::vector<Shard> S((size_t)n);
+    struct Guard { std::vector<Shard> &s; ~Guard() { release(s); } } guard{S};
+    const bool distinct = std::set<int>(devices, devices + n).size() == (size_t)n;
+    for (int g = 0; g < n; ++g) S[(size_t)g].device = devices[g];
+
+    // -- one extraction per shard: a thread per device (shards that share a device take turns on it) -------------------------------------
+    auto extract = [&](int g) {
+        Shard &s = S[(size_t)g];
+        s.rc = rgx_ctx_create(s.device, &s.ctx, s.err, sizeof s.err);
+        if (s.rc != RGX_OK) return;
+        rgx_extract_params q = *p;
+        q.shard = g; q.n_shards = n;
+        s.rc = rgx_extract_mem(s.ctx, bam, bam_len, bai, bai_len, &q, &s.table, s.err, sizeof s.err);
+    };
+    if (distinct) {
+        std::vector<std::thread> pool;
+        for (int g = 1; g < n; ++g) pool.emplace_back(extract, g);
+        extract(0);
+        for (auto &t : pool) t.join();
+    } else for (int g = 0; g < n; ++g) extract(g);
+    for (int g = 0; g < n; ++g) if (S[(size_t)g].rc != RGX_OK) return failm(err, errlen, S[(size_t)g].rc, "%s", S[(size_t)g].err);
+    // (REGTOOLS_AMD_RCCL_SELFTEST: a one-device list goes through pack, ncclCommInitAll / ncclAllGather of one rank and the device merge
+    // as well -- the collective's call sequence on the real library where only one GPU is visible)
+    const bool selftest = getenv("REGTOOLS_AMD_RCCL_SELFTEST") != nullptr;
+    if (n == 1 && !selftest) { *out = S[0].table; S[0].table = nullptr; return RGX_OK; }
+
+    // -- pack: every shard's rows, still in HBM on its device, into a block of `stride` rows ----------------------------------------------
+    uint64_t stride = 1;
+    std::vector<uint64_t> part_rows((size_t)n);
+    for (int g = 0; g < n; ++g) { part_rows[(size_t)g] = S[(size_t)g].table->n; stride = std::max<uint64_t>(stride, S[(size_t)g].table->n); }
+    const size_t block = (size_t)stride * RGX_PACKED_ROW_BYTES;
+    for (int g = 0; g < n; ++g) {
+        Shard &s = S[(size_t)g];
+        if (hipSetDevice(s.device) != hipSuccess || hipMalloc(&s.d_send, block) != hipSuccess || hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess)
+            return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no memory for the row exchange on device %d\n", s.device);
+        if ((distinct || g == 0) && hipMalloc(&s.d_recv, block * (size_t)n) != hipSuccess)
+            return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no memory for the row exchange on device %d\n", s.device);
+        if (s.table->n) {
+            // the rows of a context's LAST extraction are still on its device; with several shards on one device only the last one's are,
+            // the others go up from the host table
+            if (rgx_last_table_pack_device(s.ctx, s.table, s.d_send, stride, s.err, sizeof s.err) != RGX_OK) {
+                std::vector<uint8_t> h((size_t)s.table->n * RGX_PACKED_ROW_BYTES);
+                rgx_table_pack(s.table, h.data(), h.size());
+                if (hipMemcpy(s.d_send, h.data(), h.size(), hipMemcpyHostToDevice) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: row upload failed\n");
+            }
+        }
+    }
+
+    // -- the one collective of the job --------------------------------------------------------------------------------------------------
+    if (distinct) {
+        if (!g_rccl.load(err, errlen)) return RGX_ERR_DEVICE;
+        std::vector<nccl_comm> comms((size_t)n, nullptr);
+        int r = g_rccl.CommInitAll(comms.data(), n, devices);
+        if (r != 0) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: ncclCommInitAll failed: %s\n", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+        for (int g = 0; g < n; ++g) S[(size_t)g].comm = comms[(size_t)g];
+        r = g_rccl.GroupStart();
+        for (int g = 0; g < n && r == 0; ++g) {
+            Shard &s = S[(size_t)g];
+            if (hipSetDevice(s.device) != hipSuccess) { r = -1; break; }
+            r = g_rccl.AllGather(s.d_send, s.d_recv, block, kNcclUint8, s.comm, s.stream);
+        }
+        const int r2 = g_rccl.GroupEnd();
+        if (r != 0 || r2 != 0) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: ncclAllGather failed: %s\n", g_rccl.GetErrorString ? g_rccl.GetErrorString(r ? r : r2) : "?");
+        for (int g = 0; g < n; ++g) {
+            if (hipSetDevice(S[(size_t)g].device) != hipSuccess || hipStreamSynchronize(S[(size_t)g].stream) != hipSuccess)
+                return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: the row exchange did not complete on device %d\n", S[(size_t)g].device);
+        }
+    } else {
+        if (hipSetDevice(S[0].device) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: device %d\n", S[0].device);
+        for (int g = 0; g < n; ++g)
+            if (hipMemcpyPeer((uint8_t *)S[0].d_recv + (size_t)g * block, S[0].device, S[(size_t)g].d_send, S[(size_t)g].device, block) != hipSuccess)
+                return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: row copy from device %d failed\n", S[(size_t)g].device);
+    }
+
+    // -- merge on the first device.  A shard whose record stream ENDED (a member that does not inflate, an unreadable record) hides the
+    //    shards behind it: a sequential reader never gets there (api.cpp, rgx_table_merge) ---------------------------------------------------
+    std::vector<uint64_t> merge_rows = part_rows;
+    for (int g = 0; g < n; ++g) if (S[(size_t)g].table->stream_ended) { for (int k = g + 1; k < n; ++k) merge_rows[(size_t)k] = 0; break; }
+    rgx_junction_table *m = nullptr;
+    int rc = rgx_table_merge_device(S[0].ctx, S[0].d_recv, stride, merge_rows.data(), n, p->min_anchor, S[0].table, &m, err, errlen);
+    if (rc != RGX_OK) return rc;
+    for (int g = 0; g < n; ++g) {
+        const rgx_junction_table *t = S[(size_t)g].table;
+        m->n_records += t->n_records; m->n_events += t->n_events; m->inflated_bytes += t->inflated_bytes; m->n_members += t->n_members;
+        m->ms_inflate = std::max(m->ms_inflate, t->ms_inflate); m->ms_records = std::max(m->ms_records, t->ms_records);
+        m->ms_scan = std::max(m->ms_scan, t->ms_scan); m->ms_reduce = std::max(m->ms_reduce, t->ms_reduce); m->ms_total = std::max(m->ms_total, t->ms_total);
+        m->framing_sweeps = std::max(m->framing_sweeps, t->framing_sweeps);
+        if (t->stream_ended) { m->stream_ended = 1; break; }
+    }
+    m->compressed_bytes = bam_len;
+    *out = m;
+    return RGX_OK;
+}
+
+extern "C" int rgx_extract_multi(const int *devices, int n_devices, const char *bam_path, const rgx_extract_params *p, rgx_junction_table **out,
+                                 char *err, size_t errlen) {
+    if (!bam_path || !out) return failm(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
+    FileBytes bam; std::vector<uint8_t> bai;
+    if (!bam.open(bam_path)) return failm(err, errlen, RGX_ERR_OPEN, "Unable to open BAM/SAM file.\n\n");
+    std::string idx;
+    if (find_index(bam_path, idx) != 0 || !read_index(idx, bai)) return failm(err, errlen, RGX_ERR_INDEX, "Unable to open BAM/SAM index. Make sure alignments are indexed\n\n");
+    return rgx_extract_multi_mem(devices, n_devices, bam.data(), bam.size(), bai.data(), bai.size(), p, out, err, errlen);
+}

@@ -267,6 +267,25 @@ class JunctionsExtractor(object):
         return self._table
 
 
+def extract_multi(devices, bam=None, bam_bytes=None, bai_bytes=None, **kw):
+    """rgx_extract_multi: `junctions extract` sharded over `devices` (a host thread per device, one RCCL all-gather of the shards' rows,
+    merge on devices[0]).  kw: the JunctionsExtractor constructor's arguments.  Returns a distributed.MergedTable-like object."""
+    from . import distributed
+    lib = _ffi.lib()
+    je = JunctionsExtractor(bam=bam or "NA", **kw)
+    p = je._params()
+    devs = (C.c_int * len(devices))(*devices)
+    tab = C.POINTER(_ffi.JunctionTable)()
+    err = C.create_string_buffer(512)
+    if bam_bytes is not None:
+        rc = lib.rgx_extract_multi_mem(devs, len(devices), bam_bytes, len(bam_bytes), bai_bytes, len(bai_bytes), C.byref(p), C.byref(tab), err, len(err))
+    else:
+        rc = lib.rgx_extract_multi(devs, len(devices), bam.encode(), C.byref(p), C.byref(tab), err, len(err))
+    if rc != 0:
+        raise RegtoolsError(rc, err.value.decode())
+    return distributed.MergedTable(tab)
+
+
 def junctions_extract(argv):
     """junctions_extract() of src/junctions/junctions_main.cc:45-59: returns the process exit code."""
     import sys

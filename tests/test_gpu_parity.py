@@ -439,3 +439,41 @@ def test_host_bytes_overlapped_upload_equals_device_resident_path(gpu_ctx):
     a, b = run("device", n=cut), run("pinned", n=cut)
     assert a.bed12() == b.bed12() and a.stats["n_records"] == b.stats["n_records"] < 3_000_000
     pin.close()
+
+
+def test_multi_device_host_equals_single_gpu(gpu_ctx, synth_dir):
+    """rgx_extract_multi (the C++ host of junctions_main.cc:45-59 on a multi-GPU node): a host thread per device, one RCCL
+    all-gather of the shards' packed rows, device merge.  With N >= 2 visible GPUs the collective runs on all of them; on a one-GPU box
+    the same device is listed several times (the shards take turns, the exchange is a device copy) -- every other line is the same.
+    The bytes must be the single-GPU bytes for any device list."""
+    import torch
+    import regtools_amd
+    from regtools_amd import synth
+    p = os.path.join(str(synth_dir), "multi.bam")
+    synth.write(p, 600000, shape="short", seed=31)
+    _, single, je = gpu_extract(gpu_ctx, p, ["-s", "XS"])
+    n_gpu = torch.cuda.device_count()
+    lists = [[0], [0, 0], [0, 0, 0, 0, 0]]
+    if n_gpu >= 2:
+        lists += [list(range(n_gpu)), list(range(n_gpu - 1, -1, -1))[:2]]
+    for devs in lists:
+        m = regtools_amd.extract_multi(devs, bam=p, strandness=0)
+        assert m.bed12() == single, devs
+        assert m.table.contents.n_records == je.stats["n_records"] and m.table.contents.n_events == je.stats["n_events"], devs
+    for args, kw in ((["-s", "RF", "-a", "20"], dict(strandness=1, min_anchor_length=20)), (["-s", "XS", "-r", "chr3"], dict(strandness=0, region="chr3"))):
+        exp = gpu_extract(gpu_ctx, p, args)[1]
+        assert regtools_amd.extract_multi(lists[-1], bam=p, **kw).bed12() == exp, args
+    os.environ["REGTOOLS_AMD_RCCL_SELFTEST"] = "1"           # one rank through ncclCommInitAll / ncclAllGather (librccl.so.1 loaded at run time) + device merge
+    try:
+        assert regtools_amd.extract_multi([0], bam=p, strandness=0).bed12() == single
+    finally:
+        del os.environ["REGTOOLS_AMD_RCCL_SELFTEST"]
+    raw, bai = open(p, "rb").read(), open(p + ".bai", "rb").read()
+    assert regtools_amd.extract_multi([0, 0, 0], bam_bytes=raw, bai_bytes=bai, strandness=0).bed12() == single
+    # the CLI: REGTOOLS_AMD_DEVICES shards the file, the output file is the same
+    out = os.path.join(str(synth_dir), "multi.bed")
+    env = dict(os.environ, REGTOOLS_AMD_DEVICES=",".join(str(d) for d in lists[-1]))
+    r = subprocess.run([os.path.join(ROOT, "bin", "regtools-amd"), "junctions", "extract", "-s", "XS", "-o", out, p], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and open(out, "rb").read() == single
+    with pytest.raises(regtools_amd.RegtoolsError):
+        regtools_amd.extract_multi([0, 0], bam=p, strandness=0, output_barcodes_file="x.tsv")      # -b needs one shard
