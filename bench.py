@@ -72,6 +72,118 @@ def reference_on_all_cores(ref, bam_path, n_reads):
                 note="one reference process per contig (-r), run %d at a time" % workers)
 
 
+def run_reference(argv, timeout=600):
+    ref = os.path.join(ROOT, "oracle", "_ref", "regtools_ref")
+    if not os.path.exists(ref):
+        return None, None
+    t0 = time.time()
+    try:
+        rc = subprocess.run([ref] + argv, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout).returncode
+    except subprocess.TimeoutExpired:
+        return None, float(timeout)
+    return rc, time.time() - t0
+
+
+def extra_extract(regtools_amd, synth, ctx, label, shape, realistic, n_reads, sample_reads, seed, threads, steps=3):
+    """One more `junctions extract` workload beside the headline: the same timed region (page-locked host bytes -> table), the DEFLATE kernel's
+    roofline on its own algorithmic bytes (C + U of THIS file), and the reference timed on a bounded sample of the same shape
+    (its output compared byte for byte with the GPU's on that sample)."""
+    import torch
+    t_gen = time.time()
+    bam, bai, st = synth.generate(n_reads, shape=shape, seed=seed, threads=threads, realistic=realistic)
+    t_gen = time.time() - t_gen
+    je = regtools_amd.JunctionsExtractor(strandness=0, ctx=ctx)
+    pin = regtools_amd.PinnedBuffer(bam)
+    je.identify_junctions_from_BAM(bai_bytes=bai, host_ptr=pin.ptr, host_len=len(bam))
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(steps):
+        je.identify_junctions_from_BAM(bai_bytes=bai, host_ptr=pin.ptr, host_len=len(bam))
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.time() - t0) / steps
+    n_events = je.stats["n_events"]
+    d_bam = torch.zeros(len(bam) + 64, dtype=torch.uint8, device="cuda")
+    d_bam[: len(bam)].copy_(torch.frombuffer(bytearray(bam), dtype=torch.uint8))
+    torch.cuda.synchronize()
+    k_ms, stage = [], None
+    for _ in range(2):
+        je.identify_junctions_from_BAM(bai_bytes=bai, device_ptr=d_bam.data_ptr(), device_len=len(bam))
+        k_ms.append(je.stats["ms_inflate"])
+        stage = {k: round(je.stats["ms_" + k], 3) for k in ("inflate", "records", "scan", "reduce", "total")}
+    s = je.stats
+    alg = s["compressed_bytes"] + s["inflated_bytes"]
+    out = {"workload": label, "reads": st["n_reads"], "ms": ms, "alignments_per_s": st["n_reads"] / (ms * 1e-3), "junction_events_per_s": n_events / (ms * 1e-3),
+           "ms_device_resident": stage["total"], "stage_ms": stage, "input_generation_s": round(t_gen, 2),
+           "bytes_per_alignment": {"compressed": s["compressed_bytes"] / st["n_reads"], "inflated": s["inflated_bytes"] / st["n_reads"]},
+           "roofline": {"bound": "hbm", "kernel": "rgx::k_inflate<false>", "kernel_ms": min(k_ms), "algorithmic_bytes": alg,
+                        "achieved": alg / (min(k_ms) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (min(k_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    del d_bam, bam
+    pin.close()
+    # the reference on a bounded sample of the same shape (the full file would take it minutes)
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "sample.bam")
+        ss = synth.write(p, sample_reads, shape=shape, seed=seed + 1, threads=threads, realistic=realistic)
+        bed = os.path.join(td, "ref.bed")
+        rc, dt = run_reference(["junctions", "extract", "-s", "XS", "-o", bed, p])
+        if dt is not None:
+            jx = regtools_amd.JunctionsExtractor(bam=p, strandness=0, ctx=ctx)
+            jx.identify_junctions_from_BAM()
+            out["reference"] = {"sample": "%d reads of the same shape (seed %d), reference regtools, 1 thread" % (ss["n_reads"], seed + 1), "seconds": round(dt, 3),
+                                "alignments_per_s": ss["n_reads"] / dt if rc == 0 else None,
+                                "bed12_identical_to_gpu": bool(rc == 0 and open(bed, "rb").read() == jx.bed12())}
+    return out
+
+
+def extra_identify(regtools_amd, synth, ctx, reads, genes, variants, sample, seed, threads):
+    """configs[3]: `cis-splice-effects identify` (50 M-read BAM + 500 k-variant VCF + GENCODE-scale GTF) through rgx_identify; the interval
+    kernels' rooflines on SURVEY 8d's algorithmic bytes (B(variant) = 12 + 8 E_v, B(junction) = 20 + 8 E_j, B(window) = 8 + 16 K_w, summed by
+    the kernels themselves); the reference on a bounded sample quartet, its three output files compared byte for byte."""
+    from regtools_amd.cse import CisSpliceEffectsIdentifier
+
+    def quartet(td, tag, n_reads, n_genes, n_var):
+        pre = os.path.join(td, tag)
+        st = synth.write(pre + ".bam", n_reads, shape="short", seed=seed, n_genes=n_genes, threads=threads)
+        ann = synth.annotation(pre, n_genes, n_var, seed=seed, fasta=True, threads=threads)
+        return pre, st, ann
+
+    def run(pre, ann, tag):
+        ci = CisSpliceEffectsIdentifier(ctx=ctx)
+        ci.parse_options(["-s", "XS", "-o", pre + tag + ".tsv", "-v", pre + tag + ".vcf", "-j", pre + tag + ".bed", ann["vcf"], pre + ".bam", ann["fasta"], ann["gtf"]])
+        t = time.time()
+        ci.identify()
+        return time.time() - t, dict(ci.stats)
+
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        t_gen = time.time()
+        pre, st, ann = quartet(td, "c4", reads, genes, variants)
+        t_gen = time.time() - t_gen
+        runs = [run(pre, ann, ".gpu") for _ in range(3)]
+        wall, S = min(runs, key=lambda r: r[0])
+        b_var = 12 * S["n_variants"] + 8 * S["exon_visits_variants"]
+        b_jun = 20 * S["n_junctions"] + 8 * S["exon_visits_junctions"]
+        b_win = 8 * S["n_windows"] + 16 * S["n_pairs"]
+
+        def roof(b, ms):
+            return {"bound": "hbm", "algorithmic_bytes": b, "kernel_ms": ms, "achieved": (b / (ms * 1e-3) / 1e9) if ms > 0 else None, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": (b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else None}
+        out = {"workload": "configs[3]: cis-splice-effects identify -s XS, %d-read BAM + %d-variant VCF + %d-transcript GTF + FASTA" % (st["n_reads"], variants, genes * 4),
+               "seconds": wall, "all_seconds": [round(r[0], 4) for r in runs], "input_generation_s": round(t_gen, 2),
+               "stage_ms": {k[3:]: round(S[k], 3) for k in ("ms_gtf", "ms_variants", "ms_extract", "ms_join", "ms_annotate", "ms_output", "ms_total")},
+               "counts": {k: S[k] for k in ("n_variants", "n_relevant", "n_windows", "n_pairs", "n_junctions", "n_records", "n_events", "exon_visits_variants", "exon_visits_junctions")},
+               "roofline": {"k_variant_scan": roof(b_var, S["ms_k_variant_scan"]), "k_junction_scan": roof(b_jun, S["ms_k_junction_scan"]),
+                            "k_window_pairs": roof(b_win, S["ms_k_window_pairs"]),
+                            "note": "random gathers over the flat GTF arrays, one lane per variant / junction / window: far below the HBM line by construction (SURVEY 8d)"}}
+        spre, sst, sann = quartet(td, "s4", *sample)
+        run(spre, sann, ".gpu")
+        rc, dt = run_reference(["cis-splice-effects", "identify", "-s", "XS", "-o", spre + ".ref.tsv", "-v", spre + ".ref.vcf", "-j", spre + ".ref.bed",
+                                sann["vcf"], spre + ".bam", sann["fasta"], sann["gtf"]], timeout=300)
+        if dt is not None:
+            same = rc == 0 and all(open(spre + ".gpu." + e, "rb").read() == open(spre + ".ref." + e, "rb").read() for e in ("tsv", "vcf", "bed"))
+            out["reference"] = {"sample": "%d reads, %d genes, %d variants (same generator, seed %d), reference regtools, 1 thread" % (sample[0], sample[1], sample[2], seed),
+                                "seconds": round(dt, 3), "finished": rc is not None, "outputs_identical_to_gpu": bool(same)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +193,7 @@ def main():
     ap.add_argument("--shape", default="short", choices=["short", "long"])
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other workloads reported beside the headline (realistic payload, config 5 long reads, config 4 identify)")
     ap.add_argument("--host-only", action="store_true", help="(profiling) only the timed host-bytes pass; the roofline line then quotes the overlapped launches")
     ap.add_argument("--realistic", action="store_true", help="random bases + binned qualities instead of the named constant payload")
     args = ap.parse_args()
@@ -233,6 +346,22 @@ def main():
                     ref_bed = f.read()
                     cb["bed12_identical_to_gpu"] = ref_bed == je.bed12() and ref_bed == bed_host_path
                 line["cpu_baseline"] = cb
+        if world == 1 and not args.no_extras and not args.host_only and args.shape == "short" and not args.realistic:
+            try:
+                del d_bam
+                pin.close()
+                which = os.environ.get("BENCH_EXTRAS", "realistic,long,identify").split(",")
+                if "realistic" in which:
+                  line["realistic"] = extra_extract(regtools_amd, synth, ctx, "configs[1] shape with random bases and binned qualities (payload that does not compress to nothing)",
+                                                  "short", True, args.reads, max(1, args.reads // 10), args.seed, threads)
+                if "long" in which:
+                  line["long10M"] = extra_extract(regtools_amd, synth, ctx, "configs[4]: long reads, l_qseq 1000-10000, n_cigar <= 64, 5-20 N ops", "long", False,
+                                                max(1, args.reads // 5), max(1, args.reads // 250), args.seed, threads, steps=2)
+                if "identify" in which:
+                  line["identify_config4"] = extra_identify(regtools_amd, synth, ctx, args.reads, max(4, args.reads // 800), max(10, args.reads // 100),
+                                                          (max(1, args.reads // 25), max(4, args.reads // 20000), max(10, args.reads // 2500)), 4, threads)
+            except Exception as e:           # the headline stands on its own
+                line["extras_error"] = repr(e)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

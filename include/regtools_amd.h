@@ -214,6 +214,7 @@ typedef struct {
     uint64_t exon_visits_variants;   /* E_v summed: exon records of all candidate transcripts (SURVEY 8d algorithmic bytes) */
     uint64_t exon_visits_junctions;  /* E_j summed */
     double   ms_total, ms_gtf, ms_variants, ms_extract, ms_join, ms_annotate, ms_output;
+    double   ms_k_variant_scan, ms_k_junction_scan, ms_k_window_pairs;   /* the interval kernels alone (HIP events, both passes of each) */
 } rgx_identify_stats;
 
 void rgx_identify_params_default(rgx_identify_params *p);   /* CisSpliceEffectsIdentifier ctor, identifier.h:101-117 */

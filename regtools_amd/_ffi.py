@@ -60,7 +60,8 @@ class IdentifyParams(C.Structure):
 class IdentifyStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_variants", "n_relevant", "n_windows", "n_pairs", "n_window_rows", "n_junctions", "n_records", "n_events",
                                           "exon_visits_variants", "exon_visits_junctions")] + \
-               [(n, C.c_double) for n in ("ms_total", "ms_gtf", "ms_variants", "ms_extract", "ms_join", "ms_annotate", "ms_output")]
+               [(n, C.c_double) for n in ("ms_total", "ms_gtf", "ms_variants", "ms_extract", "ms_join", "ms_annotate", "ms_output",
+                                          "ms_k_variant_scan", "ms_k_junction_scan", "ms_k_window_pairs")]
 
 
 class VariantHits(C.Structure):

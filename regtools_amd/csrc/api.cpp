@@ -84,10 +84,30 @@ struct rgx_ctx {
     void *pinned_members = nullptr; size_t pinned_members_cap = 0;      // the host scan's member list: kernels read it in place (grow-only)
     void *pinned_rows = nullptr; size_t pinned_rows_cap = 0;
     uint64_t last_rows = 0, last_records = 0, last_events = 0, last_bytes = 0; bool last_rows_valid = false;      // rows of the last rgx_extract* call, still in the "rows_out" block in HBM   // grow-only pinned staging for whole result tables (device merge)
+    // HIP-event timing of single kernels inside a stage (the interval kernels of `identify`: roofline figures need the kernel's own
+    // duration, not the stage's wall time): event pairs wait in kpend until the call's end, kms[slot] accumulates
+    struct KPend { hipEvent_t a, b; int slot; };
+    std::vector<KPend> kpend; std::vector<hipEvent_t> kfree; double kms[3] = {0, 0, 0};
     std::string fasta_path;                            // FASTA currently resident in the "fasta" buffer
     rgx::Fasta *fasta = nullptr;
     DevBuf &buf(const char *name) { return bufs[name]; }
 };
+
+static void ktime_begin(rgx_ctx *c, int slot) {
+    hipEvent_t e[2];
+    for (auto &x : e) { if (!c->kfree.empty()) { x = c->kfree.back(); c->kfree.pop_back(); } else if (hipEventCreate(&x) != hipSuccess) return; }
+    (void)hipEventRecord(e[0], c->stream);
+    c->kpend.push_back({e[0], e[1], slot});
+}
+static void ktime_end(rgx_ctx *c) { if (!c->kpend.empty()) (void)hipEventRecord(c->kpend.back().b, c->stream); }
+static void ktime_collect(rgx_ctx *c) {
+    for (auto &k : c->kpend) {
+        float ms = 0;
+        if (hipEventSynchronize(k.b) == hipSuccess && hipEventElapsedTime(&ms, k.a, k.b) == hipSuccess) c->kms[k.slot] += ms;
+        c->kfree.push_back(k.a); c->kfree.push_back(k.b);
+    }
+    c->kpend.clear();
+}
 
 extern "C" const char *rgx_version(void) { return "regtools_amd 0.1 gfx950"; }
 
@@ -129,6 +149,8 @@ extern "C" void rgx_ctx_destroy(rgx_ctx *c) {
     for (auto &kv : c->bufs) kv.second.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->chunk_ev) if (e) (void)hipEventDestroy(e);
+    ktime_collect(c);
+    for (auto &e : c->kfree) (void)hipEventDestroy(e);
     for (auto &e : c->ev_side) if (e) (void)hipEventDestroy(e);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     for (auto &q : c->side) if (q) (void)hipStreamDestroy(q);
@@ -990,7 +1012,6 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
         }
         if (U * 40 > c->pinned_rows_cap) {
             if (c->pinned_rows) (void)hipHostFree(c->pinned_rows);
-    if (c->pinned_members) (void)hipHostFree(c->pinned_members);
             c->pinned_rows = nullptr; c->pinned_rows_cap = 0;
             const size_t want = U * 40 + U * 5 + 4096;
             HIP_TRY(hipHostMalloc(&c->pinned_rows, want, hipHostMallocDefault));
