@@ -115,7 +115,7 @@ def extra_extract(regtools_amd, synth, ctx, label, shape, realistic, n_reads, sa
     out = {"workload": label, "reads": st["n_reads"], "ms": ms, "alignments_per_s": st["n_reads"] / (ms * 1e-3), "junction_events_per_s": n_events / (ms * 1e-3),
            "ms_device_resident": stage["total"], "stage_ms": stage, "input_generation_s": round(t_gen, 2),
            "bytes_per_alignment": {"compressed": s["compressed_bytes"] / st["n_reads"], "inflated": s["inflated_bytes"] / st["n_reads"]},
-           "roofline": {"bound": "hbm", "kernel": "rgx::k_inflate<false>", "kernel_ms": min(k_ms), "algorithmic_bytes": alg,
+           "roofline": {"bound": "hbm", "kernel": "rgx::k_inflate<false, false>", "kernel_ms": min(k_ms), "algorithmic_bytes": alg,
                         "achieved": alg / (min(k_ms) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (min(k_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}}
     del d_bam, bam
     pin.close()
@@ -302,7 +302,8 @@ def main():
         # very command).  Only quoted when the committed measurement was taken on this exact workload.
         traffic, traffic_note = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pm_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+            pm = json.load(open(pm_path if os.path.exists(pm_path) else os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if n_reads == 50_000_000 and args.shape == "short" and not args.realistic and world == 1:
                 traffic = (pm["inflate_FETCH_SIZE"][0] + pm["inflate_WRITE_SIZE"][0]) * 1024.0
                 traffic_note = ("(FETCH_SIZE + WRITE_SIZE) KiB of rgx::k_inflate, uncorrected: the guide's x2 FETCH correction is for wide coalesced "
@@ -328,7 +329,7 @@ def main():
             "junction_rows": s["n_junctions"],
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "input_generation_s": round(t_gen, 2),
-            "roofline": {"bound": "hbm", "kernel": "rgx::k_inflate<false>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "rgx::k_inflate<false, false>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_note": traffic_note, "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
                          "note": "DEFLATE is a serial bit stream per member: one lane per member, bound by per-lane dependent ALU/LDS chains plus one memory round trip per symbol trip, far below the HBM line (SURVEY 8d; DESIGN.md 5)",
                          "pipeline_frac": aln_per_s / world * (alg_bytes / n_reads) / (HBM_PEAK_GBS * 1e9)},

@@ -612,7 +612,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             hipStream_t q = (j % 3 == 2) ? st : c->side[j % 3];
             if (j % 3 != 2) used_side |= 1u << (j % 3);
             HIP_TRY(hipStreamWaitEvent(q, c->chunk_ev[j], 0));
-            launch_inflate(d_bam, d_members + g_lo, g_hi - g_lo, b_arena.as<uint8_t>(), upos_lo, (uint32_t *)(b_lens.as<uint8_t>() + scratch_off), d_sc, q, ignore_below, g_lo - m_lo);
+            launch_inflate(d_bam, d_members + g_lo, g_hi - g_lo, b_arena.as<uint8_t>(), upos_lo, (uint32_t *)(b_lens.as<uint8_t>() + scratch_off), d_sc, q, ignore_below, g_lo - m_lo, /*piece=*/true);
             scratch_off += inflate_scratch_bytes(g_hi - g_lo);
             g_lo = g_hi;
         }

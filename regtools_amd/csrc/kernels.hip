@@ -89,7 +89,9 @@ struct LdsTab {
 // PROBE = false: the pipeline's launch -- member m goes to its planned place arena + upos (planned from the ISIZE footers) and must
 // inflate to exactly ISIZE bytes.  PROBE = true: the repair launch for files whose footers lie (bgzf.c:292-316 never reads ISIZE: a
 // block is as long as zlib says): every member into its own 64 KiB slot, true length (or ~0 = does not inflate) to sizes[m].
-template <bool PROBE>
+// PIECE: the same code under a second symbol -- the launches of rgx_extract_mem's overlapped upload cover a third of a file each and
+// run side by side; a profiler's per-kernel statistics keep them apart from the whole-range launches the roofline is quoted on.
+template <bool PROBE, bool PIECE = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_inflate(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
                                                 uint32_t n_members, uint8_t *__restrict__ arena, uint64_t upos_bias, uint32_t *len_scratch,
                                                 uint32_t *status, uint32_t ignore_below, uint32_t index_bias) {
@@ -250,18 +252,23 @@ static bool inflate_ring_selected() {
 static void inflate_attrs() {
     static bool done = false;
     if (done) return;
-    (void)hipFuncSetAttribute((const void *)k_inflate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+    (void)hipFuncSetAttribute((const void *)k_inflate<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+    (void)hipFuncSetAttribute((const void *)k_inflate<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate_ring<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRingLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate_ring<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRingLdsBytes);
     done = true;
 }
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
-                    uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias) {
+                    uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias, bool piece) {
     if (!n_members) return;
     inflate_attrs();
     uint32_t blocks = (n_members + 63) / 64;
-    if (!inflate_ring_selected()) { hipLaunchKernelGGL(k_inflate<false>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias); return; }
+    if (!inflate_ring_selected()) {
+        if (piece) hipLaunchKernelGGL((k_inflate<false, true>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias);
+        else hipLaunchKernelGGL((k_inflate<false, false>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias);
+        return;
+    }
     hipLaunchKernelGGL(k_inflate_ring<false>, dim3(blocks), dim3(64), kRingLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias);
 }
 void launch_inflate_probe(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *slots, uint32_t *len_scratch, uint32_t *sizes,

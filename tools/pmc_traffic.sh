@@ -6,7 +6,7 @@ hipcc --offload-arch=gfx950 -O3 $R/tools/ubench_unaligned.hip -o /tmp/ub 2>/dev/
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/cal_$c -o p -- /tmp/ub > $R/$OUT/cal_$c.log 2>&1
-  timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/bench_$c -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/$OUT/bench_$c.log 2>&1
+  timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/bench_$c -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $R/$OUT/bench_$c.log 2>&1
 done
 cd $R
 python3 - <<PY
@@ -20,7 +20,7 @@ def grab(d,kern,mingrid=0):
 res={}
 for c in ("FETCH_SIZE","WRITE_SIZE"):
     res["cal_"+c]=grab("$OUT/cal_"+c,"k_copy")
-    res["inflate_"+c]=grab("$OUT/bench_"+c,"k_inflate",100000)
+    res["inflate_"+c]=grab("$OUT/bench_"+c,"k_inflate",100000)      # the whole-file launches (the overlapped pieces have smaller grids)
 res["cal_known_bytes_each_way"]=4000*16*256*448
 json.dump(res,open("$OUT/pmc_traffic.json","w"),indent=1)
 print(json.dumps(res))
