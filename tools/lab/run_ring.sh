@@ -8,10 +8,10 @@ bin/synth_bam write /tmp/s50.bam 50000000 --threads 64 >> $O 2>&1
 bin/synth_bam write /tmp/r50.bam 50000000 --threads 64 --realistic >> $O 2>&1
 for f in /tmp/s50.bam /tmp/r50.bam; do
   echo "== $f" >> $O
-  timeout 120 tools/lab/bin/inflate_lab_base $f 3 >> $O 2>&1
+  timeout 60 tools/lab/bin/inflate_lab_base $f 3 >> $O 2>&1
   for v in ${VARIANTS:-base batch64 batch32 flush320}; do
-    REGTOOLS_AMD_INFLATE=ring timeout 120 tools/lab/bin/inflate_lab_$v $f 3 >> $O 2>&1
-    REGTOOLS_AMD_INFLATE=ring timeout 120 tools/lab/bin/inflate_lab_$v $f 2 6 >> $O 2>&1
+    REGTOOLS_AMD_INFLATE=ring timeout 60 tools/lab/bin/inflate_lab_$v $f 3 >> $O 2>&1
+    REGTOOLS_AMD_INFLATE=ring timeout 60 tools/lab/bin/inflate_lab_$v $f 2 6 >> $O 2>&1
   done
 done
 cat $O
