@@ -390,7 +390,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
                     up.recorded.store((uint32_t)j + 1, std::memory_order_release);
                 }
             });
-            overlap = scan_members_parallel(h_bam, bam_len, (int)std::min<unsigned>(24, std::max(2u, std::thread::hardware_concurrency()) - 1), hm, hm_total);
+            overlap = scan_members_parallel(h_bam, bam_len, (int)usable_threads(24), hm, hm_total);
             mark("host member scan");
             if (!overlap) {       // not a file the host vouches for: everything on the device, after the last chunk
                 up.th.join();

@@ -1,5 +1,8 @@
 // cse_host.cpp -- see cse_host.h.  Citations relative to /root/reference/src.
 #include "cse_host.h"
+
+#include <chrono>
+#include <functional>
 #include <limits.h>
 #include "host_io.h"
 
@@ -112,14 +115,22 @@ static long field_atol(const char *s, size_t n) {
 
 std::string GtfModel::load(const std::string &path) {
     FileBytes file;
-    if (!file.open(path, /*populate=*/true)) return "\nUnable to open GTF file.";
+    if (!file.open(path)) return "\nUnable to open GTF file.";      // (the scan threads fault the mapping in, each its own range)
     const char *text = (const char *)file.data();
     const size_t text_len = file.size();
-    // ---- pass 1 (threads): every line -> at most one exon record; the pieces are views into the mapped text ---------------------
-    struct Rec { const char *tid; const char *attrs; const char *chrom; uint32_t tid_len, attrs_len, chrom_len, s, e; uint8_t strand; };
-    struct Part { std::vector<Rec> recs; size_t err_pos = SIZE_MAX; const char *err = nullptr; };
-    const unsigned hw = std::thread::hardware_concurrency();
-    const size_t n_parts = text_len < (1u << 22) ? 1 : std::min<size_t>(hw ? hw : 4, 16);
+    const bool trace = getenv("REGTOOLS_AMD_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_last = now();
+    auto lap = [&](const char *what) { if (trace) { const double t = now(); fprintf(stderr, "[rgx trace] gtf: %-22s +%8.3f ms\n", what, t - t_last); t_last = t; } };
+    lap("map + populate");
+    typedef std::pair<const char *, size_t> View;                                  // a piece of the mapped text
+    struct SvHash { size_t operator()(const View &k) const { uint64_t h = 1469598103934665603ull; for (size_t i = 0; i < k.second; ++i) h = (h ^ (uint8_t)k.first[i]) * 1099511628211ull; return (size_t)h; } };
+    struct SvEq { bool operator()(const View &a, const View &b) const { return a.second == b.second && !memcmp(a.first, b.first, a.second); } };
+    // ---- pass 1 (threads): every line -> at most one exon record, filed under the part's own transcript list (first appearance order) ------
+    struct LocalTx { View id, attrs, chrom; uint64_t hash; uint8_t strand; uint32_t n; uint32_t global; uint32_t fill; };
+    struct Part { std::vector<LocalTx> tx; std::vector<uint32_t> r_tx, r_s, r_e; size_t err_pos = SIZE_MAX; const char *err = nullptr; };
+    const unsigned hw = usable_threads(32);
+    const size_t n_parts = text_len < (1u << 22) ? 1 : hw;
     std::vector<size_t> cut(n_parts + 1, text_len);
     cut[0] = 0;
     for (size_t k = 1; k < n_parts; ++k) {                                   // cut points just after a newline
@@ -130,8 +141,11 @@ std::string GtfModel::load(const std::string &path) {
     std::vector<Part> parts(n_parts);
     auto scan = [&](size_t k) {
         Part &P = parts[k];
+        std::unordered_map<View, uint32_t, SvHash, SvEq> by_id;
+        const char *last_tv = nullptr; size_t last_tl = 0; uint32_t last_k = 0;  // exon lines of a transcript are usually adjacent
         size_t pos = cut[k];
         const size_t lim = cut[k + 1];
+        P.r_tx.reserve((lim - pos) / 96 + 16); P.r_s.reserve((lim - pos) / 96 + 16); P.r_e.reserve((lim - pos) / 96 + 16);
         while (pos < lim) {
             const char *nl = (const char *)memchr(text + pos, '\n', lim - pos);
             const size_t e = nl ? (size_t)(nl - text) : lim;
@@ -155,83 +169,138 @@ std::string GtfModel::load(const std::string &path) {
             if (!(fl[2] == 4 && !memcmp(fb[2], "exon", 4))) continue;
             const char *tv; size_t tl;
             if (!gtf_attr_view(fb[8], fl[8], "transcript_id", 13, tv, tl) || (tl == 2 && !memcmp(tv, "NA", 2))) continue;   // gtf_parser.cc:118
-            P.recs.push_back(Rec{tv, fb[8], fb[0], (uint32_t)tl, (uint32_t)fl[8], (uint32_t)fl[0], (uint32_t)field_atol(fb[3], fl[3]), (uint32_t)field_atol(fb[4], fl[4]),
-                                 fl[6] == 1 ? (uint8_t)fb[6][0] : (uint8_t)'?'});
+            uint32_t t;
+            if (last_tv && tl == last_tl && !memcmp(tv, last_tv, tl)) t = last_k;
+            else if (auto it = by_id.find(View(tv, tl)); it != by_id.end()) t = it->second;
+            else {
+                t = (uint32_t)P.tx.size(); by_id.emplace(View(tv, tl), t);
+                P.tx.push_back(LocalTx{View(tv, tl), View(fb[8], fl[8]), View(fb[0], fl[0]), (uint64_t)SvHash()(View(tv, tl)), fl[6] == 1 ? (uint8_t)fb[6][0] : (uint8_t)'?', 0, 0, 0});   // first exon line seen wins (gtf_parser.cc:266-273)
+            }
+            last_tv = tv; last_tl = tl; last_k = t;
+            ++P.tx[t].n;
+            P.r_tx.push_back(t); P.r_s.push_back((uint32_t)field_atol(fb[3], fl[3])); P.r_e.push_back((uint32_t)field_atol(fb[4], fl[4]));
         }
     };
-    if (n_parts == 1) scan(0);
-    else {
+    auto run_parallel = [&](size_t n, const std::function<void(size_t)> &f) {
+        if (n <= 1) { for (size_t k = 0; k < n; ++k) f(k); return; }
         std::vector<std::thread> th;
-        for (size_t k = 0; k < n_parts; ++k) th.emplace_back(scan, k);
+        for (size_t k = 1; k < n; ++k) th.emplace_back(f, k);
+        f(0);
         for (auto &t : th) t.join();
-    }
-    // ---- pass 2 (serial, file order): group exon records by transcript; the first bad line in file order ends the run, as upstream ---
-    struct Tmp { std::string id, gene_name, gene_id; int32_t chrom; uint8_t strand; uint32_t n = 0; };
+    };
+    run_parallel(n_parts, scan);
+    lap("scan (threads)");
+    // the first bad line in file order ends the run, as upstream
+    for (size_t k = 0; k < n_parts; ++k) if (parts[k].err) return parts[k].err;
+    // ---- merge (serial, file order, one step per (part, transcript) instead of one per exon line): global transcript numbers in first-appearance
+    //      order, the contig table in the order transcripts first name a contig, and where each part's exons of a transcript go ----------------
+    struct Tmp { View id, attrs; int32_t chrom; uint8_t strand; uint32_t n = 0; };
     std::vector<Tmp> tmp;
-    std::vector<uint32_t> ex_tx, ex_s, ex_e;                                       // exon lines in file order
-    const char *last_tv = nullptr; size_t last_tl = 0; uint32_t last_k = 0;        // exon lines of a transcript are usually adjacent
-    struct SvHash { size_t operator()(const std::pair<const char *, size_t> &k) const { uint64_t h = 1469598103934665603ull; for (size_t i = 0; i < k.second; ++i) h = (h ^ (uint8_t)k.first[i]) * 1099511628211ull; return (size_t)h; } };
-    struct SvEq { bool operator()(const std::pair<const char *, size_t> &a, const std::pair<const char *, size_t> &b) const { return a.second == b.second && !memcmp(a.first, b.first, a.second); } };
-    std::unordered_map<std::pair<const char *, size_t>, uint32_t, SvHash, SvEq> by_id;     // keys are views into the mapped text
-    by_id.reserve(1 << 16);
-    { size_t total = 0; for (auto &P : parts) total += P.recs.size(); ex_tx.reserve(total); ex_s.reserve(total); ex_e.reserve(total); }
-    for (size_t k = 0; k < n_parts; ++k) {
-        const Part &P = parts[k];
-        for (const Rec &r : P.recs) {
-            uint32_t t;
-            if (last_tv && r.tid_len == last_tl && !memcmp(r.tid, last_tv, last_tl)) t = last_k;
-            else if (auto it = by_id.find({r.tid, r.tid_len}); it != by_id.end()) t = it->second;
-            else {
-                t = (uint32_t)tmp.size(); by_id.emplace(std::make_pair(r.tid, (size_t)r.tid_len), t);
-                Tmp x; x.id.assign(r.tid, r.tid_len);
-                x.gene_name = gtf_attr(r.attrs, r.attrs_len, "gene_name");          // first exon line seen wins (gtf_parser.cc:266-273)
-                x.gene_id = gtf_attr(r.attrs, r.attrs_len, "gene_id");
-                std::string cn(r.chrom, r.chrom_len);
-                auto ci = chrom_index.find(cn);
-                if (ci == chrom_index.end()) { ci = chrom_index.emplace(cn, (int32_t)chroms.size()).first; chroms.push_back(cn); }
-                x.chrom = ci->second;
-                x.strand = r.strand;
-                tmp.push_back(std::move(x));
+    {
+        // an open-addressing table over the hashes the scan threads computed: the serial part is one probe per (part, transcript)
+        size_t total_local = 0;
+        for (const Part &P : parts) total_local += P.tx.size();
+        size_t cap = 1024;
+        while (cap < total_local * 2) cap <<= 1;
+        std::vector<uint32_t> slot(cap, 0);                                        // 0 = empty, else global number + 1
+        std::vector<uint64_t> slot_hash(cap, 0);                                   // (full hashes side by side: a probe only touches the text on a real match)
+        tmp.reserve(total_local);
+        View last_chrom(nullptr, 0); int32_t last_chrom_idx = -1;                  // transcripts come contig by contig
+        for (Part &P : parts)
+            for (LocalTx &l : P.tx) {
+                size_t h = (size_t)(l.hash * 0x9e3779b97f4a7c15ull >> 20) & (cap - 1);
+                uint32_t t;
+                for (;; h = (h + 1) & (cap - 1)) {
+                    if (!slot[h]) {
+                        t = (uint32_t)tmp.size(); slot[h] = t + 1; slot_hash[h] = l.hash;
+                        if (!(last_chrom.first && last_chrom.second == l.chrom.second && !memcmp(last_chrom.first, l.chrom.first, l.chrom.second))) {
+                            std::string cn(l.chrom.first, l.chrom.second);
+                            auto ci = chrom_index.find(cn);
+                            if (ci == chrom_index.end()) { ci = chrom_index.emplace(cn, (int32_t)chroms.size()).first; chroms.push_back(cn); }
+                            last_chrom = l.chrom; last_chrom_idx = ci->second;
+                        }
+                        Tmp x; x.id = l.id; x.attrs = l.attrs; x.chrom = last_chrom_idx; x.strand = l.strand;
+                        tmp.push_back(x);
+                        break;
+                    }
+                    if (slot_hash[h] != l.hash) continue;
+                    const Tmp &c = tmp[slot[h] - 1];
+                    if (c.id.second == l.id.second && !memcmp(c.id.first, l.id.first, l.id.second)) { t = slot[h] - 1; break; }
+                }
+                l.global = t; l.fill = tmp[t].n;                                 // this part's exons follow those of the parts before it
+                tmp[t].n += l.n;
             }
-            last_tv = r.tid; last_tl = r.tid_len; last_k = t;
-            ++tmp[t].n;
-            ex_tx.push_back(t); ex_s.push_back(r.s); ex_e.push_back(r.e);
-        }
-        if (P.err) return P.err;                                                   // everything before it was consumed, nothing after it matters
     }
-    // exons grouped by transcript, file order kept inside a group (one counting pass instead of 250 k small vectors)
-    std::vector<uint32_t> goff(tmp.size() + 1, 0), gs(ex_tx.size()), ge(ex_tx.size());
-    for (size_t k = 0; k < tmp.size(); ++k) goff[k + 1] = goff[k] + tmp[k].n;
-    { std::vector<uint32_t> fill(goff.begin(), goff.end() - 1);
-      for (size_t i = 0; i < ex_tx.size(); ++i) { const uint32_t q = fill[ex_tx[i]]++; gs[q] = ex_s[i]; ge[q] = ex_e[i]; } }
-    std::vector<uint32_t> order(tmp.size());
-    std::iota(order.begin(), order.end(), 0u);
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return tmp[a].id < tmp[b].id; });   // std::map<string,Transcript>
-    es.reserve(gs.size()); ee.reserve(gs.size());
-    std::vector<uint32_t> idx;
-    for (uint32_t k : order) {
-        Tmp &t = tmp[k];
-        if (t.strand != '+' && t.strand != '-') return "Undefined strand for exon ";                          // gtf_parser.cc:193-197 exit(1)
-        const uint32_t *ts = gs.data() + goff[k], *te = ge.data() + goff[k];
-        idx.resize(t.n);
-        std::iota(idx.begin(), idx.end(), 0u);
-        // sort_exons_within_transcripts: '+' ascending start, '-' descending start (stable)
-        if (t.strand == '+') std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return ts[a] < ts[b]; });
-        else std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return ts[a] > ts[b]; });
-        tx_id.push_back(t.id); tx_gene_name.push_back(t.gene_name); tx_gene_id.push_back(t.gene_id);
-        tx_chrom.push_back(t.chrom); tx_strand.push_back(t.strand);
-        tx_exon_off.push_back((uint32_t)es.size()); tx_n_exons.push_back((uint32_t)idx.size());
-        for (uint32_t i : idx) { es.push_back(ts[i]); ee.push_back(te[i]); }
-        tx_bin.push_back(ucsc_bin(es[tx_exon_off.back()], ee.back()));                                         // gtf_parser.cc:154-160
-    }
-    // chr -> bin -> [transcript ids ascending]
-    std::vector<uint32_t> bt(tx_id.size());
-    std::iota(bt.begin(), bt.end(), 0u);
-    std::stable_sort(bt.begin(), bt.end(), [&](uint32_t a, uint32_t b) {
-        const uint64_t ka = (uint64_t)(uint32_t)tx_chrom[a] << 32 | tx_bin[a], kb = (uint64_t)(uint32_t)tx_chrom[b] << 32 | tx_bin[b];
-        return ka < kb;
+    lap("merge");
+    const size_t n_tx = tmp.size();
+    std::vector<uint32_t> goff(n_tx + 1, 0);
+    for (size_t k = 0; k < n_tx; ++k) goff[k + 1] = goff[k] + tmp[k].n;
+    // exons grouped by transcript, file order kept inside a group: every part files its own lines (threads)
+    std::vector<uint32_t> gs(goff[n_tx]), ge(goff[n_tx]);
+    run_parallel(n_parts, [&](size_t k) {
+        Part &P = parts[k];
+        for (LocalTx &l : P.tx) l.fill += goff[l.global];
+        for (size_t i = 0; i < P.r_tx.size(); ++i) { const uint32_t q = P.tx[P.r_tx[i]].fill++; gs[q] = P.r_s[i]; ge[q] = P.r_e[i]; }
     });
-    for (uint32_t t : bt) { bin_key.push_back((uint64_t)(uint32_t)tx_chrom[t] << 32 | tx_bin[t]); bin_tx.push_back(t); }
+    lap("file exons (threads)");
+    // std::map<string,Transcript> order: ascending id (bytes compared as unsigned chars, like std::string); sorted in runs by threads, merged
+    std::vector<uint32_t> order(n_tx);
+    std::iota(order.begin(), order.end(), 0u);
+    auto id_less = [&](uint32_t a, uint32_t b) {
+        const View &x = tmp[a].id, &y = tmp[b].id;
+        const int c = memcmp(x.first, y.first, std::min(x.second, y.second));
+        return c < 0 || (c == 0 && x.second < y.second);
+    };
+    {
+        const size_t runs = n_tx < (1u << 15) ? 1 : std::min<size_t>(hw, 16);
+        run_parallel(runs, [&](size_t r) { std::sort(order.begin() + (long)(n_tx * r / runs), order.begin() + (long)(n_tx * (r + 1) / runs), id_less); });
+        for (size_t w = 1; w < runs; w *= 2) {
+            std::vector<size_t> starts;
+            for (size_t r = 0; r + w < runs; r += 2 * w) starts.push_back(r);
+            run_parallel(starts.size(), [&](size_t q) {
+                const size_t r = starts[q];
+                std::inplace_merge(order.begin() + (long)(n_tx * r / runs), order.begin() + (long)(n_tx * (r + w) / runs), order.begin() + (long)(n_tx * std::min(runs, r + 2 * w) / runs), id_less);
+            });
+        }
+    }
+    lap("sort ids");
+    for (uint32_t k : order) if (tmp[k].strand != '+' && tmp[k].strand != '-') return "Undefined strand for exon ";   // gtf_parser.cc:193-197 exit(1): the first in map order
+    // the transcript tables, in that order (threads over ranges of it)
+    tx_id.resize(n_tx); tx_gene_name.resize(n_tx); tx_gene_id.resize(n_tx); tx_chrom.resize(n_tx); tx_strand.resize(n_tx);
+    tx_exon_off.resize(n_tx); tx_n_exons.resize(n_tx); tx_bin.resize(n_tx);
+    es.resize(goff[n_tx]); ee.resize(goff[n_tx]);
+    { uint32_t o = 0; for (size_t i = 0; i < n_tx; ++i) { tx_exon_off[i] = o; o += tmp[order[i]].n; } }
+    const size_t build_parts = n_tx < (1u << 12) ? 1 : hw;
+    run_parallel(build_parts, [&](size_t b) {
+        std::vector<uint32_t> idx;
+        for (size_t i = n_tx * b / build_parts; i < n_tx * (b + 1) / build_parts; ++i) {
+            const uint32_t k = order[i];
+            const Tmp &t = tmp[k];
+            const uint32_t *ts = gs.data() + goff[k], *te = ge.data() + goff[k];
+            idx.resize(t.n);
+            std::iota(idx.begin(), idx.end(), 0u);
+            // sort_exons_within_transcripts: '+' ascending start, '-' descending start (stable)
+            if (t.strand == '+') std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t c) { return ts[a] < ts[c]; });
+            else std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t c) { return ts[a] > ts[c]; });
+            tx_id[i].assign(t.id.first, t.id.second);
+            tx_gene_name[i] = gtf_attr(t.attrs.first, t.attrs.second, "gene_name");
+            tx_gene_id[i] = gtf_attr(t.attrs.first, t.attrs.second, "gene_id");
+            tx_chrom[i] = t.chrom; tx_strand[i] = t.strand; tx_n_exons[i] = t.n;
+            const uint32_t o = tx_exon_off[i];
+            for (uint32_t q = 0; q < t.n; ++q) { es[o + q] = ts[idx[q]]; ee[o + q] = te[idx[q]]; }
+            tx_bin[i] = ucsc_bin(es[o], ee[o + t.n - 1]);                                                      // gtf_parser.cc:154-160
+        }
+    });
+    lap("tables (threads)");
+    // chr -> bin -> [transcript ids ascending]
+    {
+        std::vector<std::pair<uint64_t, uint32_t>> kv(n_tx);                       // (key, transcript): plain pair order = stable by transcript
+        for (uint32_t t = 0; t < n_tx; ++t) kv[t] = {(uint64_t)(uint32_t)tx_chrom[t] << 32 | tx_bin[t], t};
+        std::sort(kv.begin(), kv.end());
+        bin_key.resize(n_tx); bin_tx.resize(n_tx);
+        for (size_t i = 0; i < n_tx; ++i) { bin_key[i] = kv[i].first; bin_tx[i] = kv[i].second; }
+    }
+    lap("bins");
     return "";
 }
 
@@ -245,21 +314,43 @@ std::string VcfText::load(const std::string &path) {
         if (plain.size() >= 3 && !memcmp(plain.data(), "BCF", 3)) return "regtools_amd: BCF input is not supported on this path\n\n";
         text.swap(plain);
     }
+    line_off.reserve(text.size() / 32 + 16);
     size_t p = 0;
     while (p < text.size()) {
         line_off.push_back(p);
-        size_t e = text.find('\n', p); if (e == std::string::npos) e = text.size();
-        p = e + 1;
+        const char *nl = (const char *)memchr(text.data() + p, '\n', text.size() - p);
+        p = nl ? (size_t)(nl - text.data()) + 1 : text.size() + 1;
     }
     line_off.push_back(text.size() + (text.empty() || text.back() == '\n' ? 0 : 1));
-    for (size_t i = 0; i + 1 < line_off.size(); ++i) {
-        const char *l; size_t n; line(i, l, n);
-        if (!n || l[0] == '#') continue;
-        const char *t1 = (const char *)memchr(l, '\t', n);
-        if (!t1) continue;
-        const char *t2 = (const char *)memchr(t1 + 1, '\t', (size_t)(l + n - t1 - 1));
-        std::string ps(t1 + 1, t2 ? (size_t)(t2 - t1 - 1) : (size_t)(l + n - t1 - 1));
-        recs.push_back({i, std::string(l, (size_t)(t1 - l)), (uint32_t)(atoi(ps.c_str()) - 1)});
+    // CHROM and POS of every record line, by several threads over ranges of lines (file order kept: the ranges are concatenated in order)
+    const size_t n_lines_ = line_off.size() - 1;
+    const size_t T = n_lines_ < (1u << 16) ? 1 : usable_threads(16);
+    std::vector<std::vector<Rec>> part(T);
+    auto scan = [&](size_t t) {
+        std::vector<Rec> &out = part[t];
+        const size_t a = n_lines_ * t / T, b = n_lines_ * (t + 1) / T;
+        out.reserve(b - a);
+        for (size_t i = a; i < b; ++i) {
+            const char *l; size_t n; line(i, l, n);
+            if (!n || l[0] == '#') continue;
+            const char *t1 = (const char *)memchr(l, '\t', n);
+            if (!t1) continue;
+            const char *t2 = (const char *)memchr(t1 + 1, '\t', (size_t)(l + n - t1 - 1));
+            std::string ps(t1 + 1, t2 ? (size_t)(t2 - t1 - 1) : (size_t)(l + n - t1 - 1));
+            out.push_back({i, std::string(l, (size_t)(t1 - l)), (uint32_t)(atoi(ps.c_str()) - 1)});
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < T; ++t) pool.emplace_back(scan, t);
+        scan(0);
+        for (auto &th : pool) th.join();
+    }
+    if (T == 1) recs.swap(part[0]);
+    else {
+        size_t total = 0; for (auto &v : part) total += v.size();
+        recs.reserve(total);
+        for (auto &v : part) for (auto &r : v) recs.push_back(std::move(r));
     }
     return "";
 }

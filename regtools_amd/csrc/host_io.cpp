@@ -37,6 +37,20 @@ void walk_members(const uint8_t *bam, size_t len, std::vector<HostMember> &out) 
     }
 }
 
+unsigned usable_threads(unsigned cap) {
+    static const unsigned limit = [] {
+        unsigned hw = std::thread::hardware_concurrency();
+        if (!hw) hw = 4;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                 // cgroup v2: "<quota> <period>" or "max <period>"
+            long long q = 0, per = 0;
+            if (fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (q + per - 1) / per));
+            fclose(f);
+        }
+        return hw;
+    }();
+    return std::max(1u, std::min(limit, cap));
+}
+
 static inline bool host_magic_at(const uint8_t *h) {
     return h[0] == 31 && h[1] == 139 && h[2] == 8 && (h[3] & 4) && h16(h + 10) == 6 && h[12] == 'B' && h[13] == 'C' && h16(h + 14) == 2;
 }

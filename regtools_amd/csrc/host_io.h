@@ -17,6 +17,10 @@ struct HostMember { uint64_t coff; uint32_t blen; uint32_t isize; };
 // malformed member (the reference would fail to read that block, ending iteration).
 void walk_members(const uint8_t *bam, size_t len, std::vector<HostMember> &out);
 
+// Host threads worth starting for a short parallel phase: the hardware's count, capped by the CPU quota of the control group the process runs
+// in (a container with cpu.max = 16 CPUs on a 256-thread host is throttled for most of a period when 48 threads run at once) and by `cap`.
+unsigned usable_threads(unsigned cap);
+
 // The member list of a WELL-FORMED file, found by several host threads at once (the upload of the file to the device runs meanwhile):
 // thread t starts at the first BGZF header at or after byte t * len / T and walks the BSIZE chain (bgzf.c:525); every walk must end
 // exactly where the next one started and the last one at the end of the file, every member must carry the header of bgzf.c:348-355, a
