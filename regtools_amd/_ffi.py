@@ -46,7 +46,7 @@ EXPORTS = ["rgx_extract_params_default", "rgx_ctx_create", "rgx_ctx_destroy", "r
            "rgx_identify_params_default", "rgx_identify", "rgx_gtf_load", "rgx_gtf_free", "rgx_gtf_info", "rgx_gtf_transcript_bin",
            "rgx_gtf_transcript_id", "rgx_variant_windows", "rgx_variant_hits_free", "rgx_annotate_junctions", "rgx_junction_annot_free",
            "rgx_associate", "rgx_variants_annotate", "rgx_junctions_annotate", "rgx_table_merge_device", "rgx_window_join", "rgx_window_rows_free", "rgx_last_table_pack_device",
-           "rgx_host_alloc", "rgx_host_free", "rgx_extract_multi", "rgx_extract_multi_mem"]
+           "rgx_host_alloc", "rgx_host_free", "rgx_extract_multi", "rgx_extract_multi_mem", "rgx_k_inflate_form"]
 
 
 class IdentifyParams(C.Structure):
@@ -133,6 +133,7 @@ def lib():
         L.rgx_table_format_barcodes.argtypes = [P(JunctionTable), C.c_int, C.c_char_p, C.c_size_t]
         L.rgx_table_format_barcodes.restype = C.c_size_t
         L.rgx_k_inflate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rgx_k_inflate_form.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rgx_identify_params_default.argtypes = [P(IdentifyParams)]
         L.rgx_identify.argtypes = [C.c_void_p, P(IdentifyParams), P(IdentifyStats), C.c_char_p, C.c_size_t]
         L.rgx_associate.argtypes = L.rgx_identify.argtypes

@@ -1230,6 +1230,11 @@ extern "C" int rgx_extract(rgx_ctx *ctx, const char *bam_path, const rgx_extract
 }
 
 extern "C" int rgx_k_inflate(const void *d_comp, const rgx_member *d_members, uint32_t n_members, void *d_arena, uint32_t *d_status, void *stream) {
+    return rgx_k_inflate_form(0, d_comp, d_members, n_members, d_arena, d_status, stream);
+}
+
+extern "C" int rgx_k_inflate_form(int form, const void *d_comp, const rgx_member *d_members, uint32_t n_members, void *d_arena, uint32_t *d_status, void *stream) {
+    if (form < 0 || form > 3) return RGX_ERR_ARG;
     static_assert(sizeof(rgx_member) == sizeof(Member), "rgx_member layout");
     // stage entry point: the code-length scratch is a process-lifetime buffer grown on demand
     static void *scratch = nullptr; static size_t scratch_cap = 0;
@@ -1239,7 +1244,7 @@ extern "C" int rgx_k_inflate(const void *d_comp, const rgx_member *d_members, ui
         if (hipMalloc(&scratch, need) != hipSuccess) { scratch = nullptr; scratch_cap = 0; return RGX_ERR_DEVICE; }
         scratch_cap = need;
     }
-    launch_inflate((const uint8_t *)d_comp, (const Member *)d_members, n_members, (uint8_t *)d_arena, 0, (uint32_t *)scratch, d_status, (hipStream_t)stream);
+    launch_inflate((const uint8_t *)d_comp, (const Member *)d_members, n_members, (uint8_t *)d_arena, 0, (uint32_t *)scratch, d_status, (hipStream_t)stream, 0, 0, false, form);
     return hipGetLastError() == hipSuccess ? RGX_OK : RGX_ERR_DEVICE;
 }
 

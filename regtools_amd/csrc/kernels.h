@@ -21,7 +21,8 @@ constexpr uint32_t kStatusEarly = 76;   // status[kStatusEarly..+1]: the same pa
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
                     uint32_t *status /* [0]=first bad member (min), [1]=its status */, hipStream_t stream, uint32_t ignore_below = 0 /* failures of members below this index are not reported */,
                     uint32_t index_bias = 0 /* added to the launch's member index in status[] and in the ignore_below test: a range launched in pieces */,
-                    bool piece = false /* one of several concurrent launches over a range (own kernel symbol, same code) */);
+                    bool piece = false /* one of several concurrent launches over a range (own kernel symbol, same code) */,
+                    int form = 0 /* 0 = chosen by member count / REGTOOLS_AMD_INFLATE; 1 = k_inflate, 2 = k_inflate_wave, 3 = k_inflate_ring */);
 
 // ---- a1 (container): BGZF member discovery on the device --------------------------------------------------
 // The member chain (bgzf.c:525: next = this + BSIZE + 1) is serial on a CPU (one dependent cache miss per member).

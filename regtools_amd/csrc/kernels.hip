@@ -7,6 +7,7 @@
 #include "bam_core.h"
 #include "inflate_core.h"
 #include "inflate_ring.h"
+#include "inflate_wave.h"
 
 namespace rgx {
 
@@ -242,6 +243,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
 size_t inflate_scratch_bytes(uint32_t n_members) { return (size_t)((n_members + 63) / 64) * 64 * kScratchWordsPerLane * 4; }
 
+// ---- the small-input form: one member per wave, the whole member in LDS (inflate_wave.h) ------------------------------------------------
+struct DevWave {
+    uint32_t lane;
+    template <class F> __device__ __forceinline__ void lanes(F f) const { f(lane); }
+    __device__ __forceinline__ void sync() const {                       // one wave per workgroup: orders the lanes' LDS traffic (and the compiler)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+};
+static_assert(sizeof(WaveShared) <= 80 * 1024, "two wave-per-member workgroups per CU");
+
+__global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *__restrict__ comp, const Member *__restrict__ members, uint32_t n_members, uint8_t *arena,
+                                                     uint64_t upos_bias, uint32_t *status, uint32_t ignore_below, uint32_t index_bias) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    WaveShared &S = *reinterpret_cast<WaveShared *>(lds);
+    const uint32_t m = blockIdx.x;
+    if (m >= n_members) return;
+    const Member mb = members[m];
+    DevWave W{threadIdx.x};
+    int st;
+    uint32_t out_len = 0;
+    // (the same refusals as k_inflate: a member whose claimed size is no BGZF block size owns no bytes of the arena)
+    if (mb.isize > kBgzfMaxBlock) st = mb.isize == 0xffffffffu ? INF_IN_OVERRUN : INF_OUT_OVERFLOW;
+    else {
+        st = inflate_wave(W, S, comp + mb.cpos, mb.clen, arena + (mb.upos - upos_bias), mb.isize, &out_len);
+        if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
+    }
+    if (st != INF_OK && threadIdx.x == 0) {
+        const uint32_t mi = m + index_bias;
+        uint32_t *slot = mi >= ignore_below ? status : status + kStatusEarly;
+        uint32_t prev = atomicMin(&slot[0], mi);
+        if (mi < prev) slot[1] = (uint32_t)st;
+    }
+}
+
 // Two forms of the decoder: k_inflate (round 1: output straight to HBM, 12 waves per CU) is what the pipeline runs; k_inflate_ring
 // (inflate_ring.h: output through a per-lane LDS window, whole lines to HBM, 4 waves per CU) moves 0.3x the HBM bytes but its symbol loop
 // has one wave per SIMD to hide its LDS round trips behind and measures 1.9x slower.  REGTOOLS_AMD_INFLATE=ring selects it.
@@ -249,22 +286,38 @@ static bool inflate_ring_selected() {
     static const bool ring = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE"); return e && !strcmp(e, "ring"); }();
     return ring;
 }
+// k_inflate_wave (one member per wave, 512 members at a time: 1.17 ms per 512 members of the bench payload, 5.9 ms of the realistic one)
+// against k_inflate (one member per lane: 7.7-9.7 ms / 25-30 ms per launch whatever its size): the wave form wins up to ~4,000 / ~2,600
+// members (tools/inflate_forms.py, profiles/r02_inflate_forms.txt).  REGTOOLS_AMD_INFLATE=lane / =wave force one or the other.
+constexpr uint32_t kWaveFormMaxMembers = 2048;
+static int inflate_form_forced() {
+    static const int f = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE"); return !e ? 0 : !strcmp(e, "lane") ? 1 : !strcmp(e, "wave") ? 2 : 0; }();
+    return f;
+}
 static void inflate_attrs() {
     static bool done = false;
     if (done) return;
     (void)hipFuncSetAttribute((const void *)k_inflate<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+    (void)hipFuncSetAttribute((const void *)k_inflate_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WaveShared));
     (void)hipFuncSetAttribute((const void *)k_inflate_ring<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRingLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate_ring<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRingLdsBytes);
     done = true;
 }
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
-                    uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias, bool piece) {
+                    uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias, bool piece, int form) {
     if (!n_members) return;
     inflate_attrs();
+    // form: 0 = the pipeline's choice (environment, member count), 1 = one member per lane, 2 = one member per wave, 3 = lane + LDS window
+    const bool ring = form ? form == 3 : inflate_ring_selected();
+    const bool wave = form ? form == 2 : (!ring && inflate_form_forced() != 1 && (n_members <= kWaveFormMaxMembers || inflate_form_forced() == 2));
     uint32_t blocks = (n_members + 63) / 64;
-    if (!inflate_ring_selected()) {
+    if (wave) {
+        hipLaunchKernelGGL(k_inflate_wave, dim3(n_members), dim3(64), (uint32_t)sizeof(WaveShared), stream, comp, members, n_members, arena, upos_bias, status, ignore_below, index_bias);
+        return;
+    }
+    if (!ring) {
         if (piece) hipLaunchKernelGGL((k_inflate<false, true>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias);
         else hipLaunchKernelGGL((k_inflate<false, false>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias);
         return;

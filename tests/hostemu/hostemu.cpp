@@ -27,6 +27,23 @@ extern "C" int emu_inflate_ring(const uint8_t *in, uint32_t in_len, uint8_t *out
     return st;
 }
 
+// the small-input decoder (inflate_wave.h: one member per wave, whole member in LDS) with the host's one-thread wave
+#include "../../regtools_amd/csrc/inflate_wave.h"
+extern "C" int emu_inflate_wave(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t cap, uint32_t *out_len, uint32_t phase) {
+    std::vector<uint8_t> ibuf((size_t)in_len + 64, 0);
+    memcpy(ibuf.data(), in, in_len);
+    std::vector<uint8_t> obuf((size_t)cap + 1024, 0xA5);
+    uint8_t *dst = (uint8_t *)(((uintptr_t)obuf.data() + 127) & ~(uintptr_t)127) + 256 + (phase & 127u);
+    static rgx::WaveShared S;
+    memset(&S, 0xCC, sizeof S);
+    rgx::HostWave W;
+    const int st = rgx::inflate_wave(W, S, ibuf.data(), in_len, dst, cap, out_len);
+    for (uint8_t *q = obuf.data(); q < dst; ++q) if (*q != 0xA5) return -100;
+    for (uint8_t *q = dst + cap; q < obuf.data() + obuf.size(); ++q) if (*q != 0xA5) return -101;
+    memcpy(out, dst, *out_len <= cap ? *out_len : cap);
+    return st;
+}
+
 // ---- the per-alignment cores of bam_core.h / cse_core.h, as the kernels call them ---------------------------------------------
 #include "../../regtools_amd/csrc/bam_core.h"
 #include "../../regtools_amd/csrc/cse_core.h"

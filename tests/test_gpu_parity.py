@@ -149,8 +149,12 @@ def test_cli_binary_writes_identical_file(gpu_ctx, tmp_path):
     assert subprocess.run([exe, "junctions", "extract", "-s", "XS", "missing.bam"], stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode == 1
 
 
-def test_inflate_kernel_against_zlib(gpu_ctx):
-    # the dominant kernel in isolation, through its C-ABI stage entry point
+FORMS = [(1, "lane"), (2, "wave"), (3, "ring")]       # rgx_k_inflate_form: k_inflate, k_inflate_wave, k_inflate_ring
+
+
+@pytest.mark.parametrize("form", [f for f, _ in FORMS], ids=[n for _, n in FORMS])
+def test_inflate_kernel_against_zlib(gpu_ctx, form):
+    # the DEFLATE kernels in isolation, through the C-ABI stage entry point
     import torch
     from regtools_amd import _ffi, synth
     bam, _, _ = synth.generate(40000, shape="short", seed=31, realistic=True)
@@ -163,16 +167,16 @@ def test_inflate_kernel_against_zlib(gpu_ctx):
     d_comp = torch.zeros(len(bam) + 64, dtype=torch.uint8, device="cuda")
     d_comp[: len(bam)].copy_(torch.frombuffer(bytearray(bam), dtype=torch.uint8))
     d_mem = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
-    d_arena = torch.zeros(upos + 256, dtype=torch.uint8, device="cuda")
+    d_arena = torch.zeros(upos + 512, dtype=torch.uint8, device="cuda")           # (the ring form reads up to 15 bytes in front of a member)
     d_status = torch.tensor([0xffffffff, 0], dtype=torch.int64).to(torch.uint32).cuda() if hasattr(torch, "uint32") else None
     if d_status is None:
         pytest.skip("torch without uint32")
     torch.cuda.synchronize()
-    rc = _ffi.lib().rgx_k_inflate(d_comp.data_ptr(), d_mem.data_ptr(), len(members), d_arena.data_ptr(), d_status.data_ptr(), None)
+    rc = _ffi.lib().rgx_k_inflate_form(form, d_comp.data_ptr(), d_mem.data_ptr(), len(members), d_arena.data_ptr() + 256, d_status.data_ptr(), None)
     torch.cuda.synchronize()
     assert rc == 0
     assert d_status.cpu().tolist()[0] == 0xffffffff
-    assert bytes(d_arena[:upos].cpu().numpy().tobytes()) == b"".join(expect)
+    assert bytes(d_arena[256:256 + upos].cpu().numpy().tobytes()) == b"".join(expect)
 
 
 def test_multi_million_read_properties(gpu_ctx, synth_dir):
@@ -257,7 +261,8 @@ def test_record_framing_runs_of_startless_segments_resolve_in_parallel(gpu_ctx, 
     assert 1 <= je.stats["framing_sweeps"] <= 48, je.stats
 
 
-def test_inflate_kernel_on_adversarial_members(gpu_ctx):
+@pytest.mark.parametrize("form", [f for f, _ in FORMS], ids=[n for _, n in FORMS])
+def test_inflate_kernel_on_adversarial_members(gpu_ctx, form):
     """The DEFLATE kernel alone on members built to hit its corners: runs (distance 1..15 with distance doubling), maximum-length matches,
     incompressible bytes (stored blocks), fixed-Huffman blocks, several blocks per member (Z_FULL_FLUSH), one-byte and empty-ish members,
     every zlib level and strategy, and 64 lanes of a wave that each see a different kind of stream.  Compared with zlib byte for byte;
@@ -304,16 +309,16 @@ def test_inflate_kernel_on_adversarial_members(gpu_ctx):
     d_comp = torch.zeros(len(blob) + 64, dtype=torch.uint8, device="cuda")
     d_comp[: len(blob)].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
     d_mem = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
-    d_arena = torch.full((total + 256,), 0xA5, dtype=torch.uint8, device="cuda")
+    d_arena = torch.full((256 + total + 256,), 0xA5, dtype=torch.uint8, device="cuda")
     d_status = torch.tensor([0xffffffff, 0], dtype=torch.int64).to(torch.uint32).cuda()
     torch.cuda.synchronize()
-    rc = _ffi.lib().rgx_k_inflate(d_comp.data_ptr(), d_mem.data_ptr(), len(members), d_arena.data_ptr(), d_status.data_ptr(), None)
+    rc = _ffi.lib().rgx_k_inflate_form(form, d_comp.data_ptr(), d_mem.data_ptr(), len(members), d_arena.data_ptr() + 256, d_status.data_ptr(), None)
     torch.cuda.synchronize()
     assert rc == 0 and d_status.cpu().tolist()[0] == 0xffffffff
     got = d_arena.cpu().numpy().tobytes()
-    want = bytearray(b"\xa5" * (total + 256))
+    want = bytearray(b"\xa5" * (256 + total + 256))
     for (cpos, up, clen, isz), d in zip(members, expect):
-        want[up: up + isz] = d
+        want[256 + up: 256 + up + isz] = d
     assert got == bytes(want)
 
 

@@ -36,6 +36,14 @@ def inflate(emu, payload, cap=65536):
     assert (st2 == 0) == (st == 0), (st, st2, _phase[0])
     if st == 0:
         assert out2.raw[:n2.value] == got, "ring decoder differs at phase %d" % _phase[0]
+    # ... and the wave-per-member decoder (inflate_wave.h): direct tables + canonical walk, whole member in (emulated) LDS
+    out3 = ctypes.create_string_buffer(cap + 64)
+    n3 = ctypes.c_uint32(0)
+    st3 = emu.emu_inflate_wave(buf, len(payload), out3, cap, ctypes.byref(n3), _phase[0])
+    assert st3 not in (-100, -101), "the wave decoder wrote outside its member"
+    assert (st3 == 0) == (st == 0), (st, st3)
+    if st == 0:
+        assert out3.raw[:n3.value] == got, "wave decoder differs"
     return st, got
 
 
