@@ -482,3 +482,34 @@ def test_multi_device_host_equals_single_gpu(gpu_ctx, synth_dir):
     assert r.returncode == 0 and open(out, "rb").read() == single
     with pytest.raises(regtools_amd.RegtoolsError):
         regtools_amd.extract_multi([0, 0], bam=p, strandness=0, output_barcodes_file="x.tsv")      # -b needs one shard
+
+
+def test_full_size_long_read_properties(gpu_ctx):
+    """BASELINE configs[4] at its real size (10 M long reads, l_qseq 1000-10000, n_cigar <= 64, 5-20 N ops: 65 GB inflated; the reference
+    needs minutes for it, bench.py compares a 200 k-read sample): the size-independent properties -- determinism, conservation of
+    events through the wave-per-read emit kernel, output order, naming, and independence of the shard count."""
+    from regtools_amd import synth, distributed
+    bam, bai, st = synth.generate(10_000_000, shape="long", seed=1)
+    import regtools_amd
+    pin = regtools_amd.PinnedBuffer(bam)
+
+    def run(**kw):
+        je = regtools_amd.JunctionsExtractor(strandness=0, ctx=gpu_ctx, **kw)
+        je.identify_junctions_from_BAM(bai_bytes=bai, host_ptr=pin.ptr, host_len=len(bam))
+        return je
+    a, b = run(), run()
+    bed = a.bed12()
+    assert bed == b.bed12() and a.stats["n_records"] == st["n_reads"] == 10_000_000
+    rows = a.get_all_junctions()
+    assert sum(j.read_count for j in rows) == a.stats["n_events"] > 50_000_000             # 5-20 junction events per read
+    assert sorted(int(j.name[4:]) for j in rows) == list(range(1, len(rows) + 1))             # first-seen names: a permutation of 1..n
+    keys = [(j.chrom, j.thick_start, j.thick_end, j.name) for j in rows]
+    assert keys == sorted(keys)                                                               # compare_junctions (h:117-140)
+    assert all(j.thick_start <= j.start < j.end <= j.thick_end for j in rows)
+    parts, keep, recs = [], [], 0
+    for g in range(2):
+        je = run(shard=g, n_shards=2)
+        keep.append(je); parts.append(distributed.pack_table(je.table)); recs += je.stats["n_records"]
+    assert recs == 10_000_000
+    assert distributed.merge_packed(parts, keep[0].table, 8).bed12() == bed
+    pin.close()
