@@ -129,8 +129,8 @@ int  rgx_extract_device(rgx_ctx *ctx, const void *d_bam, size_t bam_len,
  * (48 bytes each, still in HBM) are exchanged with one ncclAllGather (RCCL over xGMI; librccl.so.1 is loaded at run time) and merged on
  * devices[0] (rgx_table_merge_device).  Shard order is file order: the table is the single-GPU table whatever n_devices is.  A device
  * may be listed more than once: those shards take turns on it and the exchange is a device copy (how a one-GPU box tests this path).
- * Replaces the call junctions_extract() makes into JunctionsExtractor (junctions_main.cc:45-59) on a multi-GPU node.  -b is refused for
- * n_devices > 1 (a junction's barcodes would have to travel in first-seen order). */
+ * Replaces the call junctions_extract() makes into JunctionsExtractor (junctions_main.cc:45-59) on a multi-GPU node.  -b works across shards
+ * (rgx_table_merge_barcodes). */
 int  rgx_extract_multi(const int *devices, int n_devices, const char *bam_path, const rgx_extract_params *p,
                        rgx_junction_table **out, char *err, size_t errlen);
 int  rgx_extract_multi_mem(const int *devices, int n_devices, const void *bam, size_t bam_len, const void *bai, size_t bai_len,
@@ -150,6 +150,10 @@ int  rgx_table_merge(const rgx_junction_table *const *parts, int n_parts, uint32
 size_t rgx_table_pack(const rgx_junction_table *t, void *dst, size_t dst_cap); /* returns bytes needed */
 int    rgx_table_unpack(const void *src, size_t n_rows, const rgx_junction_table *names_from,
                         rgx_junction_table **out);
+/* -b across shards: fills merged->bc_* from the shards' tables (every one extracted with barcodes = 1; shard order = file order).  A junction's
+ * barcodes are the shards' lists one after the other in first-seen order, equal strings summed, handed to the container the reference keeps
+ * (junctions_extractor.cc:204-217, h:99-111).  rgx_table_merge and rgx_extract_multi call it themselves. */
+int    rgx_table_merge_barcodes(const rgx_junction_table *const *parts, int n_parts, rgx_junction_table *merged, char *err, size_t errlen);
 /* rgx_table_pack without the host: t must be the result of the LAST rgx_extract / rgx_extract_mem / rgx_extract_device call on this
  * context (its rows are then still in HBM; anything else is RGX_ERR_ARG and the caller packs on the host).  Writes t->n packed rows
  * to device memory at d_dst -- the all-gather input of the multi-GPU path. */

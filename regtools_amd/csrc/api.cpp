@@ -330,7 +330,6 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
                           bool allow_overlap = true) {
     if (!p || p->strandness < 0 || p->strandness > 3) return fail(err, errlen, RGX_ERR_ARG, "Please supply strandness mode with '-s' option!\n\n");
     if (p->strandness == 3 && !p->fasta_path) return fail(err, errlen, RGX_ERR_ARG, "Strandness mode 'intron-motif' requires a fasta file!\n\n");
-    if (p->barcodes && p->n_shards > 1) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: barcode counts (-b) need the whole file in one shard\n");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const double t_begin = now_ms();
@@ -1278,6 +1277,68 @@ extern "C" int rgx_table_unpack(const void *src, size_t n_rows, const rgx_juncti
     return RGX_OK;
 }
 
+// -b across shards.  A junction's barcode map (junctions_extractor.h:58, cc:204-217) only depends on the sequence in which DISTINCT barcodes
+// first reach it (a repeat bumps a count, it never moves a node): shard order is file order and bc_insert_rank keeps the order inside a shard,
+// so the merged junction's sequence is the shards' sequences one after the other minus the barcodes already seen -- fed, as in barcode_rows, to
+// the container the reference keeps, whose iteration order is the order print_barcodes writes (h:99-111).
+extern "C" int rgx_table_merge_barcodes(const rgx_junction_table *const *parts, int n_parts, rgx_junction_table *t, char *err, size_t errlen) {
+    if (!parts || n_parts <= 0 || !t) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: nothing to merge\n");
+    for (int g = 0; g < n_parts; ++g) if (!parts[g] || !parts[g]->bc_row_begin) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: shard %d carries no barcode counts\n", g);
+    auto cls = [](char c) { return c == '+' ? 0u : c == '-' ? 1u : 2u; };
+    struct Key { int32_t tid; uint32_t start, end, cls; bool operator==(const Key &o) const { return tid == o.tid && start == o.start && end == o.end && cls == o.cls; } };
+    struct KeyHash { size_t operator()(const Key &k) const { uint64_t h = (uint64_t)(uint32_t)k.tid * 0x9e3779b97f4a7c15ull ^ ((uint64_t)k.start << 32 | k.end) * 0xc2b2ae3d27d4eb4full ^ k.cls; return (size_t)(h ^ h >> 29); } };
+    std::unordered_map<Key, uint64_t, KeyHash> row_of;
+    row_of.reserve((size_t)t->n * 2 + 16);
+    for (uint64_t i = 0; i < t->n; ++i) row_of[Key{t->tid[i], t->start[i], t->end[i], cls(t->strand[i])}] = i;
+    struct Ent { const char *s; uint32_t len; uint32_t count; };
+    std::vector<std::vector<Ent>> per_row((size_t)t->n);
+    std::vector<uint64_t> order;
+    for (int g = 0; g < n_parts; ++g) {
+        const rgx_junction_table *p = parts[g];
+        for (uint64_t i = 0; i < p->n; ++i) {
+            auto it = row_of.find(Key{p->tid[i], p->start[i], p->end[i], cls(p->strand[i])});
+            if (it == row_of.end()) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: a shard row is missing from the merged table (shard %d row %llu: tid %d %u-%u '%c'; merged rows %llu)\n", g, (unsigned long long)i, p->tid[i], p->start[i], p->end[i], p->strand[i], (unsigned long long)t->n);
+            std::vector<Ent> &dst = per_row[(size_t)it->second];
+            const uint64_t b = p->bc_row_begin[i], e = p->bc_row_begin[i + 1];
+            order.assign(e - b, 0);
+            for (uint64_t k = b; k < e; ++k) order[p->bc_insert_rank[k]] = k;                     // the shard's first-seen order
+            for (uint64_t k : order) {
+                const char *str = p->bc_text + p->bc_str_begin[k];
+                const uint32_t len = (uint32_t)(p->bc_str_begin[k + 1] - p->bc_str_begin[k]);
+                bool found = false;
+                if (dst.size() > 16) {                                                            // many barcodes on one junction: a set, not a scan
+                    // (built lazily per call site would cost more than it saves for the common few-barcode rows)
+                    for (Ent &x : dst) if (x.len == len && !memcmp(x.s, str, len)) { x.count += p->bc_count[k]; found = true; break; }
+                } else for (Ent &x : dst) if (x.len == len && !memcmp(x.s, str, len)) { x.count += p->bc_count[k]; found = true; break; }
+                if (!found) dst.push_back(Ent{str, len, p->bc_count[k]});
+            }
+        }
+        if (p->stream_ended) break;          // upstream reads nothing behind the point where the record stream ended
+    }
+    size_t n_pairs = 0, text_len = 0;
+    for (auto &v : per_row) { n_pairs += v.size(); for (auto &x : v) text_len += x.len; }
+    free(t->bc_row_begin); free(t->bc_count); free(t->bc_str_begin); free(t->bc_text); free(t->bc_insert_rank);
+    t->bc_row_begin = (uint64_t *)calloc((size_t)t->n + 1, 8);
+    t->bc_count = (uint32_t *)calloc(n_pairs + 1, 4);
+    t->bc_str_begin = (uint64_t *)calloc(n_pairs + 1, 8);
+    t->bc_text = (char *)malloc(text_len + 1);
+    t->bc_insert_rank = (uint32_t *)calloc(n_pairs + 1, 4);
+    uint64_t o = 0, pos = 0;
+    for (uint64_t r = 0; r < t->n; ++r) {
+        t->bc_row_begin[r] = o;
+        const std::vector<Ent> &v = per_row[(size_t)r];
+        std::unordered_map<std::string, int> m;                                                    // the reference's container
+        for (size_t k = 0; k < v.size(); ++k) m.insert(std::pair<std::string, int>(std::string(v[k].s, v[k].len), (int)k));
+        for (auto it = m.begin(); it != m.end(); ++it, ++o) {
+            const Ent &x = v[(size_t)it->second];
+            t->bc_count[o] = x.count; t->bc_insert_rank[o] = (uint32_t)it->second; t->bc_str_begin[o] = pos;
+            memcpy(t->bc_text + pos, x.s, x.len); pos += x.len;
+        }
+    }
+    t->bc_row_begin[t->n] = o; t->bc_str_begin[n_pairs] = pos;
+    return RGX_OK;
+}
+
 extern "C" int rgx_table_merge(const rgx_junction_table *const *parts, int n_parts, uint32_t min_anchor, rgx_junction_table **out, char *err, size_t errlen) {
     if (n_parts <= 0 || !parts || !parts[0]) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: nothing to merge\n");
     struct Row { int32_t tid; uint32_t start, end, ts, te, cnt; uint64_t first, last; char strand; };
@@ -1331,6 +1392,9 @@ extern "C" int rgx_table_merge(const rgx_junction_table *const *parts, int n_par
         t->n_records += parts[g]->n_records; t->n_events += parts[g]->n_events; t->inflated_bytes += parts[g]->inflated_bytes;
         t->compressed_bytes = parts[g]->compressed_bytes; t->n_members += parts[g]->n_members;
     }
+    bool all_bc = true;
+    for (int g = 0; g < n_parts; ++g) if (!parts[g]->bc_row_begin) all_bc = false;
+    if (all_bc) { const int rc = rgx_table_merge_barcodes(parts, n_parts, t, err, errlen); if (rc != RGX_OK) { rgx_table_free(t); return rc; } }
     *out = t;
     return RGX_OK;
 }

@@ -91,28 +91,8 @@ int junctions_extract(int argc, char **argv) {
         if (const char *d = getenv("REGTOOLS_AMD_DEVICES")) {
             for (const char *q = d; *q;) { char *e; long v = strtol(q, &e, 10); if (e == q) break; devices.push_back((int)v); q = *e == ',' ? e + 1 : e; if (*e && *e != ',') break; }
         }
-        if (devices.size() > 1 && o.barcodes == "NA") {
-            rgx_extract_params p;
-            rgx_extract_params_default(&p);
-            p.region = o.region.c_str(); p.strandness = o.strandness;
-            p.strand_tag[0] = o.tag.size() > 0 ? o.tag[0] : 0; p.strand_tag[1] = o.tag.size() > 1 ? o.tag[1] : 0;
-            p.min_anchor = o.min_anchor; p.min_intron = o.min_intron; p.max_intron = o.max_intron;
-            p.fasta_path = o.ref == "NA" ? nullptr : o.ref.c_str();
-            rgx_junction_table *t = nullptr;
-            if (rgx_extract_multi(devices.data(), (int)devices.size(), o.bam.c_str(), &p, &t, err, sizeof err) != RGX_OK) throw std::runtime_error(err);
-            size_t n = rgx_table_format_bed12(t, 1, nullptr, 0);
-            std::vector<char> text(n + 1);
-            rgx_table_format_bed12(t, 1, text.data(), n);
-            FILE *f = o.output == "NA" ? stdout : fopen(o.output.c_str(), "w");
-            if (f) { fwrite(text.data(), 1, n, f); if (f != stdout) fclose(f); }
-            if (getenv("REGTOOLS_AMD_STATS"))
-                fprintf(stderr, "[regtools_amd] devices=%zu records=%llu events=%llu junctions=%llu\n", devices.size(), (unsigned long long)t->n_records,
-                        (unsigned long long)t->n_events, (unsigned long long)t->n);
-            rgx_table_free(t);
-            return 0;
-        }
         if (devices.size() == 1) o.device = devices[0];
-        if (rgx_ctx_create(o.device, &ctx, err, sizeof err) != RGX_OK) throw std::runtime_error(err);
+        if (devices.size() <= 1 && rgx_ctx_create(o.device, &ctx, err, sizeof err) != RGX_OK) throw std::runtime_error(err);
         rgx_extract_params p;
         rgx_extract_params_default(&p);
         p.region = o.region.c_str(); p.strandness = o.strandness;
@@ -121,8 +101,9 @@ int junctions_extract(int argc, char **argv) {
         p.fasta_path = o.ref == "NA" ? nullptr : o.ref.c_str();
         p.barcodes = o.barcodes != "NA";                                   // -b (junctions_extractor.cc:82-84, :393-395)
         rgx_junction_table *t = nullptr;
-        int rc = rgx_extract(ctx, o.bam.c_str(), &p, &t, err, sizeof err);
-        if (rc != RGX_OK) { rgx_ctx_destroy(ctx); throw std::runtime_error(err); }
+        int rc = devices.size() > 1 ? rgx_extract_multi(devices.data(), (int)devices.size(), o.bam.c_str(), &p, &t, err, sizeof err)
+                                    : rgx_extract(ctx, o.bam.c_str(), &p, &t, err, sizeof err);
+        if (rc != RGX_OK) { if (ctx) rgx_ctx_destroy(ctx); throw std::runtime_error(err); }
         size_t n = rgx_table_format_bed12(t, 1, nullptr, 0);
         std::vector<char> text(n + 1);
         rgx_table_format_bed12(t, 1, text.data(), n);
@@ -141,7 +122,7 @@ int junctions_extract(int argc, char **argv) {
                     (unsigned long long)t->n_records, (unsigned long long)t->n_events, (unsigned long long)t->n, t->ms_inflate, t->ms_records,
                     t->ms_scan, t->ms_reduce, t->ms_total);
         rgx_table_free(t);
-        rgx_ctx_destroy(ctx);
+        if (ctx) rgx_ctx_destroy(ctx);
     } catch (const HelpRequested &h) {
         std::cerr << h.text;
         return 0;

@@ -46,6 +46,9 @@ unsigned usable_threads(unsigned cap) {
             if (fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (q + per - 1) / per));
             fclose(f);
         }
+        // one process per GPU (torchrun): the node's cores are shared by the ranks on it
+        for (const char *name : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"})
+            if (const char *e = getenv(name)) { const int w = atoi(e); if (w > 1) { hw = std::max(1u, hw / (unsigned)w); break; } }
         return hw;
     }();
     return std::max(1u, std::min(limit, cap));

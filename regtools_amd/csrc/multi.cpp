@@ -21,6 +21,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <set>
 #include <thread>
 #include <vector>
@@ -68,8 +70,8 @@ Rccl g_rccl;
 const int kNcclUint8 = 1;
 
 struct Shard {
-    int device = 0;
-    rgx_ctx *ctx = nullptr;
+    int device = 0, nth = 0;                 // nth: which of the listings of this device
+    rgx_ctx *ctx = nullptr;                  // (owned by the process-wide cache)
     rgx_junction_table *table = nullptr;
     void *d_send = nullptr, *d_recv = nullptr;
     hipStream_t stream = nullptr;
@@ -77,6 +79,20 @@ struct Shard {
     int rc = RGX_OK;
     char err[512] = {0};
 };
+
+// Contexts are kept for the life of the process, one per (device, how many times the device is listed): a second call finds its HBM
+// workspace, streams and page-locked staging where the first left them (a context's first extraction allocates ~13 GB for a 50 M-read shard).
+std::mutex g_ctx_mu;
+std::map<std::pair<int, int>, rgx_ctx *> g_ctx;
+rgx_ctx *context_for(int device, int nth, char *err, size_t errlen, int &rc) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto it = g_ctx.find({device, nth});
+    if (it != g_ctx.end()) { rc = RGX_OK; return it->second; }
+    rgx_ctx *c = nullptr;
+    rc = rgx_ctx_create(device, &c, err, errlen);
+    if (rc == RGX_OK) g_ctx[{device, nth}] = c;
+    return c;
+}
 
 void release(std::vector<Shard> &S) {
     for (Shard &s : S) {
@@ -86,7 +102,6 @@ void release(std::vector<Shard> &S) {
         if (s.d_recv) (void)hipFree(s.d_recv);
         if (s.stream) (void)hipStreamDestroy(s.stream);
         if (s.table) rgx_table_free(s.table);
-        if (s.ctx) rgx_ctx_destroy(s.ctx);
     }
 }
 
@@ -96,18 +111,17 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
                                      const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen) {
     if (!devices || n_devices <= 0 || n_devices > 255 || !bam || !out || !p) return failm(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
     if (p->n_shards > 1) return failm(err, errlen, RGX_ERR_ARG, "regtools_amd: rgx_extract_multi shards the file itself\n");
-    if (p->barcodes && n_devices > 1) return failm(err, errlen, RGX_ERR_ARG, "regtools_amd: barcode counts (-b) need the whole file in one shard\n");
     *out = nullptr;
     const int n = n_devices;
     std::vector<Shard> S((size_t)n);
     struct Guard { std::vector<Shard> &s; ~Guard() { release(s); } } guard{S};
     const bool distinct = std::set<int>(devices, devices + n).size() == (size_t)n;
-    for (int g = 0; g < n; ++g) S[(size_t)g].device = devices[g];
+    { std::map<int, int> seen; for (int g = 0; g < n; ++g) { S[(size_t)g].device = devices[g]; S[(size_t)g].nth = seen[devices[g]]++; } }
 
     // -- one extraction per shard: a thread per device (shards that share a device take turns on it) -------------------------------------
     auto extract = [&](int g) {
         Shard &s = S[(size_t)g];
-        s.rc = rgx_ctx_create(s.device, &s.ctx, s.err, sizeof s.err);
+        s.ctx = context_for(s.device, s.nth, s.err, sizeof s.err, s.rc);
         if (s.rc != RGX_OK) return;
         rgx_extract_params q = *p;
         q.shard = g; q.n_shards = n;
@@ -171,6 +185,8 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
         for (int g = 0; g < n; ++g)
             if (hipMemcpyPeer((uint8_t *)S[0].d_recv + (size_t)g * block, S[0].device, S[(size_t)g].d_send, S[(size_t)g].device, block) != hipSuccess)
                 return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: row copy from device %d failed\n", S[(size_t)g].device);
+        // a device-to-device copy may return before it is done, and the merge runs on the context's own (non-blocking) stream
+        if (hipDeviceSynchronize() != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: the row copies did not complete\n");
     }
 
     // -- merge on the first device.  A shard whose record stream ENDED (a member that does not inflate, an unreadable record) hides the
@@ -189,6 +205,12 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
         if (t->stream_ended) { m->stream_ended = 1; break; }
     }
     m->compressed_bytes = bam_len;
+    if (p->barcodes) {          // -b: the shards' per-junction barcode lists, one after the other in file order (api.cpp rgx_table_merge_barcodes)
+        std::vector<const rgx_junction_table *> parts((size_t)n);
+        for (int g = 0; g < n; ++g) parts[(size_t)g] = S[(size_t)g].table;
+        rc = rgx_table_merge_barcodes(parts.data(), n, m, err, errlen);
+        if (rc != RGX_OK) { rgx_table_free(m); return rc; }
+    }
     *out = m;
     return RGX_OK;
 }

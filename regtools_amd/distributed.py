@@ -31,6 +31,15 @@ class MergedTable(object):
         lib.rgx_table_format_bed12(self._table, 1 if only_anchored else 0, buf, n)
         return buf.raw[:n]
 
+    def barcodes_text(self, only_anchored=True):
+        """Junction::print_barcodes per printed row (junctions_extractor.h:99-111) -- present when the shards were extracted with -b and merged by
+        rgx_table_merge / rgx_extract_multi (rgx_table_merge_barcodes)."""
+        lib = _ffi.lib()
+        n = lib.rgx_table_format_barcodes(self._table, 1 if only_anchored else 0, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib.rgx_table_format_barcodes(self._table, 1 if only_anchored else 0, buf, n)
+        return buf.raw[:n]
+
     def __del__(self):
         try:
             if self._table:

@@ -142,11 +142,7 @@ def test_product_barcode_errors_and_cli(gpu_ctx, tmp_path):
     je = regtools_amd.JunctionsExtractor(bam=bam, strandness=0, ctx=gpu_ctx)          # without -b the tag is never looked at
     je.identify_junctions_from_BAM()
     assert je.get_barcodes() == [[] for _ in je.get_all_junctions()] and je.barcodes_text(False) == b"0\t\n" * len(je.get_all_junctions())
-    # shards: the barcode pass needs the whole file
     good = os.path.join(bc.GOLD, "few.bam")
-    je = regtools_amd.JunctionsExtractor(bam=good, strandness=0, ctx=gpu_ctx, output_barcodes_file="x", shard=0, n_shards=2)
-    with pytest.raises(regtools_amd.RegtoolsError):
-        je.identify_junctions_from_BAM()
     # a different tag name (barcode_tag_, junctions_extractor.h:182): UB is on ~30 % of the reads
     je = regtools_amd.JunctionsExtractor(bam=good, strandness=0, ctx=gpu_ctx, output_barcodes_file="x", barcode_tag="UB")
     je.identify_junctions_from_BAM()
@@ -163,3 +159,59 @@ def test_product_barcode_errors_and_cli(gpu_ctx, tmp_path):
     assert r.returncode == 0
     n = open(tmp_path / "i.bed").read().count("\n")
     assert n > 0 and open(tmp_path / "i.bc").read() == "0\t\n" * n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,args", ALL, ids=IDS)
+def test_barcodes_across_shards_equal_the_reference(gpu_ctx, tmp_path, name, args):
+    """-b with the file cut into shards (rgx_extract_multi; rgx_table_merge_barcodes): a junction's barcode map only depends on the order in
+    which distinct barcodes first reach it, shard order is file order -- the two output files must be the reference's for any shard count."""
+    import regtools_amd
+    je = regtools_amd.JunctionsExtractor(ctx=gpu_ctx)
+    je.parse_options(list(args) + ["-b", str(tmp_path / "x.bc"), os.path.join(bc.GOLD, name + ".bam")])
+    kw = dict(strandness=je.strandness_, strand_tag=je.strand_tag_, min_anchor_length=je.min_anchor_length_, min_intron_length=je.min_intron_length_,
+              max_intron_length=je.max_intron_length_, region=je.region_, output_barcodes_file="x", barcode_tag=je.barcode_tag_)
+    for devs in ([0, 0], [0, 0, 0, 0, 0]):
+        m = regtools_amd.extract_multi(devs, bam=os.path.join(bc.GOLD, name + ".bam"), **kw)
+        assert m.bed12() == golden(name, args, "bed"), devs
+        assert m.barcodes_text() == golden(name, args, "barcodes"), devs
+
+
+@pytest.mark.gpu
+def test_barcodes_across_shards_of_a_larger_file(gpu_ctx, tmp_path):
+    """Shard cuts that really split junctions' supporting reads: a synthetic file with CB tags from a pool, 1 / 2 / 7 shards, host merge
+    (rgx_table_merge over shard tables) and rgx_extract_multi; all equal the single-shard output, which equals the oracle's."""
+    import regtools_amd
+    from regtools_amd import distributed
+    rnd = random.Random(5)
+    pool = ["".join(rnd.choice("ACGT") for _ in range(16)) + "-1" for _ in range(400)]
+    recs = []
+    for k in range(60000):
+        j = rnd.randrange(40)
+        aux = bamio.tagA("XS", "+-"[j % 2]) + (bamio.tagZ("CB", rnd.choice(pool)) if rnd.random() < 0.9 else b"")
+        recs.append((1000 + 50 * j + rnd.randrange(30), bamio.record(0, 1000 + 50 * j + rnd.randrange(30), "%dM%dN%dM" % (20 + rnd.randrange(10), 300 + 10 * j, 25), qname="q%05d" % k, aux=aux)))
+    recs.sort(key=lambda r: r[0])
+    bam = str(tmp_path / "cb.bam")
+    bamio.write_bam(bam, [("chrC", 1000000)], [r for _, r in recs], block=3000)
+    from regtools_amd import synth
+    synth.index(bam)
+    bed, bcs, _ = gpu_extract_b(gpu_ctx, bam, ["-s", "XS"], tmp_path)
+    r = subprocess.run([ORACLE, "extract", "-s", "XS", "-o", str(tmp_path / "o.bed"), "-b", str(tmp_path / "o.bc"), bam], capture_output=True)
+    assert r.returncode == 0 and bed == open(tmp_path / "o.bed", "rb").read() and bcs == open(tmp_path / "o.bc", "rb").read()
+    assert max(int(l.split(b"\t")[0]) for l in bcs.splitlines()) > 30
+    for devs in ([0, 0], [0] * 7):
+        m = regtools_amd.extract_multi(devs, bam=bam, strandness=0, output_barcodes_file="x")
+        assert m.bed12() == bed and m.barcodes_text() == bcs, devs
+    # the host merge of shard tables (what a multi-process driver without a device merge would call)
+    parts = []
+    for g in range(3):
+        je = regtools_amd.JunctionsExtractor(bam=bam, strandness=0, ctx=gpu_ctx, output_barcodes_file="x", shard=g, n_shards=3)
+        je.identify_junctions_from_BAM()
+        parts.append(je)
+    L = regtools_amd._ffi.lib()
+    ptrs = (ctypes.POINTER(regtools_amd._ffi.JunctionTable) * 3)(*[p.table for p in parts])
+    out = ctypes.POINTER(regtools_amd._ffi.JunctionTable)()
+    err = ctypes.create_string_buffer(256)
+    assert L.rgx_table_merge(ptrs, 3, 8, ctypes.byref(out), err, len(err)) == 0, err.value
+    m = distributed.MergedTable(out)
+    assert m.bed12() == bed and m.barcodes_text() == bcs

@@ -480,8 +480,11 @@ def test_multi_device_host_equals_single_gpu(gpu_ctx, synth_dir):
     env = dict(os.environ, REGTOOLS_AMD_DEVICES=",".join(str(d) for d in lists[-1]))
     r = subprocess.run([os.path.join(ROOT, "bin", "regtools-amd"), "junctions", "extract", "-s", "XS", "-o", out, p], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0 and open(out, "rb").read() == single
-    with pytest.raises(regtools_amd.RegtoolsError):
-        regtools_amd.extract_multi([0, 0], bam=p, strandness=0, output_barcodes_file="x.tsv")      # -b needs one shard
+    # -b across shards (rgx_table_merge_barcodes; tests/test_barcodes.py has the files with real CB tags): no tag here, every map is {"?": count}
+    jb = regtools_amd.JunctionsExtractor(bam=p, strandness=0, ctx=gpu_ctx, output_barcodes_file="x.tsv")
+    jb.identify_junctions_from_BAM()
+    mb = regtools_amd.extract_multi([0, 0, 0], bam=p, strandness=0, output_barcodes_file="x.tsv")
+    assert mb.bed12() == single and mb.barcodes_text() == jb.barcodes_text() and mb.barcodes_text().count(b"\n") == single.count(b"\n")
 
 
 def test_full_size_long_read_properties(gpu_ctx):
