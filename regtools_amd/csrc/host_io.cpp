@@ -62,11 +62,16 @@ bool scan_members_parallel(const uint8_t *bam, size_t len, int threads, std::vec
     out.clear(); total_inflated = 0;
     if (len < 28 || !host_magic_at(bam)) return false;
     int T = threads < 1 ? 1 : threads;
-    if ((size_t)T > len / (1u << 20) + 1) T = (int)(len / (1u << 20) + 1);          // not worth a thread per few members
-    std::vector<size_t> start((size_t)T + 1, len);
+    // The walk is a chain of dependent cache misses (BSIZE of one member names the next): every thread walks several chains in turn, so that a
+    // core keeps as many misses in flight as a dozen threads would -- the ranks of a multi-GPU job share the host's cores.
+    const int kChains = 8;
+    size_t n_seg = (size_t)T * kChains;
+    if (n_seg > len / (1u << 19) + 1) n_seg = len / (1u << 19) + 1;           // not worth a chain per few members
+    if ((size_t)T > n_seg) T = (int)n_seg;
+    std::vector<size_t> start(n_seg + 1, len);
     start[0] = 0;
-    for (int t = 1; t < T; ++t) {
-        size_t p = std::max(start[(size_t)t - 1] + 1, (size_t)((double)len * t / T));
+    for (size_t t = 1; t < n_seg; ++t) {
+        size_t p = std::max(start[t - 1] + 1, (size_t)((double)len * (double)t / (double)n_seg));
         size_t found = len;
         while (p + 18 <= len) {
             const uint8_t *q = (const uint8_t *)memchr(bam + p, 31, len - 18 - p + 1);
@@ -74,39 +79,46 @@ bool scan_members_parallel(const uint8_t *bam, size_t len, int threads, std::vec
             if (host_magic_at(q)) { found = (size_t)(q - bam); break; }
             p = (size_t)(q - bam) + 1;
         }
-        start[(size_t)t] = found;
+        start[t] = found;
     }
-    std::vector<std::vector<Member>> part((size_t)T);
-    std::vector<char> ok((size_t)T, 0);
+    std::vector<std::vector<Member>> part(n_seg);
+    std::vector<char> ok(n_seg, 0);
     auto walk = [&](int t) {
-        size_t off = start[(size_t)t];
-        const size_t end = start[(size_t)t + 1];
-        std::vector<Member> &v = part[(size_t)t];
-        v.reserve((end - off) / 2048 + 16);
-        while (off < end) {
-            if (len - off < 18 || !host_magic_at(bam + off)) return;
-            const size_t blen = (size_t)h16(bam + off + 16) + 1;
-            if (blen < 26 || off + blen > len) return;
-            Member m; m.cpos = off + 18; m.upos = 0; m.isize = h32(bam + off + blen - 4);
-            if (m.isize > kBgzfMaxBlock) return;
-            m.clen = (uint32_t)(blen - 18);
-            if (m.cpos + m.clen + 8 > len) m.clen = len > m.cpos + 8 ? (uint32_t)(len - 8 - m.cpos) : 0;      // as k_member_compact
-            v.push_back(m);
-            off += blen;
+        const size_t s0 = n_seg * (size_t)t / (size_t)T, s1 = n_seg * ((size_t)t + 1) / (size_t)T;
+        std::vector<size_t> off(s1 - s0);
+        std::vector<char> live(s1 - s0, 1);
+        for (size_t k = s0; k < s1; ++k) { off[k - s0] = start[k]; part[k].reserve((start[k + 1] - start[k]) / 2048 + 16); if (start[k] >= start[k + 1]) { live[k - s0] = 0; ok[k] = start[k] == start[k + 1]; } }
+        for (size_t alive = 1; alive;) {
+            alive = 0;
+            for (size_t k = s0; k < s1; ++k) {
+                if (!live[k - s0]) continue;
+                const size_t o = off[k - s0], end = start[k + 1];
+                if (len - o < 18 || !host_magic_at(bam + o)) { live[k - s0] = 0; continue; }
+                const size_t blen = (size_t)h16(bam + o + 16) + 1;
+                if (blen < 26 || o + blen > len) { live[k - s0] = 0; continue; }
+                Member m; m.cpos = o + 18; m.upos = 0; m.isize = h32(bam + o + blen - 4);
+                if (m.isize > kBgzfMaxBlock) { live[k - s0] = 0; continue; }
+                m.clen = (uint32_t)(blen - 18);
+                if (m.cpos + m.clen + 8 > len) m.clen = len > m.cpos + 8 ? (uint32_t)(len - 8 - m.cpos) : 0;      // as k_member_compact
+                part[k].push_back(m);
+                const size_t nx = o + blen;
+                off[k - s0] = nx;
+                if (nx >= end) { live[k - s0] = 0; ok[k] = nx == end; }
+                else { __builtin_prefetch(bam + nx + 16); ++alive; }
+            }
         }
-        ok[(size_t)t] = off == end;
     };
     std::vector<std::thread> pool;
     for (int t = 1; t < T; ++t) pool.emplace_back(walk, t);
     walk(0);
     for (auto &th : pool) th.join();
     size_t n = 0;
-    for (int t = 0; t < T; ++t) { if (!ok[(size_t)t]) return false; n += part[(size_t)t].size(); }
+    for (size_t t = 0; t < n_seg; ++t) { if (!ok[t]) return false; n += part[t].size(); }
     if (n == 0 || n >= 0xfffffff0u) return false;
     out.reserve(n + 1);
     uint64_t up = 0;
-    for (int t = 0; t < T; ++t)
-        for (Member m : part[(size_t)t]) { m.upos = up; up += m.isize; out.push_back(m); }
+    for (size_t t = 0; t < n_seg; ++t)
+        for (Member m : part[t]) { m.upos = up; up += m.isize; out.push_back(m); }
     total_inflated = up;
     return true;
 }

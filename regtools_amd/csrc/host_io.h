@@ -22,8 +22,9 @@ void walk_members(const uint8_t *bam, size_t len, std::vector<HostMember> &out);
 unsigned usable_threads(unsigned cap);
 
 // The member list of a WELL-FORMED file, found by several host threads at once (the upload of the file to the device runs meanwhile):
-// thread t starts at the first BGZF header at or after byte t * len / T and walks the BSIZE chain (bgzf.c:525); every walk must end
-// exactly where the next one started and the last one at the end of the file, every member must carry the header of bgzf.c:348-355, a
+// chain k starts at the first BGZF header at or after byte k * len / K and walks the BSIZE chain (bgzf.c:525), every thread several chains in
+// turn (memory-level parallelism without more threads); every walk must end exactly where the next one started and the last one at the end of
+// the file, every member must carry the header of bgzf.c:348-355, a
 // BSIZE of at least 26 and an ISIZE of at most 64 KiB.  Anything else -- false = the caller falls back to the device's member discovery,
 // which knows what the reference does with damaged files.  Members come out as the device kernels build them (k_member_compact).
 bool scan_members_parallel(const uint8_t *bam, size_t len, int threads, std::vector<Member> &out, uint64_t &total_inflated);

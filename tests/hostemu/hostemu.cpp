@@ -111,3 +111,12 @@ extern "C" int emu_host_header(const uint8_t *bam, size_t n, char *first_name, s
     if (!h.names.empty() && cap) { strncpy(first_name, h.names[0].c_str(), cap - 1); first_name[cap - 1] = 0; }
     return (int)h.names.size();
 }
+
+// the host's parallel BGZF member scan (host_io.cpp scan_members_parallel: what rgx_extract_mem's overlapped upload launches from): number of
+// members and total inflated size, or -1 when the file is not one the scan vouches for; members[k] = {cpos, upos, clen, isize} as 4 x u64
+extern "C" long emu_scan_members(const uint8_t *bam, size_t n, int threads, uint64_t *members, size_t cap, uint64_t *total) {
+    std::vector<rgx::Member> m;
+    if (!rgx::scan_members_parallel(bam, n, threads, m, *total)) return -1;
+    for (size_t k = 0; k < m.size() && k < cap; ++k) { members[4 * k] = m[k].cpos; members[4 * k + 1] = m[k].upos; members[4 * k + 2] = m[k].clen; members[4 * k + 3] = m[k].isize; }
+    return (long)m.size();
+}

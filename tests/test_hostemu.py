@@ -202,3 +202,36 @@ def test_ring_decoder_every_destination_phase_and_window_edge(emu):
                 n = ctypes.c_uint32(0)
                 st = emu.emu_inflate_ring(p, len(p), out, len(data), ctypes.byref(n), phase)
                 assert st == 0 and out.raw[:n.value] == data, (dist, total, phase, st)
+
+
+def test_parallel_member_scan_equals_the_serial_walk(emu):
+    """scan_members_parallel (the member list rgx_extract_mem launches the inflate from while the file is still uploading): for a well-formed
+    file exactly the BSIZE chain from offset 0, for any thread count; for a file that is not (cut inside a member, bytes appended, a member's
+    header damaged, an oversized ISIZE) it must say no -- the device's member discovery then decides what the reference would do."""
+    from regtools_amd import synth
+    emu.emu_scan_members.restype = ctypes.c_long
+    emu.emu_scan_members.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
+
+    def scan(data, threads):
+        cap = 200000
+        arr = (ctypes.c_uint64 * (4 * cap))()
+        total = ctypes.c_uint64(0)
+        n = emu.emu_scan_members(data, len(data), threads, arr, cap, ctypes.byref(total))
+        return n, [tuple(arr[4 * k: 4 * k + 4]) for k in range(max(n, 0))], total.value
+    for shape, n_reads in (("short", 400000), ("fuzz", 30000), ("long", 3000)):
+        bam, _, _ = synth.generate(n_reads, shape=shape, seed=3)
+        want, up = [], 0
+        for off, payload, isize in bamio.bgzf_members(bam):                    # (the empty EOF member included)
+            want.append((off + 18, up, len(payload) + 8, isize)); up += isize
+        for threads in (1, 2, 3, 7, 24):
+            n, got, total = scan(bam, threads)
+            assert n == len(got) and total == up
+            assert [(c, u, i) for c, u, _, i in got] == [(c, u, i) for c, u, _, i in want]
+            assert all(cl <= len(bam) - 8 - c for c, _, cl, _ in got)
+        assert scan(bam[:-40], 4)[0] == -1 and scan(bam[:len(bam) // 2], 4)[0] == -1          # cut inside a member
+        assert scan(bam + b"\0" * 100, 4)[0] == -1                                             # bytes behind the last member
+        k = got[len(got) // 2][0] - 18
+        assert scan(bam[:k] + b"\x1e" + bam[k + 1:], 4)[0] == -1                               # a header that is not one
+        big = got[len(got) // 3]
+        foot = big[0] + big[2] - 4                                                              # ISIZE footer of that member
+        assert scan(bam[:foot] + (70000).to_bytes(4, "little") + bam[foot + 4:], 4)[0] == -1   # claims more than a BGZF block holds
