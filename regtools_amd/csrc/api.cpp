@@ -70,14 +70,15 @@ struct DevBuf {
 
 }  // namespace
 
+constexpr int kSideStreams = 6;
 struct rgx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     // host input (rgx_extract_mem / rgx_extract): the file goes up in chunks on its own stream while the members that have arrived are
     // being inflated on the side streams (prepare_events)
-    hipStream_t copy_stream = nullptr, side[2] = {};
+    hipStream_t copy_stream = nullptr, side[kSideStreams] = {};
     std::vector<hipEvent_t> chunk_ev;
-    hipEvent_t ev_ready = nullptr, ev_side[2] = {};
+    hipEvent_t ev_ready = nullptr, ev_side[kSideStreams] = {};
     hipEvent_t ev[8] = {};
     std::map<std::string, DevBuf> bufs;
     void *pinned = nullptr; size_t pinned_cap = 0;     // small pinned staging for scalar readbacks
@@ -133,7 +134,13 @@ extern "C" int rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errle
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    for (auto &q : c->side) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+    {
+        // the runtime maps the streams of one priority onto four hardware queues; streams of another priority come from another pool of queues
+        int pr_least = 0, pr_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+        const int prio[kSideStreams] = {0, 0, pr_greatest, pr_greatest, pr_least, pr_least};
+        for (int k = 0; k < kSideStreams; ++k) HIP_TRY(hipStreamCreateWithPriority(&c->side[k], hipStreamNonBlocking, prio[k]));
+    }
     HIP_TRY(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
     for (auto &e : c->ev_side) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
@@ -370,9 +377,13 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             // runtime maps streams onto four hardware queues -- more pieces would queue behind each other, not overlap (profiles/r02_overlap_timeline.txt)
             // (equal thirds measured best: 31.6 ms per step against 32.4-33.3 ms for pieces that shrink towards the end -- the concurrent launches
             // share the chip; REGTOOLS_AMD_PIECES="33,67" = the cuts in % for experiments)
-            unsigned cut1 = 33, cut2 = 67;
-            if (const char *e = getenv("REGTOOLS_AMD_PIECES")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a > 0 && a < b && b < 100) { cut1 = a; cut2 = b; } }
-            for (unsigned pc : {cut1, cut2}) {
+            std::vector<unsigned> cuts = {33, 67};
+            if (const char *e = getenv("REGTOOLS_AMD_PIECES")) {
+                unsigned a = 0, b = 0;
+                if (sscanf(e, "%u,%u", &a, &b) == 2) { if (a > 0 && a < b && b < 100) cuts = {a, b}; }
+                else if (sscanf(e, "%u", &a) == 1 && a >= 1 && a <= (unsigned)kSideStreams + 1) { cuts.clear(); for (unsigned k = 1; k < a; ++k) cuts.push_back(100 * k / a); }
+            }
+            for (unsigned pc : cuts) {
                 const size_t e = ((size_t)((double)bam_len * pc / 100.0) + 4095) & ~(size_t)4095;
                 if (e < bam_len && (up.end.empty() || e > up.end.back())) up.end.push_back(e);
             }
@@ -615,8 +626,9 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             if (up.err) return fail(err, errlen, RGX_ERR_DEVICE, "regtools_amd: upload failed\n");
             // the pipeline's own stream is idle until the inflate is done: it takes every third piece (the runtime maps streams onto four
             // hardware queues round-robin; a third side stream would share its queue with the second: profiles/r02_overlap_timeline.txt)
-            hipStream_t q = (j % 3 == 2) ? st : c->side[j % 3];
-            if (j % 3 != 2) used_side |= 1u << (j % 3);
+            const bool own = j + 1 == up.end.size() || j >= (size_t)kSideStreams;
+            hipStream_t q = own ? st : c->side[j];
+            if (!own) used_side |= 1u << j;
             HIP_TRY(hipStreamWaitEvent(q, c->chunk_ev[j], 0));
             launch_inflate(d_bam, d_members + g_lo, g_hi - g_lo, b_arena.as<uint8_t>(), upos_lo, (uint32_t *)(b_lens.as<uint8_t>() + scratch_off), d_sc, q, ignore_below, g_lo - m_lo, /*piece=*/true);
             scratch_off += inflate_scratch_bytes(g_hi - g_lo);
@@ -624,7 +636,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         }
         up.th.join();
         if (up.err) return fail(err, errlen, RGX_ERR_DEVICE, "regtools_amd: upload failed\n");
-        for (unsigned k = 0; k < 2; ++k) if (used_side >> k & 1) { HIP_TRY(hipEventRecord(c->ev_side[k], c->side[k])); HIP_TRY(hipStreamWaitEvent(st, c->ev_side[k], 0)); }
+        for (unsigned k = 0; k < (unsigned)kSideStreams; ++k) if (used_side >> k & 1) { HIP_TRY(hipEventRecord(c->ev_side[k], c->side[k])); HIP_TRY(hipStreamWaitEvent(st, c->ev_side[k], 0)); }
         HIP_TRY(hipStreamWaitEvent(st, c->chunk_ev[up.end.size() - 1], 0));      // (later stages read the file too: barcodes, header)
     }
     HIP_TRY(hipEventRecord(c->ev[1], st));

@@ -304,16 +304,34 @@ std::string GtfModel::load(const std::string &path) {
     return "";
 }
 
-// gzip / bgzip input (hts_open accepts both, hts.c:204-260): host_io's gunzip_all, i.e. the product's own decoder compiled for the host
+// gzip / bgzip input (hts_open accepts both, hts.c:204-260): host_io's gunzip_all, i.e. the product's own decoder compiled for the host.
+// A stream that starts with the BCF magic is a BCF file (bcf_hdr_read vcf.c:788-818, bcf_read1_core :899-926).
 std::string VcfText::load(const std::string &path) {
     if (!slurp(path, text)) return "Unable to open file.\n\n";
     if (text.size() >= 2 && (uint8_t)text[0] == 0x1f && (uint8_t)text[1] == 0x8b) {
         std::string plain;
         std::string e = gunzip_all((const uint8_t *)text.data(), text.size(), plain);
         if (!e.empty()) return e;
-        if (plain.size() >= 3 && !memcmp(plain.data(), "BCF", 3)) return "regtools_amd: BCF input is not supported on this path\n\n";
         text.swap(plain);
     }
+    if (text.size() >= 3 && !memcmp(text.data(), "BCF", 3)) {
+        bcf = true;
+        if (text.size() < 9 || memcmp(text.data(), "BCF\2\2", 5)) return "Unable to read header.\n\n";       // "only BCFv2.2 is supported"
+        uint32_t l_text; memcpy(&l_text, text.data() + 5, 4);
+        if (text.size() - 9 < l_text) return "Unable to read header.\n\n";
+        hdr.parse(std::string(text.data() + 9, strnlen(text.data() + 9, l_text)));
+        if (!hdr.error.empty()) return hdr.error + "\n";
+        size_t o = 9 + (size_t)l_text;
+        while (text.size() - o >= 32) {
+            uint32_t x[4]; memcpy(x, text.data() + o, 16);
+            if (x[0] < 24 || text.size() - o - 8 < (size_t)x[0] + x[1]) break;                     // a record cut short: the read fails, the loop ends
+            const int32_t rid = (int32_t)x[2];
+            recs.push_back({o, rid >= 0 && (size_t)rid < hdr.contig_name.size() ? hdr.contig_name[(size_t)rid] : std::string(), x[3]});
+            o += 8 + (size_t)x[0] + x[1];
+        }
+        return "";
+    }
+    if (text.size() < 16 || memcmp(text.data(), "##fileformat=VCF", 16)) return "Unable to read header.\n\n";      // hts.c:248: nothing else is taken for a VCF
     line_off.reserve(text.size() / 32 + 16);
     size_t p = 0;
     while (p < text.size()) {
@@ -322,20 +340,50 @@ std::string VcfText::load(const std::string &path) {
         p = nl ? (size_t)(nl - text.data()) + 1 : text.size() + 1;
     }
     line_off.push_back(text.size() + (text.empty() || text.back() == '\n' ? 0 : 1));
-    // CHROM and POS of every record line, by several threads over ranges of lines (file order kept: the ranges are concatenated in order)
     const size_t n_lines_ = line_off.size() - 1;
+    // the header: every line up to the first one that does not start with "##" (vcf_hdr_read vcf.c:1242-1286; empty lines are skipped, a line
+    // that does not start with '#' in there means there is no sample line)
+    size_t first_rec_line = n_lines_;
+    {
+        std::string htxt; bool closed = false;
+        for (size_t i = 0; i < n_lines_; ++i) {
+            const char *l; size_t n; line(i, l, n);
+            if (!n) continue;
+            if (l[0] != '#') break;
+            htxt.append(l, n); htxt += '\n';
+            if (n < 2 || l[1] != '#') { closed = true; first_rec_line = i + 1; break; }
+        }
+        if (!closed) return "Unable to read header.\n\n";
+        hdr.parse(htxt);
+        if (!hdr.error.empty()) return hdr.error + "\n";
+    }
+    // CHROM and POS of every record line, by several threads over ranges of lines (file order kept: the ranges are concatenated in order).
+    // vcf_parse refuses a record whose sample columns do not match the header (vcf.c:1551-1556, 1760-1766): the read loop ends there.
+    const size_t n_samples = hdr.samples.size();
     const size_t T = n_lines_ < (1u << 16) ? 1 : usable_threads(16);
     std::vector<std::vector<Rec>> part(T);
+    std::vector<size_t> part_stop(T, SIZE_MAX);
     auto scan = [&](size_t t) {
         std::vector<Rec> &out = part[t];
-        const size_t a = n_lines_ * t / T, b = n_lines_ * (t + 1) / T;
-        out.reserve(b - a);
+        const size_t a = std::max(first_rec_line, n_lines_ * t / T), b = n_lines_ * (t + 1) / T;
+        if (b > a) out.reserve(b - a);
         for (size_t i = a; i < b; ++i) {
             const char *l; size_t n; line(i, l, n);
             if (!n || l[0] == '#') continue;
             const char *t1 = (const char *)memchr(l, '\t', n);
             if (!t1) continue;
             const char *t2 = (const char *)memchr(t1 + 1, '\t', (size_t)(l + n - t1 - 1));
+            if (n_samples && t2) {
+                // columns 9.. : FORMAT and the samples
+                const char *c = t2; int col = 2;
+                while (c && col < 8) { c = (const char *)memchr(c + 1, '\t', (size_t)(l + n - c - 1)); ++col; }
+                if (c) {                                           // c = the tab in front of FORMAT
+                    const char *f_end = (const char *)memchr(c + 1, '\t', (size_t)(l + n - c - 1));
+                    size_t have = 0;
+                    if (f_end) { have = 1; for (const char *q = f_end + 1; q < l + n; ++q) if (*q == '\t') ++have; if (l[n - 1] == '\t') --have; }
+                    if (have < n_samples) { part_stop[t] = i; break; }
+                }
+            }
             std::string ps(t1 + 1, t2 ? (size_t)(t2 - t1 - 1) : (size_t)(l + n - t1 - 1));
             out.push_back({i, std::string(l, (size_t)(t1 - l)), (uint32_t)(atoi(ps.c_str()) - 1)});
         }
@@ -350,7 +398,53 @@ std::string VcfText::load(const std::string &path) {
     else {
         size_t total = 0; for (auto &v : part) total += v.size();
         recs.reserve(total);
-        for (auto &v : part) for (auto &r : v) recs.push_back(std::move(r));
+        for (size_t t = 0; t < T; ++t) { for (auto &r : part[t]) recs.push_back(std::move(r)); if (part_stop[t] != SIZE_MAX) break; }
+    }
+    return "";
+}
+
+bool VcfText::typed(size_t i, VcfHdr &h, VcfRec &r) const {
+    if (bcf) return bcf_parse_record((const uint8_t *)text.data() + recs[i].line, text.size() - recs[i].line, r) != 0;
+    const char *l; size_t n; line(recs[i].line, l, n);
+    return vcf_parse_line(h, l, n, r) == 0;
+}
+
+std::string write_annotated_vcf_records(FILE *fv, const VcfText &vcf, const std::vector<size_t> &todo, const std::function<VcfAnnot(size_t)> &annot) {
+    VcfHdr hdr = vcf.hdr;
+    hdr.append("##INFO=<ID=genes,Number=1,Type=String,Description=\"The Variant falls in the splice region of these genes\">");
+    hdr.append("##INFO=<ID=transcripts,Number=1,Type=String,Description=\"The Variant falls in the splice region of these transcripts\">");
+    hdr.append("##INFO=<ID=distances,Number=1,Type=String,Description=\"Vector of Min(Distance from start/end of exon in the transcript.)\">");
+    hdr.append("##INFO=<ID=annotations,Number=1,Type=String,Description=\"Does the variant fall in exonic/intronic splicing related space in the transcript.\">");
+    { std::string h; hdr.format(h); fwrite(h.data(), 1, h.size(), fv); }
+    // records are independent: ranges of them are re-serialised by several threads, each with its own copy of the dictionary (a name the
+    // header does not declare joins the copy; what is printed is the name), and written in order
+    const size_t T = todo.size() < 4096 ? 1 : usable_threads(16);
+    std::vector<std::string> outs(T), fatal(T);
+    auto work = [&](size_t t) {
+        VcfHdr h = hdr;
+        VcfRec rec;
+        std::string &o = outs[t];
+        static const std::string kNA = "NA";
+        for (size_t k = todo.size() * t / T; k < todo.size() * (t + 1) / T; ++k) {
+            const size_t ri = todo[k];
+            if (!vcf.typed(ri, h, rec)) { if (!h.error.empty()) { fatal[t] = h.error; return; } continue; }
+            const VcfAnnot a = annot(ri);
+            vcf_update_info_string(h, rec, "genes", a.genes ? *a.genes : kNA);
+            vcf_update_info_string(h, rec, "transcripts", a.transcripts ? *a.transcripts : kNA);
+            vcf_update_info_string(h, rec, "distances", a.distances ? *a.distances : kNA);
+            vcf_update_info_string(h, rec, "annotations", a.annotations ? *a.annotations : kNA);
+            vcf_format_line(h, rec, o);
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < T; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool) th.join();
+    }
+    for (size_t t = 0; t < T; ++t) {
+        fwrite(outs[t].data(), 1, outs[t].size(), fv);
+        if (!fatal[t].empty()) return fatal[t];
     }
     return "";
 }
@@ -360,7 +454,7 @@ void VcfText::line(size_t i, const char *&p, size_t &len) const {
     size_t end = line_off[i + 1];
     len = end - line_off[i];
     if (len) --len;                                   // the '\n' (or the virtual one after an unterminated last line)
-    if (len && p[len - 1] == '\r') --len;
+    if (len > 1 && p[len - 1] == '\r') --len;          // kseq.h:143
 }
 
 Fasta::~Fasta() { if (data && size) munmap(const_cast<char *>(data), size); }

@@ -3,7 +3,11 @@
 #pragma once
 #include <stdint.h>
 
+#include <stdio.h>
+
+#include <functional>
 #include <string>
+#include "vcf_model.h"
 #include <unordered_map>
 #include <vector>
 
@@ -28,14 +32,24 @@ struct GtfModel {
 
 // vcf.c:1782-1958: only CHROM and POS are consumed; the text is kept for the -v pass-through
 struct VcfText {
-    std::string text;
-    std::vector<size_t> line_off;      // n_lines + 1 entries
-    struct Rec { size_t line; std::string chrom; uint32_t pos0; };
-    std::vector<Rec> recs;
+    std::string text;                  // the (inflated) file: VCF text, or a BCF stream
+    std::vector<size_t> line_off;      // text: n_lines + 1 entries
+    struct Rec { size_t line; std::string chrom; uint32_t pos0; };      // line = line index (text) / byte offset of the record (BCF)
+    std::vector<Rec> recs;             // what the reference's read loop hands out, in file order (it ends at the first record vcf_parse refuses)
+    bool bcf = false;
+    VcfHdr hdr;                        // the header dictionary as bcf_hdr_read leaves it
     std::string load(const std::string &path);
     size_t n_lines() const { return line_off.empty() ? 0 : line_off.size() - 1; }
     void line(size_t i, const char *&p, size_t &len) const;
+    // record i in BCF's typed form (h = a private copy of hdr: names the header does not declare join it).  false = unreadable.
+    bool typed(size_t i, VcfHdr &h, VcfRec &r) const;
 };
+
+// The annotated VCF: header with the four INFO lines appended, then records `todo` (indices into vcf.recs, ascending), each with the four
+// INFO values annot(i) supplies (all nullptr = "NA") -- variants_annotator.cc:130-154, 521-533 through htslib's typed round trip.
+// Returns "" or the message upstream stops with.
+struct VcfAnnot { const std::string *genes, *transcripts, *distances, *annotations; };
+std::string write_annotated_vcf_records(FILE *fv, const VcfText &vcf, const std::vector<size_t> &todo, const std::function<VcfAnnot(size_t)> &annot);
 
 // faidx.c:288-413 (uncompressed FASTA + .fai, the index is built in memory when the file is missing)
 struct Fasta {

@@ -120,3 +120,20 @@ extern "C" long emu_scan_members(const uint8_t *bam, size_t n, int threads, uint
     for (size_t k = 0; k < m.size() && k < cap; ++k) { members[4 * k] = m[k].cpos; members[4 * k + 1] = m[k].upos; members[4 * k + 2] = m[k].clen; members[4 * k + 3] = m[k].isize; }
     return (long)m.size();
 }
+
+// the annotated-VCF writer (cse_host.cpp write_annotated_vcf_records over vcf_model.cpp) with "NA" for every record: what
+// `variants annotate` writes when no transcript is near any variant.  Returns 0, 1 = load error (message in err), 2 = writer error.
+#include "../../regtools_amd/csrc/cse_host.h"
+extern "C" int emu_vcf_rewrite(const char *in_path, const char *out_path, char *err, size_t errlen) {
+    rgx::VcfText vcf;
+    std::string e = vcf.load(in_path);
+    if (!e.empty()) { snprintf(err, errlen, "%s", e.c_str()); return 1; }
+    FILE *f = fopen(out_path, "w");
+    if (!f) return 2;
+    std::vector<size_t> todo(vcf.recs.size());
+    for (size_t i = 0; i < todo.size(); ++i) todo[i] = i;
+    e = rgx::write_annotated_vcf_records(f, vcf, todo, [](size_t) { return rgx::VcfAnnot{nullptr, nullptr, nullptr, nullptr}; });
+    fclose(f);
+    if (!e.empty()) { snprintf(err, errlen, "%s", e.c_str()); return 2; }
+    return 0;
+}

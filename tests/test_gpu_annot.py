@@ -118,3 +118,32 @@ def test_malformed_gtf_exit_codes(gpu_ctx, work):
         assert got == rc, (path, msg)
         if rc == 0:
             assert ac.read(out) == ac.read(os.path.join(ac.REF, "expected-annotate.out")), path
+
+
+# -- the annotated VCF through htslib's typed round trip (regtools_amd/csrc/vcf_model.cpp): "%g" floats, FORMAT fill-in, header
+#    de-duplication, undeclared tags, gzip and BCF input -- against the real reference's output for the same input and GTF
+import json  # noqa: E402
+
+import vcf_cases  # noqa: E402
+
+VCF_GOLD = os.path.join(ROOT, "tests", "golden", "vcf_writer")
+VCF_NAMES = sorted(json.load(open(os.path.join(VCF_GOLD, "manifest.json"))))
+
+
+@pytest.fixture(scope="module")
+def vcf_inputs(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("vcf_in"))
+    gtf = os.path.join(d, "near.gtf")
+    open(gtf, "w").write(vcf_cases.GTF_NEAR)
+    return vcf_cases.build(d), gtf, d
+
+
+@pytest.mark.parametrize("name", VCF_NAMES)
+def test_annotated_vcf_equals_the_reference(gpu_ctx, vcf_inputs, name):
+    import regtools_amd
+    inputs, gtf, d = vcf_inputs
+    src, out = os.path.join(d, name + ".vcf"), os.path.join(d, name + ".out.vcf")
+    open(src, "wb").write(inputs[name])
+    rc, msg = run_mirror(regtools_amd.VariantsAnnotator(ctx=gpu_ctx), ["-o", out, src, gtf], "annotate_vcf")
+    assert rc == 0, msg
+    assert ac.read(out) == ac.read(os.path.join(VCF_GOLD, name + ".near.vcf"))

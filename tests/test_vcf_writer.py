@@ -1,0 +1,57 @@
+"""The annotated-VCF writer (`identify -v`, `variants annotate -o`) on the CPU: regtools_amd/csrc/vcf_model.cpp + cse_host.cpp compiled
+into tests/hostemu, every record given "NA" tags, against what the REAL reference writes for the same input with a GTF that is nowhere near
+a variant (tests/golden/vcf_writer/*.far.vcf, made by tests/golden/make_golden_vcf.py).  Covers htslib's typed round trip: "%g" floats,
+integer re-formatting, FORMAT fill-in, header de-duplication, undeclared tags, gzip and BCF input.  The same inputs with real annotations
+run on the GPU (tests/test_gpu_annot.py)."""
+import ctypes
+import json
+import os
+
+import pytest
+
+import vcf_cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "vcf_writer")
+MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
+
+
+@pytest.fixture(scope="module")
+def emu(built):
+    return ctypes.CDLL(os.path.join(ROOT, "tests", "hostemu", "libhostemu.so"))
+
+
+@pytest.fixture(scope="module")
+def inputs(tmp_path_factory):
+    return vcf_cases.build(str(tmp_path_factory.mktemp("vcf_in")))
+
+
+def rewrite(emu, data, tmp_path, name):
+    src = os.path.join(str(tmp_path), name + ".vcf")
+    dst = os.path.join(str(tmp_path), name + ".out.vcf")
+    open(src, "wb").write(data)
+    err = ctypes.create_string_buffer(512)
+    rc = emu.emu_vcf_rewrite(src.encode(), dst.encode(), err, 512)
+    return rc, (open(dst, "rb").read() if os.path.exists(dst) else b""), err.value.decode()
+
+
+def test_manifest_covers_every_input(inputs):
+    assert sorted(inputs) == sorted(MANIFEST)
+    assert all(v == {"far": 0, "near": 0} for v in MANIFEST.values())
+
+
+@pytest.mark.parametrize("name", sorted(MANIFEST))
+def test_writer_equals_the_reference(emu, inputs, tmp_path, name):
+    rc, got, msg = rewrite(emu, inputs[name], tmp_path, name)
+    assert rc == 0, msg
+    assert got == open(os.path.join(GOLD, name + ".far.vcf"), "rb").read()
+
+
+@pytest.mark.parametrize("data", [b"1\t100\t.\tA\tG\t30\tPASS\t.\n", b"##source=x\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n", b"##fileformat=VCFv4.2\n##source=x\n1\t5\t.\tA\tC\t.\t.\t.\n",
+                                  b"BCF\x02\x01" + b"\0" * 16, b"BCF\x02\x02\xff\xff\xff\x7f"],
+                         ids=["no_header", "not_fileformat_first", "no_sample_line", "bcf_2_1", "bcf_header_cut"])
+def test_unreadable_headers_are_refused(emu, tmp_path, data):
+    # upstream: hts_open takes only "##fileformat=VCF..." for a VCF (hts.c:248), BCF must be 2.2 (vcf.c:803), a record line before #CHROM
+    # means "no sample line" (vcf.c:1251): bcf_hdr_read returns NULL and regtools stops with "Unable to read header."
+    rc, _, msg = rewrite(emu, data, tmp_path, "bad")
+    assert rc == 1 and "Unable to read header" in msg
