@@ -373,10 +373,11 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         d_bam = b.as<uint8_t>();
         static const bool no_overlap = getenv("REGTOOLS_AMD_NO_OVERLAP") != nullptr;
         if (allow_overlap && !d_true_sizes && !no_overlap && bam_len >= ((size_t)8 << 20)) {
-            // three pieces, one per side stream: every piece is its own launch, a launch takes ~8 ms however small (one lane per member), and the
-            // runtime maps streams onto four hardware queues -- more pieces would queue behind each other, not overlap (profiles/r02_overlap_timeline.txt)
-            // (equal thirds measured best: 31.6 ms per step against 32.4-33.3 ms for pieces that shrink towards the end -- the concurrent launches
-            // share the chip; REGTOOLS_AMD_PIECES="33,67" = the cuts in % for experiments)
+            // three pieces, each its own launch on its own hardware queue (two side streams + the pipeline's own; a launch takes ~8 ms however
+            // small -- one lane per member).  Equal thirds measured best: 31.6 ms per step against 32.4-33.3 ms for pieces that shrink towards
+            // the end, and 30.9-31.5 ms for four to six equal pieces on side streams of other priorities (= other queue pools), 32.6 for seven
+            // (tools/lab/pieces.sh): the concurrent launches share the chip, finer pieces do not end sooner.
+            // REGTOOLS_AMD_PIECES="33,67" = the cuts in %, or "N" = N equal pieces, for experiments.
             std::vector<unsigned> cuts = {33, 67};
             if (const char *e = getenv("REGTOOLS_AMD_PIECES")) {
                 unsigned a = 0, b = 0;
