@@ -385,7 +385,7 @@ std::string VcfText::load(const std::string &path) {
                 }
             }
             std::string ps(t1 + 1, t2 ? (size_t)(t2 - t1 - 1) : (size_t)(l + n - t1 - 1));
-            out.push_back({i, std::string(l, (size_t)(t1 - l)), (uint32_t)(atoi(ps.c_str()) - 1)});
+            out.push_back({i, std::string(l, (size_t)(t1 - l)), (uint32_t)atoi(ps.c_str()) - 1u});
         }
     };
     {

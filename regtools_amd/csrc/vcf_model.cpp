@@ -385,7 +385,7 @@ static int parse_format(VcfHdr &h, VcfRec &v, char *p, char *q, char *end) {
                 uint32_t phased = 0;
                 for (;; ++t) {
                     if (*t == '.') { ++t; put32(o + 4 * (size_t)k++, phased); }
-                    else put32(o + 4 * (size_t)k++, (uint32_t)(((strtol(t, &t, 10) + 1) << 1) | phased));
+                    else put32(o + 4 * (size_t)k++, (uint32_t)(((uint64_t)(strtol(t, &t, 10) + 1) << 1) | phased));
                     phased = *t == '|';
                     if (*t == ':' || *t == 0) break;
                 }
@@ -445,7 +445,7 @@ int vcf_parse_line(VcfHdr &h, const char *line, size_t len, VcfRec &v) {
         *q = 0;
         const bool dot = !strcmp(p, ".");
         if (i == 0) v.rid = h.contig_or_add(p);
-        else if (i == 1) v.pos = atoi(p) - 1;
+        else if (i == 1) v.pos = (int32_t)((uint32_t)atoi(p) - 1u);
         else if (i == 2) { v.have_shared = true; v.id = dot ? enc_chars(p, 0) : enc_chars(p, (size_t)(q - p)); }
         else if (i == 3) v.alleles.push_back(enc_chars(p, (size_t)(q - p)));
         else if (i == 4) {
@@ -606,11 +606,11 @@ static void format_gt(std::string &s, const VcfRec::Typed &f, int isample) {    
 bool vcf_format_line(const VcfHdr &h, const VcfRec &v, std::string &s) {
     if ((int)h.samples.size() != v.n_sample) {
         fprintf(stderr, "[bcf_write] Broken VCF record, the number of columns at %s:%d does not match the number of samples (%d vs %d).\n",
-                name_of(h.contig_name, v.rid).c_str(), v.pos + 1, v.n_sample, (int)h.samples.size());
+                name_of(h.contig_name, v.rid).c_str(), (int32_t)((uint32_t)v.pos + 1u), v.n_sample, (int)h.samples.size());
         return false;
     }
     s += name_of(h.contig_name, v.rid);
-    s += '\t'; put_int(s, v.pos + 1);
+    s += '\t'; put_int(s, (int32_t)((uint32_t)v.pos + 1u));
     s += '\t';
     if (v.have_shared) fmt_array(s, v.id.n, VT_CHAR, (const uint8_t *)v.id.data.data()); else s += '.';
     s += '\t';
