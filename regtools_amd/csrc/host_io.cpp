@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <unordered_map>
 
 namespace rgx {
 
@@ -180,9 +181,89 @@ void bai_first_anchor_ge(const uint8_t *d, size_t len, const uint64_t *targets, 
     }
 }
 
+// The same for an image converted from a .csi of another geometry (normalize_index left the real bin numbers and the loffs behind it):
+// hts_itr_query, hts.c:1708-1800 -- min_off from the loff of the nearest bin at or left of / above beg's finest-level bin, the
+// region's bins of every level (reg2bins :1690-1706), their chunks that end behind min_off.
+static bool csi_region_span(const uint8_t *d, size_t len, int32_t tid, int32_t beg, int32_t end, uint64_t &lo, uint64_t &hi, bool &usable) {
+    const size_t ext_end = len - 20;
+    const int32_t min_shift = (int32_t)h32(d + ext_end), depth = (int32_t)h32(d + ext_end + 4);
+    const uint64_t ext_off = h64(d + ext_end + 8);
+    if (ext_off > ext_end || min_shift < 0 || min_shift > 31 || depth < 0 || depth > 12) return false;
+    size_t p = 4, x = (size_t)ext_off;
+    const int32_t n_ref = (int32_t)h32(d + p); p += 4;
+    if (tid >= n_ref) return false;
+    for (int32_t r = 0; r < n_ref; ++r) {
+        if (p + 4 > ext_off) return false;
+        const int32_t n_bin = (int32_t)h32(d + p); p += 4;
+        if (n_bin < 0 || x + (size_t)n_bin * 12 > ext_end) return false;
+        if (r == tid) {
+            usable = true;
+            if (beg < 0) beg = 0;
+            if (end <= beg) return false;
+            // this reference's bins: number -> (loff, chunks)
+            struct Bin { uint64_t loff; size_t chunks; int32_t n; };
+            std::unordered_map<uint32_t, Bin> bins;
+            bins.reserve((size_t)n_bin * 2);
+            for (int32_t b = 0; b < n_bin; ++b) {
+                if (p + 8 > ext_off) return false;
+                const int32_t n_chunk = (int32_t)h32(d + p + 4); p += 8;
+                if (n_chunk < 0 || p + (size_t)n_chunk * 16 > ext_off) return false;
+                const uint32_t bin = h32(d + x + (size_t)b * 12);
+                if (bin != kCsiMeta) bins[bin] = Bin{h64(d + x + (size_t)b * 12 + 4), p, n_chunk};
+                p += (size_t)n_chunk * 16;
+            }
+            auto first_of = [](int l) { return (uint64_t)((((uint64_t)1 << (3 * l)) - 1) / 7); };
+            uint64_t min_off = 0;
+            {
+                uint64_t bin = first_of(depth) + ((uint64_t)(uint32_t)beg >> min_shift);
+                bool found = false;
+                while (bin) {
+                    auto it = bin <= 0xffffffffull ? bins.find((uint32_t)bin) : bins.end();
+                    if (it != bins.end()) { min_off = it->second.loff; found = true; break; }
+                    const uint64_t parent = (bin - 1) >> 3, first = (parent << 3) + 1;
+                    bin = bin > first ? bin - 1 : parent;
+                }
+                if (!found) { auto it = bins.find(0u); if (it != bins.end()) min_off = it->second.loff; }
+            }
+            int64_t e = end;
+            const int top = min_shift + 3 * depth;
+            if (top < 62 && e > ((int64_t)1 << top)) e = (int64_t)1 << top;
+            const uint64_t b0 = (uint64_t)beg, e0 = (uint64_t)(e - 1);
+            uint64_t cmin = UINT64_MAX, cmax = 0;
+            for (auto &kv : bins) {
+                int l = 0;
+                while (l < depth && kv.first >= first_of(l + 1)) ++l;
+                const int sh = min_shift + 3 * (depth - l);
+                const uint64_t k = kv.first - first_of(l);
+                if (k < (b0 >> sh) || k > (e0 >> sh)) continue;
+                for (int32_t c = 0; c < kv.second.n; ++c) {
+                    const uint64_t u = h64(d + kv.second.chunks + (size_t)c * 16), v = h64(d + kv.second.chunks + (size_t)c * 16 + 8);
+                    if (v > min_off) { cmin = std::min(cmin, u); cmax = std::max(cmax, v); }
+                }
+            }
+            if (cmin == UINT64_MAX) return false;
+            lo = cmin; hi = std::max(cmax, cmin);
+            return true;
+        }
+        for (int32_t b = 0; b < n_bin; ++b) {
+            if (p + 8 > ext_off) return false;
+            const int32_t n_chunk = (int32_t)h32(d + p + 4); p += 8;
+            if (n_chunk < 0 || p + (size_t)n_chunk * 16 > ext_off) return false;
+            p += (size_t)n_chunk * 16;
+        }
+        x += (size_t)n_bin * 12;
+        if (p + 4 > ext_off) return false;
+        const int32_t n_intv = (int32_t)h32(d + p); p += 4;
+        if (n_intv < 0 || p + (size_t)n_intv * 8 > ext_off) return false;
+        p += (size_t)n_intv * 8;
+    }
+    return false;
+}
+
 bool bai_region_span(const uint8_t *d, size_t len, int32_t tid, int32_t beg, int32_t end, uint64_t &lo, uint64_t &hi, bool &usable) {
     usable = false;
     if (len < 8 || memcmp(d, "BAI\1", 4) || tid < 0) return false;
+    if (len >= 8 + 24 && !memcmp(d + len - 4, "RGXC", 4)) return csi_region_span(d, len - 0, tid, beg, end, lo, hi, usable);
     size_t p = 4;
     const int32_t n_ref = (int32_t)h32(d + p); p += 4;
     if (tid >= n_ref) return false;
@@ -348,7 +429,8 @@ bool normalize_index(const uint8_t *in, size_t n, std::vector<uint8_t> &storage,
     const int32_t min_shift = (int32_t)h32(d + 4), depth = (int32_t)h32(d + 8), l_aux = (int32_t)h32(d + 12);
     // `samtools index -c` defaults (min_shift 14, depth 5) are the BAI's own geometry: the bins keep their numbers and the level-5 bins'
     // lower bounds (the linear-index entry of their 16 KiB window, hts.c:1330-1350) stand in for the linear index, so region queries
-    // find their member range as with a .bai.  Any other geometry: the bins are renumbered kCsiBin and a region reads the whole file.
+    // find their member range as with a .bai.  Any other geometry: the bins are renumbered kCsiBin (a deeper geometry has real bins
+    // numbered like a BAI's pseudo-bin) and their numbers and loffs follow the image in a block of their own.
     const bool bai_geometry = min_shift == 14 && depth == 5;
     if (depth < 0 || depth > 12 || l_aux < 0 || 16 + (size_t)l_aux + 4 > len) return false;
     const uint32_t meta_bin = (uint32_t)((((uint64_t)1 << (3 * depth + 3)) - 1) / 7 + 1);   // META_BIN: n_bins + 1 (hts.c:1277)
@@ -357,6 +439,7 @@ bool normalize_index(const uint8_t *in, size_t n, std::vector<uint8_t> &storage,
     if (n_ref < 0) return false;
     std::vector<uint8_t> &o = storage;
     o.clear();
+    std::vector<uint32_t> ext_bins; std::vector<uint64_t> ext_loffs; std::vector<int32_t> ext_counts;
     auto w32 = [&](uint32_t v) { for (int k = 0; k < 4; ++k) o.push_back((uint8_t)(v >> (8 * k))); };
     auto w64 = [&](uint64_t v) { for (int k = 0; k < 8; ++k) o.push_back((uint8_t)(v >> (8 * k))); };
     o.insert(o.end(), {'B', 'A', 'I', 1});
@@ -377,13 +460,26 @@ bool normalize_index(const uint8_t *in, size_t n, std::vector<uint8_t> &storage,
             o.insert(o.end(), d + p, d + p + (size_t)n_chunk * 16);
             if (bai_geometry) {
                 if (bin >= 4681 && bin < 37449 && loff) { const size_t w = bin - 4681; if (loffs.size() <= w) loffs.resize(w + 1, 0); loffs[w] = loff; }
-            } else if (bin != meta_bin && loff) loffs.push_back(loff);
+            } else {
+                if (bin != meta_bin && loff) loffs.push_back(loff);
+                ext_bins.push_back(bin == meta_bin ? kCsiMeta : bin); ext_loffs.push_back(loff);
+            }
             p += (size_t)n_chunk * 16;
         }
+        ext_counts.push_back(bai_geometry ? 0 : n_bin);
         w32((uint32_t)loffs.size());                                                           // "linear index": the bins' lower bounds
         for (uint64_t v : loffs) w64(v);
     }
     w64(p + 8 <= len ? h64(d + p) : 0);
+    if (!bai_geometry) {
+        // the real bin numbers and the bins' loff, in the order of the image's bins: what a region query needs (bai_region_span);
+        // layout: per reference n_bin x (u32 bin, u64 loff), then i32 min_shift, i32 depth, u64 offset of this block, "RGXC"
+        const size_t ext_off = o.size();
+        size_t k = 0;
+        for (int32_t r = 0; r < n_ref; ++r) for (int32_t b = 0; b < ext_counts[(size_t)r]; ++b, ++k) { w32(ext_bins[k]); w64(ext_loffs[k]); }
+        w32((uint32_t)min_shift); w32((uint32_t)depth); w64(ext_off);
+        o.insert(o.end(), {'R', 'G', 'X', 'C'});
+    }
     out = o.data(); out_len = o.size();
     return true;
 }

@@ -47,9 +47,11 @@ void bai_first_anchor_ge(const uint8_t *bai, size_t len, const uint64_t *targets
 // virtual offsets, both record boundaries.  lo = the smallest chunk begin over the region's bins, raised to the linear index's entry for
 // beg's 16 KiB window (no record before that offset reaches the window, hts.c:1755-1768); hi = the largest chunk end.  A superset of
 // what the reference's iterator reads, so filtering [lo, hi) by overlap gives exactly its records.  false = nothing to read (no bin of
-// the region has a chunk) or an image whose bins are not BAI bins (converted from a .csi: kCsiBin).
+// the region has a chunk).  An image converted from a .csi of another geometry answers from the block of real bin numbers and loffs
+// normalize_index leaves behind it (min_off from the bins' loff instead of the linear index, the same bins-of-every-level walk).
 bool bai_region_span(const uint8_t *bai, size_t len, int32_t tid, int32_t beg, int32_t end, uint64_t &lo, uint64_t &hi, bool &usable);
 constexpr uint32_t kCsiBin = 0xfffffffeu;   // bin number normalize_index gives the real bins of a converted .csi
+constexpr uint32_t kCsiMeta = 0xffffffffu;  // the pseudo-bin in the block of real bin numbers behind such an image
 // The BAM header from the head of the file, inflated on the host (the product's own decoder): region queries need the contig names
 // BEFORE the device launch to turn the region into a member range.  false = not available this way (the device path will say why).
 struct BamHeader;

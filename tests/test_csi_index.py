@@ -165,7 +165,7 @@ def test_identify_with_a_csi_index(gpu_ctx, tmp_path):
 
 def test_region_span_covers_every_overlapping_record():
     """bai_region_span (the member range of a -r query): every record that overlaps the region starts inside [lo, hi), both ends are
-    record boundaries, and a converted .csi image declines (its bins are not BAI bins)."""
+    record boundaries; the same through a .csi of the BAI's geometry and of other geometries."""
     import random
     import struct
     emu = ctypes.CDLL(os.path.join(ROOT, "tests", "hostemu", "libhostemu.so"))
@@ -217,7 +217,7 @@ def test_region_span_covers_every_overlapping_record():
             else:
                 assert all(lo.value <= v < hi.value for v in inside), (shape, tid, beg, end)
                 assert lo.value in boundaries and (hi.value in boundaries or hi.value >= max(boundaries))
-        # a .csi in the default geometry (min_shift 14, depth 5 = the BAI's) gives the same kind of span; any other geometry declines
+        # a .csi in the default geometry (min_shift 14, depth 5 = the BAI's) gives the same kind of span
         csi = csi_common.csi_bytes(bai)
         for _ in range(60):
             tid = rng.randrange(len(contigs)); L = contigs[tid][1]
@@ -227,7 +227,80 @@ def test_region_span_covers_every_overlapping_record():
             assert r >= 0 and (r == 1 or not inside)
             if r == 1:
                 assert all(lo.value <= v < hi.value for v in inside) and lo.value in boundaries
-        odd = bytearray(csi_common.csi_bytes(bai, compress=False)); struct.pack_into("<i", odd, 4, 15)     # min_shift 15: not the BAI's bins
-        assert emu.emu_region_span(bytes(odd), len(odd), 0, 100, 5000, ctypes.byref(lo), ctypes.byref(hi)) == -1
+        # a .csi of any other geometry (min_shift / depth as `samtools index -c -m` takes them; contigs longer than 2^29 need one): the span
+        # comes from the real bins and their loffs (hts_itr_query, hts.c:1708-1800) and is as narrow as a .bai's
+        for min_shift, depth in ((12, 6), (10, 7), (15, 5), (14, 6)):
+            csi = csi_common.csi_from_bam(bam, min_shift, depth)
+            narrow = narrow_bai = 0
+            lo2, hi2 = ctypes.c_uint64(), ctypes.c_uint64()
+            for _ in range(40):
+                tid = rng.randrange(len(contigs)); L = contigs[tid][1]
+                beg = rng.randrange(0, max(1, L)); end = beg + rng.choice([1, 4096, 100000, L])
+                r = emu.emu_region_span(csi, len(csi), tid, beg, end, ctypes.byref(lo), ctypes.byref(hi))
+                inside = [v for t, p0, p1, v in recs if t == tid and p0 < end and p1 > beg]
+                assert r >= 0 and (r == 1 or not inside), (min_shift, depth, tid, beg, end)
+                if r == 1:
+                    assert all(lo.value <= v < hi.value for v in inside) and lo.value in boundaries
+                    narrow += (hi.value >> 16) - (lo.value >> 16) < len(bam) // 4
+                else:
+                    narrow += 1
+                if emu.emu_region_span(bai, len(bai), tid, beg, end, ctypes.byref(lo2), ctypes.byref(hi2)) == 1:
+                    narrow_bai += (hi2.value >> 16) - (lo2.value >> 16) < len(bam) // 4
+                else:
+                    narrow_bai += 1
+            assert narrow >= 3 and narrow >= narrow_bai - 2, (min_shift, depth, narrow, narrow_bai)       # small regions read a small part of the file, as with a .bai
         gz = b"".join(bamio.bgzf_member(bai[i:i + 0xff00]) for i in range(0, len(bai), 0xff00)) + bamio.EOF_MARKER
         assert emu.emu_region_span(gz, len(gz), 0, 100, 5000, ctypes.byref(lo), ctypes.byref(hi)) >= 0
+
+
+# ---- a .csi of another geometry (min_shift / depth): what a genome with contigs beyond 2^29 needs -----------------------------------------
+GEOMETRIES = ((12, 6), (10, 7), (15, 5), (14, 6))
+
+
+def make_geometry(tmp_path, min_shift, depth, shape="short", n=3000, seed=5):
+    d = tmp_path / ("g%d_%d" % (min_shift, depth))
+    d.mkdir()
+    bam = str(d / "x.bam")
+    synth.write(bam, n, shape=shape, seed=seed)
+    os.remove(bam + ".bai")
+    open(bam + ".csi", "wb").write(csi_common.csi_from_bam(open(bam, "rb").read(), min_shift, depth))
+    return bam
+
+
+def small_regions(bed_text, k=3):
+    """regions around a few junction rows of a whole-file run, plus a whole contig and an empty stretch"""
+    rows = [l.split("\t") for l in bed_text.splitlines()]
+    out = ["%s:%d-%d" % (r[0], max(1, int(r[1]) - 50), int(r[2]) + 50) for r in rows[::max(1, len(rows) // k)][:k]]
+    return out + [rows[0][0], "%s:1-2" % rows[-1][0]]
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the real reference is only built where /root/reference exists")
+@pytest.mark.parametrize("geo", GEOMETRIES, ids=["m%d_d%d" % g for g in GEOMETRIES])
+def test_oracle_equals_reference_on_other_csi_geometries(tmp_path, geo):
+    bam = make_geometry(tmp_path, *geo, n=20000, seed=9)
+    rc, _, err = run_oracle(["-s", "XS", "-o", str(tmp_path / "w.bed"), bam])
+    assert rc == 0, err
+    for region in small_regions(open(tmp_path / "w.bed").read()):
+        r = subprocess.run([REF, "junctions", "extract", "-s", "XS", "-o", str(tmp_path / "r.bed"), "-r", region, bam], capture_output=True)
+        rc, _, err = run_oracle(["-s", "XS", "-o", str(tmp_path / "o.bed"), "-r", region, bam])
+        assert r.returncode == rc == 0, (region, r.stderr, err)
+        assert open(tmp_path / "r.bed").read() == open(tmp_path / "o.bed").read(), region
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geo", GEOMETRIES, ids=["m%d_d%d" % g for g in GEOMETRIES])
+def test_product_region_queries_through_other_csi_geometries(gpu_ctx, tmp_path, geo):
+    """-r through a .csi of another geometry: equal to the oracle (pinned to the reference above), and the member range comes from the
+    index -- a small region inflates a small part of the file, as with a .bai"""
+    from test_gpu_parity import gpu_extract
+    bam = make_geometry(tmp_path, *geo, n=200000, seed=21)
+    rc, whole, je = gpu_extract(gpu_ctx, bam, ["-s", "XS"])
+    assert rc == 0 and whole.count(b"\n") > 50
+    all_members = je.stats["n_members"]
+    narrow = 0
+    for region in small_regions(whole.decode()):
+        rc, out, je = gpu_extract(gpu_ctx, bam, ["-s", "RF", "-r", region])
+        orc, exp, _ = run_oracle(["-s", "RF", "-r", region, bam])
+        assert rc == orc == 0 and out == exp, region
+        narrow += je.stats["n_members"] * 4 < all_members
+    assert narrow >= 3, (geo, narrow, all_members)
