@@ -130,7 +130,8 @@ int  rgx_extract_device(rgx_ctx *ctx, const void *d_bam, size_t bam_len,
  * devices[0] (rgx_table_merge_device).  Shard order is file order: the table is the single-GPU table whatever n_devices is.  A device
  * may be listed more than once: those shards take turns on it and the exchange is a device copy (how a one-GPU box tests this path).
  * Replaces the call junctions_extract() makes into JunctionsExtractor (junctions_main.cc:45-59) on a multi-GPU node.  -b works across shards
- * (rgx_table_merge_barcodes). */
+ * (rgx_table_merge_barcodes).  The per-device contexts (workspace, streams) are created on first use and kept for the life of the process;
+ * concurrent calls take turns. */
 int  rgx_extract_multi(const int *devices, int n_devices, const char *bam_path, const rgx_extract_params *p,
                        rgx_junction_table **out, char *err, size_t errlen);
 int  rgx_extract_multi_mem(const int *devices, int n_devices, const void *bam, size_t bam_len, const void *bai, size_t bai_len,

@@ -110,6 +110,9 @@ void release(std::vector<Shard> &S) {
 extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const void *bam, size_t bam_len, const void *bai, size_t bai_len,
                                      const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen) {
     if (!devices || n_devices <= 0 || n_devices > 255 || !bam || !out || !p) return failm(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
+    // the contexts are shared by every call of this process: calls take turns
+    static std::mutex call_mu;
+    std::lock_guard<std::mutex> call_lock(call_mu);
     if (p->n_shards > 1) return failm(err, errlen, RGX_ERR_ARG, "regtools_amd: rgx_extract_multi shards the file itself\n");
     *out = nullptr;
     const int n = n_devices;
