@@ -42,11 +42,9 @@ VARIANTS = {
     "hotload": [hot_loads],
     "nostore": [no_stores],
     "decode_only": [no_copy_loads, no_stores],
-    "occ5": [lds_bytes(32768)],
     "batch64": [batch(64)],
-    "batch96": [batch(96)],
-    "condwait": [cond_wait],
-    "occ16": [occ16],
+    "batch64_noload": [batch(64), no_copy_loads],
+    "batch64_hotload": [batch(64), hot_loads],
 }
 
 if __name__ == "__main__":
