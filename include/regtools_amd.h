@@ -151,6 +151,11 @@ int  rgx_table_merge(const rgx_junction_table *const *parts, int n_parts, uint32
 size_t rgx_table_pack(const rgx_junction_table *t, void *dst, size_t dst_cap); /* returns bytes needed */
 int    rgx_table_unpack(const void *src, size_t n_rows, const rgx_junction_table *names_from,
                         rgx_junction_table **out);
+/* The barcode lists of a table as one byte block, and back onto a table of the same rows (rgx_table_unpack): what the ranks of the
+ * one-process-per-GPU driver exchange next to the packed rows so that -b works there too (junctions_extractor.cc:204-217).  pack returns the bytes
+ * needed (0 = no barcode lists) and writes when dst_cap suffices; unpack validates every offset. */
+size_t rgx_table_pack_barcodes(const rgx_junction_table *t, void *dst, size_t dst_cap);
+int    rgx_table_unpack_barcodes(rgx_junction_table *t, const void *src, size_t len);
 /* -b across shards: fills merged->bc_* from the shards' tables (every one extracted with barcodes = 1; shard order = file order).  A junction's
  * barcodes are the shards' lists one after the other in first-seen order, equal strings summed, handed to the container the reference keeps
  * (junctions_extractor.cc:204-217, h:99-111).  rgx_table_merge and rgx_extract_multi call it themselves. */

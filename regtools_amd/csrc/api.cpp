@@ -1290,6 +1290,60 @@ extern "C" int rgx_table_unpack(const void *src, size_t n_rows, const rgx_juncti
     return RGX_OK;
 }
 
+// The barcode lists of a table as one byte block (the wire format of the one-process-per-GPU driver, next to the 48-byte rows):
+// u64 rows, u64 entries, u64 text bytes, then bc_row_begin (rows + 1 u64), bc_str_begin (entries + 1 u64), bc_count and bc_insert_rank
+// (entries u32 each), the text.  Returns the bytes needed; writes when dst_cap suffices.  0 = the table carries no barcode lists.
+extern "C" size_t rgx_table_pack_barcodes(const rgx_junction_table *t, void *dst, size_t dst_cap) {
+    if (!t || !t->bc_row_begin) return 0;
+    const uint64_t n = t->n, E = t->bc_row_begin[n], T = t->bc_str_begin ? t->bc_str_begin[E] : 0;
+    const size_t need = 24 + (size_t)(n + 1) * 8 + (size_t)(E + 1) * 8 + (size_t)E * 8 + (size_t)T;
+    if (!dst || dst_cap < need) return need;
+    uint8_t *q = (uint8_t *)dst;
+    const uint64_t head[3] = {n, E, T};
+    memcpy(q, head, 24); q += 24;
+    memcpy(q, t->bc_row_begin, (size_t)(n + 1) * 8); q += (size_t)(n + 1) * 8;
+    memcpy(q, t->bc_str_begin, (size_t)(E + 1) * 8); q += (size_t)(E + 1) * 8;
+    memcpy(q, t->bc_count, (size_t)E * 4); q += (size_t)E * 4;
+    memcpy(q, t->bc_insert_rank, (size_t)E * 4); q += (size_t)E * 4;
+    memcpy(q, t->bc_text, (size_t)T);
+    return need;
+}
+
+// ... and back, onto a table of the same rows (rgx_table_unpack of the shard's packed rows).  Every offset is checked: the block crossed a wire.
+extern "C" int rgx_table_unpack_barcodes(rgx_junction_table *t, const void *src, size_t len) {
+    if (!t || !src || len < 24) return RGX_ERR_ARG;
+    const uint8_t *q = (const uint8_t *)src;
+    uint64_t head[3]; memcpy(head, q, 24); q += 24;
+    const uint64_t n = head[0], E = head[1], T = head[2];
+    if (n != t->n || E > (len >> 3) || T > len) return RGX_ERR_ARG;
+    const size_t need = 24 + (size_t)(n + 1) * 8 + (size_t)(E + 1) * 8 + (size_t)E * 8 + (size_t)T;
+    if (len < need) return RGX_ERR_ARG;
+    uint64_t *row_begin = (uint64_t *)calloc((size_t)n + 1, 8), *str_begin = (uint64_t *)calloc((size_t)E + 1, 8);
+    uint32_t *count = (uint32_t *)calloc((size_t)E + 1, 4), *rank = (uint32_t *)calloc((size_t)E + 1, 4);
+    char *text = (char *)malloc((size_t)T + 1);
+    bool ok = row_begin && str_begin && count && rank && text;
+    if (ok) {
+        memcpy(row_begin, q, (size_t)(n + 1) * 8); q += (size_t)(n + 1) * 8;
+        memcpy(str_begin, q, (size_t)(E + 1) * 8); q += (size_t)(E + 1) * 8;
+        memcpy(count, q, (size_t)E * 4); q += (size_t)E * 4;
+        memcpy(rank, q, (size_t)E * 4); q += (size_t)E * 4;
+        memcpy(text, q, (size_t)T);
+        ok = row_begin[0] == 0 && row_begin[n] == E && str_begin[0] == 0 && str_begin[E] == T;
+        for (uint64_t i = 0; ok && i < n; ++i) ok = row_begin[i] <= row_begin[i + 1];
+        for (uint64_t k = 0; ok && k < E; ++k) ok = str_begin[k] <= str_begin[k + 1];
+        // a row's ranks are a permutation of 0 .. (its entries - 1): rgx_table_merge_barcodes indexes by them
+        for (uint64_t i = 0; ok && i < n; ++i) {
+            const uint64_t b = row_begin[i], e = row_begin[i + 1];
+            std::vector<uint8_t> seen((size_t)(e - b), 0);
+            for (uint64_t k = b; ok && k < e; ++k) { ok = rank[k] < e - b && !seen[rank[k]]; if (ok) seen[rank[k]] = 1; }
+        }
+    }
+    if (!ok) { free(row_begin); free(str_begin); free(count); free(rank); free(text); return RGX_ERR_ARG; }
+    free(t->bc_row_begin); free(t->bc_count); free(t->bc_str_begin); free(t->bc_text); free(t->bc_insert_rank);
+    t->bc_row_begin = row_begin; t->bc_str_begin = str_begin; t->bc_count = count; t->bc_insert_rank = rank; t->bc_text = text;
+    return RGX_OK;
+}
+
 // -b across shards.  A junction's barcode map (junctions_extractor.h:58, cc:204-217) only depends on the sequence in which DISTINCT barcodes
 // first reach it (a repeat bumps a count, it never moves a node): shard order is file order and bc_insert_rank keeps the order inside a shard,
 // so the merged junction's sequence is the shards' sequences one after the other minus the barcodes already seen -- fed, as in barcode_rows, to

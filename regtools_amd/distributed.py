@@ -57,9 +57,18 @@ def pack_table(table_ptr):
     return bytes(buf)[: n * ROW], n
 
 
-def merge_packed(parts, names_from, min_anchor, ended=None):
-    """parts: list of (bytes, n_rows) in shard order; names_from: any JunctionTable* carrying the contig table; ended: per shard, the
-    table's stream_ended flag (the shards behind the first one that ended are ignored, as a sequential reader never gets there)."""
+def pack_barcodes(table_ptr):
+    """the table's -b lists as bytes (rgx_table_pack_barcodes); b"" when it carries none"""
+    lib = _ffi.lib()
+    n = lib.rgx_table_pack_barcodes(table_ptr, None, 0)
+    if not n:
+        return b""
+    buf = (C.c_uint8 * n)()
+    lib.rgx_table_pack_barcodes(table_ptr, buf, n)
+    return bytes(buf)
+
+
+def _unpack_parts(parts, names_from, ended=None, barcodes=None):
     lib = _ffi.lib()
     ptrs = (C.POINTER(_ffi.JunctionTable) * len(parts))()
     for i, (b, n) in enumerate(parts):
@@ -68,7 +77,23 @@ def merge_packed(parts, names_from, min_anchor, ended=None):
         lib.rgx_table_unpack(raw, n, names_from, C.byref(t))
         if ended is not None and ended[i]:
             t.contents.stream_ended = 1
+        if barcodes is not None:
+            bc = barcodes[i]
+            if lib.rgx_table_unpack_barcodes(t, (C.c_uint8 * max(1, len(bc))).from_buffer_copy(bc if len(bc) else b"\0"), len(bc)) != 0:
+                for j in range(i):
+                    lib.rgx_table_free(ptrs[j])
+                lib.rgx_table_free(t)
+                raise RuntimeError("regtools_amd: shard %d's barcode block does not fit its rows" % i)
         ptrs[i] = t
+    return ptrs
+
+
+def merge_packed(parts, names_from, min_anchor, ended=None, barcodes=None):
+    """parts: list of (bytes, n_rows) in shard order; names_from: any JunctionTable* carrying the contig table; ended: per shard, the
+    table's stream_ended flag (the shards behind the first one that ended are ignored, as a sequential reader never gets there);
+    barcodes: per shard, its pack_barcodes() bytes -- the merged table then carries the merged -b lists (rgx_table_merge does it)."""
+    lib = _ffi.lib()
+    ptrs = _unpack_parts(parts, names_from, ended, barcodes)
     out = C.POINTER(_ffi.JunctionTable)()
     err = C.create_string_buffer(256)
     rc = lib.rgx_table_merge(ptrs, len(parts), min_anchor, C.byref(out), err, len(err))
@@ -105,21 +130,24 @@ def gather_and_merge(je_or_table, min_anchor=8, group=None, ctx=None):
     if dev == "cuda" and ctx is not None:
         return _gather_and_merge_device(table, ctx, min_anchor, group, world)
     payload, n = pack_table(table)
-    sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([n, int(table.contents.stream_ended)], dtype=torch.int64, device=dev), group=group)
+    bc = pack_barcodes(table)                     # -b: the rank's barcode lists travel behind its rows, in the same collective
+    sizes = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([n, int(table.contents.stream_ended), len(bc)], dtype=torch.int64, device=dev), group=group)
     ended = [bool(int(s[1].item())) for s in sizes]
+    bc_sizes = [int(s[2].item()) for s in sizes]
     sizes = [int(s[0].item()) for s in sizes]
-    cap = max(1, max(sizes)) * ROW
+    cap = max(1, max(sz * ROW + b for sz, b in zip(sizes, bc_sizes)))
     local = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    if n:
-        local[: n * ROW].copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+    if n or bc:
+        local[: n * ROW + len(bc)].copy_(torch.frombuffer(bytearray(payload + bc), dtype=torch.uint8))
     gathered = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
     dist.all_gather(gathered, local, group=group)          # the one collective of the whole job
-    parts = []
+    parts, bcs = [], []
     for r in range(world):
-        raw = gathered[r][: sizes[r] * ROW].cpu().numpy().tobytes()
-        parts.append((raw, sizes[r]))
-    return merge_packed(parts, table, min_anchor, ended)
+        raw = gathered[r][: sizes[r] * ROW + bc_sizes[r]].cpu().numpy().tobytes()
+        parts.append((raw[: sizes[r] * ROW], sizes[r]))
+        bcs.append(raw[sizes[r] * ROW:])
+    return merge_packed(parts, table, min_anchor, ended, bcs if all(bc_sizes) else None)
 
 
 _pinned = {}
@@ -158,4 +186,29 @@ def _gather_and_merge_device(table, ctx, min_anchor, group, world):
     big = torch.empty(cap * world, dtype=torch.uint8, device="cuda")
     dist.all_gather_into_tensor(big, local, group=group)      # the one data collective of the whole job; the rows stay in HBM
     torch.cuda.current_stream().synchronize()
-    return merge_device(ctx, big.data_ptr(), stride, merge_sizes, table, min_anchor)
+    merged = merge_device(ctx, big.data_ptr(), stride, merge_sizes, table, min_anchor)
+    bc = pack_barcodes(table)
+    if bc:
+        # -b: the barcode lists are host data (rgx_junction_table.bc_*): a second, small all-gather of bytes, then the host-side merge onto the
+        # device-merged rows (rgx_table_merge_barcodes)
+        bsz = torch.zeros(world, dtype=torch.int64, device="cuda")
+        dist.all_gather_into_tensor(bsz, torch.tensor([len(bc)], dtype=torch.int64, device="cuda"), group=group)
+        bsz = [int(x) for x in bsz.tolist()]
+        bcap = max(bsz)
+        mine = torch.zeros(bcap, dtype=torch.uint8, device="cuda")
+        mine[: len(bc)].copy_(torch.frombuffer(bytearray(bc), dtype=torch.uint8))
+        allbc = torch.empty(bcap * world, dtype=torch.uint8, device="cuda")
+        dist.all_gather_into_tensor(allbc, mine, group=group)
+        rows_host = big.cpu().numpy().tobytes()
+        bc_host = allbc.cpu().numpy().tobytes()
+        parts = [(rows_host[r * cap: r * cap + merge_sizes[r] * ROW], merge_sizes[r]) for r in range(world)]
+        bcs = [bc_host[r * bcap: r * bcap + bsz[r]] if merge_sizes[r] == sizes[r] else None for r in range(world)]
+        keep = [r for r in range(world) if bcs[r] is not None]
+        ptrs = _unpack_parts([parts[r] for r in keep], table, None, [bcs[r] for r in keep])
+        err = C.create_string_buffer(256)
+        rc = lib.rgx_table_merge_barcodes(ptrs, len(keep), merged.table, err, len(err))
+        for i in range(len(keep)):
+            lib.rgx_table_free(ptrs[i])
+        if rc:
+            raise RuntimeError(err.value.decode())
+    return merged

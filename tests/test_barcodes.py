@@ -215,3 +215,25 @@ def test_barcodes_across_shards_of_a_larger_file(gpu_ctx, tmp_path):
     assert L.rgx_table_merge(ptrs, 3, 8, ctypes.byref(out), err, len(err)) == 0, err.value
     m = distributed.MergedTable(out)
     assert m.bed12() == bed and m.barcodes_text() == bcs
+    # the same over the wire format of the one-process-per-GPU driver: every shard's packed rows and its barcode block as bytes
+    # (rgx_table_pack / rgx_table_pack_barcodes), unpacked and merged where they arrive (distributed.merge_packed)
+    wire = [(distributed.pack_table(p.table), distributed.pack_barcodes(p.table)) for p in parts]
+    assert all(len(b) >= 40 for _, b in wire) and any(len(b) > 1000 for _, b in wire)
+    m2 = distributed.merge_packed([w for w, _ in wire], parts[0].table, 8, None, [b for _, b in wire])
+    assert m2.bed12() == bed and m2.barcodes_text() == bcs
+    # a damaged block is refused, not trusted
+    bad = bytearray(wire[1][1]); bad[30] ^= 0x40
+    with pytest.raises(RuntimeError):
+        distributed.merge_packed([w for w, _ in wire], parts[0].table, 8, None, [wire[0][1], bytes(bad), wire[2][1]])
+    # ... and through a process group (nccl = RCCL, one rank): rows merged on the device, barcode lists gathered behind them
+    import socket
+    import torch.distributed as dist
+    je1 = regtools_amd.JunctionsExtractor(bam=bam, strandness=0, ctx=gpu_ctx, output_barcodes_file="x")
+    je1.identify_junctions_from_BAM()
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        m3 = distributed.gather_and_merge(je1, min_anchor=8)
+        assert m3.bed12() == bed and m3.barcodes_text() == bcs
+    finally:
+        dist.destroy_process_group()
