@@ -209,3 +209,22 @@ def test_compressed_vcf_inputs(gpu_ctx, work):
     q["vcf"] = bad
     rc, files, ci, msg = gpu_identify(gpu_ctx, ["-s", "XS"], q, os.path.join(str(work), "gz_bad"))
     assert rc == 1
+
+
+def test_bcf_input(gpu_ctx, work):
+    """The variants as a BCF (bcf_hdr_read / bcf_read, vcf.c:788-818, 899-926): the reference's three outputs for the .bcf are the ones for the
+    .vcf (checked against oracle/_ref when the fixtures were made), so the product's must be the stored goldens too -- including the -v file,
+    which is re-serialised from the typed records."""
+    import vcf_cases
+    done = 0
+    for case in MANIFEST:
+        if case["rc"] != 0 or uses_motif(case["args"]) or done >= 3:
+            continue
+        q = dict(quartet(case["seed"], case["n_genes"], work))
+        q["vcf"] = vcf_cases.simple_vcf_to_bcf(open(q["vcf"]).read(), os.path.join(str(work), "s%d.bcf" % case["seed"]))
+        rc, files, ci, msg = gpu_identify(gpu_ctx, case["args"], q, os.path.join(str(work), "bcf_" + case["name"]))
+        assert rc == 0, msg
+        for ext in ("tsv", "vcf", "bed"):
+            assert open(files[ext], "rb").read() == open(os.path.join(CSE, "%s.%s" % (case["name"], ext)), "rb").read(), (case["name"], ext)
+        done += 1
+    assert done == 3

@@ -201,3 +201,26 @@ def build(tmpdir):
     bcfio.write_bcf(p, BCF_HDR, _bcf_records()); out["typed_bcf"] = open(p, "rb").read()
     bcfio.write_bcf(p, BCF_HDR, _bcf_records(), compress=False); out["typed_bcf_raw"] = open(p, "rb").read()
     return out
+
+
+def simple_vcf_to_bcf(vcf_text, path):
+    """BCF form of a VCF whose records carry at most `DP=<int>` in INFO (tests/cse_synth.py writes those): header text as is, typed
+    records by hand.  -> path"""
+    lines = vcf_text.splitlines()
+    hdr = [l for l in lines if l.startswith("#")]
+    contigs = [l.split("ID=")[1].split(",")[0].rstrip(">") for l in hdr if l.startswith("##contig")]
+    ids = ["PASS"] + [l.split("ID=")[1].split(",")[0] for l in hdr if l.startswith(("##INFO", "##FILTER", "##FORMAT")) and "ID=PASS" not in l]
+    recs = []
+    for l in lines:
+        if not l or l.startswith("#"):
+            continue
+        f = l.split("\t")
+        info = []
+        if f[7] != ".":
+            k, v = f[7].split("=")
+            v = int(v)
+            info.append((ids.index(k), INT8 if -120 <= v <= 127 else INT16, [v]))
+        recs.append(record(contigs.index(f[0]), int(f[1]) - 1, b"" if f[2] == "." else f[2].encode(), [f[3].encode()] + ([] if f[4] == "." else [a.encode() for a in f[4].split(",")]),
+                           None if f[5] == "." else float(f[5]), [] if f[6] == "." else [ids.index(x) for x in f[6].split(";")], info))
+    bcfio.write_bcf(path, "\n".join(hdr) + "\n", recs)
+    return path
