@@ -208,10 +208,15 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # (BENCH_DEVICE / BENCH_BACKEND: test knobs -- several ranks on ONE GPU with the gloo backend exercise this script's N > 1 path where no
+    # multi-GPU node is at hand; the driver's runs use neither)
+    device_index = int(os.environ.get("BENCH_DEVICE", local_rank))
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     import regtools_amd
     from regtools_amd import _ffi, synth
@@ -224,7 +229,7 @@ def main():
                                   slice_index=rank, n_slices=world)
     t_gen = time.time() - t_gen
     n_reads = st["n_reads"]
-    ctx = regtools_amd.Context(local_rank)
+    ctx = regtools_amd.Context(device_index)
     je = regtools_amd.JunctionsExtractor(strandness=0, ctx=ctx)
     # The timed region: file bytes in page-locked HOST memory -> sorted junction table in host memory.  The upload is part of
     # every step (chunked over a copy stream, the members of the chunks that have arrived inflate meanwhile: rgx_extract_mem).
@@ -280,10 +285,10 @@ def main():
     fence()
     dt_res = (time.time() - t1) * (args.steps if args.host_only else 1)
     if world > 1:
-        tt = torch.tensor([dt, dt_res], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt, dt_res], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, dt_res = float(tt[0].item()), float(tt[1].item())
-        cnt = torch.tensor([float(n_reads), float(n_events)], dtype=torch.float64, device="cuda")
+        cnt = torch.tensor([float(n_reads), float(n_events)], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         total_reads, total_events = cnt[0].item(), cnt[1].item()
     else:
