@@ -334,7 +334,7 @@ struct Prep {
 
 static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_bam, size_t bam_len, const uint8_t *bai, size_t bai_len,
                           const rgx_extract_params *p, bool want_read_span, Prep &P, char *err, size_t errlen, const uint32_t *d_true_sizes = nullptr,
-                          bool allow_overlap = true) {
+                          bool allow_overlap = true, bool region_to_file_end = false) {
     if (!p || p->strandness < 0 || p->strandness > 3) return fail(err, errlen, RGX_ERR_ARG, "Please supply strandness mode with '-s' option!\n\n");
     if (p->strandness == 3 && !p->fasta_path) return fail(err, errlen, RGX_ERR_ARG, "Strandness mode 'intron-motif' requires a fasta file!\n\n");
     HIP_TRY(hipSetDevice(c->device));
@@ -362,7 +362,10 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     struct Upload {
         std::thread th; std::atomic<uint32_t> recorded{0}; std::atomic<int> err{0};
         std::vector<size_t> end;                            // end[j] = bytes resident once chunk event j has fired
-        ~Upload() { if (th.joinable()) th.join(); }
+        hipStream_t copy_stream = nullptr;
+        // every way out of this function: the helper has enqueued its copies and the DMA out of the caller's buffer is over (the caller
+        // may free or reuse that buffer as soon as the call returns)
+        ~Upload() { if (th.joinable()) th.join(); if (copy_stream) (void)hipStreamSynchronize(copy_stream); }
     } up;
     bool overlap = false;
     std::vector<Member> hm;                                  // the host scan's member list (overlap only)
@@ -391,6 +394,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             up.end.push_back(bam_len);
             while (c->chunk_ev.size() < up.end.size()) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->chunk_ev.push_back(e); }
             uint8_t *dst = b.as<uint8_t>();
+            up.copy_stream = c->copy_stream;
             up.th = std::thread([c, dst, h_bam, &up] {
                 if (hipSetDevice(c->device) != hipSuccess) { up.err = 1; up.recorded = (uint32_t)up.end.size(); return; }
                 size_t o = 0;
@@ -511,10 +515,14 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         mark("shard cuts");
     }
 
-    // region queries: the member range comes from the index, as the reference's iterator seeks (hts_itr_query, hts.c:1733-1800) -- the
-    // overlap predicate in k_decode_seg stays the judge, the span only spares inflating members no record of the region can be in.
-    // Needs the contig names before the launch: the header is inflated on the host from the head of the file.  Anything unusual
-    // (header not readable this way, a .csi, a region the parser rejects) leaves the range alone and the full path decides.
+    // region queries: the reference's iterator reads the CHUNKS the index lists for the region's bins, one seek each, and ends at the first
+    // record it reads that lies on another contig or at / behind the region's end (hts_itr_query / hts_itr_next, hts.c:1733-1800, :1924-1965).
+    // The chunk list is computed here, from the index; the members between the first chunk's begin and the last one's end are inflated,
+    // every chunk becomes its own record chain (SegGeom) and k_decode_seg applies the end rule.  Needs the contig names before the
+    // launch: the header is inflated on the host from the head of the file.  A header that cannot be read that way leaves the range
+    // alone: the whole file is read and filtered by overlap (such a header is not readable upstream either).
+    std::vector<VChunk> chunks;
+    bool chunked = false;
     if (!whole && p->n_shards <= 1 && p->region) {
         const size_t head_len = std::min<size_t>(bam_len, (size_t)8 << 20);
         std::vector<uint8_t> head_copy;
@@ -522,13 +530,17 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         if (!head) { head_copy.resize(head_len); HIP_TRY(hipMemcpy(head_copy.data(), d_bam, head_len, hipMemcpyDeviceToHost)); head = head_copy.data(); }
         BamHeader hh;
         int32_t tid = -1, beg = 0, end = 0;
-        uint64_t lo = 0, hi = 0; bool usable = false;
-        if (host_bam_header(head, head_len, hh) && parse_region(hh, p->region, tid, beg, end) && tid < bi.n_ref && end >= beg) {
-            // like the iterator's bgzf_seek: reading starts at lo whatever the state of the members in front of it
-            if (bai_region_span(bai, bai_len, tid, beg, end, lo, hi, usable)) { cut_lo = lo; cut_hi = hi; seek = true; seek_voff = lo; }
-            else if (usable && bi.have_start && bi.start_voff) { cut_lo = cut_hi = bi.start_voff; seek = true; seek_voff = cut_lo; }     // no bin of the region holds a record: nothing to inflate
+        if (host_bam_header(head, head_len, hh) && parse_region(hh, p->region, tid, beg, end) && tid < bi.n_ref && end >= beg &&
+            region_chunks(bai, bai_len, tid, beg, end, chunks)) {
+            chunked = true;
+            if (!chunks.empty()) {
+                // like the iterator's bgzf_seek: reading starts at the first chunk whatever the state of the members in front of it
+                uint64_t hi = 0;
+                for (const VChunk &ch : chunks) hi = std::max(hi, ch.v);
+                cut_lo = chunks.front().u; cut_hi = std::max(hi, cut_lo); seek = true; seek_voff = cut_lo;
+            } else if (bi.have_start && bi.start_voff) { cut_lo = cut_hi = bi.start_voff; seek = true; seek_voff = cut_lo; }     // no bin of the region holds a record: nothing to inflate
         }
-        mark("region span");
+        mark("region chunks");
     }
 
     bool empty_stream = false;
@@ -552,7 +564,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         up.th.join();
         HIP_TRY(hipStreamSynchronize(c->copy_stream));
         HIP_TRY(hipStreamSynchronize(st));
-        const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, nullptr, false);
+        const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, nullptr, false, region_to_file_end);
         P.t_begin = t_begin;
         return rc2;
     }
@@ -584,7 +596,11 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     uint32_t m_hi = stop;                                                  // exclusive
     if (cut_hi != UINT64_MAX) {
         const uint32_t mh = h_sc[26];
-        m_hi = std::min(stop, (mh < n_members_all && (cut_hi & 0xffff)) ? mh + 1 : mh);
+        const uint32_t hi_m = (mh < n_members_all && (cut_hi & 0xffff)) ? mh + 1 : mh;
+        // a region's chunks: each is a seek of its own, so an empty member between two of them ends nothing (the chunks' own limits do
+        // that, below); two members more than the index asks for, for the records of a stale index that run past their chunk's end
+        if (chunked) m_hi = region_to_file_end ? n_members_all : (uint32_t)std::min<uint64_t>(n_members_all, (uint64_t)hi_m + 2);
+        else m_hi = std::min(stop, hi_m);
     }
     if (m_lo > m_hi) m_lo = m_hi;
     // arena offsets of the range ends
@@ -606,7 +622,14 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     HIP_TRY(b_lens.ensure(inflate_scratch_bytes(std::max<uint32_t>(n_range, 64))));
     // with a seek, the members in front of its target are only inflated for the header's sake (same launch): their failures end nothing
     const uint32_t ignore_below = (seek && first_member < n_members_all && first_member > m_lo) ? first_member - m_lo : 0;
-    if (!overlap) launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below);
+    uint8_t *d_bad = nullptr;                                 // region queries: which members of the range did not inflate (every chunk has its own end of stream)
+    if (chunked && !chunks.empty() && n_range) {
+        DevBuf &b_bad = c->buf("bad_members");
+        HIP_TRY(b_bad.ensure((size_t)n_range + 64));
+        d_bad = b_bad.as<uint8_t>();
+        HIP_TRY(hipMemsetAsync(d_bad, 0, n_range, st));
+    }
+    if (!overlap) launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below, 0, false, 0, d_bad);
     else {
         // one launch per upload chunk, on the side streams: the members whose bytes (plus the decoder's 16-byte look-ahead) have arrived with
         // chunk j start as soon as its event fires, next to the launches of the chunks before it
@@ -631,7 +654,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             hipStream_t q = own ? st : c->side[j];
             if (!own) used_side |= 1u << j;
             HIP_TRY(hipStreamWaitEvent(q, c->chunk_ev[j], 0));
-            launch_inflate(d_bam, d_members + g_lo, g_hi - g_lo, b_arena.as<uint8_t>(), upos_lo, (uint32_t *)(b_lens.as<uint8_t>() + scratch_off), d_sc, q, ignore_below, g_lo - m_lo, /*piece=*/true);
+            launch_inflate(d_bam, d_members + g_lo, g_hi - g_lo, b_arena.as<uint8_t>(), upos_lo, (uint32_t *)(b_lens.as<uint8_t>() + scratch_off), d_sc, q, ignore_below, g_lo - m_lo, /*piece=*/true, 0, d_bad);
             scratch_off += inflate_scratch_bytes(g_hi - g_lo);
             g_lo = g_hi;
         }
@@ -670,7 +693,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             launch_inflate_probe(d_bam, d_members, n_members_all, b_slots.as<uint8_t>(), b_lens.as<uint32_t>(), b_sizes.as<uint32_t>(), st);
             HIP_TRY(hipStreamSynchronize(st));
             b_slots.release();                                  // 64 KiB per member: not kept
-            const int rc2 = prepare_events(c, d_bam_in, h_bam, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, b_sizes.as<uint32_t>());
+            const int rc2 = prepare_events(c, d_bam_in, h_bam, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, b_sizes.as<uint32_t>(), true, region_to_file_end);
             P.t_begin = t_begin;
             return rc2;
         }
@@ -786,10 +809,69 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         cfg.fa_data = c->buf("fasta").as<uint8_t>(); cfg.fa_tab = bt.as<FaContig>(); cfg.fa_missing = d_sc + 64;
     }
 
+    // -- region queries: one record chain per chunk of the iterator -----------------------------------------------------------------
+    // chunk c = virtual offsets [u, v): a seek to u (bgzf_seek: the member at u >> 16, the offset inside it clipped to its length; no such
+    // member = the read fails and the iteration is over), then records while the position in front of the next one is below v.
+    SegGeom geom; memset(&geom, 0, sizeof geom);
+    std::vector<SegChunk> seg_chunks;
+    if (chunked && chunks.empty()) lim = pos0;                // an iterator without chunks returns nothing
+    if (chunked && !chunks.empty() && !empty_stream) {
+        std::vector<Member> rm(n_range);
+        std::vector<uint8_t> bad(n_range, 0);
+        if (n_range) {
+            HIP_TRY(hipMemcpyAsync(rm.data(), d_members + m_lo, (size_t)n_range * sizeof(Member), from_members, st));
+            HIP_TRY(hipMemcpyAsync(bad.data(), d_bad, n_range, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        for (uint32_t k = 0; k < n_range; ++k) if (rm[k].isize == 0 || rm[k].isize > kBgzfMaxBlock) bad[k] = 1;     // bgzf.c:548-578: an empty block reads as the end of the file
+        std::vector<uint32_t> next_bad((size_t)n_range + 1, n_range);
+        for (uint32_t k = n_range; k-- > 0;) next_bad[k] = bad[k] ? k : next_bad[k + 1];
+        auto usize = [&](uint32_t k) { return rm[k].isize <= kBgzfMaxBlock ? rm[k].isize : 0u; };
+        auto lower = [&](uint64_t cfile) {                    // first member of the range at or behind file offset cfile
+            uint32_t lo_ = 0, hi_ = n_range;
+            while (lo_ < hi_) { const uint32_t mid = lo_ + (hi_ - lo_) / 2; if (rm[mid].cpos - 18 < cfile) lo_ = mid + 1; else hi_ = mid; }
+            return lo_;
+        };
+        uint32_t seg_total = 0;
+        for (const VChunk &ch : chunks) {
+            const uint32_t k = lower(ch.u >> 16);
+            if (k >= n_range || rm[k].cpos - 18 != (ch.u >> 16)) break;        // the seek lands on no member: upstream's next read fails, nothing behind it is read
+            SegChunk sc; memset(&sc, 0, sizeof sc);
+            sc.a = rm[k].upos - upos_lo + std::min<uint64_t>(ch.u & 0xffff, usize(k));
+            const uint32_t kv = lower(ch.v >> 16);
+            if (kv >= n_range) sc.b = total;
+            else sc.b = rm[kv].upos - upos_lo + (rm[kv].cpos - 18 == (ch.v >> 16) ? std::min<uint64_t>(ch.v & 0xffff, usize(kv)) : 0);
+            if (sc.b <= sc.a) sc.b = sc.a + 1;                              // the first record behind a seek is read whatever the chunk's end says
+            const uint32_t nb = next_bad[k];
+            sc.dlim = nb < n_range ? rm[nb].upos - upos_lo : total;
+            sc.seg_base = seg_total;
+            const uint64_t ns = (sc.b - sc.a + kSegBytes - 1) / kSegBytes;
+            if (seg_total + ns > 0x7fffffffull) return fail(err, errlen, RGX_ERR_FORMAT, "regtools_amd: region too large\n");
+            seg_total += (uint32_t)ns;
+            seg_chunks.push_back(sc);
+        }
+        if (seg_chunks.empty()) lim = pos0;
+        else {
+            DevBuf &b_ch = c->buf("seg_chunks");
+            HIP_TRY(b_ch.ensure(seg_chunks.size() * sizeof(SegChunk) + 64));
+            HIP_TRY(hipMemcpyAsync(b_ch.p, seg_chunks.data(), seg_chunks.size() * sizeof(SegChunk), hipMemcpyHostToDevice, st));
+            geom.chunks = b_ch.as<SegChunk>(); geom.n_chunks = (uint32_t)seg_chunks.size();
+        }
+        mark("chunk table");
+    }
+
     // -- record framing ------------------------------------------------------------------------------------------------
     const uint8_t *arena = b_arena.as<uint8_t>();
-    const uint64_t span = lim - pos0;
-    const uint32_t n_seg = (uint32_t)((span + kSegBytes - 1) / kSegBytes);
+    uint64_t span = lim - pos0;
+    uint32_t n_seg = (uint32_t)((span + kSegBytes - 1) / kSegBytes);
+    geom.pos0 = pos0; geom.lim = lim; geom.data_end = lim;
+    if (geom.chunks) {
+        span = 0;
+        for (const SegChunk &sc : seg_chunks) span += sc.b - sc.a;
+        const SegChunk &lastc = seg_chunks.back();
+        n_seg = lastc.seg_base + (uint32_t)((lastc.b - lastc.a + kSegBytes - 1) / kSegBytes);
+        geom.data_end = total;
+    }
     uint32_t n_rec = 0;
     DevBuf &b_seg = c->buf("seg"), &b_tmp = c->buf("tmp");
     HIP_TRY(hipEventRecord(c->ev[2], st));
@@ -807,11 +889,11 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         for (int k = 0; k < 2; ++k) { seg_cnt[k] = (uint32_t *)q; q += per * 4; }
         seg_base = (uint32_t *)q;
         HIP_TRY(b_tmp.ensure(scan_tmp_words(n_seg) * 4 + 64));
-        launch_seg_walk(arena, pos0, lim, n_seg, n_ref, seg_start[0], seg_exit[0], seg_cnt[0], seg_cp, st);
+        launch_seg_walk(arena, geom, n_seg, n_ref, seg_start[0], seg_exit[0], seg_cnt[0], seg_cp, st);
         // d_sc[10]: leftmost disagreeing segment, d_sc[11]: leftmost chain end, d_sc[3]: record total
         for (int iter = 0;; ++iter) {
             HIP_TRY(hipMemsetAsync(d_sc + 10, 0xff, 8, st));
-            launch_seg_verify(arena, pos0, lim, n_seg, seg_start[cur], seg_exit[cur], seg_cnt[cur], seg_start[cur ^ 1], seg_exit[cur ^ 1],
+            launch_seg_verify(arena, geom, n_seg, seg_start[cur], seg_exit[cur], seg_cnt[cur], seg_start[cur ^ 1], seg_exit[cur ^ 1],
                               seg_cnt[cur ^ 1], d_sc + 10, seg_cp, st);
             cur ^= 1;
             launch_scan_u32(seg_cnt[cur], seg_base, n_seg, d_sc + 3, b_tmp.as<uint32_t>(), st);
@@ -820,19 +902,30 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             HIP_TRY(hipStreamSynchronize(st));
             ++P.framing_sweeps;
             if (h_sc[11] != 0xffffffffu) chain_ended = true;     // some segment's chain ends: an unreadable / cut-off record (sam.c:421-423)
-            if (h_sc[10] == 0xffffffffu) break;
-            if (h_sc[11] < h_sc[10]) {     // the chain ends inside the exact prefix: nothing starts after that segment
-                launch_seg_truncate(pos0, lim, n_seg, h_sc[11], seg_start[cur], seg_exit[cur], seg_cnt[cur], st);
+            // the chain ends inside the exact prefix (or everything is exact): nothing starts after that segment -- with one chain the
+            // end already spread to the right by itself; the chains of later chunks would not know
+            if (h_sc[11] != 0xffffffffu && (h_sc[11] < h_sc[10] || (h_sc[10] == 0xffffffffu && geom.chunks))) {
+                launch_seg_truncate(geom, n_seg, h_sc[11], seg_start[cur], seg_exit[cur], seg_cnt[cur], st);
                 launch_scan_u32(seg_cnt[cur], seg_base, n_seg, d_sc + 3, b_tmp.as<uint32_t>(), st);
                 HIP_TRY(hipMemcpyAsync(h_sc + 3, d_sc + 3, 4, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 break;
             }
+            if (h_sc[10] == 0xffffffffu) break;
             if (iter > 1 << 20) return fail(err, errlen, RGX_ERR_FORMAT, "regtools_amd: record framing did not converge\n");
         }
         n_rec = h_sc[3];
     }
     if (chain_ended) P.stream_ended = true;
+    if (chain_ended && geom.chunks && m_hi < n_members_all && !region_to_file_end) {
+        // a chunk's chain stopped -- possibly only because a record runs past the members the index asked for (an index that does not
+        // describe this file): once more with everything up to the end of the file inflated
+        mark("region: chain ended, re-reading to the end of the file");
+        if (overlap) { HIP_TRY(hipStreamSynchronize(c->copy_stream)); }
+        const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, d_true_sizes, false, true);
+        P.t_begin = t_begin;
+        return rc2;
+    }
     HIP_TRY(hipEventRecord(c->ev[3], st));
     mark("framing (sync)");
 
@@ -854,13 +947,26 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         HIP_TRY(b_tmp.ensure(scan_tmp_words(n_rec) * 4 + 64));
         // per-segment outputs (no hot atomics): reuse the spare segment arrays as seg_iter / seg_long
         uint32_t *seg_iter = seg_cnt[cur ^ 1], *seg_long = (uint32_t *)seg_start[cur ^ 1], *seg_long_base = (uint32_t *)seg_exit[cur ^ 1];
-        launch_decode_seg(arena, pos0, lim, n_seg, seg_start[cur], seg_base, seg_cnt[cur], cfg, soa, seg_iter, seg_long, seg_cp,
-                          /*staged=*/span / n_rec <= kSparseRecordBytes, st);
-        launch_scan_u32(soa.n_ev, ev_base, n_rec, d_sc + 4, b_tmp.as<uint32_t>(), st);
-        launch_scan_u32(seg_iter, seg_iter, n_seg, d_sc + 8, b_tmp.as<uint32_t>(), st);
-        launch_scan_u32(seg_long, seg_long_base, n_seg, d_sc + 5, b_tmp.as<uint32_t>(), st);
-        HIP_TRY(hipMemcpyAsync(h_sc + 4, d_sc + 4, 24, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        // the iterator's end rule only where the iterator's chunks are followed (hts_itr_next, hts.c:1946-1950): the first pass finds the
+        // first record that ends the iteration and the last one that passed the overlap test; when one of those lies behind the other
+        // (records out of order -- no indexer writes such a file) the pass is repeated with the stop in place
+        if (geom.chunks) {
+            cfg.stop_out = d_sc + 80; cfg.stop_index = 0xffffffffu;
+            HIP_TRY(hipMemsetAsync(d_sc + 80, 0xff, 4, st));
+            HIP_TRY(hipMemsetAsync(d_sc + 81, 0, 4, st));
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+            launch_decode_seg(arena, geom, n_seg, seg_start[cur], seg_base, seg_cnt[cur], cfg, soa, seg_iter, seg_long, seg_cp,
+                              /*staged=*/span / n_rec <= kSparseRecordBytes, st);
+            launch_scan_u32(soa.n_ev, ev_base, n_rec, d_sc + 4, b_tmp.as<uint32_t>(), st);
+            launch_scan_u32(seg_iter, seg_iter, n_seg, d_sc + 8, b_tmp.as<uint32_t>(), st);
+            launch_scan_u32(seg_long, seg_long_base, n_seg, d_sc + 5, b_tmp.as<uint32_t>(), st);
+            HIP_TRY(hipMemcpyAsync(h_sc + 4, d_sc + 4, 24, hipMemcpyDeviceToHost, st));
+            if (cfg.stop_out) HIP_TRY(hipMemcpyAsync(h_sc + 80, d_sc + 80, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (pass || !cfg.stop_out || h_sc[80] == 0xffffffffu || h_sc[81] <= h_sc[80] + 1) break;
+            cfg.stop_index = h_sc[80];
+        }
         n_events = h_sc[4]; n_long = h_sc[5];
         n_iterated = h_sc[8];
         if (n_long) launch_long_fill(n_seg, seg_base, seg_cnt[cur], seg_long_base, cfg, soa, long_list, st);

@@ -181,134 +181,113 @@ void bai_first_anchor_ge(const uint8_t *d, size_t len, const uint64_t *targets, 
     }
 }
 
-// The same for an image converted from a .csi of another geometry (normalize_index left the real bin numbers and the loffs behind it):
-// hts_itr_query, hts.c:1708-1800 -- min_off from the loff of the nearest bin at or left of / above beg's finest-level bin, the
-// region's bins of every level (reg2bins :1690-1706), their chunks that end behind min_off.
-static bool csi_region_span(const uint8_t *d, size_t len, int32_t tid, int32_t beg, int32_t end, uint64_t &lo, uint64_t &hi, bool &usable) {
-    const size_t ext_end = len - 20;
-    const int32_t min_shift = (int32_t)h32(d + ext_end), depth = (int32_t)h32(d + ext_end + 4);
-    const uint64_t ext_off = h64(d + ext_end + 8);
-    if (ext_off > ext_end || min_shift < 0 || min_shift > 31 || depth < 0 || depth > 12) return false;
-    size_t p = 4, x = (size_t)ext_off;
+// hts_itr_query (hts.c:1733-1800) for one reference of a BAI image (or of an image converted from a .csi: normalize_index leaves the real
+// bin numbers, the bins' loffs and the geometry behind it): min_off = loff of the nearest existing bin at / left of / above beg's
+// finest-level bin (:1771-1783; a BAI's loffs come from its zero-filled linear index, update_loff :1330-1350 with the load-time fill
+// :1543-1547), the chunks of the region's bins of every level (reg2bins :1690-1706) that end behind min_off, sorted, contained chunks
+// dropped, overlaps cut, chunks that meet inside one compressed block joined (:1787-1797).
+bool region_chunks(const uint8_t *d, size_t len, int32_t tid, int32_t beg, int32_t end, std::vector<VChunk> &out) {
+    out.clear();
+    if (len < 8 || memcmp(d, "BAI\1", 4) || tid < 0) return false;
+    int32_t min_shift = 14, depth = 5;
+    size_t body_end = len, x = 0;
+    const bool ext = len >= 8 + 24 && !memcmp(d + len - 4, "RGXC", 4);
+    if (ext) {
+        const size_t ext_end = len - 20;
+        min_shift = (int32_t)h32(d + ext_end); depth = (int32_t)h32(d + ext_end + 4);
+        const uint64_t ext_off = h64(d + ext_end + 8);
+        if (ext_off > ext_end || min_shift < 0 || min_shift > 31 || depth < 0 || depth > 12) return false;
+        body_end = (size_t)ext_off; x = (size_t)ext_off;
+    }
+    size_t p = 4;
     const int32_t n_ref = (int32_t)h32(d + p); p += 4;
     if (tid >= n_ref) return false;
-    for (int32_t r = 0; r < n_ref; ++r) {
-        if (p + 4 > ext_off) return false;
+    auto first_of = [](int l) { return (uint64_t)((((uint64_t)1 << (3 * l)) - 1) / 7); };
+    const uint64_t n_bins = first_of(depth + 1);
+    for (int32_t r = 0; r <= tid; ++r) {
+        if (p + 4 > body_end) return false;
         const int32_t n_bin = (int32_t)h32(d + p); p += 4;
-        if (n_bin < 0 || x + (size_t)n_bin * 12 > ext_end) return false;
-        if (r == tid) {
-            usable = true;
-            if (beg < 0) beg = 0;
-            if (end <= beg) return false;
-            // this reference's bins: number -> (loff, chunks)
-            struct Bin { uint64_t loff; size_t chunks; int32_t n; };
-            std::unordered_map<uint32_t, Bin> bins;
-            bins.reserve((size_t)n_bin * 2);
-            for (int32_t b = 0; b < n_bin; ++b) {
-                if (p + 8 > ext_off) return false;
-                const int32_t n_chunk = (int32_t)h32(d + p + 4); p += 8;
-                if (n_chunk < 0 || p + (size_t)n_chunk * 16 > ext_off) return false;
-                const uint32_t bin = h32(d + x + (size_t)b * 12);
-                if (bin != kCsiMeta) bins[bin] = Bin{h64(d + x + (size_t)b * 12 + 4), p, n_chunk};
-                p += (size_t)n_chunk * 16;
-            }
-            auto first_of = [](int l) { return (uint64_t)((((uint64_t)1 << (3 * l)) - 1) / 7); };
-            uint64_t min_off = 0;
-            {
-                uint64_t bin = first_of(depth) + ((uint64_t)(uint32_t)beg >> min_shift);
-                bool found = false;
-                while (bin) {
-                    auto it = bin <= 0xffffffffull ? bins.find((uint32_t)bin) : bins.end();
-                    if (it != bins.end()) { min_off = it->second.loff; found = true; break; }
-                    const uint64_t parent = (bin - 1) >> 3, first = (parent << 3) + 1;
-                    bin = bin > first ? bin - 1 : parent;
-                }
-                if (!found) { auto it = bins.find(0u); if (it != bins.end()) min_off = it->second.loff; }
-            }
-            int64_t e = end;
-            const int top = min_shift + 3 * depth;
-            if (top < 62 && e > ((int64_t)1 << top)) e = (int64_t)1 << top;
-            const uint64_t b0 = (uint64_t)beg, e0 = (uint64_t)(e - 1);
-            uint64_t cmin = UINT64_MAX, cmax = 0;
-            for (auto &kv : bins) {
-                int l = 0;
-                while (l < depth && kv.first >= first_of(l + 1)) ++l;
-                const int sh = min_shift + 3 * (depth - l);
-                const uint64_t k = kv.first - first_of(l);
-                if (k < (b0 >> sh) || k > (e0 >> sh)) continue;
-                for (int32_t c = 0; c < kv.second.n; ++c) {
-                    const uint64_t u = h64(d + kv.second.chunks + (size_t)c * 16), v = h64(d + kv.second.chunks + (size_t)c * 16 + 8);
-                    if (v > min_off) { cmin = std::min(cmin, u); cmax = std::max(cmax, v); }
-                }
-            }
-            if (cmin == UINT64_MAX) return false;
-            lo = cmin; hi = std::max(cmax, cmin);
-            return true;
-        }
+        if (n_bin < 0 || (ext && x + (size_t)n_bin * 12 > len - 20)) return false;
+        struct Bin { uint64_t loff; size_t chunks; int32_t n; };
+        std::unordered_map<uint64_t, Bin> bins;
+        if (r == tid) bins.reserve((size_t)n_bin * 2);
         for (int32_t b = 0; b < n_bin; ++b) {
-            if (p + 8 > ext_off) return false;
-            const int32_t n_chunk = (int32_t)h32(d + p + 4); p += 8;
-            if (n_chunk < 0 || p + (size_t)n_chunk * 16 > ext_off) return false;
+            if (p + 8 > body_end) return false;
+            uint64_t bin = h32(d + p); const int32_t n_chunk = (int32_t)h32(d + p + 4); p += 8;
+            if (n_chunk < 0 || p + (size_t)n_chunk * 16 > body_end) return false;
+            if (r == tid) {
+                uint64_t loff = 0;
+                if (ext) { const uint32_t real = h32(d + x + (size_t)b * 12); bin = real == kCsiMeta ? n_bins + 1 : real; loff = h64(d + x + (size_t)b * 12 + 4); }
+                if (bin < n_bins) bins[bin] = Bin{loff, p, n_chunk};          // (the pseudo-bin n_bins + 1 holds no alignments)
+            }
             p += (size_t)n_chunk * 16;
         }
         x += (size_t)n_bin * 12;
-        if (p + 4 > ext_off) return false;
+        if (p + 4 > body_end) return false;
         const int32_t n_intv = (int32_t)h32(d + p); p += 4;
-        if (n_intv < 0 || p + (size_t)n_intv * 8 > ext_off) return false;
-        p += (size_t)n_intv * 8;
+        if (n_intv < 0 || p + (size_t)n_intv * 8 > body_end) return false;
+        if (r != tid) { p += (size_t)n_intv * 8; continue; }
+        if (!ext) {
+            std::vector<uint64_t> lin((size_t)n_intv);
+            for (int32_t i = 0; i < n_intv; ++i) { lin[(size_t)i] = h64(d + p + (size_t)i * 8); if (i > 0 && !lin[(size_t)i]) lin[(size_t)i] = lin[(size_t)i - 1]; }
+            for (auto &kv : bins) {
+                int l = 0;
+                while (l < depth && kv.first >= first_of(l + 1)) ++l;
+                const uint64_t bot = (kv.first - first_of(l)) << (3 * (depth - l));
+                kv.second.loff = bot < (uint64_t)n_intv ? lin[(size_t)bot] : 0;
+            }
+        }
+        if (beg < 0) beg = 0;
+        if (end <= beg) return true;                                             // reg2bins: no bins, an iterator that returns nothing
+        uint64_t min_off = 0;
+        {
+            uint64_t bin = first_of(depth) + ((uint64_t)(uint32_t)beg >> min_shift);
+            bool found = false;
+            do {
+                auto it = bins.find(bin);
+                if (it != bins.end()) { min_off = it->second.loff; found = true; break; }
+                if (!bin) break;
+                const uint64_t parent = (bin - 1) >> 3, first = (parent << 3) + 1;
+                bin = bin > first ? bin - 1 : parent;
+            } while (bin);
+            if (!found) { auto it = bins.find(0); if (it != bins.end()) min_off = it->second.loff; }
+        }
+        int64_t e = end;
+        const int top = min_shift + 3 * depth;
+        if (top < 62 && e >= ((int64_t)1 << top)) e = (int64_t)1 << top;
+        const uint64_t b0 = (uint64_t)beg, e0 = (uint64_t)(e - 1);
+        for (auto &kv : bins) {
+            int l = 0;
+            while (l < depth && kv.first >= first_of(l + 1)) ++l;
+            const int sh = min_shift + 3 * (depth - l);
+            const uint64_t k = kv.first - first_of(l);
+            if (k < (b0 >> sh) || k > (e0 >> sh)) continue;
+            for (int32_t c = 0; c < kv.second.n; ++c) {
+                const uint64_t u = h64(d + kv.second.chunks + (size_t)c * 16), v = h64(d + kv.second.chunks + (size_t)c * 16 + 8);
+                if (v > min_off) out.push_back(VChunk{u, v});
+            }
+        }
+        if (out.empty()) return true;
+        std::sort(out.begin(), out.end(), [](const VChunk &a, const VChunk &b) { return a.u != b.u ? a.u < b.u : a.v < b.v; });
+        size_t l = 0;
+        for (size_t i = 1; i < out.size(); ++i) if (out[l].v < out[i].v) out[++l] = out[i];
+        out.resize(l + 1);
+        for (size_t i = 1; i < out.size(); ++i) if (out[i - 1].v >= out[i].u) out[i - 1].v = out[i].u;
+        l = 0;
+        for (size_t i = 1; i < out.size(); ++i) { if (out[l].v >> 16 == out[i].u >> 16) out[l].v = out[i].v; else out[++l] = out[i]; }
+        out.resize(l + 1);
+        return true;
     }
     return false;
 }
 
 bool bai_region_span(const uint8_t *d, size_t len, int32_t tid, int32_t beg, int32_t end, uint64_t &lo, uint64_t &hi, bool &usable) {
-    usable = false;
-    if (len < 8 || memcmp(d, "BAI\1", 4) || tid < 0) return false;
-    if (len >= 8 + 24 && !memcmp(d + len - 4, "RGXC", 4)) return csi_region_span(d, len - 0, tid, beg, end, lo, hi, usable);
-    size_t p = 4;
-    const int32_t n_ref = (int32_t)h32(d + p); p += 4;
-    if (tid >= n_ref) return false;
-    if (beg < 0) beg = 0;
-    if (end <= beg) { usable = true; return false; }
-    int64_t e = end; if (e > (1ll << 29)) e = 1ll << 29;                  // reg2bins: min_shift 14, depth 5
-    const uint32_t b0 = (uint32_t)beg, e0 = (uint32_t)(e - 1);
-    auto in_region = [&](uint32_t bin) {
-        uint32_t t = 0;
-        for (int l = 0, s = 29; l <= 5; ++l, s -= 3) {
-            const uint32_t n_l = 1u << (3 * l);
-            if (bin < t + n_l) { const uint32_t k = bin - t; return k >= (b0 >> s) && k <= (e0 >> s); }
-            t += n_l;
-        }
-        return false;
-    };
-    for (int32_t r = 0; r < n_ref; ++r) {
-        if (p + 4 > len) return false;
-        const int32_t n_bin = (int32_t)h32(d + p); p += 4;
-        uint64_t cmin = UINT64_MAX, cmax = 0;
-        for (int32_t b = 0; b < n_bin; ++b) {
-            if (p + 8 > len) return false;
-            const uint32_t bin = h32(d + p); const int32_t n_chunk = (int32_t)h32(d + p + 4); p += 8;
-            if (n_chunk < 0 || p + (size_t)n_chunk * 16 > len) return false;
-            if (bin == kCsiBin) return false;
-            if (r == tid && bin != 37450 && in_region(bin))
-                for (int32_t c = 0; c < n_chunk; ++c) { cmin = std::min(cmin, h64(d + p + (size_t)c * 16)); cmax = std::max(cmax, h64(d + p + (size_t)c * 16 + 8)); }
-            p += (size_t)n_chunk * 16;
-        }
-        if (p + 4 > len) return false;
-        const int32_t n_intv = (int32_t)h32(d + p); p += 4;
-        if (n_intv < 0 || p + (size_t)n_intv * 8 > len) return false;
-        if (r == tid) {
-            usable = true;
-            if (cmin == UINT64_MAX) return false;
-            uint64_t lin = 0;                                             // entry of beg's window, zeros filled from the left (hts.c:1543-1547)
-            const int32_t w = std::min<int32_t>(beg >> 14, n_intv - 1);
-            for (int32_t i = w; i >= 0 && !lin; --i) lin = h64(d + p + (size_t)i * 8);
-            lo = std::max(cmin, lin); hi = cmax;
-            if (hi < lo) hi = lo;
-            return true;
-        }
-        p += (size_t)n_intv * 8;
-    }
-    return false;
+    std::vector<VChunk> ch;
+    usable = region_chunks(d, len, tid, beg, end, ch);
+    if (!usable || ch.empty()) return false;
+    lo = ch.front().u; hi = ch.front().v;
+    for (const VChunk &c : ch) hi = std::max(hi, c.v);
+    return true;
 }
 
 bool host_bam_header(const uint8_t *d, size_t n, BamHeader &h) {
@@ -460,19 +439,18 @@ bool normalize_index(const uint8_t *in, size_t n, std::vector<uint8_t> &storage,
             o.insert(o.end(), d + p, d + p + (size_t)n_chunk * 16);
             if (bai_geometry) {
                 if (bin >= 4681 && bin < 37449 && loff) { const size_t w = bin - 4681; if (loffs.size() <= w) loffs.resize(w + 1, 0); loffs[w] = loff; }
-            } else {
-                if (bin != meta_bin && loff) loffs.push_back(loff);
-                ext_bins.push_back(bin == meta_bin ? kCsiMeta : bin); ext_loffs.push_back(loff);
-            }
+            } else if (bin != meta_bin && loff) loffs.push_back(loff);
+            ext_bins.push_back(bin == meta_bin ? kCsiMeta : bin); ext_loffs.push_back(loff);
             p += (size_t)n_chunk * 16;
         }
-        ext_counts.push_back(bai_geometry ? 0 : n_bin);
+        ext_counts.push_back(n_bin);
         w32((uint32_t)loffs.size());                                                           // "linear index": the bins' lower bounds
         for (uint64_t v : loffs) w64(v);
     }
     w64(p + 8 <= len ? h64(d + p) : 0);
-    if (!bai_geometry) {
-        // the real bin numbers and the bins' loff, in the order of the image's bins: what a region query needs (bai_region_span);
+    {
+        // the real bin numbers and the bins' loff, in the order of the image's bins: what a region query needs (region_chunks; also for the
+        // default geometry: the loff a .csi stores for a bin is not always what a BAI loader would derive from a linear index);
         // layout: per reference n_bin x (u32 bin, u64 loff), then i32 min_shift, i32 depth, u64 offset of this block, "RGXC"
         const size_t ext_off = o.size();
         size_t k = 0;

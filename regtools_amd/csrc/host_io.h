@@ -43,12 +43,12 @@ bool parse_bai(const uint8_t *bai, size_t len, BaiInfo &out, bool collect_anchor
 // for each target virtual offset: the smallest record-start offset listed in the index that is >= target
 // (UINT64_MAX when none); one linear pass, no sorting.
 void bai_first_anchor_ge(const uint8_t *bai, size_t len, const uint64_t *targets, int n, uint64_t *out);
-// Where the records that can overlap [beg, end) of reference tid lie in the file (hts_itr_query, hts.c:1733-1800, reg2bins :1668-1681): [lo, hi) in
-// virtual offsets, both record boundaries.  lo = the smallest chunk begin over the region's bins, raised to the linear index's entry for
-// beg's 16 KiB window (no record before that offset reaches the window, hts.c:1755-1768); hi = the largest chunk end.  A superset of
-// what the reference's iterator reads, so filtering [lo, hi) by overlap gives exactly its records.  false = nothing to read (no bin of
-// the region has a chunk).  An image converted from a .csi of another geometry answers from the block of real bin numbers and loffs
-// normalize_index leaves behind it (min_off from the bins' loff instead of the linear index, the same bins-of-every-level walk).
+// The chunks the reference's iterator over [beg, end) of reference tid reads, in order (hts_itr_query, hts.c:1733-1800): virtual-offset
+// pairs, sorted, merged exactly as upstream merges them.  false = the index cannot answer (tid beyond it, damaged); an empty list =
+// an iterator that returns nothing.
+struct VChunk { uint64_t u, v; };
+bool region_chunks(const uint8_t *bai, size_t len, int32_t tid, int32_t beg, int32_t end, std::vector<VChunk> &out);
+// [first chunk begin, largest chunk end) of region_chunks (tests; false = nothing to read)
 bool bai_region_span(const uint8_t *bai, size_t len, int32_t tid, int32_t beg, int32_t end, uint64_t &lo, uint64_t &hi, bool &usable);
 constexpr uint32_t kCsiBin = 0xfffffffeu;   // bin number normalize_index gives the real bins of a converted .csi
 constexpr uint32_t kCsiMeta = 0xffffffffu;  // the pseudo-bin in the block of real bin numbers behind such an image

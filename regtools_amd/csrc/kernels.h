@@ -22,7 +22,8 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
                     uint32_t *status /* [0]=first bad member (min), [1]=its status */, hipStream_t stream, uint32_t ignore_below = 0 /* failures of members below this index are not reported */,
                     uint32_t index_bias = 0 /* added to the launch's member index in status[] and in the ignore_below test: a range launched in pieces */,
                     bool piece = false /* one of several concurrent launches over a range (own kernel symbol, same code) */,
-                    int form = 0 /* 0 = chosen by member count / REGTOOLS_AMD_INFLATE; 1 = k_inflate, 2 = k_inflate_wave, 3 = k_inflate_ring */);
+                    int form = 0 /* 0 = chosen by member count / REGTOOLS_AMD_INFLATE; 1 = k_inflate, 2 = k_inflate_wave, 3 = k_inflate_ring */,
+                    uint8_t *bad_flags = nullptr /* optional, zeroed by the caller: [index in the caller's range] = 1 for every member that did not inflate */);
 
 // ---- a1 (container): BGZF member discovery on the device --------------------------------------------------
 // The member chain (bgzf.c:525: next = this + BSIZE + 1) is serial on a CPU (one dependent cache miss per member).
@@ -58,18 +59,29 @@ void launch_member_stop(const Member *members, uint32_t max_members, const uint3
                         hipStream_t stream);
 
 // ---- a2: record framing ---------------------------------------------------------------------------------
-// Segment s covers arena [pos0 + s*kSegBytes, +kSegBytes) clipped to lim. seg_start[s] = guessed (s>0) or exact
-// (s==0) first record start >= segment begin; seg_exit[s] = first record start >= segment end reached by the
-// chain from seg_start[s]; seg_cnt[s] = records that start inside the segment.
-void launch_seg_walk(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, int32_t n_ref,
+// Which bytes of the arena hold the record stream.  One chain (whole-file runs, shards): segment s covers arena [pos0 + s*kSegBytes,
+// +kSegBytes) clipped to lim, and only segment 0 starts at an exact offset.  Region queries: ONE CHAIN PER CHUNK the reference's iterator
+// reads (hts_itr_next, hts.c:1924-1965: a seek to the chunk's begin, then records as long as the position in front of the next one is
+// below the chunk's end -- the first record after the seek is read whatever its position): chunk c owns segments [seg_base, next
+// chunk's seg_base), its first segment starts exactly at a, its chain is followed up to b, and dlim is where the bytes a reader that
+// started at a can get end (the next empty or unreadable member).  The chunk table lives in HBM; null = the one chain.
+struct SegChunk { uint64_t a, b, dlim; uint32_t seg_base, pad; };
+struct SegGeom {
+    uint64_t pos0, lim;
+    uint64_t data_end;             // end of the inflated bytes (k_decode_seg's staging window may reach past a chunk's end)
+    const SegChunk *chunks; uint32_t n_chunks;
+};
+// seg_start[s] = guessed (or, for a chain's first segment, exact) first record start >= segment begin; seg_exit[s] = first record
+// start >= segment end reached by the chain from seg_start[s]; seg_cnt[s] = records that start inside the segment.
+void launch_seg_walk(const uint8_t *arena, SegGeom g, uint32_t n_seg, int32_t n_ref,
                      uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, uint16_t *seg_cp /* n_seg * kSegCpSlots */, hipStream_t stream);
 // One verification sweep: segment s re-walks from seg_exit_in[s-1] when that differs from seg_start_in[s].
 // *changed is incremented when anything changed. Reads *_in, writes *_out (all segments).
-void launch_seg_verify(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg,
+void launch_seg_verify(const uint8_t *arena, SegGeom g, uint32_t n_seg,
                        const uint64_t *seg_start_in, const uint64_t *seg_exit_in, const uint32_t *seg_cnt_in,
                        uint64_t *seg_start_out, uint64_t *seg_exit_out, uint32_t *seg_cnt_out,
                        uint32_t *status /* [0] leftmost disagreeing segment, [1] leftmost chain end; both preset to ~0u */, uint16_t *seg_cp, hipStream_t stream);
-void launch_seg_truncate(uint64_t pos0, uint64_t lim, uint32_t n_seg, uint32_t last, uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, hipStream_t stream);
+void launch_seg_truncate(SegGeom g, uint32_t n_seg, uint32_t last, uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, hipStream_t stream);
 
 // ---- a2/a3/a5/a6: SoA decode + per-read event count ---------------------------------------------------------
 struct ReadSoA {
@@ -92,11 +104,16 @@ struct ExtractCfg {
     const uint8_t *fa_data;
     const struct FaContig *fa_tab;
     uint32_t *fa_missing;          // [0] set to 1+tid when a junction lies on a contig the FASTA does not have
+    // the iterator's end rule (hts_itr_next, hts.c:1946-1950: the first record read whose tid is not the region's or whose pos is not below
+    // its end finishes the iteration, whatever follows).  stop_out (null = off): [0] = smallest index of such a record (preset ~0),
+    // [1] = 1 + largest index of a record that passed the overlap test (preset 0); records at or behind stop_index are not iterated.
+    uint32_t *stop_out;
+    uint32_t stop_index;
 };
 
 // one wave per framing segment, segment bytes staged through LDS (replaces launch_seg_fill + launch_decode on the hot path)
 // seg_iter[s] = records of segment s that pass the region filter; seg_long[s] = its reads for the wave-per-read kernel
-void launch_decode_seg(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, const uint64_t *seg_start, const uint32_t *seg_base,
+void launch_decode_seg(const uint8_t *arena, SegGeom g, uint32_t n_seg, const uint64_t *seg_start, const uint32_t *seg_base,
                        const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, const uint16_t *seg_cp,
                        bool staged /* segment bytes through LDS (short records) or read in place (long records) */, hipStream_t stream);
 void launch_long_fill(uint32_t n_seg, const uint32_t *seg_base, const uint32_t *seg_cnt, const uint32_t *seg_long_base, ExtractCfg cfg, ReadSoA soa,

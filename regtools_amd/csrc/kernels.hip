@@ -4,6 +4,8 @@
 // deliberately no MFMA.  Wave width is 64 everywhere (ballot masks are 64-bit).
 #include "kernels.h"
 
+#include <mutex>
+
 #include "bam_core.h"
 #include "inflate_core.h"
 #include "inflate_ring.h"
@@ -95,7 +97,7 @@ struct LdsTab {
 template <bool PROBE, bool PIECE = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_inflate(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
                                                 uint32_t n_members, uint8_t *__restrict__ arena, uint64_t upos_bias, uint32_t *len_scratch,
-                                                uint32_t *status, uint32_t ignore_below, uint32_t index_bias) {
+                                                uint32_t *status, uint32_t ignore_below, uint32_t index_bias, uint8_t *bad) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t m = blockIdx.x * 64 + threadIdx.x;
     if (m >= n_members) return;
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         // members in front of a seek target are inflated for the header only: their failures do not end the record stream and are
         // reported apart (the header read and the footer check still want to know)
         const uint32_t mi = m + index_bias;       // (index in the caller's member range: a range may be launched in several pieces)
+        if (bad) bad[mi] = 1;
         uint32_t *slot = mi >= ignore_below ? status : status + kStatusEarly;
         uint32_t prev = atomicMin(&slot[0], mi);
         if (mi < prev) slot[1] = (uint32_t)st;    // best effort: status of (one of) the earliest bad members
@@ -210,7 +213,7 @@ struct WaveCoop {
 template <bool PROBE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_inflate_ring(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
                                                 uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
-                                                uint32_t *status, uint32_t ignore_below, uint32_t index_bias) {
+                                                uint32_t *status, uint32_t ignore_below, uint32_t index_bias, uint8_t *bad) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
     const uint32_t m = blockIdx.x * 64 + lane;
@@ -235,6 +238,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     else if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
     if (st != INF_OK) {
         const uint32_t mi = m + index_bias;
+        if (bad) bad[mi] = 1;
         uint32_t *slot = mi >= ignore_below ? status : status + kStatusEarly;
         uint32_t prev = atomicMin(&slot[0], mi);
         if (mi < prev) slot[1] = (uint32_t)st;
@@ -256,7 +260,7 @@ struct DevWave {
 static_assert(sizeof(WaveShared) <= 80 * 1024, "two wave-per-member workgroups per CU");
 
 __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *__restrict__ comp, const Member *__restrict__ members, uint32_t n_members, uint8_t *arena,
-                                                     uint64_t upos_bias, uint32_t *status, uint32_t ignore_below, uint32_t index_bias) {
+                                                     uint64_t upos_bias, uint32_t *status, uint32_t ignore_below, uint32_t index_bias, uint8_t *bad) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     WaveShared &S = *reinterpret_cast<WaveShared *>(lds);
     const uint32_t m = blockIdx.x;
@@ -273,6 +277,7 @@ __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *__restrict__
     }
     if (st != INF_OK && threadIdx.x == 0) {
         const uint32_t mi = m + index_bias;
+        if (bad) bad[mi] = 1;
         uint32_t *slot = mi >= ignore_below ? status : status + kStatusEarly;
         uint32_t prev = atomicMin(&slot[0], mi);
         if (mi < prev) slot[1] = (uint32_t)st;
@@ -294,8 +299,15 @@ static int inflate_form_forced() {
     static const int f = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE"); return !e ? 0 : !strcmp(e, "lane") ? 1 : !strcmp(e, "wave") ? 2 : 0; }();
     return f;
 }
+// (the attribute belongs to the current device's copy of the function: once per device, and the shard threads of rgx_extract_multi
+// may get here together)
 static void inflate_attrs() {
-    static bool done = false;
+    static std::mutex mu;
+    static bool done_dev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    bool &done = done_dev[dev];
     if (done) return;
     (void)hipFuncSetAttribute((const void *)k_inflate<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
@@ -306,7 +318,7 @@ static void inflate_attrs() {
     done = true;
 }
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
-                    uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias, bool piece, int form) {
+                    uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias, bool piece, int form, uint8_t *bad) {
     if (!n_members) return;
     inflate_attrs();
     // form: 0 = the pipeline's choice (environment, member count), 1 = one member per lane, 2 = one member per wave, 3 = lane + LDS window
@@ -314,22 +326,22 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
     const bool wave = form ? form == 2 : (!ring && inflate_form_forced() != 1 && (n_members <= kWaveFormMaxMembers || inflate_form_forced() == 2));
     uint32_t blocks = (n_members + 63) / 64;
     if (wave) {
-        hipLaunchKernelGGL(k_inflate_wave, dim3(n_members), dim3(64), (uint32_t)sizeof(WaveShared), stream, comp, members, n_members, arena, upos_bias, status, ignore_below, index_bias);
+        hipLaunchKernelGGL(k_inflate_wave, dim3(n_members), dim3(64), (uint32_t)sizeof(WaveShared), stream, comp, members, n_members, arena, upos_bias, status, ignore_below, index_bias, bad);
         return;
     }
     if (!ring) {
-        if (piece) hipLaunchKernelGGL((k_inflate<false, true>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias);
-        else hipLaunchKernelGGL((k_inflate<false, false>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias);
+        if (piece) hipLaunchKernelGGL((k_inflate<false, true>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad);
+        else hipLaunchKernelGGL((k_inflate<false, false>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad);
         return;
     }
-    hipLaunchKernelGGL(k_inflate_ring<false>, dim3(blocks), dim3(64), kRingLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias);
+    hipLaunchKernelGGL(k_inflate_ring<false>, dim3(blocks), dim3(64), kRingLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad);
 }
 void launch_inflate_probe(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *slots, uint32_t *len_scratch, uint32_t *sizes,
                           hipStream_t stream) {
     if (!n_members) return;
     inflate_attrs();
-    if (!inflate_ring_selected()) { hipLaunchKernelGGL(k_inflate<true>, dim3((n_members + 63) / 64), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u); return; }
-    hipLaunchKernelGGL(k_inflate_ring<true>, dim3((n_members + 63) / 64), dim3(64), kRingLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u);
+    if (!inflate_ring_selected()) { hipLaunchKernelGGL(k_inflate<true>, dim3((n_members + 63) / 64), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr); return; }
+    hipLaunchKernelGGL(k_inflate_ring<true>, dim3((n_members + 63) / 64), dim3(64), kRingLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr);
 }
 
 // =====================================================================================================
@@ -355,16 +367,30 @@ __device__ __forceinline__ uint64_t walk_chain(const uint8_t *arena, uint64_t o,
     return o;
 }
 
-__global__ void k_seg_walk(const uint8_t *__restrict__ arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, int32_t n_ref,
+// the bytes segment s covers: [a, b), where its chain's readable bytes end (lim), and whether s is the first segment of its chain
+__device__ __forceinline__ void seg_of(const SegGeom &g, uint32_t s, uint64_t &a, uint64_t &b, uint64_t &lim, bool &first) {
+    if (!g.chunks) {
+        a = g.pos0 + (uint64_t)s * kSegBytes; b = a + kSegBytes; lim = g.lim; first = s == 0;
+        if (b > lim) b = lim;
+        return;
+    }
+    uint32_t lo = 0, hi = g.n_chunks;                    // the last chunk whose seg_base is <= s (few chunks, the table stays in the caches)
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g.chunks[mid].seg_base <= s) lo = mid; else hi = mid; }
+    const SegChunk c = g.chunks[lo];
+    a = c.a + (uint64_t)(s - c.seg_base) * kSegBytes; b = a + kSegBytes; lim = c.dlim; first = s == c.seg_base;
+    if (b > c.b) b = c.b;
+}
+
+__global__ void k_seg_walk(const uint8_t *__restrict__ arena, SegGeom g, uint32_t n_seg, int32_t n_ref,
                            uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, uint16_t *seg_cp) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seg) return;
     uint16_t *cp = seg_cp + (size_t)s * kSegCpSlots;
-    uint64_t a = pos0 + (uint64_t)s * kSegBytes, b = a + kSegBytes;
-    if (b > lim) b = lim;
+    uint64_t a, b, lim; bool first;
+    seg_of(g, s, a, b, lim, first);
     uint64_t o = a, ex = kChainEnd;
     uint32_t cnt = 0;
-    if (s > 0) {
+    if (!first) {
         // guess: first offset in the segment where three chained records all look like records AND the block_size chain from
         // there leaves the segment through readable records.  A false start almost never survives that (a 16 KiB walk is dozens
         // of records), so wrong exits -- the expensive kind of misprediction, see k_seg_verify -- are rare.
@@ -415,9 +441,7 @@ __global__ void k_seg_walk(const uint8_t *__restrict__ arena, uint64_t pos0, uin
 }
 
 // is segment s (> 0) framed the way its left neighbour's exit says it must be?
-__device__ __forceinline__ bool seg_consistent(uint64_t pos0, uint64_t lim, uint32_t s, uint64_t expect, uint64_t st, uint64_t ex, uint32_t cnt) {
-    uint64_t b = pos0 + (uint64_t)s * kSegBytes + kSegBytes;
-    if (b > lim) b = lim;
+__device__ __forceinline__ bool seg_consistent(uint64_t b /* the segment's end */, uint64_t expect, uint64_t st, uint64_t ex, uint32_t cnt) {
     return expect >= b ? (st == b && ex == expect && cnt == 0) : st == expect;   // expect >= b (incl. kChainEnd): no record starts here
 }
 
@@ -432,27 +456,28 @@ __device__ __forceinline__ bool seg_consistent(uint64_t pos0, uint64_t lim, uint
 // that is not final yet, so the loop ends only when the whole chain agrees -- which, segment 0 being exact, means it is exact.
 // status[1] = leftmost segment whose chain ends (kChainEnd): when that one lies in the exact prefix the stream really ends there
 // (truncated / unreadable record, sam.c:421-423) and the host empties everything to its right in one launch.
-__global__ void k_seg_verify(const uint8_t *__restrict__ arena, uint64_t pos0, uint64_t lim, uint32_t n_seg,
+__global__ void k_seg_verify(const uint8_t *__restrict__ arena, SegGeom g, uint32_t n_seg,
                              const uint64_t *__restrict__ st_in, const uint64_t *__restrict__ ex_in, const uint32_t *__restrict__ cnt_in,
                              uint64_t *st_out, uint64_t *ex_out, uint32_t *cnt_out, uint32_t *status, uint16_t *seg_cp) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seg) return;
     uint64_t st = st_in[s], ex = ex_in[s];
     uint32_t cnt = cnt_in[s];
-    if (ex == kChainEnd && (s == 0 || ex_in[s - 1] != kChainEnd)) atomicMin(status + 1, s);
-    if (s > 0) {
+    uint64_t a, b, lim; bool first;
+    seg_of(g, s, a, b, lim, first);
+    if (ex == kChainEnd && (first || ex_in[s - 1] != kChainEnd)) atomicMin(status + 1, s);
+    if (!first) {                                                               // (a chain's first segment starts at an exact offset)
         const uint64_t expect = ex_in[s - 1];
         if (expect == kChainUnknown) atomicMin(status, s);                      // the left neighbour knows nothing yet: wait
-        else if (!seg_consistent(pos0, lim, s, expect, st, ex, cnt)) {
+        else if (!seg_consistent(b, expect, st, ex, cnt)) {
             atomicMin(status, s);
             const bool placeholder = ex == kChainUnknown;
-            const bool left_settled = s == 1 || (ex_in[s - 2] != kChainUnknown &&
-                                                 seg_consistent(pos0, lim, s - 1, ex_in[s - 2], st_in[s - 1], expect, cnt_in[s - 1]));
+            uint64_t a1, b1, lim1; bool first1;
+            seg_of(g, s - 1, a1, b1, lim1, first1);
+            const bool left_settled = first1 || (ex_in[s - 2] != kChainUnknown && seg_consistent(b1, ex_in[s - 2], st_in[s - 1], expect, cnt_in[s - 1]));
             if (placeholder || left_settled) {
-                uint64_t b = pos0 + (uint64_t)s * kSegBytes + kSegBytes;
-                if (b > lim) b = lim;
                 if (expect >= b) { st = b; ex = expect; cnt = 0; }
-                else { st = expect; ex = walk_chain(arena, st, b, lim, cnt, seg_cp + (size_t)s * kSegCpSlots, pos0 + (uint64_t)s * kSegBytes); }
+                else { st = expect; ex = walk_chain(arena, st, b, lim, cnt, seg_cp + (size_t)s * kSegCpSlots, a); }
             }
         }
     }
@@ -460,29 +485,29 @@ __global__ void k_seg_verify(const uint8_t *__restrict__ arena, uint64_t pos0, u
 }
 
 // the record chain ended inside segment `last`: no record starts to its right
-__global__ void k_seg_truncate(uint64_t pos0, uint64_t lim, uint32_t n_seg, uint32_t last, uint64_t *st, uint64_t *ex, uint32_t *cnt) {
+__global__ void k_seg_truncate(SegGeom g, uint32_t n_seg, uint32_t last, uint64_t *st, uint64_t *ex, uint32_t *cnt) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seg || s <= last) return;
-    uint64_t b = pos0 + (uint64_t)s * kSegBytes + kSegBytes;
-    if (b > lim) b = lim;
+    uint64_t a, b, lim; bool first;
+    seg_of(g, s, a, b, lim, first);
     st[s] = b; ex[s] = kChainEnd; cnt[s] = 0;
 }
 
-void launch_seg_walk(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, int32_t n_ref, uint64_t *seg_start,
+void launch_seg_walk(const uint8_t *arena, SegGeom g, uint32_t n_seg, int32_t n_ref, uint64_t *seg_start,
                      uint64_t *seg_exit, uint32_t *seg_cnt, uint16_t *seg_cp, hipStream_t stream) {
     if (!n_seg) return;
-    hipLaunchKernelGGL(k_seg_walk, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, pos0, lim, n_seg, n_ref, seg_start, seg_exit, seg_cnt, seg_cp);
+    hipLaunchKernelGGL(k_seg_walk, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, g, n_seg, n_ref, seg_start, seg_exit, seg_cnt, seg_cp);
 }
-void launch_seg_verify(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, const uint64_t *seg_start_in,
+void launch_seg_verify(const uint8_t *arena, SegGeom g, uint32_t n_seg, const uint64_t *seg_start_in,
                        const uint64_t *seg_exit_in, const uint32_t *seg_cnt_in, uint64_t *seg_start_out, uint64_t *seg_exit_out,
                        uint32_t *seg_cnt_out, uint32_t *status, uint16_t *seg_cp, hipStream_t stream) {
     if (!n_seg) return;
-    hipLaunchKernelGGL(k_seg_verify, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, pos0, lim, n_seg, seg_start_in, seg_exit_in,
+    hipLaunchKernelGGL(k_seg_verify, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, g, n_seg, seg_start_in, seg_exit_in,
                        seg_cnt_in, seg_start_out, seg_exit_out, seg_cnt_out, status, seg_cp);
 }
-void launch_seg_truncate(uint64_t pos0, uint64_t lim, uint32_t n_seg, uint32_t last, uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, hipStream_t stream) {
+void launch_seg_truncate(SegGeom g, uint32_t n_seg, uint32_t last, uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, hipStream_t stream) {
     if (!n_seg) return;
-    hipLaunchKernelGGL(k_seg_truncate, dim3((n_seg + 255) / 256), dim3(256), 0, stream, pos0, lim, n_seg, last, seg_start, seg_exit, seg_cnt);
+    hipLaunchKernelGGL(k_seg_truncate, dim3((n_seg + 255) / 256), dim3(256), 0, stream, g, n_seg, last, seg_start, seg_exit, seg_cnt);
 }
 
 // =====================================================================================================
@@ -498,7 +523,7 @@ constexpr uint32_t kSegMaxRecs = kSegBytes / 36 + 2;     // a record is at least
 // nothing is staged, heads / CIGAR / aux are read where they lie, and the 95 % of the stream that is sequence and quality never
 // leaves HBM.  The host picks it when the mean record is longer than kSparseRecordBytes.
 template <bool STAGED>
-__global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ arena, uint64_t pos0, uint64_t lim, uint32_t n_seg,
+__global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ arena, SegGeom g, uint32_t n_seg,
                                                    const uint64_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_base,
                                                    const uint32_t *__restrict__ seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter,
                                                    uint32_t *seg_long, const uint16_t *__restrict__ seg_cp) {
@@ -507,11 +532,12 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
     const uint32_t s = blockIdx.x, lane = threadIdx.x;
     const uint32_t cnt = seg_cnt[s];
     if (cnt == 0) { if (lane == 0) { seg_iter[s] = 0; seg_long[s] = 0; } return; }
-    const uint64_t a = pos0 + (uint64_t)s * kSegBytes;
+    uint64_t a, seg_b, seg_lim; bool seg_first;
+    seg_of(g, s, a, seg_b, seg_lim, seg_first);
     // window [w0, w1): 16-byte aligned start at/below the segment begin, end = segment end + tail, clipped to the arena
     const uint64_t w0 = a & ~15ull;
     uint64_t w1 = a + kSegBytes + kSegTail;
-    if (w1 > lim) w1 = lim;
+    if (w1 > g.data_end) w1 = g.data_end;
     if constexpr (STAGED) {
         // all loads of the window in flight at once (18 x 1 KiB per wave), then the LDS stores: one HBM latency, not eighteen
         constexpr int kChunks = (kSegBytes + kSegTail + 16 + 1023) / 1024;
@@ -548,6 +574,7 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
     __syncthreads();
     const uint32_t base = seg_base[s];
     uint32_t n_iter = 0, n_long = 0;
+    uint32_t first_stop = 0xffffffffu, last_in = 0;
     for (uint32_t k = lane; k < cnt; k += 64) {
         const uint32_t ro = s_off[k];
         const uint64_t o = w0 + ro;
@@ -586,6 +613,10 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
         bool in_region = true;
         if (cfg.region_tid != -2) {
             in_region = h.tid == cfg.region_tid && h.pos < cfg.region_end;
+            if (cfg.stop_out) {                                // hts_itr_next's end rule (hts.c:1946-1950), see ExtractCfg
+                if (i >= cfg.stop_index) in_region = false;
+                else if (!in_region) first_stop = min(first_stop, i);
+            }
             if (in_region) {                                   // bam_endpos (sam.c:336-342)
                 int32_t endpos = h.pos + 1;
                 if (!(h.flag & 4) && h.n_cigar > 0) {
@@ -597,6 +628,7 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
             }
         }
         n_iter += in_region ? 1u : 0u;
+        if (in_region) last_in = i + 1;
         uint32_t nev = 0;
         char strand = '?';
         if (in_region && h.n_cigar > 1 && h.tid >= 0 && h.tid < cfg.n_ref) {
@@ -620,6 +652,15 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
     // per-segment totals instead of global atomics: one hot address serialises at ~90 atomics/us
     n_iter = wave_incl_scan(n_iter); n_long = wave_incl_scan(n_long);
     if (lane == 63) { seg_iter[s] = n_iter; seg_long[s] = n_long; }
+    if (cfg.stop_out) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { first_stop = min(first_stop, (uint32_t)__shfl_xor((int)first_stop, d, 64)); last_in = max(last_in, (uint32_t)__shfl_xor((int)last_in, d, 64)); }
+        // (segments are launched roughly in order: after the first few, the values in memory already beat most candidates)
+        if (lane == 0) {
+            if (first_stop < *(volatile uint32_t *)&cfg.stop_out[0]) atomicMin(&cfg.stop_out[0], first_stop);
+            if (last_in > *(volatile uint32_t *)&cfg.stop_out[1]) atomicMax(&cfg.stop_out[1], last_in);
+        }
+    }
 }
 
 // list of the reads that go to the wave-per-read kernel, built without atomics: one wave per segment, positions from the
@@ -639,11 +680,11 @@ __global__ __launch_bounds__(64) void k_long_fill(uint32_t n_seg, const uint32_t
     }
 }
 
-void launch_decode_seg(const uint8_t *arena, uint64_t pos0, uint64_t lim, uint32_t n_seg, const uint64_t *seg_start, const uint32_t *seg_base,
+void launch_decode_seg(const uint8_t *arena, SegGeom g, uint32_t n_seg, const uint64_t *seg_start, const uint32_t *seg_base,
                        const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, const uint16_t *seg_cp, bool staged, hipStream_t stream) {
     if (!n_seg) return;
-    if (staged) hipLaunchKernelGGL(k_decode_seg<true>, dim3(n_seg), dim3(64), kSegBytes + kSegTail + 48, stream, arena, pos0, lim, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
-    else hipLaunchKernelGGL(k_decode_seg<false>, dim3(n_seg), dim3(64), 0, stream, arena, pos0, lim, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
+    if (staged) hipLaunchKernelGGL(k_decode_seg<true>, dim3(n_seg), dim3(64), kSegBytes + kSegTail + 48, stream, arena, g, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
+    else hipLaunchKernelGGL(k_decode_seg<false>, dim3(n_seg), dim3(64), 0, stream, arena, g, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
 }
 void launch_long_fill(uint32_t n_seg, const uint32_t *seg_base, const uint32_t *seg_cnt, const uint32_t *seg_long_base, ExtractCfg cfg, ReadSoA soa,
                       uint32_t *long_list, hipStream_t stream) {
