@@ -629,7 +629,8 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         d_bad = b_bad.as<uint8_t>();
         HIP_TRY(hipMemsetAsync(d_bad, 0, n_range, st));
     }
-    if (!overlap) launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below, 0, false, 0, d_bad);
+    const int pairs = inflate_pairs_for(bam_len, total_all);     // (the whole file's ratio: a range of it is the same kind of payload)
+    if (!overlap) launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below, 0, false, 0, d_bad, pairs);
     else {
         // one launch per upload chunk, on the side streams: the members whose bytes (plus the decoder's 16-byte look-ahead) have arrived with
         // chunk j start as soon as its event fires, next to the launches of the chunks before it
@@ -654,7 +655,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             hipStream_t q = own ? st : c->side[j];
             if (!own) used_side |= 1u << j;
             HIP_TRY(hipStreamWaitEvent(q, c->chunk_ev[j], 0));
-            launch_inflate(d_bam, d_members + g_lo, g_hi - g_lo, b_arena.as<uint8_t>(), upos_lo, (uint32_t *)(b_lens.as<uint8_t>() + scratch_off), d_sc, q, ignore_below, g_lo - m_lo, /*piece=*/true, 0, d_bad);
+            launch_inflate(d_bam, d_members + g_lo, g_hi - g_lo, b_arena.as<uint8_t>(), upos_lo, (uint32_t *)(b_lens.as<uint8_t>() + scratch_off), d_sc, q, ignore_below, g_lo - m_lo, /*piece=*/true, 0, d_bad, pairs);
             scratch_off += inflate_scratch_bytes(g_hi - g_lo);
             g_lo = g_hi;
         }
@@ -1352,7 +1353,7 @@ extern "C" int rgx_k_inflate(const void *d_comp, const rgx_member *d_members, ui
 }
 
 extern "C" int rgx_k_inflate_form(int form, const void *d_comp, const rgx_member *d_members, uint32_t n_members, void *d_arena, uint32_t *d_status, void *stream) {
-    if (form < 0 || form > 3) return RGX_ERR_ARG;
+    if (form < 0 || form > 4) return RGX_ERR_ARG;
     static_assert(sizeof(rgx_member) == sizeof(Member), "rgx_member layout");
     // stage entry point: the code-length scratch is a process-lifetime buffer grown on demand
     static void *scratch = nullptr; static size_t scratch_cap = 0;

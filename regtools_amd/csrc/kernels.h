@@ -23,7 +23,10 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
                     uint32_t index_bias = 0 /* added to the launch's member index in status[] and in the ignore_below test: a range launched in pieces */,
                     bool piece = false /* one of several concurrent launches over a range (own kernel symbol, same code) */,
                     int form = 0 /* 0 = chosen by member count / REGTOOLS_AMD_INFLATE; 1 = k_inflate, 2 = k_inflate_wave, 3 = k_inflate_ring */,
-                    uint8_t *bad_flags = nullptr /* optional, zeroed by the caller: [index in the caller's range] = 1 for every member that did not inflate */);
+                    uint8_t *bad_flags = nullptr /* optional, zeroed by the caller: [index in the caller's range] = 1 for every member that did not inflate */,
+                    int pairs = 1 /* k_inflate_coop: a literal and the symbol behind it in one trip (inflate_pairs_for) */);
+// literal pairs pay on payloads with many literals and cost on run-length payloads: on when the file compresses to more than 1/32 of its size
+inline int inflate_pairs_for(uint64_t compressed_bytes, uint64_t inflated_bytes) { return compressed_bytes * 32 > inflated_bytes; }
 
 // ---- a1 (container): BGZF member discovery on the device --------------------------------------------------
 // The member chain (bgzf.c:525: next = this + BSIZE + 1) is serial on a CPU (one dependent cache miss per member).

@@ -8,6 +8,7 @@
 
 #include "bam_core.h"
 #include "inflate_core.h"
+#include "inflate_coop.h"
 #include "inflate_ring.h"
 #include "inflate_wave.h"
 
@@ -245,6 +246,94 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 }
 
+// ---- round 3: long copies moved by the wave (inflate_coop.h) ---------------------------------------------------------------------------
+// The wave as a copying machine.  A round serves up to four pending long copies, sixteen lanes each: the owners' lane numbers come from a
+// ballot (scalar bit scans), every lane pulls its group's copy -- destination of the first whole chunk (relative to the wave's lowest output
+// address: the members of a wave lie next to each other in the arena), distance, chunk count -- with two ds_bpermute, loads 16 bytes from
+// (chunk j) - distance and, after the trip's one wait, stores them to chunk j: aligned, and 256 consecutive bytes per group.  Up to
+// kCoopRounds rounds are in flight per trip (one per four lanes that start a long match in the same trip; the bench payload averages two);
+// a trip with more finishes the earlier ones on the spot.
+constexpr int kCoopRounds = 4;
+struct WaveCopy {
+    uint8_t *wave_base;
+    uint32_t lane;
+    u32x4 d0, d1, d2, d3;
+    uint32_t t0, t1, t2, t3;          // destination (relative) of what d* holds, ~0 = nothing
+    __device__ __forceinline__ bool any(bool b) const { return __builtin_amdgcn_ballot_w64(b) != 0; }
+    __device__ __forceinline__ void stores() {
+        if (t0 != 0xffffffffu) *(u32x4 *)(wave_base + t0) = d0;
+        if (t1 != 0xffffffffu) *(u32x4 *)(wave_base + t1) = d1;
+        if (t2 != 0xffffffffu) *(u32x4 *)(wave_base + t2) = d2;
+        if (t3 != 0xffffffffu) *(u32x4 *)(wave_base + t3) = d3;
+        t0 = t1 = t2 = t3 = 0xffffffffu;
+    }
+    __device__ __forceinline__ void begin(bool want, uint8_t *out, uint32_t o_body, uint32_t dist, uint32_t nb) {
+        uint64_t mask = __builtin_amdgcn_ballot_w64(want);
+        if (!mask) return;
+        const uint32_t rel = (uint32_t)(out - wave_base) + o_body, packed = dist | nb << 16;
+        const uint32_t g = lane >> 4, j = lane & 15u;
+        for (;;) {
+#define RGX_ROUND(D, Tg)                                                                                                         \
+            if (mask) {                                                                                                          \
+                const int l0 = __builtin_ctzll(mask); mask &= mask - 1;                                                          \
+                const int l1 = mask ? __builtin_ctzll(mask) : -1; mask &= mask - 1;                                              \
+                const int l2 = mask ? __builtin_ctzll(mask) : -1; mask &= mask - 1;                                              \
+                const int l3 = mask ? __builtin_ctzll(mask) : -1; mask &= mask - 1;                                              \
+                const int lg = g == 0 ? l0 : g == 1 ? l1 : g == 2 ? l2 : l3;                                                     \
+                const uint32_t dd = (uint32_t)__builtin_amdgcn_ds_bpermute((lg < 0 ? 0 : lg) << 2, (int)rel);                    \
+                const uint32_t pp = (uint32_t)__builtin_amdgcn_ds_bpermute((lg < 0 ? 0 : lg) << 2, (int)packed);                 \
+                if (lg >= 0 && j < (pp >> 16)) { Tg = dd + 16u * j; D = ld128(wave_base + Tg - (pp & 0xffffu)); }                 \
+            }
+            RGX_ROUND(d0, t0) RGX_ROUND(d1, t1) RGX_ROUND(d2, t2) RGX_ROUND(d3, t3)
+#undef RGX_ROUND
+            if (!mask) break;
+            __builtin_amdgcn_s_waitcnt(0x0F70);                   // more than kCoopRounds rounds in one trip: finish these now
+            stores();
+        }
+    }
+    __device__ __forceinline__ void end() { stores(); }
+};
+
+// one lane per member like k_inflate; no lane leaves before the wave is done (the lanes without a member serve the others' copies)
+template <bool PROBE, bool PIECE = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_inflate_coop(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
+                                                uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
+                                                uint32_t *status, uint32_t ignore_below, uint32_t index_bias, uint8_t *bad, uint32_t pairs) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t m = blockIdx.x * 64 + lane;
+    const bool have = m < n_members;
+    const Member mb = members[have ? m : n_members - 1];
+    LdsTab T{lds + lane, len_scratch + (have ? m : 0), gridDim.x * 64};
+    // the wave's lowest output address: lane 0's member (upos grows with the member index; PROBE: slot m)
+    const uint64_t base_off = PROBE ? (uint64_t)(blockIdx.x * 64) * kBgzfMaxBlock : members[blockIdx.x * 64].upos - upos_bias;
+    WaveCopy C;
+    C.wave_base = arena + base_off; C.lane = lane;
+    C.d0 = C.d1 = C.d2 = C.d3 = u32x4{0, 0, 0, 0};
+    C.t0 = C.t1 = C.t2 = C.t3 = 0xffffffffu;
+    uint32_t out_len = 0;
+    if (PROBE) {
+        const bool run = have && mb.isize != 0xffffffffu;         // ~0: BSIZE runs past the end of the file (or is < 26): the read fails upstream
+        const int st = inflate_coop(comp + mb.cpos, mb.clen, arena + (uint64_t)(have ? m : 0) * kBgzfMaxBlock, kBgzfMaxBlock, &out_len, T, C, run, pairs != 0);
+        if (have) status[m] = run && st == INF_OK ? out_len : 0xffffffffu;
+        return;
+    }
+    // a member whose claimed size is no BGZF block size owns no bytes of the arena (k_member_compact): it must not write any, whatever
+    // range the host asked for.  ~0 = the member runs past the end of the file (k_member_link).
+    const bool run = have && mb.isize <= kBgzfMaxBlock;
+    int st = inflate_coop(comp + mb.cpos, mb.clen, run ? arena + (mb.upos - upos_bias) : C.wave_base, run ? mb.isize : 0, &out_len, T, C, run, pairs != 0);
+    if (!have) return;
+    if (!run) st = mb.isize == 0xffffffffu ? INF_IN_OVERRUN : INF_OUT_OVERFLOW;
+    else if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
+    if (st != INF_OK) {
+        const uint32_t mi = m + index_bias;
+        if (bad) bad[mi] = 1;
+        uint32_t *slot = mi >= ignore_below ? status : status + kStatusEarly;
+        uint32_t prev = atomicMin(&slot[0], mi);
+        if (mi < prev) slot[1] = (uint32_t)st;
+    }
+}
+
 size_t inflate_scratch_bytes(uint32_t n_members) { return (size_t)((n_members + 63) / 64) * 64 * kScratchWordsPerLane * 4; }
 
 // ---- the small-input form: one member per wave, the whole member in LDS (inflate_wave.h) ------------------------------------------------
@@ -284,19 +373,20 @@ __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *__restrict__
     }
 }
 
-// Two forms of the decoder: k_inflate (round 1: output straight to HBM, 12 waves per CU) is what the pipeline runs; k_inflate_ring
-// (inflate_ring.h: output through a per-lane LDS window, whole lines to HBM, 4 waves per CU) moves 0.3x the HBM bytes but its symbol loop
-// has one wave per SIMD to hide its LDS round trips behind and measures 1.9x slower.  REGTOOLS_AMD_INFLATE=ring selects it.
-static bool inflate_ring_selected() {
-    static const bool ring = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE"); return e && !strcmp(e, "ring"); }();
-    return ring;
-}
-// k_inflate_wave (one member per wave, 512 members at a time: 1.17 ms per 512 members of the bench payload, 5.9 ms of the realistic one)
-// against k_inflate (one member per lane: 7.7-9.7 ms / 25-30 ms per launch whatever its size): the wave form wins up to ~4,000 / ~2,600
-// members (tools/inflate_forms.py, profiles/r02_inflate_forms.txt).  REGTOOLS_AMD_INFLATE=lane / =wave force one or the other.
+// Four forms of the decoder (rgx_k_inflate_form / REGTOOLS_AMD_INFLATE = lane | wave | ring | coop):
+//   1 lane  k_inflate       (round 1: one member per lane, every lane copies its own matches, 12 waves per CU)
+//   2 wave  k_inflate_wave  (round 2: one member per WAVE, member in LDS: small inputs -- 1.17 ms per 512 members against the lane forms'
+//                            7.7-9.7 ms per launch whatever its size; wins up to ~4,000 members, tools/inflate_forms.py)
+//   3 ring  k_inflate_ring  (round 2: lane form with a per-lane LDS window; 0.5x the HBM traffic, 4 waves per CU, 1.9x slower: DESIGN.md 5.1)
+//   4 coop  k_inflate_coop  (round 3: lane form, long matches moved by the wave in aligned 256-byte pieces: inflate_coop.h)
+// The pipeline (form 0) takes the wave form up to kWaveFormMaxMembers members and kDefaultLaneForm beyond.
 constexpr uint32_t kWaveFormMaxMembers = 2048;
-static int inflate_form_forced() {
-    static const int f = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE"); return !e ? 0 : !strcmp(e, "lane") ? 1 : !strcmp(e, "wave") ? 2 : 0; }();
+constexpr int kDefaultLaneForm = 4;
+static int inflate_form_env() {
+    static const int f = [] {
+        const char *e = getenv("REGTOOLS_AMD_INFLATE");
+        return !e ? 0 : !strcmp(e, "lane") ? 1 : !strcmp(e, "wave") ? 2 : !strcmp(e, "ring") ? 3 : !strcmp(e, "coop") ? 4 : 0;
+    }();
     return f;
 }
 // (the attribute belongs to the current device's copy of the function: once per device, and the shard threads of rgx_extract_multi
@@ -312,36 +402,48 @@ static void inflate_attrs() {
     (void)hipFuncSetAttribute((const void *)k_inflate<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+    (void)hipFuncSetAttribute((const void *)k_inflate_coop<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+    (void)hipFuncSetAttribute((const void *)k_inflate_coop<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+    (void)hipFuncSetAttribute((const void *)k_inflate_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WaveShared));
     (void)hipFuncSetAttribute((const void *)k_inflate_ring<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRingLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate_ring<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRingLdsBytes);
     done = true;
 }
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
-                    uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias, bool piece, int form, uint8_t *bad) {
+                    uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias, bool piece, int form, uint8_t *bad, int pairs) {
     if (!n_members) return;
     inflate_attrs();
-    // form: 0 = the pipeline's choice (environment, member count), 1 = one member per lane, 2 = one member per wave, 3 = lane + LDS window
-    const bool ring = form ? form == 3 : inflate_ring_selected();
-    const bool wave = form ? form == 2 : (!ring && inflate_form_forced() != 1 && (n_members <= kWaveFormMaxMembers || inflate_form_forced() == 2));
-    uint32_t blocks = (n_members + 63) / 64;
-    if (wave) {
+    static const int env_pairs = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE_PAIRS"); return e ? atoi(e) != 0 : -1; }();
+    const uint32_t two = env_pairs >= 0 ? (uint32_t)env_pairs : pairs != 0;
+    if (!form) form = inflate_form_env();
+    if (!form) form = n_members <= kWaveFormMaxMembers ? 2 : kDefaultLaneForm;
+    const uint32_t blocks = (n_members + 63) / 64;
+    switch (form) {
+    case 2:
         hipLaunchKernelGGL(k_inflate_wave, dim3(n_members), dim3(64), (uint32_t)sizeof(WaveShared), stream, comp, members, n_members, arena, upos_bias, status, ignore_below, index_bias, bad);
-        return;
-    }
-    if (!ring) {
+        break;
+    case 3:
+        hipLaunchKernelGGL(k_inflate_ring<false>, dim3(blocks), dim3(64), kRingLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad);
+        break;
+    case 4:
+        if (piece) hipLaunchKernelGGL((k_inflate_coop<false, true>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad, two);
+        else hipLaunchKernelGGL((k_inflate_coop<false, false>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad, two);
+        break;
+    default:
         if (piece) hipLaunchKernelGGL((k_inflate<false, true>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad);
         else hipLaunchKernelGGL((k_inflate<false, false>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad);
-        return;
     }
-    hipLaunchKernelGGL(k_inflate_ring<false>, dim3(blocks), dim3(64), kRingLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad);
 }
 void launch_inflate_probe(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *slots, uint32_t *len_scratch, uint32_t *sizes,
                           hipStream_t stream) {
     if (!n_members) return;
     inflate_attrs();
-    if (!inflate_ring_selected()) { hipLaunchKernelGGL(k_inflate<true>, dim3((n_members + 63) / 64), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr); return; }
-    hipLaunchKernelGGL(k_inflate_ring<true>, dim3((n_members + 63) / 64), dim3(64), kRingLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr);
+    const int form = inflate_form_env() ? inflate_form_env() : kDefaultLaneForm;
+    const uint32_t blocks = (n_members + 63) / 64;
+    if (form == 3) hipLaunchKernelGGL(k_inflate_ring<true>, dim3(blocks), dim3(64), kRingLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr);
+    else if (form == 4) hipLaunchKernelGGL(k_inflate_coop<true>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr, 1u);
+    else hipLaunchKernelGGL(k_inflate<true>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr);
 }
 
 // =====================================================================================================

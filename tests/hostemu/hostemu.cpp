@@ -27,6 +27,21 @@ extern "C" int emu_inflate_ring(const uint8_t *in, uint32_t in_len, uint8_t *out
     return st;
 }
 
+// the round-3 decoder (inflate_coop.h: long matches handed to the wave) with a one-lane wave; same guard bytes, every destination phase
+#include "../../regtools_amd/csrc/inflate_coop.h"
+extern "C" int emu_inflate_coop(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t cap, uint32_t *out_len, uint32_t phase, int pairs) {
+    std::vector<uint8_t> ibuf((size_t)in_len + 64, 0);
+    memcpy(ibuf.data(), in, in_len);
+    std::vector<uint8_t> obuf((size_t)cap + 1024, 0xA5);
+    uint8_t *dst = (uint8_t *)(((uintptr_t)obuf.data() + 127) & ~(uintptr_t)127) + 256 + (phase & 127u);
+    rgx::HostTab T; rgx::HostCopy C;
+    const int st = rgx::inflate_coop(ibuf.data(), in_len, dst, cap, out_len, T, C, true, pairs != 0);
+    for (uint8_t *q = obuf.data(); q < dst; ++q) if (*q != 0xA5) return -100;
+    for (uint8_t *q = dst + cap; q < obuf.data() + obuf.size(); ++q) if (*q != 0xA5) return -101;
+    memcpy(out, dst, *out_len <= cap ? *out_len : cap);
+    return st;
+}
+
 // the small-input decoder (inflate_wave.h: one member per wave, whole member in LDS) with the host's one-thread wave
 #include "../../regtools_amd/csrc/inflate_wave.h"
 extern "C" int emu_inflate_wave(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t cap, uint32_t *out_len, uint32_t phase) {

@@ -44,6 +44,15 @@ def inflate(emu, payload, cap=65536):
     assert (st3 == 0) == (st == 0), (st, st3)
     if st == 0:
         assert out3.raw[:n3.value] == got, "wave decoder differs"
+    # ... and round 3's decoder (inflate_coop.h): long matches split into head / wave-copied aligned body / tail
+    for pairs in (0, 1):                               # with and without the second symbol of a trip
+        out4 = ctypes.create_string_buffer(cap + 64)
+        n4 = ctypes.c_uint32(0)
+        st4 = emu.emu_inflate_coop(buf, len(payload), out4, cap, ctypes.byref(n4), _phase[0], pairs)
+        assert st4 not in (-100, -101), "the coop decoder wrote outside its member (phase %d)" % _phase[0]
+        assert (st4 == 0) == (st == 0), (st, st4, _phase[0], pairs)
+        if st == 0:
+            assert out4.raw[:n4.value] == got, "coop decoder differs at phase %d (pairs %d)" % (_phase[0], pairs)
     return st, got
 
 
@@ -201,6 +210,24 @@ def test_ring_decoder_every_destination_phase_and_window_edge(emu):
                 out = ctypes.create_string_buffer(len(data) + 64)
                 n = ctypes.c_uint32(0)
                 st = emu.emu_inflate_ring(p, len(p), out, len(data), ctypes.byref(n), phase)
+                assert st == 0 and out.raw[:n.value] == data, (dist, total, phase, st)
+
+
+def test_coop_decoder_every_destination_phase_and_copy_split(emu):
+    """inflate_coop.h: matches around the lane / wave hand-over (64 bytes), around whole-chunk counts (head + 16 k + tail) and the longest
+    match, distances from runs to the window's end, at every destination phase of a 16-byte chunk; guard bytes around the member must stay
+    untouched (emu_inflate_coop checks them)."""
+    rnd = random.Random(29)
+    for dist in (1, 2, 3, 15, 16, 17, 63, 64, 65, 66, 79, 80, 81, 127, 128, 129, 221, 257, 258, 259, 300, 1000, 32768):
+        seed = bytes(rnd.randrange(256) for _ in range(dist))
+        for total in (dist + 3, dist + 64, dist + 65, dist + 80, dist + 130, dist + 258, dist + 259, dist + 700):
+            data = (seed * (total // dist + 2))[:total]
+            c = zlib.compressobj(9, zlib.DEFLATED, -15, 9)
+            p = c.compress(data) + c.flush()
+            for phase in list(range(16)) + [31, 100, 127]:
+                out = ctypes.create_string_buffer(len(data) + 64)
+                n = ctypes.c_uint32(0)
+                st = emu.emu_inflate_coop(p, len(p), out, len(data), ctypes.byref(n), phase, phase & 1)
                 assert st == 0 and out.raw[:n.value] == data, (dist, total, phase, st)
 
 
