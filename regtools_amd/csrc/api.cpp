@@ -89,6 +89,7 @@ struct rgx_ctx {
     // duration, not the stage's wall time): event pairs wait in kpend until the call's end, kms[slot] accumulates
     struct KPend { hipEvent_t a, b; int slot; };
     std::vector<KPend> kpend; std::vector<hipEvent_t> kfree; double kms[3] = {0, 0, 0};
+    std::vector<uint32_t> rank_stage;                  // host copy of a group-rank table while its upload is in flight
     std::string fasta_path;                            // FASTA currently resident in the "fasta" buffer
     rgx::Fasta *fasta = nullptr;
     DevBuf &buf(const char *name) { return bufs[name]; }
@@ -523,6 +524,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // alone: the whole file is read and filtered by overlap (such a header is not readable upstream either).
     std::vector<VChunk> chunks;
     bool chunked = false;
+    const bool geom_chunked_hint = !whole;                    // (region queries keep the checked path: their chunk table wants the members' verdicts)
     if (!whole && p->n_shards <= 1 && p->region) {
         const size_t head_len = std::min<size_t>(bam_len, (size_t)8 << 20);
         std::vector<uint8_t> head_copy;
@@ -546,6 +548,22 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     bool empty_stream = false;
     auto query = [&]() -> hipError_t {
         uint64_t q[3] = {seek ? (seek_voff >> 16) : 0, cut_lo >> 16, cut_hi == UINT64_MAX ? UINT64_MAX - 64 : (cut_hi >> 16)};
+        if (overlap) {
+            // the member list is on the host (scan_members_parallel): what k_member_query / k_member_stop would answer, without a round trip
+            const uint32_t nm = (uint32_t)hm.size();
+            uint64_t q_up[3];
+            for (int k = 0; k < 3; ++k) {
+                uint32_t lo_ = 0, hi_ = nm;
+                while (lo_ < hi_) { const uint32_t mid = lo_ + (hi_ - lo_) / 2; if (hm[mid].cpos < q[k] + 18) lo_ = mid + 1; else hi_ = mid; }
+                const bool hit = lo_ < nm && hm[lo_].cpos == q[k] + 18;
+                h_sc[24 + k] = hit ? lo_ : nm; q_up[k] = hit ? hm[lo_].upos : ~0ull;
+            }
+            memcpy(h_sc + 32, q_up, sizeof q_up);
+            uint32_t stop_ = 0xffffffffu;
+            for (uint32_t i = h_sc[24]; i < nm; ++i) if (hm[i].isize == 0 || hm[i].isize > kBgzfMaxBlock) { stop_ = i; break; }
+            h_sc[18] = stop_; h_sc[17] = nm; memcpy(h_sc + 20, &hm_total, 8);
+            return hipSuccess;
+        }
         memcpy(h_sc + 40, q, sizeof q);
         hipError_t e = hipMemcpyAsync(d_sc + 40, h_sc + 40, sizeof q, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) return e;
@@ -672,16 +690,27 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // zlib says, at most 64 KiB).  When a member inflates to another length than its footer claims, or the member that ends the
     // stream is not the plain empty block it claims to be, every member is inflated once into its own 64 KiB slot to learn the true
     // lengths and the pipeline starts over with those.  Costs two extra inflate passes; only malformed files ever pay them.
-    HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(h_sc + kStatusEarly, d_sc + kStatusEarly, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    // Host input whose members the host scan vouched for: no round trip here.  The header comes from the host's own inflate of the file's head,
+    // the stages behind the inflate are enqueued on the assumption that every member inflates to its footer's length (what a well-formed file
+    // does), and the launch's verdict is read with the framing's counts: anything else starts over on the device-resident path below.
+    BamHeader hdr_host;
+    const bool spec = overlap && !d_true_sizes && !geom_chunked_hint && host_bam_header(h_bam, std::min<size_t>(bam_len, (size_t)8 << 20), hdr_host);
+    if (spec) { h_sc[0] = h_sc[1] = 0xffffffffu; h_sc[kStatusEarly] = h_sc[kStatusEarly + 1] = 0xffffffffu; }
+    else {
+        HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_sc + kStatusEarly, d_sc + kStatusEarly, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     if (!d_true_sizes) {
         auto size_trouble = [&](uint32_t k) { return h_sc[k] != 0xffffffffu && (h_sc[k + 1] == 12u /* INF_SIZE_MISMATCH */ || h_sc[k + 1] == 10u /* INF_OUT_OVERFLOW */); };
         bool lies = size_trouble(0) || size_trouble(kStatusEarly);
         if (!lies && stop < n_members_all) {
             Member ms; uint8_t two[2] = {0, 0};
             HIP_TRY(hipMemcpy(&ms, d_members + stop, sizeof ms, from_members));
-            if (ms.isize == 0 && ms.clen >= 2) HIP_TRY(hipMemcpy(two, d_bam + ms.cpos, 2, hipMemcpyDeviceToHost));
+            if (ms.isize == 0 && ms.clen >= 2) {
+                if (h_bam && ms.cpos + 2 <= bam_len) memcpy(two, h_bam + ms.cpos, 2);
+                else HIP_TRY(hipMemcpy(two, d_bam + ms.cpos, 2, hipMemcpyDeviceToHost));
+            }
             // fine: an empty block (03 00, the EOF marker) or a member cut off by the end of the file
             lies = !(ms.isize == 0 && two[0] == 3 && two[1] == 0) && ms.isize != 0xffffffffu;
         }
@@ -703,7 +732,8 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // -- header (sam.c:114-223): it sits at the start of the arena when the range starts at member 0; otherwise the head of
     //    the file is inflated into its own small arena -----------------------------------------------------------------------
     BamHeader hdr;
-    {
+    if (spec) hdr = hdr_host;
+    else {
         const uint32_t h_early = h_sc[kStatusEarly];            // read back right after the launch finished (below the footer check)
         uint32_t n_h = std::min<uint32_t>(n_members_all, 4);
         for (;;) {
@@ -900,7 +930,19 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             launch_scan_u32(seg_cnt[cur], seg_base, n_seg, d_sc + 3, b_tmp.as<uint32_t>(), st);
             HIP_TRY(hipMemcpyAsync(h_sc + 3, d_sc + 3, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(h_sc + 10, d_sc + 10, 8, hipMemcpyDeviceToHost, st));
+            if (spec && iter == 0) {
+                HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 8, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(h_sc + kStatusEarly, d_sc + kStatusEarly, 8, hipMemcpyDeviceToHost, st));
+            }
             HIP_TRY(hipStreamSynchronize(st));
+            if (spec && iter == 0 && (h_sc[0] != 0xffffffffu || h_sc[kStatusEarly] != 0xffffffffu)) {
+                // some member did not inflate to its footer's length: nothing enqueued since is worth anything
+                mark("inflate verdict: not clean, starting over device-resident");
+                HIP_TRY(hipStreamSynchronize(c->copy_stream));
+                const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, nullptr, false, region_to_file_end);
+                P.t_begin = t_begin;
+                return rc2;
+            }
             ++P.framing_sweeps;
             if (h_sc[11] != 0xffffffffu) chain_ended = true;     // some segment's chain ends: an unreadable / cut-off record (sam.c:421-423)
             // the chain ends inside the exact prefix (or everything is exact): nothing starts after that segment -- with one chain the
@@ -916,6 +958,17 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             if (iter > 1 << 20) return fail(err, errlen, RGX_ERR_FORMAT, "regtools_amd: record framing did not converge\n");
         }
         n_rec = h_sc[3];
+    }
+    if (spec && !n_seg) {                                     // (no framing, no sync yet: the inflate's verdict is still due)
+        HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_sc + kStatusEarly, d_sc + kStatusEarly, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h_sc[0] != 0xffffffffu || h_sc[kStatusEarly] != 0xffffffffu) {
+            HIP_TRY(hipStreamSynchronize(c->copy_stream));
+            const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, nullptr, false, region_to_file_end);
+            P.t_begin = t_begin;
+            return rc2;
+        }
     }
     if (chain_ended) P.stream_ended = true;
     if (chain_ended && geom.chunks && m_hi < n_members_all && !region_to_file_end) {
@@ -1097,7 +1150,8 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
         for (uint32_t i = 0; i < n_groups; ++i) rk = std::max(rk, rank_of_group_host[i]);
         DevBuf &b_rank = c->buf("rank");
         HIP_TRY(b_rank.ensure((size_t)n_groups * 4 + 64));
-        HIP_TRY(hipMemcpyAsync(b_rank.p, rank_of_group_host, (size_t)n_groups * 4, hipMemcpyHostToDevice, st));
+        c->rank_stage.assign(rank_of_group_host, rank_of_group_host + n_groups);      // (outlives the asynchronous copy: every call ends with a sync of the stream)
+        HIP_TRY(hipMemcpyAsync(b_rank.p, c->rank_stage.data(), (size_t)n_groups * 4, hipMemcpyHostToDevice, st));
         launch_gather_u32(n_unique, b_rank.as<uint32_t>(), u.tid, chrom_rank_rows, st);
         int upc = -1;
         auto usort = [&](const uint32_t *word, uint32_t nbits) {
@@ -1114,7 +1168,7 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
         usort(chrom_rank_rows, std::max<uint32_t>(1, bitlen(rk)));
         final_perm = uperm[upc];
         if (row_map) launch_inverse_perm(final_perm, n_unique, row_map->urow_pos, st);
-        HIP_TRY(hipStreamSynchronize(st));   // the host rank table must outlive the async copy
+        if (!n_unique) HIP_TRY(hipStreamSynchronize(st));
     }
 
     if (n_unique) {

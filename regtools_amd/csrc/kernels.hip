@@ -1058,9 +1058,21 @@ __global__ __launch_bounds__(64) void k_radix_hist(const uint32_t *__restrict__ 
 template <bool KEYED>
 __global__ __launch_bounds__(64) void k_radix_scatter(const uint32_t *__restrict__ word, uint32_t shift, uint32_t mask,
                                                       const uint32_t *__restrict__ perm_in, uint32_t *perm_out, uint32_t n,
-                                                      uint32_t n_tiles, const uint32_t *__restrict__ hist_scan, uint32_t *key_out) {
+                                                      uint32_t n_tiles, const uint32_t *__restrict__ hist_scan, uint32_t *key_out,
+                                                      const uint32_t *__restrict__ digit_total) {
     __shared__ uint32_t s_base[256];
-    for (uint32_t k = threadIdx.x; k < 256; k += 64) s_base[k] = hist_scan[(size_t)k * n_tiles + blockIdx.x];
+    {
+        // where digit d starts in the output = the totals of the digits below it: 256 numbers, scanned by every workgroup for itself
+        // (4 per lane + a wave scan) instead of one more launch; + this tile's rank inside the digit (k_radix_offsets)
+        const uint32_t k0 = threadIdx.x * 4;
+        const uint32_t t0 = digit_total[k0], t1 = digit_total[k0 + 1], t2 = digit_total[k0 + 2], t3 = digit_total[k0 + 3];
+        const uint32_t incl = wave_incl_scan(t0 + t1 + t2 + t3);
+        uint32_t run = incl - (t0 + t1 + t2 + t3);
+        s_base[k0] = run + hist_scan[(size_t)k0 * n_tiles + blockIdx.x]; run += t0;
+        s_base[k0 + 1] = run + hist_scan[(size_t)(k0 + 1) * n_tiles + blockIdx.x]; run += t1;
+        s_base[k0 + 2] = run + hist_scan[(size_t)(k0 + 2) * n_tiles + blockIdx.x]; run += t2;
+        s_base[k0 + 3] = run + hist_scan[(size_t)(k0 + 3) * n_tiles + blockIdx.x];
+    }
     __syncthreads();
     const uint32_t base = blockIdx.x * kRadixTile;
     for (uint32_t r = 0; r < kRadixRows; ++r) {
@@ -1084,30 +1096,49 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const uint32_t *__restrict
     }
 }
 
-size_t radix_tmp_words(uint32_t n) {
-    const size_t tiles = ((size_t)n + kRadixTile - 1) / kRadixTile;
-    return 256 * tiles + scan_tmp_words((uint32_t)(256 * tiles)) + 4;
+// one workgroup per digit: exclusive scan of that digit's per-tile counts (in place) + the digit's total
+__global__ __launch_bounds__(256) void k_radix_offsets(uint32_t *hist, uint32_t n_tiles, uint32_t *digit_total) {
+    __shared__ uint32_t s_wave[4];
+    uint32_t *row = hist + (size_t)blockIdx.x * n_tiles;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_tiles; base += 256 * 8) {
+        const uint32_t i0 = base + threadIdx.x * 8;
+        uint32_t v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = i0 + k < n_tiles ? row[i0 + k] : 0u; sum += v[k]; }
+        uint32_t tot; uint32_t ex = carry + block_excl_scan_256(sum, s_wave, tot);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { if (i0 + k < n_tiles) row[i0 + k] = ex; ex += v[k]; }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
 }
 
+size_t radix_tmp_words(uint32_t n) {
+    const size_t tiles = ((size_t)n + kRadixTile - 1) / kRadixTile;
+    return 256 * tiles + 256 + 4;
+}
+
+// a pass = three launches: per-tile digit counts, per-digit scan over the tiles, scatter
 void launch_radix_pass(const uint32_t *word, uint32_t shift, uint32_t bits, const uint32_t *perm_in, uint32_t *perm_out, uint32_t n,
                        uint32_t *tmp, hipStream_t stream) {
     if (!n) return;
     const uint32_t tiles = (n + kRadixTile - 1) / kRadixTile;
     const uint32_t mask = (1u << bits) - 1u;
-    uint32_t *hist = tmp, *scan_tmp = tmp + (size_t)256 * tiles;
+    uint32_t *hist = tmp, *totals = tmp + (size_t)256 * tiles;
     hipLaunchKernelGGL(k_radix_hist<false>, dim3(tiles), dim3(64), 0, stream, word, shift, mask, perm_in, n, tiles, hist);
-    launch_scan_u32(hist, hist, 256 * tiles, nullptr, scan_tmp, stream);
-    hipLaunchKernelGGL(k_radix_scatter<false>, dim3(tiles), dim3(64), 0, stream, word, shift, mask, perm_in, perm_out, n, tiles, hist, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_radix_offsets, dim3(256), dim3(256), 0, stream, hist, tiles, totals);
+    hipLaunchKernelGGL(k_radix_scatter<false>, dim3(tiles), dim3(64), 0, stream, word, shift, mask, perm_in, perm_out, n, tiles, hist, (uint32_t *)nullptr, totals);
 }
 void launch_radix_pass_keyed(const uint32_t *key_in, uint32_t *key_out, uint32_t shift, uint32_t bits, const uint32_t *perm_in, uint32_t *perm_out,
                              uint32_t n, uint32_t *tmp, hipStream_t stream) {
     if (!n) return;
     const uint32_t tiles = (n + kRadixTile - 1) / kRadixTile;
     const uint32_t mask = (1u << bits) - 1u;
-    uint32_t *hist = tmp, *scan_tmp = tmp + (size_t)256 * tiles;
+    uint32_t *hist = tmp, *totals = tmp + (size_t)256 * tiles;
     hipLaunchKernelGGL(k_radix_hist<true>, dim3(tiles), dim3(64), 0, stream, key_in, shift, mask, perm_in, n, tiles, hist);
-    launch_scan_u32(hist, hist, 256 * tiles, nullptr, scan_tmp, stream);
-    hipLaunchKernelGGL(k_radix_scatter<true>, dim3(tiles), dim3(64), 0, stream, key_in, shift, mask, perm_in, perm_out, n, tiles, hist, key_out);
+    hipLaunchKernelGGL(k_radix_offsets, dim3(256), dim3(256), 0, stream, hist, tiles, totals);
+    hipLaunchKernelGGL(k_radix_scatter<true>, dim3(tiles), dim3(64), 0, stream, key_in, shift, mask, perm_in, perm_out, n, tiles, hist, key_out, totals);
 }
 
 
