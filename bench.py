@@ -25,6 +25,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# the whole-file launch of the DEFLATE kernel the pipeline runs above 2048 members (kernels.hip launch_inflate; REGTOOLS_AMD_INFLATE overrides)
+INFLATE_KERNEL = {"lane": "rgx::k_inflate<false, false>", "ring": "rgx::k_inflate_ring<false>", "wave": "rgx::k_inflate_wave"}.get(
+    os.environ.get("REGTOOLS_AMD_INFLATE", ""), "rgx::k_inflate_coop<false, false>")
 
 
 def cpu_baseline(bam_path, n_reads, n_events):
@@ -115,7 +118,7 @@ def extra_extract(regtools_amd, synth, ctx, label, shape, realistic, n_reads, sa
     out = {"workload": label, "reads": st["n_reads"], "ms": ms, "alignments_per_s": st["n_reads"] / (ms * 1e-3), "junction_events_per_s": n_events / (ms * 1e-3),
            "ms_device_resident": stage["total"], "stage_ms": stage, "input_generation_s": round(t_gen, 2),
            "bytes_per_alignment": {"compressed": s["compressed_bytes"] / st["n_reads"], "inflated": s["inflated_bytes"] / st["n_reads"]},
-           "roofline": {"bound": "hbm", "kernel": "rgx::k_inflate<false, false>", "kernel_ms": min(k_ms), "algorithmic_bytes": alg,
+           "roofline": {"bound": "hbm", "kernel": INFLATE_KERNEL, "kernel_ms": min(k_ms), "algorithmic_bytes": alg,
                         "achieved": alg / (min(k_ms) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (min(k_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}}
     del d_bam, bam
     pin.close()
@@ -305,17 +308,15 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         # HBM-side traffic of the same kernel from rocprofv3 PMC passes (tools/pmc_traffic.sh; separate --pmc runs of this
         # very command).  Only quoted when the committed measurement was taken on this exact workload.
-        traffic, traffic_note = None, None
+        traffic, traffic_note, traffic_source = None, None, None
         try:
-            pm_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-            pm = json.load(open(pm_path if os.path.exists(pm_path) else os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if n_reads == 50_000_000 and args.shape == "short" and not args.realistic and world == 1:
-                traffic = (pm["inflate_FETCH_SIZE"][0] + pm["inflate_WRITE_SIZE"][0]) * 1024.0
-                traffic_note = ("(FETCH_SIZE + WRITE_SIZE) KiB of rgx::k_inflate, uncorrected: the guide's x2 FETCH correction is for wide coalesced "
-                                "streams; a calibration kernel with this kernel's scattered 16-B-per-lane pattern and known bytes reads "
-                                "%.2fx (FETCH) / %.2fx (WRITE) of its true bytes (median of 8 launches)" % (
-                                    sorted(pm["cal_FETCH_SIZE"])[len(pm["cal_FETCH_SIZE"]) // 2] * 1024.0 / pm["cal_known_bytes_each_way"],
-                                    sorted(pm["cal_WRITE_SIZE"])[len(pm["cal_WRITE_SIZE"]) // 2] * 1024.0 / pm["cal_known_bytes_each_way"]))
+            pm_path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+            pm = json.load(open(pm_path))
+            if n_reads == 50_000_000 and args.shape == "short" and not args.realistic and world == 1 and pm.get("kernel") == INFLATE_KERNEL:
+                traffic = (pm["FETCH_SIZE_KiB"] + pm["WRITE_SIZE_KiB"]) * 1024.0
+                traffic_source = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel on this workload, tools/pmc_inflate.sh; a committed measurement, not taken in this run)"
+                traffic_note = ("(FETCH_SIZE + WRITE_SIZE) KiB, uncorrected: the guide's x2 FETCH correction is for wide coalesced streams; this kernel's reads are "
+                                "8-byte bit-stream words and 16-byte copy sources of 64 lanes in 64 different lines (DESIGN.md 5.2 splits the figure by source)")
         except Exception:
             pass
         line = {
@@ -334,9 +335,9 @@ def main():
             "junction_rows": s["n_junctions"],
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "input_generation_s": round(t_gen, 2),
-            "roofline": {"bound": "hbm", "kernel": "rgx::k_inflate<false, false>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_note": traffic_note, "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
-                         "note": "DEFLATE is a serial bit stream per member: one lane per member, bound by per-lane dependent ALU/LDS chains plus one memory round trip per symbol trip, far below the HBM line (SURVEY 8d; DESIGN.md 5)",
+            "roofline": {"bound": "hbm", "kernel": INFLATE_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_source, "traffic_note": traffic_note, "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
+                         "note": "DEFLATE is a serial bit stream per member: one lane per member (long matches copied by the wave), bound by per-lane dependent ALU/LDS chains, the L1's rate of scattered per-lane accesses and one memory round trip per symbol trip, far below the HBM line (SURVEY 8d; DESIGN.md 5)",
                          "pipeline_frac": aln_per_s / world * (alg_bytes / n_reads) / (HBM_PEAK_GBS * 1e9)},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -352,6 +353,22 @@ def main():
                     ref_bed = f.read()
                     cb["bed12_identical_to_gpu"] = ref_bed == je.bed12() and ref_bed == bed_host_path
                 line["cpu_baseline"] = cb
+                # the TOOL, not the loop: a cold `regtools-amd junctions extract -s XS -o out.bed bench.bam` process on the same file (page cache),
+                # against the cold reference process timed above -- context creation, HBM allocation, file mapping, upload from pageable memory,
+                # BED12 text and the write included
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import cli_wall
+                    cw = cli_wall.measure(path, runs=3, with_reference=False)
+                    cli_bed = open(path + ".cli.bed", "rb").read()
+                    line["cli"] = {"command": "bin/regtools-amd junctions extract -s XS -o out.bed bench.bam (cold process, file in the page cache)",
+                                   "wall_s": cw["wall_s"], "runs": cw["runs"], "reference_wall_s": cb.get("seconds") if cb.get("kind") == "reference" else None,
+                                   "identical_file": cli_bed == ref_bed,
+                                   "ratio_process": round(cb["seconds"] / cw["wall_s"], 1) if cb.get("kind") == "reference" else None,
+                                   "ratio_pipeline": round(cb["seconds"] / (ms_step * 1e-3), 1) if cb.get("kind") == "reference" else None,
+                                   "note": "ratio_process = reference process wall / this process wall; ratio_pipeline = reference process wall / one warm in-process step (the headline's region)"}
+                except Exception as e:
+                    line["cli"] = {"error": repr(e)}
         if world == 1 and not args.no_extras and not args.host_only and args.shape == "short" and not args.realistic:
             try:
                 del d_bam

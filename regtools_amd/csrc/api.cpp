@@ -89,6 +89,7 @@ struct rgx_ctx {
     // duration, not the stage's wall time): event pairs wait in kpend until the call's end, kms[slot] accumulates
     struct KPend { hipEvent_t a, b; int slot; };
     std::vector<KPend> kpend; std::vector<hipEvent_t> kfree; double kms[3] = {0, 0, 0};
+    uint64_t tables_made = 0;
     std::vector<uint32_t> rank_stage;                  // host copy of a group-rank table while its upload is in flight
     std::string fasta_path;                            // FASTA currently resident in the "fasta" buffer
     rgx::Fasta *fasta = nullptr;
@@ -134,21 +135,30 @@ extern "C" int rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errle
     rgx_ctx *c = new rgx_ctx();
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    {
-        // the runtime maps the streams of one priority onto four hardware queues; streams of another priority come from another pool of queues
-        int pr_least = 0, pr_greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
-        const int prio[kSideStreams] = {0, 0, pr_greatest, pr_greatest, pr_least, pr_least};
-        for (int k = 0; k < kSideStreams; ++k) HIP_TRY(hipStreamCreateWithPriority(&c->side[k], hipStreamNonBlocking, prio[k]));
-    }
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-    for (auto &e : c->ev_side) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
     c->pinned_cap = 4096;
     *out = c;
     return RGX_OK;
+}
+
+// the copy stream and the side streams of the overlapped upload: made when a call first takes that path (a one-shot process that reads a
+// small file never pays for them; eight stream creations are ~100 ms of a cold start)
+static hipError_t ensure_upload_streams(rgx_ctx *c) {
+    if (c->copy_stream) return hipSuccess;
+    hipError_t e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+    // the runtime maps the streams of one priority onto four hardware queues; streams of another priority come from another pool of queues
+    int pr_least = 0, pr_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+    const int prio[kSideStreams] = {0, 0, pr_greatest, pr_greatest, pr_least, pr_least};
+    const unsigned want = 2;                                  // (three pieces: two side streams + the pipeline's own; REGTOOLS_AMD_PIECES may ask for more)
+    for (int k = 0; k < kSideStreams; ++k) {
+        if ((unsigned)k >= want && !getenv("REGTOOLS_AMD_PIECES")) break;
+        if ((e = hipStreamCreateWithPriority(&c->side[k], hipStreamNonBlocking, prio[k])) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&c->ev_side[k], hipEventDisableTiming)) != hipSuccess) return e;
+    }
+    return hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
 }
 
 extern "C" void rgx_ctx_destroy(rgx_ctx *c) {
@@ -283,21 +293,35 @@ static void host_sort_rows(rgx_junction_table *t) {
     permute(t->name_index); permute(t->strand); permute(t->left_ok); permute(t->right_ok); permute(t->first_seen); permute(t->last_seen);
 }
 
-extern "C" size_t rgx_table_format_bed12(const rgx_junction_table *t, int only_anchored, char *buf, size_t cap) {
-    size_t need = 0;
+// Junction::print (junctions_extractor.h:90-98) for rows [r0, r1): appended to `out`.  The name is copied as it is: the BAM header puts no
+// limit on its length.
+static void format_bed12_rows(const rgx_junction_table *t, int only_anchored, uint64_t r0, uint64_t r1, std::string &out) {
     char tail[256];                                        // everything behind the contig name: ten bounded numeric fields
-    for (uint64_t i = 0; i < t->n; ++i) {
+    for (uint64_t i = r0; i < r1; ++i) {
         if (only_anchored && !(t->left_ok[i] && t->right_ok[i])) continue;
-        // Junction::print (junctions_extractor.h:90-98).  The name is copied as it is: the BAM header puts no limit on its length.
         const char *name = t->ref_name[t->tid[i]];
-        const size_t ln = strlen(name);
         const int n = snprintf(tail, sizeof tail, "\t%u\t%u\tJUNC%08llu\t%u\t%c\t%u\t%u\t255,0,0\t2\t%u,%u\t0,%u\n",
                                t->thick_start[i], t->thick_end[i], (unsigned long long)t->name_index[i], t->read_count[i], t->strand[i],
                                t->thick_start[i], t->thick_end[i], (uint32_t)(t->start[i] - t->thick_start[i]),
                                (uint32_t)(t->thick_end[i] - t->end[i]), (uint32_t)(t->end[i] - t->thick_start[i]));
-        if (buf && need + ln + (size_t)n <= cap) { memcpy(buf + need, name, ln); memcpy(buf + need + ln, tail, (size_t)n); }
-        need += ln + (size_t)n;
+        out.append(name); out.append(tail, (size_t)n);
     }
+}
+
+extern "C" size_t rgx_table_format_bed12(const rgx_junction_table *t, int only_anchored, char *buf, size_t cap) {
+    // text work of ~170 ns per row on one core: ranges of rows on the host's cores (55 -> 6 ms for 300 k rows)
+    const unsigned n_thr = t->n >= 20000 ? std::max(1u, std::min<unsigned>(usable_threads(16), (unsigned)(t->n / 8192))) : 1u;
+    std::vector<std::string> part(n_thr);
+    if (n_thr == 1) format_bed12_rows(t, only_anchored, 0, t->n, part[0]);
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < n_thr; ++w)
+            pool.emplace_back([&, w] { part[w].reserve((size_t)(t->n / n_thr + 1) * 96); format_bed12_rows(t, only_anchored, t->n * w / n_thr, t->n * (w + 1) / n_thr, part[w]); });
+        for (auto &th : pool) th.join();
+    }
+    size_t need = 0;
+    for (const std::string &q : part) need += q.size();
+    if (buf && need <= cap) { size_t o = 0; for (const std::string &q : part) { memcpy(buf + o, q.data(), q.size()); o += q.size(); } }
     return need;
 }
 
@@ -377,6 +401,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         d_bam = b.as<uint8_t>();
         static const bool no_overlap = getenv("REGTOOLS_AMD_NO_OVERLAP") != nullptr;
         if (allow_overlap && !d_true_sizes && !no_overlap && bam_len >= ((size_t)8 << 20)) {
+            HIP_TRY(ensure_upload_streams(c));
             // three pieces, each its own launch on its own hardware queue (two side streams + the pipeline's own; a launch takes ~8 ms however
             // small -- one lane per member).  Equal thirds measured best: 31.6 ms per step against 32.4-33.3 ms for pieces that shrink towards
             // the end, and 30.9-31.5 ms for four to six equal pieces on side streams of other priorities (= other queue pools), 32.6 for seven
@@ -654,7 +679,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         // chunk j start as soon as its event fires, next to the launches of the chunks before it
         HIP_TRY(b_lens.ensure(inflate_scratch_bytes(std::max<uint32_t>(n_range, 64)) + up.end.size() * inflate_scratch_bytes(64)));
         HIP_TRY(hipEventRecord(c->ev_ready, st));
-        for (auto &q : c->side) HIP_TRY(hipStreamWaitEvent(q, c->ev_ready, 0));
+        for (auto &q : c->side) if (q) HIP_TRY(hipStreamWaitEvent(q, c->ev_ready, 0));
         uint32_t g_lo = m_lo; size_t scratch_off = 0; unsigned used_side = 0;
         for (size_t j = 0; j < up.end.size() && g_lo < m_hi; ++j) {
             uint32_t g_hi = m_hi;
@@ -669,7 +694,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             if (up.err) return fail(err, errlen, RGX_ERR_DEVICE, "regtools_amd: upload failed\n");
             // the pipeline's own stream is idle until the inflate is done: it takes every third piece (the runtime maps streams onto four
             // hardware queues round-robin; a third side stream would share its queue with the second: profiles/r02_overlap_timeline.txt)
-            const bool own = j + 1 == up.end.size() || j >= (size_t)kSideStreams;
+            const bool own = j + 1 == up.end.size() || j >= (size_t)kSideStreams || !c->side[j];
             hipStream_t q = own ? st : c->side[j];
             if (!own) used_side |= 1u << j;
             HIP_TRY(hipStreamWaitEvent(q, c->chunk_ev[j], 0));
@@ -1182,7 +1207,9 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
             const size_t bytes = table_block_bytes(U);
             HIP_TRY(b_tab.ensure(bytes + 256));
             launch_rows_table(u, final_perm, n_unique, sink->min_anchor, b_tab.as<uint8_t>(), st);
-            rgx_junction_table *t = table_alloc(*sink->hdr, U, /*zero=*/false, /*pinned=*/true);
+            // page-locking a block costs ~10 ms, a copy into pageable memory ~2 ms more than one into page-locked memory: the first table of a
+            // context (a one-shot process has no second) is pageable, the loop that runs step after step gets its recycled page-locked block
+            rgx_junction_table *t = table_alloc(*sink->hdr, U, /*zero=*/false, /*pinned=*/c->tables_made++ > 0);
             if (!t) { (void)hipStreamSynchronize(st); return fail(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no memory for the result table\n"); }
             hipError_t e_ = hipMemcpyAsync(((TableBox *)t)->block, b_tab.p, bytes, hipMemcpyDeviceToHost, st);
             if (e_ == hipSuccess) e_ = hipStreamSynchronize(st);

@@ -83,6 +83,7 @@ VARIANTS = {
     "ntcoop": [NT_COOP],
     "ntall": [NT_STAGE, NT_COOP],
     "ntbits": [NT_BITS],
+    "bitwin_noload": BITWIN + NO_LANE_LOADS + [NO_COOP_LOADS],
     "hotbits": [HOT_BITS],
     "hotbits_nostore": [HOT_BITS, NO_STAGE_STORES, NO_COOP_STORES],
 }
