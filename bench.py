@@ -199,7 +199,13 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the other workloads reported beside the headline (realistic payload, config 5 long reads, config 4 identify)")
     ap.add_argument("--host-only", action="store_true", help="(profiling) only the timed host-bytes pass; the roofline line then quotes the overlapped launches")
     ap.add_argument("--realistic", action="store_true", help="random bases + binned qualities instead of the named constant payload")
+    ap.add_argument("--multi-host", default="ranks", choices=["ranks", "cpp"],
+                    help="N > 1: 'ranks' = one process per GPU, torch.distributed over RCCL (what torchrun launches; the default); 'cpp' = THIS process drives "
+                         "all N devices through rgx_extract_multi (the C++ host of the CLI: a thread per device, one RCCL gather); without torchrun only")
+    ap.add_argument("--dump-bed", default=None, help="(tests) rank 0 writes the last step's BED12 here")
     args = ap.parse_args()
+    if args.multi_host == "cpp" and args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        return main_cpp_host(args)
 
     import torch
     import torch.distributed as dist
@@ -238,10 +244,15 @@ def main():
     # every step (chunked over a copy stream, the members of the chunks that have arrived inflate meanwhile: rgx_extract_mem).
     pin = regtools_amd.PinnedBuffer(bam)
 
+    merge_ms = []
+
     def step():
         je.identify_junctions_from_BAM(bai_bytes=bai, host_ptr=pin.ptr, host_len=len(bam))
         if world > 1:
-            return rdist.gather_and_merge(je, min_anchor=8)
+            tm = time.time()
+            m = rdist.gather_and_merge(je, min_anchor=8)
+            merge_ms.append(1e3 * (time.time() - tm))
+            return m
         return je.table
 
     def fence():
@@ -253,13 +264,27 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    del merge_ms[:]
     t0 = time.time()
+    last = None
     for _ in range(args.steps):
-        step()
+        last = step()
     fence()
     dt = time.time() - t0
     n_events = je.stats["n_events"]
     bed_host_path = je.bed12() if world == 1 else None
+    if args.dump_bed and rank == 0:
+        with open(args.dump_bed, "wb") as f:
+            f.write(je.bed12() if world == 1 else last.bed12())
+    # N > 1: what every rank spent where, for a scaling line that checks itself (one small all-gather, outside the timed region)
+    rank_report = None
+    if world > 1:
+        mine = torch.tensor([je.stats["ms_inflate"], je.stats["ms_records"], je.stats["ms_scan"], je.stats["ms_reduce"], je.stats["ms_total"],
+                             sum(merge_ms) / max(1, len(merge_ms)), float(n_reads), float(je.stats["n_junctions"])], dtype=torch.float64, device=coll_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_report = [dict(rank=r, inflate_ms=round(v[0].item(), 3), records_ms=round(v[1].item(), 3), scan_ms=round(v[2].item(), 3), reduce_ms=round(v[3].item(), 3),
+                            extract_total_ms=round(v[4].item(), 3), gather_and_merge_ms=round(v[5].item(), 3), reads=int(v[6].item()), rows=int(v[7].item())) for r, v in enumerate(allr)]
 
     # Second, untimed-for-the-headline pass with the file ALREADY RESIDENT in HBM: one k_inflate launch over the whole file, which is what
     # the roofline of the dominant kernel is quoted on (HIP events on the pipeline's stream), and the per-stage times.
@@ -332,7 +357,11 @@ def main():
             "junction_events_per_s": total_events * args.steps / dt,
             "timed_region": "file bytes in page-locked host memory -> sorted junction table in host memory (SURVEY.md 8d): chunked H2D upload inside every step, overlapped with the inflate",
             "value_device_resident": total_reads * args.steps / dt_res, "ms_per_step_device_resident": 1e3 * dt_res / args.steps,
-            "junction_rows": s["n_junctions"],
+            "junction_rows": s["n_junctions"] if world == 1 else int(last.n),
+            "multi_gpu": None if world == 1 else {"host": "one process per GPU (torchrun), torch.distributed backend %s" % backend, "rccl_ranks": world if backend == "nccl" else 0,
+                                                  "exchange": "all_gather_into_tensor of the ranks' packed 48-byte rows into HBM + rgx_table_merge_device on every rank" if backend == "nccl"
+                                                              else "all_gather of packed rows on the host + rgx_table_merge (test backend)",
+                                                  "merge_ms": round(max(r["gather_and_merge_ms"] for r in rank_report), 3), "per_rank": rank_report},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "input_generation_s": round(t_gen, 2),
             "roofline": {"bound": "hbm", "kernel": INFLATE_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -390,6 +419,48 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def main_cpp_host(args):
+    """--multi-host cpp: this one process drives N devices through rgx_extract_multi_mem -- the C++ host the CLI uses with REGTOOLS_AMD_DEVICES
+    (multi.cpp: the members scanned once, a thread + context per device uploading only its shard's byte range, one RCCL send/recv gather of the
+    packed rows to the first device, merge there).  Strong scaling of ONE file of N x --reads reads.  A device list longer than the visible GPUs
+    repeats device 0 (the shards then take turns: exercises the code, measures nothing)."""
+    import torch
+    import regtools_amd
+    from regtools_amd import synth
+    n = args.gpus
+    visible = torch.cuda.device_count()
+    devices = list(range(n)) if visible >= n else [0] * n
+    bam, bai, st = synth.generate(args.reads * n, shape=args.shape, seed=args.seed, realistic=args.realistic)
+    pin = regtools_amd.PinnedBuffer(bam)
+    kw = dict(strandness=0)
+
+    def step():
+        return regtools_amd.extract_multi(devices, bam_bytes=None, bai_bytes=bai, host_ptr=pin.ptr, host_len=len(bam), **kw)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        m = step()
+    dt = time.time() - t0
+    if args.dump_bed:
+        with open(args.dump_bed, "wb") as f:
+            f.write(m.bed12())
+    tc = m.table.contents
+    line = {"metric": "alignments/sec + junctions/sec, junctions extract, 1/2/4/8 MI355X", "value": st["n_reads"] * args.steps / dt, "unit": "alignments/s",
+            "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
+            "config": {"workload": "one synthetic %d-read 101 bp BAM sharded by BGZF member range over %d devices (rgx_extract_multi)" % (st["n_reads"], n), "devices": devices,
+                       "distinct_devices": len(set(devices)) == n},
+            "junction_events_per_s": tc.n_events * args.steps / dt, "junction_rows": int(tc.n),
+            "multi_gpu": {"host": "one process, a thread and a context per device (multi.cpp)", "rccl_ranks": n if len(set(devices)) == n else 0,
+                          "exchange": "ncclSend / ncclRecv gather of packed rows to the first device + rgx_table_merge_device" if len(set(devices)) == n else "device copies (one GPU listed several times)",
+                          "max_stage_ms": {"inflate": tc.ms_inflate, "records": tc.ms_records, "scan": tc.ms_scan, "reduce": tc.ms_reduce, "shard_total": tc.ms_total}}}
+    print(json.dumps(line), flush=True)
+    pin.close()
 
 
 if __name__ == "__main__":

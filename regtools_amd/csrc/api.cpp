@@ -344,6 +344,10 @@ extern "C" size_t rgx_table_format_barcodes(const rgx_junction_table *t, int onl
 }
 
 // ---- the pipeline ------------------------------------------------------------------------------------------------
+// The member list of a file scanned ONCE by a caller that runs several shards of it (rgx_extract_multi): every shard then uploads only the
+// header's members and its own byte range instead of the whole file, and none repeats the scan.
+struct SharedMembers { const std::vector<Member> *members; uint64_t total_inflated; };
+
 // Everything the later stages need from the front half of the pipeline (file bytes -> junction events in file order).
 struct Prep {
     BamHeader hdr;
@@ -359,7 +363,7 @@ struct Prep {
 
 static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_bam, size_t bam_len, const uint8_t *bai, size_t bai_len,
                           const rgx_extract_params *p, bool want_read_span, Prep &P, char *err, size_t errlen, const uint32_t *d_true_sizes = nullptr,
-                          bool allow_overlap = true, bool region_to_file_end = false) {
+                          bool allow_overlap = true, bool region_to_file_end = false, const SharedMembers *shared = nullptr) {
     if (!p || p->strandness < 0 || p->strandness > 3) return fail(err, errlen, RGX_ERR_ARG, "Please supply strandness mode with '-s' option!\n\n");
     if (p->strandness == 3 && !p->fasta_path) return fail(err, errlen, RGX_ERR_ARG, "Strandness mode 'intron-motif' requires a fasta file!\n\n");
     HIP_TRY(hipSetDevice(c->device));
@@ -386,7 +390,8 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     const uint8_t *d_bam = d_bam_in;
     struct Upload {
         std::thread th; std::atomic<uint32_t> recorded{0}; std::atomic<int> err{0};
-        std::vector<size_t> end;                            // end[j] = bytes resident once chunk event j has fired
+        std::vector<size_t> end;                            // end[j] = bytes [lo, end[j]) resident once chunk event j has fired
+        size_t lo = 0, hi = 0, hdr_hi = 0;                  // the byte range that goes up (a shard's, + the header's [0, hdr_hi); the whole file otherwise)
         hipStream_t copy_stream = nullptr;
         // every way out of this function: the helper has enqueued its copies and the DMA out of the caller's buffer is over (the caller
         // may free or reuse that buffer as soon as the call returns)
@@ -402,6 +407,31 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         static const bool no_overlap = getenv("REGTOOLS_AMD_NO_OVERLAP") != nullptr;
         if (allow_overlap && !d_true_sizes && !no_overlap && bam_len >= ((size_t)8 << 20)) {
             HIP_TRY(ensure_upload_streams(c));
+            // A shard of a file whose members the caller scanned: only the bytes this shard reads go up -- the header's members and the
+            // range between its two cuts (the same cuts as below, from the index) -- N shards then move the file once, not N times.
+            size_t up_lo = 0, up_hi = bam_len, hdr_hi = 0;
+            if (shared && p->n_shards > 1 && p->shard >= 0 && p->shard < p->n_shards) {
+                if (bai_thread.joinable()) bai_thread.join();
+                BamHeader hh; size_t hb = 0;
+                if (bai_ok && host_bam_header(h_bam, std::min<size_t>(bam_len, (size_t)8 << 20), hh, &hb)) {
+                    const bool rest0 = p->region && !strcmp(p->region, "*"), whole0 = rest0 || !strcmp(p->region ? p->region : ".", ".");
+                    uint64_t sv = 0;
+                    if (rest0 && bi.have_nocoor) sv = bi.nocoor_voff; else if (whole0 && !rest0 && bi.have_start) sv = bi.start_voff;
+                    uint64_t tgt[2], got[2];
+                    for (int k = 0; k < 2; ++k) tgt[k] = std::max<uint64_t>((uint64_t)((double)bam_len * (p->shard + k) / p->n_shards) << 16, sv ? sv : 1);
+                    bai_first_anchor_ge(bai, bai_len, tgt, 2, got);
+                    if (p->shard > 0 && got[0] != UINT64_MAX) up_lo = std::min<size_t>(bam_len, (size_t)(got[0] >> 16));
+                    else if (p->shard > 0) up_lo = bam_len;
+                    if (p->shard + 1 < p->n_shards && got[1] != UINT64_MAX) up_hi = std::min<size_t>(bam_len, (size_t)(got[1] >> 16) + 2 * kBgzfMaxBlock + 64);
+                    if (up_hi < up_lo) up_hi = up_lo;
+                    // (the header's members, and at least the four the device-side header read starts with)
+                    const std::vector<Member> &sm = *shared->members;
+                    if (!sm.empty()) { const Member &m4 = sm[std::min<size_t>(sm.size(), 4) - 1]; hb = std::max<size_t>(hb, (size_t)m4.cpos + m4.clen + 8); }
+                    hdr_hi = std::min(up_lo, hb + 64);
+                    up_lo &= ~(size_t)4095;
+                    if (up_lo < hdr_hi) { up_lo = 0; hdr_hi = 0; }
+                }
+            }
             // three pieces, each its own launch on its own hardware queue (two side streams + the pipeline's own; a launch takes ~8 ms however
             // small -- one lane per member).  Equal thirds measured best: 31.6 ms per step against 32.4-33.3 ms for pieces that shrink towards
             // the end, and 30.9-31.5 ms for four to six equal pieces on side streams of other priorities (= other queue pools), 32.6 for seven
@@ -414,32 +444,51 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
                 else if (sscanf(e, "%u", &a) == 1 && a >= 1 && a <= (unsigned)kSideStreams + 1) { cuts.clear(); for (unsigned k = 1; k < a; ++k) cuts.push_back(100 * k / a); }
             }
             for (unsigned pc : cuts) {
-                const size_t e = ((size_t)((double)bam_len * pc / 100.0) + 4095) & ~(size_t)4095;
-                if (e < bam_len && (up.end.empty() || e > up.end.back())) up.end.push_back(e);
+                const size_t e = (up_lo + (size_t)((double)(up_hi - up_lo) * pc / 100.0) + 4095) & ~(size_t)4095;
+                if (e < up_hi && e > up_lo && (up.end.empty() || e > up.end.back())) up.end.push_back(e);
             }
-            up.end.push_back(bam_len);
+            up.end.push_back(up_hi);
+            up.lo = up_lo; up.hi = up_hi; up.hdr_hi = hdr_hi;
             while (c->chunk_ev.size() < up.end.size()) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->chunk_ev.push_back(e); }
             uint8_t *dst = b.as<uint8_t>();
             up.copy_stream = c->copy_stream;
-            up.th = std::thread([c, dst, h_bam, &up] {
+            up.th = std::thread([c, dst, h_bam, hdr_hi, up_lo, &up] {
                 if (hipSetDevice(c->device) != hipSuccess) { up.err = 1; up.recorded = (uint32_t)up.end.size(); return; }
-                size_t o = 0;
+                if (hdr_hi && hipMemcpyAsync(dst, h_bam, hdr_hi, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) up.err = 1;
+                size_t o = up_lo;
                 for (size_t j = 0; j < up.end.size(); ++j) {
-                    if (hipMemcpyAsync(dst + o, h_bam + o, up.end[j] - o, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
+                    if ((up.end[j] > o && hipMemcpyAsync(dst + o, h_bam + o, up.end[j] - o, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) ||
                         hipEventRecord(c->chunk_ev[j], c->copy_stream) != hipSuccess) up.err = 1;
                     o = up.end[j];
                     up.recorded.store((uint32_t)j + 1, std::memory_order_release);
                 }
             });
-            overlap = scan_members_parallel(h_bam, bam_len, (int)usable_threads(24), hm, hm_total);
+            if (shared) { hm = *shared->members; hm_total = shared->total_inflated; overlap = !hm.empty(); }
+            else overlap = scan_members_parallel(h_bam, bam_len, (int)usable_threads(24), hm, hm_total);
             mark("host member scan");
             if (!overlap) {       // not a file the host vouches for: everything on the device, after the last chunk
                 up.th.join();
                 if (up.err) return fail(err, errlen, RGX_ERR_DEVICE, "regtools_amd: upload failed\n");
+                if (up_lo || up_hi < bam_len) {                 // (only a range went up: the rest before the device looks at the file)
+                    if (up_lo > hdr_hi) HIP_TRY(hipMemcpyAsync(dst + hdr_hi, h_bam + hdr_hi, up_lo - hdr_hi, hipMemcpyHostToDevice, c->copy_stream));
+                    if (up_hi < bam_len) HIP_TRY(hipMemcpyAsync(dst + up_hi, h_bam + up_hi, bam_len - up_hi, hipMemcpyHostToDevice, c->copy_stream));
+                    HIP_TRY(hipEventRecord(c->chunk_ev[up.end.size() - 1], c->copy_stream));
+                }
                 HIP_TRY(hipStreamWaitEvent(st, c->chunk_ev[up.end.size() - 1], 0));
             }
         } else HIP_TRY(hipMemcpyAsync(b.p, h_bam, bam_len, hipMemcpyHostToDevice, st));
     }
+    // before anything looks at the file through the device (the fallbacks of damaged files): the bytes a shard did not send
+    auto complete_upload = [&]() -> hipError_t {
+        if (!h_bam || !(up.lo || (up.hi && up.hi < bam_len))) return hipSuccess;
+        if (up.th.joinable()) up.th.join();
+        hipError_t e = hipStreamSynchronize(c->copy_stream);
+        uint8_t *dst = c->buf("bam").as<uint8_t>();
+        if (e == hipSuccess && up.lo > up.hdr_hi) e = hipMemcpy(dst + up.hdr_hi, h_bam + up.hdr_hi, up.lo - up.hdr_hi, hipMemcpyHostToDevice);
+        if (e == hipSuccess && up.hi < bam_len) e = hipMemcpy(dst + up.hi, h_bam + up.hi, bam_len - up.hi, hipMemcpyHostToDevice);
+        up.lo = 0; up.hi = bam_len; up.hdr_hi = 0;
+        return e;
+    };
     DevBuf &b_arena = c->buf("arena"), &b_members = c->buf("members"), &b_scalars = c->buf("scalars"), &b_hdr = c->buf("hdr_arena"), &b_disc = c->buf("discover");
     HIP_TRY(b_scalars.ensure(512));
     // u32 scalars: [0]=first bad member [1]=its status [2]=changed [3]=n_rec [4]=n_events [5]=n_long [6]=n_unique [8..9]=n_iterated(u64)
@@ -508,7 +557,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         launch_member_upos(d_members, c_isz2, d_sc + 17, (uint64_t *)(d_sc + 20), st);
     };
     if (!overlap) chain(UINT64_MAX);
-    bai_thread.join();
+    if (bai_thread.joinable()) bai_thread.join();
     if (!bai_ok) return (void)hipStreamSynchronize(st), fail(err, errlen, RGX_ERR_INDEX, "%s", kMsgIndex);
     mark("parse_bai");
     // "." = every record from the first one on; "*" = every record behind the last reference's reads (hts_itr_querys, hts.c:1901-1904:
@@ -605,6 +654,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     if (overlap && seek && (seek_voff >> 16) != 0 && h_sc[24] >= h_sc[17]) {
         // the index points at something that is no member of this (well-formed) file: the device's discovery decides what that means
         up.th.join();
+        HIP_TRY(complete_upload());
         HIP_TRY(hipStreamSynchronize(c->copy_stream));
         HIP_TRY(hipStreamSynchronize(st));
         const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, nullptr, false, region_to_file_end);
@@ -646,6 +696,19 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         else m_hi = std::min(stop, hi_m);
     }
     if (m_lo > m_hi) m_lo = m_hi;
+    if (overlap && (up.lo || up.hi < bam_len) && m_hi > m_lo) {
+        // only a byte range of the file went up (a shard of a shared scan): it must hold every member of this call's range
+        const uint64_t need_lo = hm[m_lo].cpos - 18, need_hi = hm[m_hi - 1].cpos + hm[m_hi - 1].clen + 16;
+        if (need_lo < up.lo || need_hi > up.hi) {
+            mark("shard range does not cover its members: whole-file upload");
+            up.th.join();
+            HIP_TRY(hipStreamSynchronize(c->copy_stream));
+            HIP_TRY(hipStreamSynchronize(st));
+            const int rc2 = prepare_events(c, d_bam_in, h_bam, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, d_true_sizes, allow_overlap, region_to_file_end, nullptr);
+            P.t_begin = t_begin;
+            return rc2;
+        }
+    }
     // arena offsets of the range ends
     auto upos_of = [&](uint32_t k, uint64_t &out_v) -> hipError_t {
         if (k >= n_members_all) { out_v = total_all; return hipSuccess; }
@@ -683,7 +746,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         uint32_t g_lo = m_lo; size_t scratch_off = 0; unsigned used_side = 0;
         for (size_t j = 0; j < up.end.size() && g_lo < m_hi; ++j) {
             uint32_t g_hi = m_hi;
-            if (up.end[j] < bam_len) {       // first member of [g_lo, m_hi) that needs bytes beyond this chunk
+            if (j + 1 < up.end.size()) {     // first member of [g_lo, m_hi) that needs bytes beyond this chunk
                 const uint64_t lim_b = up.end[j];
                 uint32_t lo = g_lo, hi = m_hi;
                 while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (hm[mid].cpos + hm[mid].clen + 16 <= lim_b) lo = mid + 1; else hi = mid; }
@@ -963,6 +1026,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             if (spec && iter == 0 && (h_sc[0] != 0xffffffffu || h_sc[kStatusEarly] != 0xffffffffu)) {
                 // some member did not inflate to its footer's length: nothing enqueued since is worth anything
                 mark("inflate verdict: not clean, starting over device-resident");
+                HIP_TRY(complete_upload());
                 HIP_TRY(hipStreamSynchronize(c->copy_stream));
                 const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, nullptr, false, region_to_file_end);
                 P.t_begin = t_begin;
@@ -989,6 +1053,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         HIP_TRY(hipMemcpyAsync(h_sc + kStatusEarly, d_sc + kStatusEarly, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (h_sc[0] != 0xffffffffu || h_sc[kStatusEarly] != 0xffffffffu) {
+            HIP_TRY(complete_upload());
             HIP_TRY(hipStreamSynchronize(c->copy_stream));
             const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, nullptr, false, region_to_file_end);
             P.t_begin = t_begin;
@@ -1000,7 +1065,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         // a chunk's chain stopped -- possibly only because a record runs past the members the index asked for (an index that does not
         // describe this file): once more with everything up to the end of the file inflated
         mark("region: chain ended, re-reading to the end of the file");
-        if (overlap) { HIP_TRY(hipStreamSynchronize(c->copy_stream)); }
+        if (overlap) { HIP_TRY(complete_upload()); HIP_TRY(hipStreamSynchronize(c->copy_stream)); }
         const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, d_true_sizes, false, true);
         P.t_begin = t_begin;
         return rc2;
@@ -1361,11 +1426,11 @@ static void chrom_string_ranks(const BamHeader &hdr, std::vector<uint32_t> &rank
 }
 
 static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_bam, size_t bam_len, const uint8_t *bai, size_t bai_len,
-                        const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen) {
+                        const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen, const SharedMembers *shared = nullptr) {
     *out = nullptr;
     c->last_rows_valid = false;
     Prep P;
-    int rc = prepare_events(c, d_bam_in, h_bam, bam_len, bai, bai_len, p, false, P, err, errlen);
+    int rc = prepare_events(c, d_bam_in, h_bam, bam_len, bai, bai_len, p, false, P, err, errlen, nullptr, true, false, shared);
     if (rc != RGX_OK) return rc;
     hipStream_t st = c->stream;
     const int32_t n_ref = (int32_t)P.hdr.names.size();
@@ -1411,6 +1476,14 @@ extern "C" int rgx_extract_mem(rgx_ctx *ctx, const void *bam, size_t bam_len, co
                                rgx_junction_table **out, char *err, size_t errlen) {
     if (!ctx || !bam || !out) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
     return run_pipeline(ctx, nullptr, (const uint8_t *)bam, bam_len, (const uint8_t *)bai, bai_len, p, out, err, errlen);
+}
+
+// rgx_extract_multi's shards: the same call with the member list the caller scanned once (multi.cpp)
+int rgx_extract_mem_scanned(rgx_ctx *ctx, const void *bam, size_t bam_len, const void *bai, size_t bai_len, const rgx_extract_params *p,
+                            const std::vector<rgx::Member> *members, uint64_t total_inflated, rgx_junction_table **out, char *err, size_t errlen) {
+    if (!ctx || !bam || !out) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
+    SharedMembers sm{members, total_inflated};
+    return run_pipeline(ctx, nullptr, (const uint8_t *)bam, bam_len, (const uint8_t *)bai, bai_len, p, out, err, errlen, members && !members->empty() ? &sm : nullptr);
 }
 
 extern "C" void *rgx_host_alloc(size_t bytes) {

@@ -290,7 +290,7 @@ bool bai_region_span(const uint8_t *d, size_t len, int32_t tid, int32_t beg, int
     return true;
 }
 
-bool host_bam_header(const uint8_t *d, size_t n, BamHeader &h) {
+bool host_bam_header(const uint8_t *d, size_t n, BamHeader &h, size_t *consumed) {
     std::string plain;
     size_t off = 0;
     for (int members = 0; off + 18 <= n && members < 4096; ++members) {
@@ -307,7 +307,7 @@ bool host_bam_header(const uint8_t *d, size_t n, BamHeader &h) {
         off += bl;
         uint64_t need = 0;
         const int r = parse_bam_header((const uint8_t *)plain.data(), plain.size(), h, need);
-        if (r == 0) return true;
+        if (r == 0) { if (consumed) *consumed = off; return true; }
         if (r == 2) return false;
     }
     return false;

@@ -251,10 +251,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // ballot (scalar bit scans), every lane pulls its group's copy -- destination of the first whole chunk (relative to the wave's lowest output
 // address: the members of a wave lie next to each other in the arena), distance, chunk count -- with two ds_bpermute, loads 16 bytes from
 // (chunk j) - distance and, after the trip's one wait, stores them to chunk j: aligned, and 256 consecutive bytes per group.  Up to
-// kCoopRounds rounds are in flight per trip (one per four lanes that start a long match in the same trip; the bench payload averages two);
+// four rounds are in flight per trip (one per four lanes that start a long match in the same trip; the bench payload averages two);
 // a trip with more finishes the earlier ones on the spot.
-constexpr int kCoopRounds = 4;
-struct WaveCopy {
+struct WaveCopy {                     // (kCoopRounds = 4 rounds in flight: d0..d3 / t0..t3)
     uint8_t *wave_base;
     uint32_t lane;
     u32x4 d0, d1, d2, d3;
@@ -287,7 +286,7 @@ struct WaveCopy {
             RGX_ROUND(d0, t0) RGX_ROUND(d1, t1) RGX_ROUND(d2, t2) RGX_ROUND(d3, t3)
 #undef RGX_ROUND
             if (!mask) break;
-            __builtin_amdgcn_s_waitcnt(0x0F70);                   // more than kCoopRounds rounds in one trip: finish these now
+            __builtin_amdgcn_s_waitcnt(0x0F70);                   // more than four rounds in one trip: finish these now
             stores();
         }
     }

@@ -5,8 +5,12 @@
 // (/root/reference/src/junctions/junctions_main.cc:45-59).  One host thread, one context and one stream per device:
 //   thread g:  shard g of n (contiguous BGZF member range cut at record starts the index lists, api.cpp prepare_events) ->
 //              the whole single-GPU pipeline on device g -> its unique rows packed in HBM (48 bytes per row)
-//   exchange:  ONE ncclAllGather of the padded row blocks over xGMI (RCCL, loaded at run time: librccl.so.1 is the only thing this
-//              library needs from it, and a process that also runs PyTorch must not end up with two RCCL copies bound at link time)
+//   exchange:  ONE grouped gather of the padded row blocks to the first device over xGMI (ncclSend / ncclRecv in one group; RCCL is loaded
+//              at run time: librccl.so.1 is the only thing this library needs from it, and a process that also runs PyTorch must not end
+//              up with two RCCL copies bound at link time).  Communicators, exchange buffers and streams are made once per device list
+//              and kept for the life of the process, like the contexts.
+//   host:      the file's BGZF members are found ONCE (scan_members_parallel) and every shard uploads only the header's members and its
+//              own byte range (api.cpp prepare_events): N shards move the file over PCIe once, not N times.
 //   merge:     on the first device, rgx_table_merge_device: radix sort by key, sum / min / max, first-seen naming by (shard, rank),
 //              strand of the last shard that saw the key, output order.  Shard order = file order, so the table is the single-GPU table.
 // The same device may be listed more than once (the shards then run one after the other on it and the exchange is a device copy): that
@@ -19,6 +23,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <map>
@@ -28,6 +33,10 @@
 #include <vector>
 
 #include "host_io.h"
+
+// api.cpp: rgx_extract_mem with the member list the caller scanned (not part of the C ABI)
+int rgx_extract_mem_scanned(rgx_ctx *ctx, const void *bam, size_t bam_len, const void *bai, size_t bai_len, const rgx_extract_params *p,
+                            const std::vector<rgx::Member> *members, uint64_t total_inflated, rgx_junction_table **out, char *err, size_t errlen);
 
 using namespace rgx;
 
@@ -48,6 +57,8 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, nccl_comm, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     bool load(char *err, size_t errlen) {
         if (so) return true;
@@ -58,6 +69,8 @@ struct Rccl {
         GroupStart = (decltype(GroupStart))dlsym(so, "ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))dlsym(so, "ncclGroupEnd");
         AllGather = (decltype(AllGather))dlsym(so, "ncclAllGather");
+        Send = (decltype(Send))dlsym(so, "ncclSend");
+        Recv = (decltype(Recv))dlsym(so, "ncclRecv");
         GetErrorString = (decltype(GetErrorString))dlsym(so, "ncclGetErrorString");
         if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !AllGather) {
             failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: librccl.so.1 lacks a symbol this path needs\n");
@@ -73,11 +86,9 @@ struct Shard {
     int device = 0, nth = 0;                 // nth: which of the listings of this device
     rgx_ctx *ctx = nullptr;                  // (owned by the process-wide cache)
     rgx_junction_table *table = nullptr;
-    void *d_send = nullptr, *d_recv = nullptr;
-    hipStream_t stream = nullptr;
-    nccl_comm comm = nullptr;
     int rc = RGX_OK;
     char err[512] = {0};
+    double ms_extract = 0;
 };
 
 // Contexts are kept for the life of the process, one per (device, how many times the device is listed): a second call finds its HBM
@@ -94,16 +105,58 @@ rgx_ctx *context_for(int device, int nth, char *err, size_t errlen, int &rc) {
     return c;
 }
 
-void release(std::vector<Shard> &S) {
-    for (Shard &s : S) {
-        (void)hipSetDevice(s.device);
-        if (s.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s.comm);
-        if (s.d_send) (void)hipFree(s.d_send);
-        if (s.d_recv) (void)hipFree(s.d_recv);
-        if (s.stream) (void)hipStreamDestroy(s.stream);
-        if (s.table) rgx_table_free(s.table);
+// What the exchange needs besides the contexts, per device LIST: RCCL communicators (ncclCommInitAll on an 8-GPU node takes hundreds of
+// milliseconds -- once, not per call), one stream and one send buffer per entry, the receive block on the first device.  Buffers grow,
+// nothing is handed back before the process ends (rgx_extract_multi calls take turns: call_mu).
+struct Exchange {
+    std::vector<int> devices;
+    std::vector<nccl_comm> comms;            // empty while the list repeats a device (no collective then)
+    std::vector<hipStream_t> streams;
+    std::vector<void *> d_send; std::vector<size_t> send_cap;
+    void *d_recv = nullptr; size_t recv_cap = 0;
+};
+std::map<std::vector<int>, Exchange> g_exchange;
+
+int exchange_for(const int *devices, int n, bool distinct, size_t block, Exchange *&out, char *err, size_t errlen) {
+    std::vector<int> key(devices, devices + n);
+    Exchange &x = g_exchange[key];
+    if (x.devices.empty()) {
+        x.devices = key; x.streams.assign((size_t)n, nullptr); x.d_send.assign((size_t)n, nullptr); x.send_cap.assign((size_t)n, 0);
+        for (int g = 0; g < n; ++g)
+            if (hipSetDevice(devices[g]) != hipSuccess || hipStreamCreateWithFlags(&x.streams[(size_t)g], hipStreamNonBlocking) != hipSuccess)
+                return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no stream for the row exchange on device %d\n", devices[g]);
+        if (distinct && n > 1) {
+            if (!g_rccl.load(err, errlen)) return RGX_ERR_DEVICE;
+            x.comms.assign((size_t)n, nullptr);
+            const int r = g_rccl.CommInitAll(x.comms.data(), n, devices);
+            if (r != 0) { x.comms.clear(); return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: ncclCommInitAll failed: %s\n", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); }
+        }
     }
+    for (int g = 0; g < n; ++g) {
+        if (x.send_cap[(size_t)g] >= block) continue;
+        if (hipSetDevice(devices[g]) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: device %d\n", devices[g]);
+        if (x.d_send[(size_t)g]) (void)hipFree(x.d_send[(size_t)g]);
+        x.d_send[(size_t)g] = nullptr; x.send_cap[(size_t)g] = 0;
+        if (hipMalloc(&x.d_send[(size_t)g], block + block / 4 + 4096) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no memory for the row exchange on device %d\n", devices[g]);
+        x.send_cap[(size_t)g] = block + block / 4 + 4096;
+    }
+    if (x.recv_cap < block * (size_t)n) {
+        if (hipSetDevice(devices[0]) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: device %d\n", devices[0]);
+        if (x.d_recv) (void)hipFree(x.d_recv);
+        x.d_recv = nullptr; x.recv_cap = 0;
+        const size_t want = (block + block / 4 + 4096) * (size_t)n;
+        if (hipMalloc(&x.d_recv, want) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no memory for the row exchange on device %d\n", devices[0]);
+        x.recv_cap = want;
+    }
+    out = &x;
+    return RGX_OK;
 }
+
+void release(std::vector<Shard> &S) {
+    for (Shard &s : S) if (s.table) rgx_table_free(s.table);
+}
+
+double now_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
 }  // namespace
 
@@ -121,14 +174,22 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
     const bool distinct = std::set<int>(devices, devices + n).size() == (size_t)n;
     { std::map<int, int> seen; for (int g = 0; g < n; ++g) { S[(size_t)g].device = devices[g]; S[(size_t)g].nth = seen[devices[g]]++; } }
 
+    // -- the file's members, found once for all shards (a file the host scan does not vouch for: every shard takes the device's member
+    //    discovery on the whole file, as a single-GPU call would) -----------------------------------------------------------------------
+    const double t_begin = now_ms();
+    std::vector<Member> members; uint64_t total_inflated = 0;
+    if (n > 1 && bam_len >= ((size_t)8 << 20) && !scan_members_parallel((const uint8_t *)bam, bam_len, (int)usable_threads(24), members, total_inflated)) members.clear();
+    const double t_scan = now_ms();
     // -- one extraction per shard: a thread per device (shards that share a device take turns on it) -------------------------------------
     auto extract = [&](int g) {
         Shard &s = S[(size_t)g];
+        const double t0 = now_ms();
         s.ctx = context_for(s.device, s.nth, s.err, sizeof s.err, s.rc);
         if (s.rc != RGX_OK) return;
         rgx_extract_params q = *p;
         q.shard = g; q.n_shards = n;
-        s.rc = rgx_extract_mem(s.ctx, bam, bam_len, bai, bai_len, &q, &s.table, s.err, sizeof s.err);
+        s.rc = rgx_extract_mem_scanned(s.ctx, bam, bam_len, bai, bai_len, &q, &members, total_inflated, &s.table, s.err, sizeof s.err);
+        s.ms_extract = now_ms() - t0;
     };
     if (distinct) {
         std::vector<std::thread> pool;
@@ -141,64 +202,98 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
     // as well -- the collective's call sequence on the real library where only one GPU is visible)
     const bool selftest = getenv("REGTOOLS_AMD_RCCL_SELFTEST") != nullptr;
     if (n == 1 && !selftest) { *out = S[0].table; S[0].table = nullptr; return RGX_OK; }
+    if (n == 1) {
+        // one rank through ncclCommInitAll / ncclAllGather on the real library (no peer to send to)
+        if (!g_rccl.load(err, errlen)) return RGX_ERR_DEVICE;
+        nccl_comm comm = nullptr; void *d_a = nullptr, *d_b = nullptr; hipStream_t st1 = nullptr;
+        const size_t blk = std::max<size_t>(1, (size_t)S[0].table->n) * RGX_PACKED_ROW_BYTES;
+        int r = g_rccl.CommInitAll(&comm, 1, devices);
+        bool ok = r == 0 && hipSetDevice(devices[0]) == hipSuccess && hipMalloc(&d_a, blk) == hipSuccess && hipMalloc(&d_b, blk) == hipSuccess &&
+                  hipStreamCreateWithFlags(&st1, hipStreamNonBlocking) == hipSuccess;
+        if (ok && S[0].table->n) ok = rgx_last_table_pack_device(S[0].ctx, S[0].table, d_a, S[0].table->n, err, errlen) == RGX_OK;
+        if (ok) { r = g_rccl.GroupStart(); if (r == 0) r = g_rccl.AllGather(d_a, d_b, blk, kNcclUint8, comm, st1); const int r2 = g_rccl.GroupEnd(); ok = r == 0 && r2 == 0 && hipStreamSynchronize(st1) == hipSuccess; }
+        rgx_junction_table *m1 = nullptr;
+        uint64_t rows1 = S[0].table->n;
+        int rc1 = ok ? rgx_table_merge_device(S[0].ctx, d_b, std::max<uint64_t>(1, rows1), &rows1, 1, p->min_anchor, S[0].table, &m1, err, errlen) : RGX_ERR_DEVICE;
+        if (comm) g_rccl.CommDestroy(comm);
+        if (d_a) (void)hipFree(d_a);
+        if (d_b) (void)hipFree(d_b);
+        if (st1) (void)hipStreamDestroy(st1);
+        if (rc1 != RGX_OK) return ok ? rc1 : failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: RCCL self test failed\n");
+        const rgx_junction_table *t = S[0].table;
+        m1->n_records = t->n_records; m1->n_events = t->n_events; m1->inflated_bytes = t->inflated_bytes; m1->n_members = t->n_members; m1->compressed_bytes = bam_len;
+        m1->stream_ended = t->stream_ended; m1->framing_sweeps = t->framing_sweeps;
+        if (p->barcodes) { const rgx_junction_table *parts1[1] = {t}; rc1 = rgx_table_merge_barcodes(parts1, 1, m1, err, errlen); if (rc1 != RGX_OK) { rgx_table_free(m1); return rc1; } }
+        *out = m1;
+        return RGX_OK;
+    }
 
     // -- pack: every shard's rows, still in HBM on its device, into a block of `stride` rows ----------------------------------------------
+    const double t_extract = now_ms();
     uint64_t stride = 1;
     std::vector<uint64_t> part_rows((size_t)n);
     for (int g = 0; g < n; ++g) { part_rows[(size_t)g] = S[(size_t)g].table->n; stride = std::max<uint64_t>(stride, S[(size_t)g].table->n); }
     const size_t block = (size_t)stride * RGX_PACKED_ROW_BYTES;
+    Exchange *X = nullptr;
+    { const int rcx = exchange_for(devices, n, distinct, block, X, err, errlen); if (rcx != RGX_OK) return rcx; }
     for (int g = 0; g < n; ++g) {
         Shard &s = S[(size_t)g];
-        if (hipSetDevice(s.device) != hipSuccess || hipMalloc(&s.d_send, block) != hipSuccess || hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess)
-            return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no memory for the row exchange on device %d\n", s.device);
-        if ((distinct || g == 0) && hipMalloc(&s.d_recv, block * (size_t)n) != hipSuccess)
-            return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no memory for the row exchange on device %d\n", s.device);
+        if (hipSetDevice(s.device) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: device %d\n", s.device);
         if (s.table->n) {
             // the rows of a context's LAST extraction are still on its device; with several shards on one device only the last one's are,
             // the others go up from the host table
-            if (rgx_last_table_pack_device(s.ctx, s.table, s.d_send, stride, s.err, sizeof s.err) != RGX_OK) {
+            if (rgx_last_table_pack_device(s.ctx, s.table, X->d_send[(size_t)g], stride, s.err, sizeof s.err) != RGX_OK) {
                 std::vector<uint8_t> h((size_t)s.table->n * RGX_PACKED_ROW_BYTES);
                 rgx_table_pack(s.table, h.data(), h.size());
-                if (hipMemcpy(s.d_send, h.data(), h.size(), hipMemcpyHostToDevice) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: row upload failed\n");
+                if (hipMemcpy(X->d_send[(size_t)g], h.data(), h.size(), hipMemcpyHostToDevice) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: row upload failed\n");
             }
         }
     }
 
-    // -- the one collective of the job --------------------------------------------------------------------------------------------------
+    // -- the one exchange of the job: every shard's block to the first device ------------------------------------------------------------------
     if (distinct) {
-        if (!g_rccl.load(err, errlen)) return RGX_ERR_DEVICE;
-        std::vector<nccl_comm> comms((size_t)n, nullptr);
-        int r = g_rccl.CommInitAll(comms.data(), n, devices);
-        if (r != 0) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: ncclCommInitAll failed: %s\n", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
-        for (int g = 0; g < n; ++g) S[(size_t)g].comm = comms[(size_t)g];
-        r = g_rccl.GroupStart();
-        for (int g = 0; g < n && r == 0; ++g) {
-            Shard &s = S[(size_t)g];
-            if (hipSetDevice(s.device) != hipSuccess) { r = -1; break; }
-            r = g_rccl.AllGather(s.d_send, s.d_recv, block, kNcclUint8, s.comm, s.stream);
-        }
+        int r = g_rccl.GroupStart();
+        if (g_rccl.Send && g_rccl.Recv) {
+            // a gather: rank g sends its block, rank 0 receives n of them (its own as a device copy inside the group)
+            for (int g = 0; g < n && r == 0; ++g) {
+                if (hipSetDevice(devices[g]) != hipSuccess) { r = -1; break; }
+                if (g > 0) r = g_rccl.Send(X->d_send[(size_t)g], block, kNcclUint8, 0, X->comms[(size_t)g], X->streams[(size_t)g]);
+            }
+            if (r == 0 && hipSetDevice(devices[0]) != hipSuccess) r = -1;
+            for (int g = 1; g < n && r == 0; ++g) r = g_rccl.Recv((uint8_t *)X->d_recv + (size_t)g * block, block, kNcclUint8, g, X->comms[0], X->streams[0]);
+            if (r == 0 && hipMemcpyAsync(X->d_recv, X->d_send[0], block, hipMemcpyDeviceToDevice, X->streams[0]) != hipSuccess) r = -1;
+        } else r = -1;                                        // (a library without point-to-point calls: reported below)
         const int r2 = g_rccl.GroupEnd();
-        if (r != 0 || r2 != 0) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: ncclAllGather failed: %s\n", g_rccl.GetErrorString ? g_rccl.GetErrorString(r ? r : r2) : "?");
+        if (r != 0 || r2 != 0) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: the RCCL row gather failed: %s\n",
+                                            !(g_rccl.Send && g_rccl.Recv) ? "this librccl has no ncclSend / ncclRecv" : g_rccl.GetErrorString ? g_rccl.GetErrorString(r > 0 ? r : r2) : "?");
         for (int g = 0; g < n; ++g) {
-            if (hipSetDevice(S[(size_t)g].device) != hipSuccess || hipStreamSynchronize(S[(size_t)g].stream) != hipSuccess)
-                return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: the row exchange did not complete on device %d\n", S[(size_t)g].device);
+            if (hipSetDevice(devices[g]) != hipSuccess || hipStreamSynchronize(X->streams[(size_t)g]) != hipSuccess)
+                return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: the row exchange did not complete on device %d\n", devices[g]);
         }
     } else {
         if (hipSetDevice(S[0].device) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: device %d\n", S[0].device);
         for (int g = 0; g < n; ++g)
-            if (hipMemcpyPeer((uint8_t *)S[0].d_recv + (size_t)g * block, S[0].device, S[(size_t)g].d_send, S[(size_t)g].device, block) != hipSuccess)
+            if (hipMemcpyPeer((uint8_t *)X->d_recv + (size_t)g * block, S[0].device, X->d_send[(size_t)g], S[(size_t)g].device, block) != hipSuccess)
                 return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: row copy from device %d failed\n", S[(size_t)g].device);
         // a device-to-device copy may return before it is done, and the merge runs on the context's own (non-blocking) stream
         if (hipDeviceSynchronize() != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: the row copies did not complete\n");
     }
+    const double t_exchange = now_ms();
 
     // -- merge on the first device.  A shard whose record stream ENDED (a member that does not inflate, an unreadable record) hides the
     //    shards behind it: a sequential reader never gets there (api.cpp, rgx_table_merge) ---------------------------------------------------
     std::vector<uint64_t> merge_rows = part_rows;
     for (int g = 0; g < n; ++g) if (S[(size_t)g].table->stream_ended) { for (int k = g + 1; k < n; ++k) merge_rows[(size_t)k] = 0; break; }
     rgx_junction_table *m = nullptr;
-    int rc = rgx_table_merge_device(S[0].ctx, S[0].d_recv, stride, merge_rows.data(), n, p->min_anchor, S[0].table, &m, err, errlen);
+    int rc = rgx_table_merge_device(S[0].ctx, X->d_recv, stride, merge_rows.data(), n, p->min_anchor, S[0].table, &m, err, errlen);
     if (rc != RGX_OK) return rc;
+    const double t_merge = now_ms();
+    if (getenv("REGTOOLS_AMD_TRACE")) {
+        fprintf(stderr, "[rgx trace] multi: %d shards (%s), member scan %.3f ms, shards %.3f ms (", n, distinct ? (g_rccl.Send ? "RCCL send/recv gather" : "RCCL") : "one device, copies",
+                t_scan - t_begin, t_extract - t_scan);
+        for (int g = 0; g < n; ++g) fprintf(stderr, "%s%.1f", g ? " " : "", S[(size_t)g].ms_extract);
+        fprintf(stderr, "), pack + exchange %.3f ms, merge %.3f ms\n", t_exchange - t_extract, t_merge - t_exchange);
+    }
     for (int g = 0; g < n; ++g) {
         const rgx_junction_table *t = S[(size_t)g].table;
         m->n_records += t->n_records; m->n_events += t->n_events; m->inflated_bytes += t->inflated_bytes; m->n_members += t->n_members;

@@ -267,9 +267,10 @@ class JunctionsExtractor(object):
         return self._table
 
 
-def extract_multi(devices, bam=None, bam_bytes=None, bai_bytes=None, **kw):
-    """rgx_extract_multi: `junctions extract` sharded over `devices` (a host thread per device, one RCCL all-gather of the shards' rows,
-    merge on devices[0]).  kw: the JunctionsExtractor constructor's arguments.  Returns a distributed.MergedTable-like object."""
+def extract_multi(devices, bam=None, bam_bytes=None, bai_bytes=None, host_ptr=None, host_len=0, **kw):
+    """rgx_extract_multi: `junctions extract` sharded over `devices` (a host thread per device, one RCCL gather of the shards' rows to
+    devices[0], merge there).  kw: the JunctionsExtractor constructor's arguments.  host_ptr / host_len: the file in (page-locked) host memory
+    instead of bam_bytes.  Returns a distributed.MergedTable-like object."""
     from . import distributed
     lib = _ffi.lib()
     je = JunctionsExtractor(bam=bam or "NA", **kw)
@@ -277,7 +278,9 @@ def extract_multi(devices, bam=None, bam_bytes=None, bai_bytes=None, **kw):
     devs = (C.c_int * len(devices))(*devices)
     tab = C.POINTER(_ffi.JunctionTable)()
     err = C.create_string_buffer(512)
-    if bam_bytes is not None:
+    if host_ptr is not None:
+        rc = lib.rgx_extract_multi_mem(devs, len(devices), C.c_void_p(host_ptr), host_len, bai_bytes, len(bai_bytes), C.byref(p), C.byref(tab), err, len(err))
+    elif bam_bytes is not None:
         rc = lib.rgx_extract_multi_mem(devs, len(devices), bam_bytes, len(bam_bytes), bai_bytes, len(bai_bytes), C.byref(p), C.byref(tab), err, len(err))
     else:
         rc = lib.rgx_extract_multi(devs, len(devices), bam.encode(), C.byref(p), C.byref(tab), err, len(err))

@@ -516,3 +516,41 @@ def test_full_size_long_read_properties(gpu_ctx):
     assert recs == 10_000_000
     assert distributed.merge_packed(parts, keep[0].table, 8).bed12() == bed
     pin.close()
+
+
+def test_bench_multi_rank_path_on_one_gpu(gpu_ctx, tmp_path):
+    """bench.py's N > 1 path (what the driver launches on a multi-GPU node) with two ranks on THIS GPU over gloo (BENCH_BACKEND / BENCH_DEVICE):
+    every rank extracts its coordinate slice, the packed rows are gathered and merged -- the table rank 0 reports must be the merge of the two
+    slices' tables made here, one after the other.  And bench.py's C++ host mode (--multi-host cpp, rgx_extract_multi on the device list
+    [0, 0]): the table of one file of twice the reads, sharded, must be that file's single-GPU table."""
+    import json
+    import sys
+    from regtools_amd import synth
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    bed2 = str(tmp_path / "ranks2.bed")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29617",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "200000", "--no-cpu-baseline", "--no-extras", "--dump-bed", bed2],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["multi_gpu"]["per_rank"][1]["reads"] == 200000 and line["multi_gpu"]["merge_ms"] > 0
+    # the same two slices, one rank each, merged here
+    import regtools_amd
+    from regtools_amd import distributed
+    parts, keep = [], []
+    for rk in range(2):
+        bam, bai, _ = synth.generate(200000, shape="short", seed=1, slice_index=rk, n_slices=2)
+        je = regtools_amd.JunctionsExtractor(strandness=0, ctx=gpu_ctx)
+        je.identify_junctions_from_BAM(bam_bytes=bam, bai_bytes=bai)
+        keep.append(je); parts.append(distributed.pack_table(je.table))
+    want = distributed.merge_packed(parts, keep[0].table, 8).bed12()
+    assert open(bed2, "rb").read() == want
+    # ... and bench.py's C++ host mode: one file of 2 x 200000 reads over the device list [0, 0] == the single-GPU table of that file
+    bedc = str(tmp_path / "cpp.bed")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--multi-host", "cpp", "--steps", "1", "--warmup", "1", "--reads", "200000", "--dump-bed", bedc],
+                       env=os.environ, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    bam, bai, _ = synth.generate(400000, shape="short", seed=1)
+    je = regtools_amd.JunctionsExtractor(strandness=0, ctx=gpu_ctx)
+    je.identify_junctions_from_BAM(bam_bytes=bam, bai_bytes=bai)
+    assert open(bedc, "rb").read() == je.bed12()
