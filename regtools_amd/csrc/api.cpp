@@ -735,7 +735,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         d_bad = b_bad.as<uint8_t>();
         HIP_TRY(hipMemsetAsync(d_bad, 0, n_range, st));
     }
-    const int pairs = inflate_pairs_for(bam_len, total_all);     // (the whole file's ratio: a range of it is the same kind of payload)
+    const int pairs = inflate_plan_for(bam_len, total_all);      // (the whole file's ratio: a range of it is the same kind of payload)
     if (!overlap) launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below, 0, false, 0, d_bad, pairs);
     else {
         // one launch per upload chunk, on the side streams: the members whose bytes (plus the decoder's 16-byte look-ahead) have arrived with

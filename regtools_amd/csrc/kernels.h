@@ -24,9 +24,15 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
                     bool piece = false /* one of several concurrent launches over a range (own kernel symbol, same code) */,
                     int form = 0 /* 0 = chosen by member count / REGTOOLS_AMD_INFLATE; 1 = k_inflate, 2 = k_inflate_wave, 3 = k_inflate_ring */,
                     uint8_t *bad_flags = nullptr /* optional, zeroed by the caller: [index in the caller's range] = 1 for every member that did not inflate */,
-                    int pairs = 1 /* k_inflate_coop: a literal and the symbol behind it in one trip (inflate_pairs_for) */);
-// literal pairs pay on payloads with many literals and cost on run-length payloads: on when the file compresses to more than 1/32 of its size
-inline int inflate_pairs_for(uint64_t compressed_bytes, uint64_t inflated_bytes) { return compressed_bytes * 32 > inflated_bytes; }
+                    int plan = 1 /* inflate_plan_for: bit 0 = k_inflate_coop takes a literal and the symbol behind it in one trip, bit 1 = the lane form is k_inflate */);
+// Which lane form suits a payload, from how well the file compresses (measured on 50 M-read files, all three byte-equal to zlib):
+//   inflated / compressed > 32  (long reads: run-length copies)       k_inflate_coop, one symbol per trip   126.7 ms against k_inflate's 135.6
+//   8 .. 32                     (the bench payload: 21)                k_inflate_coop, literal pairs          16.0 against 20.0
+//   < 8                         (random bases + binned qualities: 3.6) k_inflate                              49.2 against 51-52: few matches are
+//                               long enough for the wave to move, and the cooperative rounds' bookkeeping is paid by every trip
+inline int inflate_plan_for(uint64_t compressed_bytes, uint64_t inflated_bytes) {
+    return (compressed_bytes * 32 > inflated_bytes ? 1 : 0) | (compressed_bytes * 8 > inflated_bytes ? 2 : 0);
+}
 
 // ---- a1 (container): BGZF member discovery on the device --------------------------------------------------
 // The member chain (bgzf.c:525: next = this + BSIZE + 1) is serial on a CPU (one dependent cache miss per member).

@@ -410,13 +410,13 @@ static void inflate_attrs() {
     done = true;
 }
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
-                    uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias, bool piece, int form, uint8_t *bad, int pairs) {
+                    uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias, bool piece, int form, uint8_t *bad, int plan) {
     if (!n_members) return;
     inflate_attrs();
     static const int env_pairs = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE_PAIRS"); return e ? atoi(e) != 0 : -1; }();
-    const uint32_t two = env_pairs >= 0 ? (uint32_t)env_pairs : pairs != 0;
+    const uint32_t two = env_pairs >= 0 ? (uint32_t)env_pairs : (plan & 1) != 0;
     if (!form) form = inflate_form_env();
-    if (!form) form = n_members <= kWaveFormMaxMembers ? 2 : kDefaultLaneForm;
+    if (!form) form = n_members <= kWaveFormMaxMembers ? 2 : (plan & 2) ? 1 : kDefaultLaneForm;
     const uint32_t blocks = (n_members + 63) / 64;
     switch (form) {
     case 2:
