@@ -356,22 +356,46 @@ std::string VcfText::load(const std::string &path) {
         if (!closed) return "Unable to read header.\n\n";
         hdr.parse(htxt);
         if (!hdr.error.empty()) return hdr.error + "\n";
+        // a tabix index next to the file: the sequence names it lists that the header does not declare join the header as ##contig lines
+        // (vcf_hdr_read, vcf.c:1289-1309) -- they are written out with it, and a record on such a contig draws no warning.  An index that
+        // cannot be read is no index (tbx_index_load returns NULL).
+        std::string tbi_path;
+        std::vector<uint8_t> raw;
+        if (find_tbi(path, tbi_path) && read_file(tbi_path, raw)) {
+            std::string idx;
+            const uint8_t *d = raw.data(); size_t n = raw.size();
+            if (n >= 2 && d[0] == 0x1f && d[1] == 0x8b) { if (gunzip_all(d, n, idx).empty()) { d = (const uint8_t *)idx.data(); n = idx.size(); } else n = 0; }
+            if (n >= 36 && !memcmp(d, "TBI\1", 4)) {
+                int32_t n_ref, l_nm; memcpy(&n_ref, d + 4, 4); memcpy(&l_nm, d + 32, 4);
+                if (n_ref >= 0 && l_nm >= 0 && (size_t)l_nm <= n - 36) {
+                    const char *q = (const char *)d + 36, *e = q + l_nm;
+                    for (int32_t k = 0; k < n_ref && q < e; ++k) {
+                        const size_t ln = strnlen(q, (size_t)(e - q));
+                        const std::string name(q, ln);
+                        if (hdr.contigs.find(name) == hdr.contigs.end()) hdr.append("##contig=<ID=" + name + ">");
+                        q += ln + 1;
+                    }
+                }
+            }
+        }
     }
     // CHROM and POS of every record line, by several threads over ranges of lines (file order kept: the ranges are concatenated in order).
     // vcf_parse refuses a record whose sample columns do not match the header (vcf.c:1551-1556, 1760-1766): the read loop ends there.
     const size_t n_samples = hdr.samples.size();
     const size_t T = n_lines_ < (1u << 16) ? 1 : usable_threads(16);
     std::vector<std::vector<Rec>> part(T);
-    std::vector<size_t> part_stop(T, SIZE_MAX);
+    std::vector<size_t> part_stop(T, SIZE_MAX), part_first_id(T, SIZE_MAX);       // (first record of the range that has an ID column)
     auto scan = [&](size_t t) {
         std::vector<Rec> &out = part[t];
         const size_t a = std::max(first_rec_line, n_lines_ * t / T), b = n_lines_ * (t + 1) / T;
         if (b > a) out.reserve(b - a);
         for (size_t i = a; i < b; ++i) {
             const char *l; size_t n; line(i, l, n);
-            if (!n || l[0] == '#') continue;
+            // Every line behind the header is a record upstream (vcf_read, vcf.c:1958-1964: hts_getline + vcf_parse, no look at what the line
+            // is): a blank line, a '#' line or any text without a tab is CHROM = the whole line with everything else left as bcf_clear1
+            // left it (POS 1, no ID / REF / ALT / QUAL / FILTER / INFO)
             const char *t1 = (const char *)memchr(l, '\t', n);
-            if (!t1) continue;
+            if (!t1) { out.push_back({i, std::string(l, n), 0u}); continue; }
             const char *t2 = (const char *)memchr(t1 + 1, '\t', (size_t)(l + n - t1 - 1));
             if (n_samples && t2) {
                 // columns 9.. : FORMAT and the samples
@@ -385,6 +409,7 @@ std::string VcfText::load(const std::string &path) {
                 }
             }
             std::string ps(t1 + 1, t2 ? (size_t)(t2 - t1 - 1) : (size_t)(l + n - t1 - 1));
+            if (t2 && part_first_id[t] == SIZE_MAX) part_first_id[t] = out.size();
             out.push_back({i, std::string(l, (size_t)(t1 - l)), (uint32_t)atoi(ps.c_str()) - 1u});
         }
     };
@@ -394,11 +419,16 @@ std::string VcfText::load(const std::string &path) {
         scan(0);
         for (auto &th : pool) th.join();
     }
-    if (T == 1) recs.swap(part[0]);
+    first_with_id = SIZE_MAX;
+    if (T == 1) { first_with_id = part_first_id[0]; recs.swap(part[0]); }
     else {
         size_t total = 0; for (auto &v : part) total += v.size();
         recs.reserve(total);
-        for (size_t t = 0; t < T; ++t) { for (auto &r : part[t]) recs.push_back(std::move(r)); if (part_stop[t] != SIZE_MAX) break; }
+        for (size_t t = 0; t < T; ++t) {
+            if (first_with_id == SIZE_MAX && part_first_id[t] != SIZE_MAX) first_with_id = recs.size() + part_first_id[t];
+            for (auto &r : part[t]) recs.push_back(std::move(r));
+            if (part_stop[t] != SIZE_MAX) break;
+        }
     }
     return "";
 }
@@ -428,6 +458,7 @@ std::string write_annotated_vcf_records(FILE *fv, const VcfText &vcf, const std:
         for (size_t k = todo.size() * t / T; k < todo.size() * (t + 1) / T; ++k) {
             const size_t ri = todo[k];
             if (!vcf.typed(ri, h, rec)) { if (!h.error.empty()) { fatal[t] = h.error; return; } continue; }
+            rec.id_buffer_used = vcf.first_with_id < ri;
             const VcfAnnot a = annot(ri);
             vcf_update_info_string(h, rec, "genes", a.genes ? *a.genes : kNA);
             vcf_update_info_string(h, rec, "transcripts", a.transcripts ? *a.transcripts : kNA);

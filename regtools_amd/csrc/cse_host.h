@@ -37,6 +37,8 @@ struct VcfText {
     struct Rec { size_t line; std::string chrom; uint32_t pos0; };      // line = line index (text) / byte offset of the record (BCF)
     std::vector<Rec> recs;             // what the reference's read loop hands out, in file order (it ends at the first record vcf_parse refuses)
     bool bcf = false;
+    size_t first_with_id = (size_t)-1; // first record that carries an ID column: bcf_unpack gives the reader's record its ID buffer there, and a
+                                       // later record WITHOUT the column prints that buffer, emptied, where an earlier one prints "." (vcf.c:2012-2018, :2075)
     VcfHdr hdr;                        // the header dictionary as bcf_hdr_read leaves it
     std::string load(const std::string &path);
     size_t n_lines() const { return line_off.empty() ? 0 : line_off.size() - 1; }

@@ -326,6 +326,8 @@ static bool idx_name(const std::string &fn, const char *ext, std::string &out) {
     return false;
 }
 
+bool find_tbi(const std::string &path, std::string &out) { return idx_name(path, ".tbi", out); }       // hts_idx_getfn, as for the BAM indexes
+
 int find_index(const std::string &bam_path, std::string &out) {      // hts_idx_load: <fn>.csi, <stem>.csi, <fn>.bai, <stem>.bai (hts.c:2031-2042)
     if (idx_name(bam_path, ".csi", out)) return 0;
     if (idx_name(bam_path, ".bai", out)) return 0;

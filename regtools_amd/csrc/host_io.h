@@ -61,6 +61,9 @@ bool host_bam_header(const uint8_t *bam_head, size_t len, BamHeader &h, size_t *
 // returns 0 found, 1 none
 int find_index(const std::string &bam_path, std::string &out);
 
+// "<fn>.tbi", then "<fn minus extension>.tbi" (tbx_index_load -> hts_idx_getfn)
+bool find_tbi(const std::string &path, std::string &out);
+
 bool read_file(const std::string &path, std::vector<uint8_t> &out);
 
 // gzip / BGZF bytes -> plain bytes, with the product's own decoder compiled for the host (no zlib).  "" on success.

@@ -612,7 +612,7 @@ bool vcf_format_line(const VcfHdr &h, const VcfRec &v, std::string &s) {
     s += name_of(h.contig_name, v.rid);
     s += '\t'; put_int(s, (int32_t)((uint32_t)v.pos + 1u));
     s += '\t';
-    if (v.have_shared) fmt_array(s, v.id.n, VT_CHAR, (const uint8_t *)v.id.data.data()); else s += '.';
+    if (v.have_shared) fmt_array(s, v.id.n, VT_CHAR, (const uint8_t *)v.id.data.data()); else if (!v.id_buffer_used) s += '.';
     s += '\t';
     if (!v.alleles.empty()) fmt_array(s, v.alleles[0].n, VT_CHAR, (const uint8_t *)v.alleles[0].data.data()); else s += '.';
     s += '\t';

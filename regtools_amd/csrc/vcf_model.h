@@ -56,6 +56,7 @@ struct VcfRec {
     int32_t rid = 0, pos = 0;
     uint32_t qual_bits = 0x7F800001u;   // bcf_float_missing
     bool have_shared = false;           // false = only CHROM / POS were present (bcf_unpack leaves everything at its cleared state)
+    bool id_buffer_used = false;        // an earlier record of the file had an ID column (set by the writer): see VcfText::first_with_id
     Typed id;
     std::vector<Typed> alleles;
     std::vector<int32_t> flt;

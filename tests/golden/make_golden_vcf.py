@@ -28,6 +28,8 @@ def main():
         for name, data in sorted(vcf_cases.build(td).items()):
             src = os.path.join(td, name + ".vcf")
             open(src, "wb").write(data)
+            for suffix, blob in vcf_cases.companions().get(name, {}).items():
+                open(os.path.join(td, name + suffix), "wb").write(blob)
             manifest[name] = {}
             for kind in ("far", "near"):
                 dst = os.path.join(out, "%s.%s.vcf" % (name, kind))

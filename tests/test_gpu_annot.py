@@ -144,6 +144,8 @@ def test_annotated_vcf_equals_the_reference(gpu_ctx, vcf_inputs, name):
     inputs, gtf, d = vcf_inputs
     src, out = os.path.join(d, name + ".vcf"), os.path.join(d, name + ".out.vcf")
     open(src, "wb").write(inputs[name])
+    for suffix, blob in vcf_cases.companions().get(name, {}).items():
+        open(os.path.join(d, name + suffix), "wb").write(blob)
     rc, msg = run_mirror(regtools_amd.VariantsAnnotator(ctx=gpu_ctx), ["-o", out, src, gtf], "annotate_vcf")
     assert rc == 0, msg
     assert ac.read(out) == ac.read(os.path.join(VCF_GOLD, name + ".near.vcf"))

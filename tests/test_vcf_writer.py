@@ -30,6 +30,8 @@ def rewrite(emu, data, tmp_path, name):
     src = os.path.join(str(tmp_path), name + ".vcf")
     dst = os.path.join(str(tmp_path), name + ".out.vcf")
     open(src, "wb").write(data)
+    for suffix, blob in vcf_cases.companions().get(name, {}).items():
+        open(os.path.join(str(tmp_path), name + suffix), "wb").write(blob)
     err = ctypes.create_string_buffer(512)
     rc = emu.emu_vcf_rewrite(src.encode(), dst.encode(), err, 512)
     return rc, (open(dst, "rb").read() if os.path.exists(dst) else b""), err.value.decode()

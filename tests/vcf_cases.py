@@ -190,10 +190,53 @@ def _bcf_records():
     ]
 
 
+def _line_cases():
+    """Lines behind the header that are no ordinary records: upstream's read loop parses every one of them (vcf_read, vcf.c:1958-1964) -- a
+    blank line, a '#' line, text without a tab, a record cut short behind POS; the ID such a record prints depends on whether an earlier
+    record of the file had an ID column (round 3)."""
+    r = ["1\t100\t.\tA\tG\t30\tPASS\tDP=10", "1\t1005\t.\tC\tT\t40\tPASS\tDP=11", "1\t2100\trs1\tG\tA\t50\tPASS\tDP=12"]
+    h = HDR + S0
+    return {
+        "lines_blank_mid": h + r[0] + "\n\n" + r[1] + "\n" + r[2] + "\n",
+        "lines_blank_end": h + "\n".join(r) + "\n\n",
+        "lines_blank_first": h + "\n\n" + r[0] + "\n",
+        "lines_hash_mid": h + r[0] + "\n#comment line\n" + r[1] + "\n##INFO=<ID=XX,Number=1,Type=Integer,Description=\"x\">\n" + r[2] + "\n",
+        "lines_header_again": h + r[0] + "\n" + S0 + r[1] + "\n",
+        "lines_notab": h + r[0] + "\nhello world\n   \n" + r[1] + "\n",
+        "lines_short": h + "1\t50\n" + r[0] + "\n1\t95\n" + r[2] + "\n1\t70\n\n",
+    }
+
+
+def _tbi(names):
+    """a tabix index that lists these sequence names and no bins (BGZF-compressed, as tabix writes it)"""
+    import struct
+    import bamio
+    nm = b"".join(n.encode() + b"\0" for n in names)
+    body = b"TBI\1" + struct.pack("<iiiiiii", len(names), 2, 1, 2, 0, ord("#"), 0) + struct.pack("<i", len(nm)) + nm
+    for _ in names:
+        body += struct.pack("<ii", 0, 0)
+    return bamio.bgzf_member(body) + bamio.EOF_MARKER
+
+
+_TBI_VCF = HDR + S0 + "1\t100\t.\tA\tG\t30\tPASS\tDP=10\n7\t1005\t.\tC\tT\t40\tPASS\tDP=11\n8\t5\t.\tC\tT\t40\tPASS\tDP=11\n"
+
+
+def companions():
+    """{case name: {file suffix replacing / following ".vcf": bytes}}: files the test harness writes next to NAME.vcf.  A .tbi's sequence names
+    that the header does not declare join the header (vcf_hdr_read, vcf.c:1289-1309); the index is looked for as NAME.vcf.tbi, then NAME.tbi;
+    one that cannot be read is no index."""
+    return {"tbi_contigs": {".vcf.tbi": _tbi(["1", "7", "chrUn", "2"])},
+            "tbi_stem": {".tbi": _tbi(["zz", "7"])},
+            "tbi_broken": {".vcf.tbi": b"TBI\1 this is not a tabix index"}}
+
+
 def build(tmpdir):
     """{name: bytes}; tmpdir is scratch for the BCF writer"""
     import os
     out = {k: v.encode() for k, v in _text_cases().items()}
+    out.update({k: v.encode() for k, v in _line_cases().items()})
+    for k in companions():
+        out[k] = _TBI_VCF.encode()
     for seed in range(1, 9):
         out["random%d" % seed] = _random_vcf(seed).encode()
     out["floats_gz"] = gzip.compress(out["floats"], mtime=0)
