@@ -36,11 +36,11 @@ struct HostCopy {
 
 // Every lane of the wave must call this together (Coop::any / begin / end are wave-wide); `active` = false: the lane has no member and
 // only serves the others' copies.  Returns an InflateStatus; *out_len = bytes produced (all of them in memory on return, also after an error).
-template <class Tab, class Coop>
+template <class BR, class Tab, class Coop>
 RGX_HD int inflate_coop(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len, Tab &T, Coop &C, bool active,
                         bool pairs /* a literal and the symbol behind it in one trip (same for every lane of the wave) */, uint32_t *in_used = nullptr) {
-    BitReader br;
-    br.p = in; br.in = in; br.in_len = in_len; br.buf = 0; br.cnt = 0; br.next = 0;
+    BR br;                                                     // BitReader, or BitReaderWin where trips are memory-bound (inflate_core.h)
+    br.p = in; br.in = in; br.in_len = in_len; br.buf = 0; br.cnt = 0; br.idle();
     if (active) br.init(in, in_len);
     OutStage S; S.init(out, out_cap);
     uint32_t o = 0;

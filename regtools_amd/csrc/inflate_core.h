@@ -142,6 +142,48 @@ struct BitReader {
     // byte-aligned raw access for stored blocks: address of the next unconsumed byte once cnt == 0
     RGX_HD const uint8_t *byte_ptr() const { return p; }
     RGX_HD void restart_at(const uint8_t *q) { p = q; buf = 0; cnt = 0; next = ld64(p); }
+    RGX_HD void idle() { next = 0; }
+};
+
+// The same reader with a 16-byte look-ahead window in registers: one 16-byte load serves the refills of the next 8 consumed bytes, where
+// BitReader loads the 8 bytes at p again at every refill.  On payloads that compress 20x and more a trip consumes about one byte, so that is
+// 8x fewer bit-stream requests -- and the bit-stream lines (one per lane, 196 k of them) no longer sit in the L2 being touched every trip,
+// crowding out the output lines (FETCH_SIZE of the bench file's launch 32 -> 15 GB).  Costs ~12 VALU instructions per refill: pays where trips
+// are memory-bound (k_inflate_coop: -6 %), loses where they are instruction-bound (random bases and qualities: +23 %, which keep BitReader).
+struct BitReaderWin {
+    const uint8_t *p, *in;
+    uint32_t in_len;
+    uint64_t buf;
+    uint32_t cnt;
+    uint64_t w0, w1;       // the 16 bytes at p - off
+    uint32_t off;          // <= 8 between refills, so the 8 bytes at p are always inside the window
+    RGX_HD void load_window() {
+        // a corrupt stream may ask for bits that do not exist: never read more than 16 bytes past the payload
+        const uint8_t *wp = (size_t)(p - in) > (size_t)in_len ? in + in_len : p;
+        off = (uint32_t)(p - wp);
+        const u32x4 v = ld128(wp);
+        w0 = (uint64_t)v[0] | (uint64_t)v[1] << 32; w1 = (uint64_t)v[2] | (uint64_t)v[3] << 32;
+    }
+    RGX_HD void init(const uint8_t *i, uint32_t n) { in = i; in_len = n; p = i; buf = 0; cnt = 0; load_window(); }
+    RGX_HD void refill() {
+        const uint32_t sh = 8 * off;
+        const uint64_t next = (sh >= 64 ? 0 : w0 >> sh) | (sh == 0 ? 0 : w1 << ((64 - sh) & 63));      // the 8 bytes at p
+        buf |= next << cnt;
+        const uint32_t adv = (63u - cnt) >> 3;
+        p += adv; off += adv;
+        cnt |= 56u;
+        // overran() is true from here on when p left the payload, and the run ends at the next check or at out_cap
+        if ((size_t)(p - in) > (size_t)in_len + 8) { off -= (uint32_t)((size_t)(p - in) - ((size_t)in_len + 8)); p = in + in_len + 8; }
+        if (off > 8) load_window();
+    }
+    RGX_HD void ensure(uint32_t n) { if (cnt < n) refill(); }
+    RGX_HD uint32_t peek(uint32_t n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
+    RGX_HD void drop(uint32_t n) { buf >>= n; cnt -= n; }
+    RGX_HD uint32_t bits(uint32_t n) { uint32_t v = peek(n); drop(n); return v; }
+    RGX_HD bool overran() const { return (uint64_t)(p - in) * 8 > (uint64_t)in_len * 8 + cnt; }
+    RGX_HD const uint8_t *byte_ptr() const { return p; }
+    RGX_HD void restart_at(const uint8_t *q) { p = q; buf = 0; cnt = 0; load_window(); }
+    RGX_HD void idle() { w0 = 0; w1 = 0; off = 0; }
 };
 
 RGX_HD uint32_t rev15(uint32_t v) {
@@ -221,8 +263,8 @@ struct OutStage {
 
 // The tables of a fixed (btype 1) or dynamic (btype 2) block, bit reader positioned right after the 3 header bits.
 // Returns 1 = symbols follow, 0 = status says why not.
-template <class Tab>
-RGX_HD int build_block_codes(BitReader &br, Tab &T, Code &LL, Code &DD, uint32_t btype, int &status) {
+template <class BR, class Tab>
+RGX_HD int build_block_codes(BR &br, Tab &T, Code &LL, Code &DD, uint32_t btype, int &status) {
     T.clear_syms();
     if (btype == 1) {
         // fixed code (RFC 1951 3.2.6): lengths 8 x144, 9 x112, 7 x24, 8 x8; 32 distance codes of length 5 (30,31 rejected at decode)
@@ -324,8 +366,8 @@ RGX_HD int build_block_codes(BitReader &br, Tab &T, Code &LL, Code &DD, uint32_t
 // ---- block header ------------------------------------------------------------------------------------------------
 // Parses one DEFLATE block header.  Dynamic/fixed blocks: builds the two canonical codes (returns 1 = symbols follow).
 // Stored blocks: copies the raw bytes and returns 0 (= another header follows, or the stream ends if *last).
-template <class Tab>
-RGX_HD int block_header(BitReader &br, Tab &T, Code &LL, Code &DD, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t &o,
+template <class BR, class Tab>
+RGX_HD int block_header(BR &br, Tab &T, Code &LL, Code &DD, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t &o,
                         uint32_t out_cap, uint32_t &last, int &status, OutStage &S) {
     if (br.overran()) { status = INF_IN_OVERRUN; return 0; }     // a run of empty stored blocks must not walk off the input
     br.ensure(32);

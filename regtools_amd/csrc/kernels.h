@@ -24,12 +24,15 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
                     bool piece = false /* one of several concurrent launches over a range (own kernel symbol, same code) */,
                     int form = 0 /* 0 = chosen by member count / REGTOOLS_AMD_INFLATE; 1 = k_inflate, 2 = k_inflate_wave, 3 = k_inflate_ring */,
                     uint8_t *bad_flags = nullptr /* optional, zeroed by the caller: [index in the caller's range] = 1 for every member that did not inflate */,
-                    int plan = 1 /* inflate_plan_for: bit 0 = k_inflate_coop takes a literal and the symbol behind it in one trip, bit 1 = the lane form is k_inflate */);
-// Which lane form suits a payload, from how well the file compresses (measured on 50 M-read files, all three byte-equal to zlib):
-//   inflated / compressed > 32  (long reads: run-length copies)       k_inflate_coop, one symbol per trip   126.7 ms against k_inflate's 135.6
-//   8 .. 32                     (the bench payload: 21)                k_inflate_coop, literal pairs          16.0 against 20.0
-//   < 8                         (random bases + binned qualities: 3.6) k_inflate                              49.2 against 51-52: few matches are
-//                               long enough for the wave to move, and the cooperative rounds' bookkeeping is paid by every trip
+                    int plan = 1 /* inflate_plan_for */);
+// Which lane form suits a payload, from how well the file compresses (measured on 50 M-read files, all byte-equal to zlib):
+//   inflated / compressed > 32  (long reads: run-length copies)        k_inflate_coop: one symbol per trip, plain bit reader, lanes in file order
+//                                                                      126.7 ms against k_inflate's 135.6 (windowed reader + sorted lanes: 141)
+//   8 .. 32                     (the bench payload: 21)                 k_inflate_coop: literal pairs, windowed bit reader, lanes sorted by
+//                                                                      compressed length per 1024 members: 14.1 ms against 20.0
+//   < 8                         (random bases + binned qualities: 3.6)  k_inflate: 49.2 against 51-52 -- few matches are long enough for the wave
+//                                                                      to move, and the cooperative rounds' bookkeeping is paid by every trip
+// bit 0 = the middle class's options, bit 1 = the lane form is k_inflate.
 inline int inflate_plan_for(uint64_t compressed_bytes, uint64_t inflated_bytes) {
     return (compressed_bytes * 32 > inflated_bytes ? 1 : 0) | (compressed_bytes * 8 > inflated_bytes ? 2 : 0);
 }

@@ -5,6 +5,7 @@
 #include "kernels.h"
 
 #include <mutex>
+#include <type_traits>
 
 #include "bam_core.h"
 #include "inflate_core.h"
@@ -293,19 +294,50 @@ struct WaveCopy {                     // (kCoopRounds = 4 rounds in flight: d0..
     __device__ __forceinline__ void end() { stores(); }
 };
 
+// Lane assignment: per group of kSortGroup consecutive members, their indices sorted by compressed length (bitonic sort in LDS, one
+// workgroup per group).  A group spans at most kSortGroup x 64 KiB = 64 MiB of the arena: offsets relative to its first member fit 32 bits.
+constexpr uint32_t kSortGroup = 1024;
+__global__ __launch_bounds__(256) void k_member_sort(const Member *__restrict__ members, uint32_t n_members, uint32_t *perm) {
+    __shared__ uint32_t key[kSortGroup];
+    const uint32_t g0 = blockIdx.x * kSortGroup;
+    for (uint32_t t = threadIdx.x; t < kSortGroup; t += 256) {
+        const uint32_t i = g0 + t;
+        key[t] = i < n_members ? (min(members[i].clen, 0x1fffffu) << 10 | t) : 0xffffffffu;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= kSortGroup; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < kSortGroup; t += 256) {
+                const uint32_t x = t ^ j;
+                if (x > t) {
+                    const uint32_t a = key[t], b = key[x];
+                    const bool up = (t & k) == 0;
+                    if ((a > b) == up) { key[t] = b; key[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t t = threadIdx.x; t < kSortGroup; t += 256) if (g0 + t < n_members) perm[g0 + t] = g0 + (key[t] & 1023u);
+}
+
 // one lane per member like k_inflate; no lane leaves before the wave is done (the lanes without a member serve the others' copies)
-template <bool PROBE, bool PIECE = false>
+template <bool PROBE, bool PIECE = false, bool WIN = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_inflate_coop(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
                                                 uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
-                                                uint32_t *status, uint32_t ignore_below, uint32_t index_bias, uint8_t *bad, uint32_t pairs) {
+                                                uint32_t *status, uint32_t ignore_below, uint32_t index_bias, uint8_t *bad, uint32_t pairs,
+                                                const uint32_t *__restrict__ perm) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
-    const uint32_t m = blockIdx.x * 64 + lane;
-    const bool have = m < n_members;
-    const Member mb = members[have ? m : n_members - 1];
-    LdsTab T{lds + lane, len_scratch + (have ? m : 0), gridDim.x * 64};
-    // the wave's lowest output address: lane 0's member (upos grows with the member index; PROBE: slot m)
-    const uint64_t base_off = PROBE ? (uint64_t)(blockIdx.x * 64) * kBgzfMaxBlock : members[blockIdx.x * 64].upos - upos_bias;
+    const uint32_t slot = blockIdx.x * 64 + lane;
+    const bool have = slot < n_members;
+    // which member this lane decodes: the members of a group of kSortGroup come sorted by compressed length (k_member_sort), so that the 64
+    // lanes of a wave need about the same number of trips (a wave runs as long as its longest lane: 93.5 -> 98.6 % of the lanes busy)
+    const uint32_t m = have ? (perm ? perm[slot] : slot) : n_members - 1;
+    const Member mb = members[m];
+    LdsTab T{lds + lane, len_scratch + (have ? slot : 0), gridDim.x * 64};
+    // the lowest output address the wave's lanes can have: the first member of the wave's group (upos grows with the member index; PROBE: slot m)
+    const uint32_t first = perm ? (blockIdx.x * 64 / kSortGroup) * kSortGroup : blockIdx.x * 64;
+    const uint64_t base_off = PROBE ? (uint64_t)first * kBgzfMaxBlock : members[first].upos - upos_bias;
     WaveCopy C;
     C.wave_base = arena + base_off; C.lane = lane;
     C.d0 = C.d1 = C.d2 = C.d3 = u32x4{0, 0, 0, 0};
@@ -313,27 +345,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     uint32_t out_len = 0;
     if (PROBE) {
         const bool run = have && mb.isize != 0xffffffffu;         // ~0: BSIZE runs past the end of the file (or is < 26): the read fails upstream
-        const int st = inflate_coop(comp + mb.cpos, mb.clen, arena + (uint64_t)(have ? m : 0) * kBgzfMaxBlock, kBgzfMaxBlock, &out_len, T, C, run, pairs != 0);
+        const int st = inflate_coop<BitReader>(comp + mb.cpos, mb.clen, arena + (uint64_t)(have ? m : first) * kBgzfMaxBlock, kBgzfMaxBlock, &out_len, T, C, run, pairs != 0);
         if (have) status[m] = run && st == INF_OK ? out_len : 0xffffffffu;
         return;
     }
     // a member whose claimed size is no BGZF block size owns no bytes of the arena (k_member_compact): it must not write any, whatever
     // range the host asked for.  ~0 = the member runs past the end of the file (k_member_link).
     const bool run = have && mb.isize <= kBgzfMaxBlock;
-    int st = inflate_coop(comp + mb.cpos, mb.clen, run ? arena + (mb.upos - upos_bias) : C.wave_base, run ? mb.isize : 0, &out_len, T, C, run, pairs != 0);
+    typedef typename std::conditional<WIN, BitReaderWin, BitReader>::type BR;
+    int st = inflate_coop<BR>(comp + mb.cpos, mb.clen, run ? arena + (mb.upos - upos_bias) : C.wave_base, run ? mb.isize : 0, &out_len, T, C, run, pairs != 0);
     if (!have) return;
     if (!run) st = mb.isize == 0xffffffffu ? INF_IN_OVERRUN : INF_OUT_OVERFLOW;
     else if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
     if (st != INF_OK) {
         const uint32_t mi = m + index_bias;
         if (bad) bad[mi] = 1;
-        uint32_t *slot = mi >= ignore_below ? status : status + kStatusEarly;
-        uint32_t prev = atomicMin(&slot[0], mi);
-        if (mi < prev) slot[1] = (uint32_t)st;
+        uint32_t *sl = mi >= ignore_below ? status : status + kStatusEarly;
+        uint32_t prev = atomicMin(&sl[0], mi);
+        if (mi < prev) sl[1] = (uint32_t)st;
     }
 }
 
-size_t inflate_scratch_bytes(uint32_t n_members) { return (size_t)((n_members + 63) / 64) * 64 * kScratchWordsPerLane * 4; }
+// (the code-length / cold-symbol scratch of every lane, + the lane assignment of k_inflate_coop behind it)
+static size_t inflate_scratch_words(uint32_t n_members) { return (size_t)((n_members + 63) / 64) * 64 * kScratchWordsPerLane; }
+size_t inflate_scratch_bytes(uint32_t n_members) { return (inflate_scratch_words(n_members) + ((size_t)n_members + 63) / 64 * 64 + kSortGroup) * 4; }
 
 // ---- the small-input form: one member per wave, the whole member in LDS (inflate_wave.h) ------------------------------------------------
 struct DevWave {
@@ -401,8 +436,10 @@ static void inflate_attrs() {
     (void)hipFuncSetAttribute((const void *)k_inflate<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
-    (void)hipFuncSetAttribute((const void *)k_inflate_coop<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
-    (void)hipFuncSetAttribute((const void *)k_inflate_coop<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+    (void)hipFuncSetAttribute((const void *)k_inflate_coop<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+    (void)hipFuncSetAttribute((const void *)k_inflate_coop<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+    (void)hipFuncSetAttribute((const void *)k_inflate_coop<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+    (void)hipFuncSetAttribute((const void *)k_inflate_coop<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WaveShared));
     (void)hipFuncSetAttribute((const void *)k_inflate_ring<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRingLdsBytes);
@@ -425,10 +462,19 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
     case 3:
         hipLaunchKernelGGL(k_inflate_ring<false>, dim3(blocks), dim3(64), kRingLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad);
         break;
-    case 4:
-        if (piece) hipLaunchKernelGGL((k_inflate_coop<false, true>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad, two);
-        else hipLaunchKernelGGL((k_inflate_coop<false, false>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad, two);
+    case 4: {
+        // plan bit 0 set = the payload class of the bench file (8 .. 32 x): lanes sorted by compressed length and the windowed bit reader
+        // (14.1 ms against 16.0); long reads (> 32 x) lose with both (141 against 127 ms) and keep file order and the plain reader
+        static const int env_tune = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE_TUNE"); return e ? atoi(e) : -1; }();      // (lab) bit 0 sort, bit 1 window
+        const bool sort = env_tune >= 0 ? (env_tune & 1) != 0 : (plan & 1) != 0, win = env_tune >= 0 ? (env_tune & 2) != 0 : (plan & 1) != 0;
+        uint32_t *perm = sort ? len_scratch + inflate_scratch_words(n_members) : nullptr;
+        if (perm) hipLaunchKernelGGL(k_member_sort, dim3((n_members + kSortGroup - 1) / kSortGroup), dim3(256), 0, stream, members, n_members, perm);
+#define RGX_COOP(PIECE_, WIN_) hipLaunchKernelGGL((k_inflate_coop<false, PIECE_, WIN_>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad, two, perm)
+        if (piece) { if (win) RGX_COOP(true, true); else RGX_COOP(true, false); }
+        else { if (win) RGX_COOP(false, true); else RGX_COOP(false, false); }
+#undef RGX_COOP
         break;
+    }
     default:
         if (piece) hipLaunchKernelGGL((k_inflate<false, true>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad);
         else hipLaunchKernelGGL((k_inflate<false, false>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad);
@@ -441,7 +487,7 @@ void launch_inflate_probe(const uint8_t *comp, const Member *members, uint32_t n
     const int form = inflate_form_env() ? inflate_form_env() : kDefaultLaneForm;
     const uint32_t blocks = (n_members + 63) / 64;
     if (form == 3) hipLaunchKernelGGL(k_inflate_ring<true>, dim3(blocks), dim3(64), kRingLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr);
-    else if (form == 4) hipLaunchKernelGGL(k_inflate_coop<true>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr, 1u);
+    else if (form == 4) hipLaunchKernelGGL(k_inflate_coop<true>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr, 1u, (const uint32_t *)nullptr);
     else hipLaunchKernelGGL(k_inflate<true>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr);
 }
 

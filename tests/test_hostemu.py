@@ -45,7 +45,7 @@ def inflate(emu, payload, cap=65536):
     if st == 0:
         assert out3.raw[:n3.value] == got, "wave decoder differs"
     # ... and round 3's decoder (inflate_coop.h): long matches split into head / wave-copied aligned body / tail
-    for pairs in (0, 1):                               # with and without the second symbol of a trip
+    for pairs in (0, 1, 2, 3):                         # with and without the second symbol of a trip (bit 0), plain / windowed bit reader (bit 1)
         out4 = ctypes.create_string_buffer(cap + 64)
         n4 = ctypes.c_uint32(0)
         st4 = emu.emu_inflate_coop(buf, len(payload), out4, cap, ctypes.byref(n4), _phase[0], pairs)
@@ -227,7 +227,7 @@ def test_coop_decoder_every_destination_phase_and_copy_split(emu):
             for phase in list(range(16)) + [31, 100, 127]:
                 out = ctypes.create_string_buffer(len(data) + 64)
                 n = ctypes.c_uint32(0)
-                st = emu.emu_inflate_coop(p, len(p), out, len(data), ctypes.byref(n), phase, phase & 1)
+                st = emu.emu_inflate_coop(p, len(p), out, len(data), ctypes.byref(n), phase, phase & 3)
                 assert st == 0 and out.raw[:n.value] == data, (dist, total, phase, st)
 
 
