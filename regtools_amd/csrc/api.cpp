@@ -24,6 +24,7 @@
 
 #include "cse_host.h"
 #include "host_io.h"
+#include <sys/stat.h>
 #include "kernels.h"
 
 using namespace rgx;
@@ -93,8 +94,26 @@ struct rgx_ctx {
     std::vector<uint32_t> rank_stage;                  // host copy of a group-rank table while its upload is in flight
     std::string fasta_path;                            // FASTA currently resident in the "fasta" buffer
     rgx::Fasta *fasta = nullptr;
+    // The genome the output stages look splice sites up in (host_fasta below): its mapping stays with the context from call to call
+    rgx::Fasta *host_fasta = nullptr; std::string host_fasta_path; uint64_t host_fasta_key[4] = {0, 0, 0, 0};
     DevBuf &buf(const char *name) { return bufs[name]; }
 };
+
+// The FASTA at `path`, mapped (cse_host.h).  A context keeps the last one: what a call's 10^5 two-base lookups cost is mostly page-table work --
+// faulting the pages in (sixteen per fault) and, dearer, taking two million entries down again when the mapping goes (11 ms of config 4's
+// `identify`) -- and a caller that runs one sample after the other against the same genome pays both once.  The file is recognised by device,
+// inode, size and modification time; anything else is a new file.  nullptr = it cannot be opened.
+static rgx::Fasta *host_fasta(rgx_ctx *c, const char *path) {
+    struct stat st;
+    if (!path || stat(path, &st) != 0) return nullptr;
+    const uint64_t key[4] = {(uint64_t)st.st_dev, (uint64_t)st.st_ino, (uint64_t)st.st_size, (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec};
+    if (c->host_fasta && c->host_fasta_path == path && !memcmp(key, c->host_fasta_key, sizeof key)) return c->host_fasta;
+    delete c->host_fasta; c->host_fasta = nullptr;
+    rgx::Fasta *f = new rgx::Fasta();
+    if (!f->load(path)) { delete f; return nullptr; }
+    c->host_fasta = f; c->host_fasta_path = path; memcpy(c->host_fasta_key, key, sizeof key);
+    return f;
+}
 
 static void ktime_begin(rgx_ctx *c, int slot) {
     hipEvent_t e[2];
@@ -174,6 +193,7 @@ extern "C" void rgx_ctx_destroy(rgx_ctx *c) {
     for (auto &q : c->side) if (q) (void)hipStreamDestroy(q);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c->fasta;
+    delete c->host_fasta;
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned_rows) (void)hipHostFree(c->pinned_rows);
     if (c->pinned_members) (void)hipHostFree(c->pinned_members);

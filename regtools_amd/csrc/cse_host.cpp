@@ -1,5 +1,6 @@
 // cse_host.cpp -- see cse_host.h.  Citations relative to /root/reference/src.
 #include "cse_host.h"
+#include "worker_pool.h"
 
 #include <chrono>
 #include <functional>
@@ -127,10 +128,13 @@ std::string GtfModel::load(const std::string &path) {
     struct SvHash { size_t operator()(const View &k) const { uint64_t h = 1469598103934665603ull; for (size_t i = 0; i < k.second; ++i) h = (h ^ (uint8_t)k.first[i]) * 1099511628211ull; return (size_t)h; } };
     struct SvEq { bool operator()(const View &a, const View &b) const { return a.second == b.second && !memcmp(a.first, b.first, a.second); } };
     // ---- pass 1 (threads): every line -> at most one exon record, filed under the part's own transcript list (first appearance order) ------
-    struct LocalTx { View id, attrs, chrom; uint64_t hash; uint8_t strand; uint32_t n; uint32_t global; uint32_t fill; };
-    struct Part { std::vector<LocalTx> tx; std::vector<uint32_t> r_tx, r_s, r_e; size_t err_pos = SIZE_MAX; const char *err = nullptr; };
-    const unsigned hw = usable_threads(32);
-    const size_t n_parts = text_len < (1u << 22) ? 1 : hw;
+    struct LocalTx { View id, attrs, chrom; uint64_t hash; uint8_t strand; uint32_t n; uint32_t global; uint32_t fill; int32_t fill_chrom; };
+    struct Part { BigVec<LocalTx> tx; std::vector<View> chroms; BigVec<uint32_t> r_tx, r_s, r_e; size_t err_pos = SIZE_MAX; const char *err = nullptr; };
+    static const unsigned thread_cap = [] { const char *e = getenv("REGTOOLS_AMD_GTF_THREADS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 256 ? (unsigned)v : 32u; }();   // (lab)
+    const unsigned hw = usable_threads(thread_cap);
+    // (four parts per thread, handed out as threads come free: on a host whose CPU quota is shared with the rest of the call, equal parts do not take equal time)
+    size_t n_parts = text_len < (1u << 22) ? 1 : std::min<size_t>((size_t)hw * 4, text_len >> 20);
+    if (const char *e = getenv("REGTOOLS_AMD_GTF_PARTS")) { const long v = atol(e); if (v >= 1 && v <= 256) n_parts = (size_t)v; }   // (tests: the threaded path on small files)
     std::vector<size_t> cut(n_parts + 1, text_len);
     cut[0] = 0;
     for (size_t k = 1; k < n_parts; ++k) {                                   // cut points just after a newline
@@ -139,10 +143,14 @@ std::string GtfModel::load(const std::string &path) {
         cut[k] = nl ? (size_t)(nl - text) + 1 : text_len;
     }
     std::vector<Part> parts(n_parts);
+    std::vector<double> scan_ms(n_parts, 0);
     auto scan = [&](size_t k) {
         Part &P = parts[k];
+        const double t_scan = trace ? now() : 0;
+        struct Stamp { std::vector<double> &v; size_t k; double t0; bool on; std::function<double()> clk; ~Stamp() { if (on) v[k] = clk() - t0; } } stamp{scan_ms, k, t_scan, trace, now};
         std::unordered_map<View, uint32_t, SvHash, SvEq> by_id;
         const char *last_tv = nullptr; size_t last_tl = 0; uint32_t last_k = 0;  // exon lines of a transcript are usually adjacent
+        const char *last_attrs = nullptr; size_t last_plen = 0;
         size_t pos = cut[k];
         const size_t lim = cut[k + 1];
         P.r_tx.reserve((lim - pos) / 96 + 16); P.r_s.reserve((lim - pos) / 96 + 16); P.r_e.reserve((lim - pos) / 96 + 16);
@@ -156,121 +164,177 @@ std::string GtfModel::load(const std::string &path) {
             if (line[0] == '#') continue;
             // Tokenize on tabs (std::getline semantics: no empty field after a trailing tab); exactly 9 fields or the run dies
             const char *fb[10]; size_t fl[10]; size_t nf = 0;
-            for (size_t i = 0;;) {
-                const char *t = (const char *)memchr(line + i, '\t', ll - i);
-                const size_t j = t ? (size_t)(t - line) : ll;
-                if (nf < 10) { fb[nf] = line + i; fl[nf] = j - i; }
-                ++nf;
-                if (j >= ll) break;
-                i = j + 1;
-                if (i >= ll) break;
+            {
+                // (the first eight fields are a few bytes each: a byte loop; the attribute column is one memchr for a tab that should not be there)
+                size_t i = 0, f0 = 0;
+                for (; i < ll && nf < 8; ++i) if (line[i] == '\t') { fb[nf] = line + f0; fl[nf] = i - f0; ++nf; f0 = i + 1; }
+                if (nf == 8 && f0 < ll) {
+                    const char *t = (const char *)memchr(line + f0, '\t', ll - f0);
+                    if (!t) { fb[8] = line + f0; fl[8] = ll - f0; nf = 9; }
+                    else {                                                          // a tenth field (or a trailing tab, which getline does not count)
+                        nf = 9; fb[8] = line + f0; fl[8] = (size_t)(t - line) - f0;
+                        if ((size_t)(t - line) + 1 < ll) nf = 10;
+                    }
+                } else if (nf < 8) { if (f0 < ll || nf == 0) ++nf; }              // the last field of a short line (none after a trailing tab)
             }
             if (nf != 9) { P.err_pos = line_pos; P.err = "Expected 9 fields in GTF line."; return; }   // gtf_parser.cc:67-70
             if (!(fl[2] == 4 && !memcmp(fb[2], "exon", 4))) continue;
             const char *tv; size_t tl;
-            if (!gtf_attr_view(fb[8], fl[8], "transcript_id", 13, tv, tl) || (tl == 2 && !memcmp(tv, "NA", 2))) continue;   // gtf_parser.cc:118
             uint32_t t;
+            // exon lines of a transcript are usually adjacent and start their attribute column with the same bytes: when this line's column
+            // repeats the last one's up to and including the delimiter that ended the transcript_id value there, the search below would walk
+            // the same bytes to the same answer
+            if (last_plen && fl[8] >= last_plen && !memcmp(fb[8], last_attrs, last_plen)) { tv = last_tv; tl = last_tl; t = last_k; }
+            else {
+            if (!gtf_attr_view(fb[8], fl[8], "transcript_id", 13, tv, tl) || (tl == 2 && !memcmp(tv, "NA", 2))) continue;   // gtf_parser.cc:118
+            {   // where the value's token ended: behind an optional closing quote; the byte there (a blank or the ';') is part of the prefix
+                const char *tok_end = tv + tl;
+                if (tok_end < fb[8] + fl[8] && *tok_end == '"' && tv > fb[8] && tv[-1] == '"') ++tok_end;
+                last_attrs = fb[8];
+                last_plen = tok_end < fb[8] + fl[8] && (*tok_end == ' ' || *tok_end == ';') ? (size_t)(tok_end - fb[8]) + 1 : 0;
+            }
             if (last_tv && tl == last_tl && !memcmp(tv, last_tv, tl)) t = last_k;
             else if (auto it = by_id.find(View(tv, tl)); it != by_id.end()) t = it->second;
             else {
                 t = (uint32_t)P.tx.size(); by_id.emplace(View(tv, tl), t);
-                P.tx.push_back(LocalTx{View(tv, tl), View(fb[8], fl[8]), View(fb[0], fl[0]), (uint64_t)SvHash()(View(tv, tl)), fl[6] == 1 ? (uint8_t)fb[6][0] : (uint8_t)'?', 0, 0, 0});   // first exon line seen wins (gtf_parser.cc:266-273)
+                int32_t lc = -1;                                                         // the part's own contig list (the text is at hand here, not in the merge)
+                for (size_t q = P.chroms.size(); q-- > 0;) if (P.chroms[q].second == fl[0] && !memcmp(P.chroms[q].first, fb[0], fl[0])) { lc = (int32_t)q; break; }
+                if (lc < 0) { lc = (int32_t)P.chroms.size(); P.chroms.push_back(View(fb[0], fl[0])); }
+                P.tx.push_back(LocalTx{View(tv, tl), View(fb[8], fl[8]), View(fb[0], fl[0]), 0 /* set by the merge: this entry opened its transcript */, fl[6] == 1 ? (uint8_t)fb[6][0] : (uint8_t)'?', 0, 0, 0, lc});   // first exon line seen wins (gtf_parser.cc:266-273)
+            }
             }
             last_tv = tv; last_tl = tl; last_k = t;
             ++P.tx[t].n;
             P.r_tx.push_back(t); P.r_s.push_back((uint32_t)field_atol(fb[3], fl[3])); P.r_e.push_back((uint32_t)field_atol(fb[4], fl[4]));
         }
     };
-    auto run_parallel = [&](size_t n, const std::function<void(size_t)> &f) {
-        if (n <= 1) { for (size_t k = 0; k < n; ++k) f(k); return; }
-        std::vector<std::thread> th;
-        for (size_t k = 1; k < n; ++k) th.emplace_back(f, k);
-        f(0);
-        for (auto &t : th) t.join();
-    };
+    WorkerPool pool(n_parts > 1 ? hw : 1);
+    auto run_parallel = [&](size_t n, const std::function<void(size_t)> &f) { pool.run(n, f); };
     run_parallel(n_parts, scan);
+    if (trace) { double lo = 1e9, hi = 0, sum = 0; for (double v : scan_ms) { lo = std::min(lo, v); hi = std::max(hi, v); sum += v; } fprintf(stderr, "[rgx trace] gtf: scan threads: %zu parts, min %.3f avg %.3f max %.3f ms\n", n_parts, lo, sum / (double)n_parts, hi); }
     lap("scan (threads)");
     // the first bad line in file order ends the run, as upstream
     for (size_t k = 0; k < n_parts; ++k) if (parts[k].err) return parts[k].err;
-    // ---- merge (serial, file order, one step per (part, transcript) instead of one per exon line): global transcript numbers in first-appearance
-    //      order, the contig table in the order transcripts first name a contig, and where each part's exons of a transcript go ----------------
-    struct Tmp { View id, attrs; int32_t chrom; uint8_t strand; uint32_t n = 0; };
-    std::vector<Tmp> tmp;
+    // ---- merge: every part's transcript list, sorted together by id (threads; equal ids keep file order = part order).  A run of equal ids is one
+    //      transcript, its first member the first exon line the file has for it (whose attributes and strand win, gtf_parser.cc:266-273), its
+    //      position among the runs the transcript's place in std::map<string,Transcript> order (ids compared as unsigned bytes, like std::string):
+    //      the global transcript number IS that rank, so exons are filed straight into the final order ------------------------------------------
+    // (the id's first sixteen bytes travel with the entry, big-endian: the sort and the grouping below rarely leave this array)
+    struct Ref { uint64_t p0, p1; const char *id; uint32_t len, part, idx; };
+    BigVec<Ref> refs;
     {
-        // an open-addressing table over the hashes the scan threads computed: the serial part is one probe per (part, transcript)
-        size_t total_local = 0;
-        for (const Part &P : parts) total_local += P.tx.size();
-        size_t cap = 1024;
-        while (cap < total_local * 2) cap <<= 1;
-        std::vector<uint32_t> slot(cap, 0);                                        // 0 = empty, else global number + 1
-        std::vector<uint64_t> slot_hash(cap, 0);                                   // (full hashes side by side: a probe only touches the text on a real match)
-        tmp.reserve(total_local);
-        View last_chrom(nullptr, 0); int32_t last_chrom_idx = -1;                  // transcripts come contig by contig
-        for (Part &P : parts)
-            for (LocalTx &l : P.tx) {
-                size_t h = (size_t)(l.hash * 0x9e3779b97f4a7c15ull >> 20) & (cap - 1);
-                uint32_t t;
-                for (;; h = (h + 1) & (cap - 1)) {
-                    if (!slot[h]) {
-                        t = (uint32_t)tmp.size(); slot[h] = t + 1; slot_hash[h] = l.hash;
-                        if (!(last_chrom.first && last_chrom.second == l.chrom.second && !memcmp(last_chrom.first, l.chrom.first, l.chrom.second))) {
-                            std::string cn(l.chrom.first, l.chrom.second);
-                            auto ci = chrom_index.find(cn);
-                            if (ci == chrom_index.end()) { ci = chrom_index.emplace(cn, (int32_t)chroms.size()).first; chroms.push_back(cn); }
-                            last_chrom = l.chrom; last_chrom_idx = ci->second;
-                        }
-                        Tmp x; x.id = l.id; x.attrs = l.attrs; x.chrom = last_chrom_idx; x.strand = l.strand;
-                        tmp.push_back(x);
-                        break;
-                    }
-                    if (slot_hash[h] != l.hash) continue;
-                    const Tmp &c = tmp[slot[h] - 1];
-                    if (c.id.second == l.id.second && !memcmp(c.id.first, l.id.first, l.id.second)) { t = slot[h] - 1; break; }
-                }
-                l.global = t; l.fill = tmp[t].n;                                 // this part's exons follow those of the parts before it
-                tmp[t].n += l.n;
+        std::vector<size_t> base(n_parts + 1, 0);
+        for (size_t k = 0; k < n_parts; ++k) base[k + 1] = base[k] + parts[k].tx.size();
+        refs.resize(base[n_parts]);
+        run_parallel(n_parts, [&](size_t k) {
+            for (size_t i = 0; i < parts[k].tx.size(); ++i) {
+                const View &v = parts[k].tx[i].id;
+                uint8_t pre[16] = {0};
+                memcpy(pre, v.first, std::min<size_t>(16, v.second));
+                uint64_t p0, p1; memcpy(&p0, pre, 8); memcpy(&p1, pre + 8, 8);
+                refs[base[k] + i] = Ref{__builtin_bswap64(p0), __builtin_bswap64(p1), v.first, (uint32_t)v.second, (uint32_t)k, (uint32_t)i};
             }
+        });
     }
+    // ids as unsigned bytes, a proper prefix first (std::string's order); equal ids in part order.  The zero padding of a short id's key can only
+    // tie with real NUL bytes of a longer one, and then the lengths decide the same way the bytes would.
+    auto id_cmp = [](const Ref &a, const Ref &b) -> int {
+        if (a.p0 != b.p0) return a.p0 < b.p0 ? -1 : 1;
+        if (a.p1 != b.p1) return a.p1 < b.p1 ? -1 : 1;
+        if (a.len > 16 && b.len > 16) { const int c = memcmp(a.id + 16, b.id + 16, std::min(a.len, b.len) - 16); if (c) return c; }
+        return a.len < b.len ? -1 : a.len > b.len ? 1 : 0;
+    };
+    auto ref_less = [&](const Ref &a, const Ref &b) { const int c = id_cmp(a, b); return c ? c < 0 : a.part < b.part; };   // (one entry per part and id)
+    const size_t n_refs = refs.size();
+    {
+        const size_t n = n_refs;
+        const size_t runs = n < (1u << 15) ? 1 : std::min<size_t>(hw, 16);
+        run_parallel(runs, [&](size_t r) { std::sort(refs.begin() + (long)(n * r / runs), refs.begin() + (long)(n * (r + 1) / runs), ref_less); });
+        for (size_t w = 1; w < runs; w *= 2) {
+            std::vector<size_t> starts;
+            for (size_t r = 0; r + w < runs; r += 2 * w) starts.push_back(r);
+            run_parallel(starts.size(), [&](size_t q) {
+                const size_t r = starts[q];
+                std::inplace_merge(refs.begin() + (long)(n * r / runs), refs.begin() + (long)(n * (r + w) / runs), refs.begin() + (long)(n * std::min(runs, r + 2 * w) / runs), ref_less);
+            });
+        }
+    }
+    lap("sort ids (threads)");
+    struct Tmp { View id, attrs; int32_t chrom; uint8_t strand; uint32_t n, first_part, first_idx; };
+    // rank[i] = the transcript entry i belongs to (one pass over the sorted ids), then every thread fills the transcripts that open in its range
+    BigVec<uint32_t> rank(n_refs);
+    {
+        const size_t fp = n_refs < (1u << 12) ? 1 : hw;
+        run_parallel(fp, [&](size_t b) { for (size_t i = n_refs * b / fp; i < n_refs * (b + 1) / fp; ++i) rank[i] = i && id_cmp(refs[i], refs[i - 1]) != 0; });
+        uint32_t r = 0;
+        for (size_t i = 0; i < n_refs; ++i) { r += rank[i]; rank[i] = r; }
+    }
+    lap("ranks");
+    BigVec<Tmp> tmp(n_refs ? (size_t)rank[n_refs - 1] + 1 : 0);               // in final (id) order
+    const size_t merge_parts = n_refs < (1u << 12) ? 1 : hw;
+    run_parallel(merge_parts, [&](size_t b) {
+        size_t i = n_refs * b / merge_parts;
+        const size_t lim = n_refs * (b + 1) / merge_parts;
+        while (i < lim && i && rank[i] == rank[i - 1]) ++i;                        // (a transcript that opened in the range before this one)
+        while (i < lim) {
+            LocalTx &f = parts[refs[i].part].tx[refs[i].idx];
+            Tmp &x = tmp[rank[i]];
+            x.id = f.id; x.attrs = f.attrs; x.chrom = -1; x.strand = f.strand; x.n = 0; x.first_part = refs[i].part; x.first_idx = refs[i].idx;
+            f.hash = 1;                                                            // (the hash slot now says: this entry opened its transcript)
+            size_t j = i;
+            for (; j < n_refs && rank[j] == rank[i]; ++j) {
+                LocalTx &l = parts[refs[j].part].tx[refs[j].idx];
+                if (j != i) l.hash = 0;
+                l.global = rank[i]; l.fill = x.n;                                  // this part's exons follow those of the parts before it
+                x.n += l.n;
+            }
+            i = j;
+        }
+    });
+    lap("group (threads)");
+    // the contig table, in the order in which the file's transcripts first name a contig (file order = part order, then list order)
+    {
+        for (Part &P : parts) {
+            std::vector<int32_t> global(P.chroms.size(), -2);                      // -2: no transcript of this part that opens here has named it yet
+            for (LocalTx &l : P.tx) {
+                if (!l.hash) continue;
+                int32_t &gi = global[(size_t)l.fill_chrom];
+                if (gi == -2) {
+                    std::string cn(P.chroms[(size_t)l.fill_chrom].first, P.chroms[(size_t)l.fill_chrom].second);
+                    auto ci = chrom_index.find(cn);
+                    if (ci == chrom_index.end()) { ci = chrom_index.emplace(cn, (int32_t)chroms.size()).first; chroms.push_back(cn); }
+                    gi = ci->second;
+                }
+                l.fill_chrom = gi;
+            }
+        }
+    }
+    run_parallel(merge_parts, [&](size_t b) {
+        for (size_t t = tmp.size() * b / merge_parts; t < tmp.size() * (b + 1) / merge_parts; ++t) tmp[t].chrom = parts[tmp[t].first_part].tx[tmp[t].first_idx].fill_chrom;
+    });
     lap("merge");
     const size_t n_tx = tmp.size();
-    std::vector<uint32_t> goff(n_tx + 1, 0);
+    BigVec<uint32_t> goff(n_tx + 1, 0);
     for (size_t k = 0; k < n_tx; ++k) goff[k + 1] = goff[k] + tmp[k].n;
     // exons grouped by transcript, file order kept inside a group: every part files its own lines (threads)
-    std::vector<uint32_t> gs(goff[n_tx]), ge(goff[n_tx]);
+    BigVec<uint32_t> gs(goff[n_tx]), ge(goff[n_tx]);
+    lap("allocate exon lists");
     run_parallel(n_parts, [&](size_t k) {
         Part &P = parts[k];
         for (LocalTx &l : P.tx) l.fill += goff[l.global];
         for (size_t i = 0; i < P.r_tx.size(); ++i) { const uint32_t q = P.tx[P.r_tx[i]].fill++; gs[q] = P.r_s[i]; ge[q] = P.r_e[i]; }
     });
     lap("file exons (threads)");
-    // std::map<string,Transcript> order: ascending id (bytes compared as unsigned chars, like std::string); sorted in runs by threads, merged
-    std::vector<uint32_t> order(n_tx);
+    BigVec<uint32_t> order(n_tx);
     std::iota(order.begin(), order.end(), 0u);
-    auto id_less = [&](uint32_t a, uint32_t b) {
-        const View &x = tmp[a].id, &y = tmp[b].id;
-        const int c = memcmp(x.first, y.first, std::min(x.second, y.second));
-        return c < 0 || (c == 0 && x.second < y.second);
-    };
-    {
-        const size_t runs = n_tx < (1u << 15) ? 1 : std::min<size_t>(hw, 16);
-        run_parallel(runs, [&](size_t r) { std::sort(order.begin() + (long)(n_tx * r / runs), order.begin() + (long)(n_tx * (r + 1) / runs), id_less); });
-        for (size_t w = 1; w < runs; w *= 2) {
-            std::vector<size_t> starts;
-            for (size_t r = 0; r + w < runs; r += 2 * w) starts.push_back(r);
-            run_parallel(starts.size(), [&](size_t q) {
-                const size_t r = starts[q];
-                std::inplace_merge(order.begin() + (long)(n_tx * r / runs), order.begin() + (long)(n_tx * (r + w) / runs), order.begin() + (long)(n_tx * std::min(runs, r + 2 * w) / runs), id_less);
-            });
-        }
-    }
-    lap("sort ids");
     for (uint32_t k : order) if (tmp[k].strand != '+' && tmp[k].strand != '-') return "Undefined strand for exon ";   // gtf_parser.cc:193-197 exit(1): the first in map order
     // the transcript tables, in that order (threads over ranges of it)
     tx_id.resize(n_tx); tx_gene_name.resize(n_tx); tx_gene_id.resize(n_tx); tx_chrom.resize(n_tx); tx_strand.resize(n_tx);
     tx_exon_off.resize(n_tx); tx_n_exons.resize(n_tx); tx_bin.resize(n_tx);
     es.resize(goff[n_tx]); ee.resize(goff[n_tx]);
     { uint32_t o = 0; for (size_t i = 0; i < n_tx; ++i) { tx_exon_off[i] = o; o += tmp[order[i]].n; } }
-    const size_t build_parts = n_tx < (1u << 12) ? 1 : hw;
+    lap("allocate tables");
+    const size_t build_parts = n_tx < (1u << 12) ? 1 : (size_t)hw * 4;
     run_parallel(build_parts, [&](size_t b) {
         std::vector<uint32_t> idx;
         for (size_t i = n_tx * b / build_parts; i < n_tx * (b + 1) / build_parts; ++i) {
@@ -280,7 +344,15 @@ std::string GtfModel::load(const std::string &path) {
             idx.resize(t.n);
             std::iota(idx.begin(), idx.end(), 0u);
             // sort_exons_within_transcripts: '+' ascending start, '-' descending start (stable)
-            if (t.strand == '+') std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t c) { return ts[a] < ts[c]; });
+            if (t.n <= 24) {                                                       // (an insertion sort is stable and asks for no buffer)
+                const bool asc = t.strand == '+';
+                for (uint32_t q = 1; q < t.n; ++q) {
+                    const uint32_t v = idx[q], key = ts[v];
+                    uint32_t r = q;
+                    while (r > 0 && (asc ? ts[idx[r - 1]] > key : ts[idx[r - 1]] < key)) { idx[r] = idx[r - 1]; --r; }
+                    idx[r] = v;
+                }
+            } else if (t.strand == '+') std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t c) { return ts[a] < ts[c]; });
             else std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t c) { return ts[a] > ts[c]; });
             tx_id[i].assign(t.id.first, t.id.second);
             tx_gene_name[i] = gtf_attr(t.attrs.first, t.attrs.second, "gene_name");
@@ -292,13 +364,27 @@ std::string GtfModel::load(const std::string &path) {
         }
     });
     lap("tables (threads)");
-    // chr -> bin -> [transcript ids ascending]
+    // chr -> bin -> [transcript ids ascending]: a stable counting sort over (contig, bin) -- bins are < 70,200 for coordinates below 2^29
     {
-        std::vector<std::pair<uint64_t, uint32_t>> kv(n_tx);                       // (key, transcript): plain pair order = stable by transcript
-        for (uint32_t t = 0; t < n_tx; ++t) kv[t] = {(uint64_t)(uint32_t)tx_chrom[t] << 32 | tx_bin[t], t};
-        std::sort(kv.begin(), kv.end());
+        uint32_t max_bin = 0;
+        for (uint32_t t = 0; t < n_tx; ++t) max_bin = std::max(max_bin, tx_bin[t]);
+        const uint64_t buckets = (uint64_t)chroms.size() * ((uint64_t)max_bin + 1);
         bin_key.resize(n_tx); bin_tx.resize(n_tx);
-        for (size_t i = 0; i < n_tx; ++i) { bin_key[i] = kv[i].first; bin_tx[i] = kv[i].second; }
+        if (buckets <= (1u << 23)) {
+            const uint64_t nb = (uint64_t)max_bin + 1;
+            BigVec<uint32_t> head((size_t)buckets + 1, 0);
+            for (uint32_t t = 0; t < n_tx; ++t) ++head[(size_t)((uint64_t)(uint32_t)tx_chrom[t] * nb + tx_bin[t]) + 1];
+            for (size_t k = 0; k < (size_t)buckets; ++k) head[k + 1] += head[k];
+            for (uint32_t t = 0; t < n_tx; ++t) {
+                const uint32_t q = head[(size_t)((uint64_t)(uint32_t)tx_chrom[t] * nb + tx_bin[t])]++;
+                bin_key[q] = (uint64_t)(uint32_t)tx_chrom[t] << 32 | tx_bin[t]; bin_tx[q] = t;
+            }
+        } else {
+            std::vector<std::pair<uint64_t, uint32_t>> kv(n_tx);                   // (key, transcript): plain pair order = stable by transcript
+            for (uint32_t t = 0; t < n_tx; ++t) kv[t] = {(uint64_t)(uint32_t)tx_chrom[t] << 32 | tx_bin[t], t};
+            std::sort(kv.begin(), kv.end());
+            for (size_t i = 0; i < n_tx; ++i) { bin_key[i] = kv[i].first; bin_tx[i] = kv[i].second; }
+        }
     }
     lap("bins");
     return "";
@@ -488,7 +574,8 @@ void VcfText::line(size_t i, const char *&p, size_t &len) const {
     if (len > 1 && p[len - 1] == '\r') --len;          // kseq.h:143
 }
 
-Fasta::~Fasta() { if (data && size) munmap(const_cast<char *>(data), size); }
+Fasta::~Fasta() { unmap(); }
+void Fasta::unmap() { if (data && size) munmap(const_cast<char *>(data), size); data = nullptr; size = 0; }
 
 bool Fasta::load(const std::string &path) {
     const int fd = open(path.c_str(), O_RDONLY);

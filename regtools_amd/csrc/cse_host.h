@@ -7,6 +7,7 @@
 
 #include <functional>
 #include <string>
+#include "bigvec.h"
 #include "vcf_model.h"
 #include <unordered_map>
 #include <vector>
@@ -18,13 +19,14 @@ struct GtfModel {
     std::vector<std::string> chroms;                      // GTF contig names, first-seen order
     std::unordered_map<std::string, int32_t> chrom_index;
     // transcripts in std::map<string,...> order (ascending id)
-    std::vector<std::string> tx_id, tx_gene_name, tx_gene_id;
-    std::vector<int32_t>  tx_chrom;
-    std::vector<uint8_t>  tx_strand;
-    std::vector<uint32_t> tx_exon_off, tx_n_exons, tx_bin;
-    std::vector<uint32_t> es, ee;                          // strand-sorted per transcript
-    std::vector<uint64_t> bin_key;                         // (chrom << 32 | bin), sorted, ties in transcript order
-    std::vector<uint32_t> bin_tx;
+    // (BigVec: large blocks on huge pages, integers not zeroed by resize() -- the threads that fill the tables take the page faults)
+    BigVec<std::string> tx_id, tx_gene_name, tx_gene_id;
+    BigVec<int32_t>  tx_chrom;
+    BigVec<uint8_t>  tx_strand;
+    BigVec<uint32_t> tx_exon_off, tx_n_exons, tx_bin;
+    BigVec<uint32_t> es, ee;                               // strand-sorted per transcript
+    BigVec<uint64_t> bin_key;                              // (chrom << 32 | bin), sorted, ties in transcript order
+    BigVec<uint32_t> bin_tx;
     // returns "" on success, else the message the reference would die with
     std::string load(const std::string &path);
     int32_t chrom_of(const std::string &name) const { auto it = chrom_index.find(name); return it == chrom_index.end() ? -1 : it->second; }
@@ -56,8 +58,9 @@ std::string write_annotated_vcf_records(FILE *fv, const VcfText &vcf, const std:
 // faidx.c:288-413 (uncompressed FASTA + .fai, the index is built in memory when the file is missing)
 struct Fasta {
     struct Seq { std::string name; int64_t len, offset; int line_blen, line_len; };
-    const char *data = nullptr;   // the file, mmap'd read-only: splice-site lookups touch a few pages of a multi-GB genome
+    const char *data = nullptr;   // the file, mmap'd read-only (lookups touch a few pages of a multi-GB genome)
     size_t size = 0;
+    void unmap();
     std::vector<Seq> seqs;
     Fasta() = default;
     Fasta(const Fasta &) = delete;

@@ -473,7 +473,8 @@ bool read_index(const std::string &path, std::vector<uint8_t> &out) {
     return true;
 }
 
-FileBytes::~FileBytes() { if (mapped && p && n) munmap(const_cast<uint8_t *>(p), n); }
+FileBytes::~FileBytes() { release(); }
+void FileBytes::release() { if (mapped && p && n) munmap(const_cast<uint8_t *>(p), n); p = nullptr; n = 0; mapped = false; std::vector<uint8_t>().swap(own); }
 
 bool FileBytes::open(const std::string &path, bool populate) {
     const int fd = ::open(path.c_str(), O_RDONLY);

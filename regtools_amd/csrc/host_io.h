@@ -87,6 +87,7 @@ struct FileBytes {
     FileBytes(const FileBytes &) = delete;
     FileBytes &operator=(const FileBytes &) = delete;
     ~FileBytes();
+    void release();
     // populate: fault the whole mapping in at once (text files that several threads are about to scan)
     bool open(const std::string &path, bool populate = false);
     const uint8_t *data() const { return p; }

@@ -1,0 +1,67 @@
+// worker_pool.h -- host threads that outlive one parallel phase.  A phase of the text loaders is a millisecond or two of work per thread; starting
+// 31 std::threads for it costs about as much again (they are created one after the other), and a loader has six to eight such phases.  The pool's
+// threads are started once per load and woken per phase; tasks are handed out through one atomic counter, the caller works too.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace rgx {
+
+class WorkerPool {
+  public:
+    explicit WorkerPool(size_t threads) {
+        for (size_t k = 1; k < threads; ++k) workers_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; ++phase_; }
+        wake_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    WorkerPool(const WorkerPool &) = delete;
+    WorkerPool &operator=(const WorkerPool &) = delete;
+    size_t threads() const { return workers_.size() + 1; }
+    // f(k) for k in [0, n), each exactly once, on the pool's threads and the caller; returns when all are done
+    void run(size_t n, const std::function<void(size_t)> &f) {
+        if (n == 0) return;
+        if (n == 1 || workers_.empty()) { for (size_t k = 0; k < n; ++k) f(k); return; }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            f_ = &f; n_ = n; next_.store(0, std::memory_order_relaxed); pending_ = workers_.size(); ++phase_;
+        }
+        wake_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return pending_ == 0; });
+        f_ = nullptr;
+    }
+
+  private:
+    void work() { for (size_t k; (k = next_.fetch_add(1, std::memory_order_relaxed)) < n_;) (*f_)(k); }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                wake_.wait(g, [&] { return phase_ != seen; });
+                seen = phase_;
+                if (stop_) return;
+            }
+            work();
+            { std::lock_guard<std::mutex> g(m_); if (--pending_ == 0) done_.notify_one(); }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    const std::function<void(size_t)> *f_ = nullptr;
+    size_t n_ = 0, pending_ = 0;
+    std::atomic<size_t> next_{0};
+    uint64_t phase_ = 0;
+    bool stop_ = false;
+};
+
+}  // namespace rgx

@@ -154,3 +154,21 @@ extern "C" int emu_vcf_rewrite(const char *in_path, const char *out_path, char *
     if (!e.empty()) { snprintf(err, errlen, "%s", e.c_str()); return 2; }
     return 0;
 }
+
+// GtfModel::load on the host (it has no device part): every table, as text, for tests/test_hostemu.py
+extern "C" int emu_gtf_dump(const char *gtf_path, const char *out_path, char *err, size_t errlen) {
+    rgx::GtfModel m;
+    const std::string e = m.load(gtf_path);
+    if (!e.empty()) { snprintf(err, errlen, "%s", e.c_str()); return 1; }
+    FILE *f = fopen(out_path, "w");
+    if (!f) return 2;
+    for (size_t i = 0; i < m.chroms.size(); ++i) fprintf(f, "chrom %zu %s\n", i, m.chroms[i].c_str());
+    for (size_t t = 0; t < m.tx_id.size(); ++t) {
+        fprintf(f, "tx %s %s %s %d %c %u", m.tx_id[t].c_str(), m.tx_gene_name[t].c_str(), m.tx_gene_id[t].c_str(), m.tx_chrom[t], m.tx_strand[t], m.tx_bin[t]);
+        for (uint32_t q = 0; q < m.tx_n_exons[t]; ++q) fprintf(f, " %u-%u", m.es[m.tx_exon_off[t] + q], m.ee[m.tx_exon_off[t] + q]);
+        fputc('\n', f);
+    }
+    for (size_t i = 0; i < m.bin_key.size(); ++i) fprintf(f, "bin %llu %u %u\n", (unsigned long long)(m.bin_key[i] >> 32), (unsigned)(m.bin_key[i] & 0xffffffffu), m.bin_tx[i]);
+    fclose(f);
+    return 0;
+}

@@ -149,3 +149,29 @@ def test_annotated_vcf_equals_the_reference(gpu_ctx, vcf_inputs, name):
     rc, msg = run_mirror(regtools_amd.VariantsAnnotator(ctx=gpu_ctx), ["-o", out, src, gtf], "annotate_vcf")
     assert rc == 0, msg
     assert ac.read(out) == ac.read(os.path.join(VCF_GOLD, name + ".near.vcf"))
+
+
+def test_a_genome_rewritten_between_two_calls_is_read_again(gpu_ctx, work):
+    """The context keeps the last FASTA mapped from call to call (api.cpp host_fasta): a file that changed under the same name is a new file."""
+    import regtools_amd
+    src = ac.read(os.path.join(ac.CSE_REF, "test_chr22.fa")).decode()
+    fa = os.path.join(str(work), "again.fa")
+    bed, gtf = os.path.join(ac.REF, "test_hcc1395_junctions.bed"), os.path.join(ac.REF, "test_ensemble_chr22.gtf")
+    out = os.path.join(str(work), "again.out")
+
+    def sites(text):
+        open(fa, "w").write(text)
+        if os.path.exists(fa + ".fai"):
+            os.remove(fa + ".fai")
+        ja = regtools_amd.JunctionsAnnotator(ctx=gpu_ctx)
+        rc, msg = run_mirror(ja, ["-o", out, bed, fa, gtf], "annotate")
+        assert rc == 0, msg
+        return [l.split("\t")[6] for l in ac.read(out).decode().splitlines()[1:]]
+
+    first = sites(src)
+    assert first == [l.split("\t")[6] for l in ac.read(os.path.join(ac.REF, "expected-annotate.out")).decode().splitlines()[1:]]
+    head, body = src.split("\n", 1)
+    swapped = head + "\n" + body.translate(str.maketrans("ACGTacgt", "CATGcatg"))          # same size, same name, other bases
+    second = sites(swapped)
+    assert second == [s.translate(str.maketrans("ACGT", "CATG")) for s in first] and second != first
+    assert sites(src) == first
