@@ -24,6 +24,7 @@
 
 #include "cse_host.h"
 #include "host_io.h"
+#include "worker_pool.h"
 #include <sys/stat.h>
 #include "kernels.h"
 

@@ -2,6 +2,7 @@
 // 31 std::threads for it costs about as much again (they are created one after the other), and a loader has six to eight such phases.  The pool's
 // threads are started once per load and woken per phase; tasks are handed out through one atomic counter, the caller works too.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -63,5 +64,23 @@ class WorkerPool {
     uint64_t phase_ = 0;
     bool stop_ = false;
 };
+
+// std::sort's result on [b, e), by the pool: runs sorted side by side, then merged pairwise (a stable merge of sorted runs of distinct keys --
+// callers whose keys can tie and who care about the order of ties put the tie-breaker into `less`)
+template <class It, class Less>
+void parallel_sort(WorkerPool &pool, It b, It e, Less less) {
+    const size_t n = (size_t)(e - b);
+    const size_t runs = n < (1u << 14) ? 1 : std::min<size_t>(pool.threads(), 16);
+    if (runs <= 1) { std::sort(b, e, less); return; }
+    pool.run(runs, [&](size_t r) { std::sort(b + (long)(n * r / runs), b + (long)(n * (r + 1) / runs), less); });
+    for (size_t w = 1; w < runs; w *= 2) {
+        std::vector<size_t> starts;
+        for (size_t r = 0; r + w < runs; r += 2 * w) starts.push_back(r);
+        pool.run(starts.size(), [&](size_t q) {
+            const size_t r = starts[q];
+            std::inplace_merge(b + (long)(n * r / runs), b + (long)(n * (r + w) / runs), b + (long)(n * std::min(runs, r + 2 * w) / runs), less);
+        });
+    }
+}
 
 }  // namespace rgx
