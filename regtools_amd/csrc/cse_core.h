@@ -14,6 +14,10 @@ struct GtfView {
     const uint64_t *bin_key;      // sorted (chrom index << 32 | UCSC bin); ties keep transcript-id order
     const uint32_t *bin_tx;       // transcript of each bin_key entry
     uint32_t n_bin;
+    // optional direct index into the table above: entries of (contig c, bin b) are [bin_start[c * bin_stride + b], bin_start[c * bin_stride + b + 1]);
+    // b < bin_stride (= the largest bin any transcript has, + 1).  nullptr: binary search (annotations with absurdly many contigs x bins)
+    const uint32_t *bin_start;
+    uint32_t bin_stride;
 };
 
 // bedFile.h:49-63: 7 levels, offsets with the upstream 32678 typo, first shift 14, next shift 3
@@ -31,6 +35,21 @@ RGX_HD uint32_t bin_lower_bound(const GtfView &g, uint64_t key) {
     uint32_t lo = 0, hi = g.n_bin;
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (g.bin_key[mid] < key) lo = mid + 1; else hi = mid; }
     return lo;
+}
+
+// entries of the (contig, bin) table for bins b0 .. b1 of contig c: [lo, hi)
+RGX_HD void bin_range(const GtfView &g, uint32_t c, uint32_t b0, uint32_t b1, uint32_t &lo, uint32_t &hi) {
+    if (g.bin_start) {
+        if (b0 >= g.bin_stride) { lo = hi = 0; return; }
+        if (b1 >= g.bin_stride) b1 = g.bin_stride - 1;
+        lo = g.bin_start[(size_t)c * g.bin_stride + b0]; hi = g.bin_start[(size_t)c * g.bin_stride + b1 + 1];
+        return;
+    }
+    lo = bin_lower_bound(g, (uint64_t)c << 32 | b0);
+    uint32_t a = lo, b = g.n_bin;
+    const uint64_t k1 = (uint64_t)c << 32 | b1;
+    while (a < b) { const uint32_t mid = (a + b) >> 1; if (g.bin_key[mid] <= k1) a = mid + 1; else b = mid; }
+    hi = a;
 }
 
 enum : uint32_t { ANN_NONE = 0, ANN_EXONIC = 1, ANN_INTRONIC = 2, ANN_SPL_EXONIC = 3, ANN_SPL_INTRONIC = 4 };
@@ -97,8 +116,9 @@ RGX_HD void variant_scan(const GtfView &g, int32_t chrom, uint32_t pos0, const V
     for (int lvl = 0; lvl < 7; ++lvl) {
         const uint32_t off = bin_offset(lvl);
         if (sb <= eb) {
-            const uint64_t k0 = (uint64_t)(uint32_t)chrom << 32 | (uint64_t)(uint32_t)(sb + off), k1 = (uint64_t)(uint32_t)chrom << 32 | (uint64_t)(uint32_t)(eb + off);
-            for (uint32_t j = bin_lower_bound(g, k0); j < g.n_bin && g.bin_key[j] <= k1; ++j) {
+            uint32_t j0, j1;
+            bin_range(g, (uint32_t)chrom, sb + off, eb + off, j0, j1);
+            for (uint32_t j = j0; j < j1; ++j) {
                 const uint32_t t = g.bin_tx[j], n = g.tx_n_exons[t];
                 if (o.skip_single && n == 1) continue;
                 exon_visits += n;
@@ -168,8 +188,9 @@ RGX_HD void junction_scan(const GtfView &g, int32_t chrom, uint32_t js, uint32_t
     for (int lvl = 0; lvl < 7; ++lvl) {
         const uint32_t off = bin_offset(lvl);
         if (sb <= eb) {
-            const uint64_t k0 = (uint64_t)(uint32_t)chrom << 32 | (uint64_t)(uint32_t)(sb + off), k1 = (uint64_t)(uint32_t)chrom << 32 | (uint64_t)(uint32_t)(eb + off);
-            for (uint32_t j = bin_lower_bound(g, k0); j < g.n_bin && g.bin_key[j] <= k1; ++j) {
+            uint32_t j0, j1;
+            bin_range(g, (uint32_t)chrom, sb + off, eb + off, j0, j1);
+            for (uint32_t j = j0; j < j1; ++j) {
                 const uint32_t t = g.bin_tx[j];
                 if ((char)g.tx_strand[t] != strand) continue;
                 exon_visits += g.tx_n_exons[t];

@@ -375,6 +375,7 @@ std::string GtfModel::load(const std::string &path) {
             BigVec<uint32_t> head((size_t)buckets + 1, 0);
             for (uint32_t t = 0; t < n_tx; ++t) ++head[(size_t)((uint64_t)(uint32_t)tx_chrom[t] * nb + tx_bin[t]) + 1];
             for (size_t k = 0; k < (size_t)buckets; ++k) head[k + 1] += head[k];
+            bin_start.assign(head.begin(), head.end()); bin_stride = (uint32_t)nb;     // the kernels' direct index (cse_core.h bin_range)
             for (uint32_t t = 0; t < n_tx; ++t) {
                 const uint32_t q = head[(size_t)((uint64_t)(uint32_t)tx_chrom[t] * nb + tx_bin[t])]++;
                 bin_key[q] = (uint64_t)(uint32_t)tx_chrom[t] << 32 | tx_bin[t]; bin_tx[q] = t;

@@ -27,6 +27,8 @@ struct GtfModel {
     BigVec<uint32_t> es, ee;                               // strand-sorted per transcript
     BigVec<uint64_t> bin_key;                              // (chrom << 32 | bin), sorted, ties in transcript order
     BigVec<uint32_t> bin_tx;
+    BigVec<uint32_t> bin_start;                            // contigs x bin_stride + 1 entries: where (contig, bin)'s entries begin (empty: too many to index)
+    uint32_t bin_stride = 0;
     // returns "" on success, else the message the reference would die with
     std::string load(const std::string &path);
     int32_t chrom_of(const std::string &name) const { auto it = chrom_index.find(name); return it == chrom_index.end() ? -1 : it->second; }

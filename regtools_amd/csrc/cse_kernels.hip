@@ -8,6 +8,9 @@
 
 #include "cse_core.h"
 
+#include <stdlib.h>
+#include <string.h>
+
 namespace rgx {
 
 __device__ __forceinline__ uint32_t lane_id2() { return threadIdx.x & 63u; }
@@ -52,6 +55,96 @@ __global__ void k_junction_scan(GtfView g, uint32_t n, const int32_t *__restrict
         if (!FILL) { count[i] = k; flags[i] = f.known_donor | f.known_acceptor << 1 | f.known_junction << 2; }
     }
     if (!FILL) wave_add_visits(ev, visits);
+}
+
+// a11, one WAVE per junction.  The lane form above walks ~450 exon records per junction (config 4) on one lane: a chain of dependent gathers
+// a few hundred long, on 1,000 waves.  Here the junction's candidate transcripts -- seven contiguous ranges of the (contig, bin) table, found by
+// seven lanes at once -- are dealt to the lanes, one transcript each, sixty-four per turn: a lane's chain is one transcript's exons.
+// What made upstream's loop serial is kept by two wave scans per turn: a transcript is listed when the donor / acceptor / junction flags of ALL
+// transcripts visited so far (itself included) are not all clear (an inclusive OR scan in visiting order, carried from turn to
+// turn), and the items land in visiting order (an exclusive sum scan of the lanes' item counts).  A transcript's own flags and skipped elements
+// do not depend on the flags before it (junction_vs_transcript only reads them for its return value).
+__device__ __forceinline__ uint32_t wave_scan_or(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d, 64); if (lane >= (uint32_t)d) v |= o; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d, 64); if (lane >= (uint32_t)d) v += o; }
+    return v;
+}
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_junction_scan_wave(GtfView g, uint32_t n, const int32_t *__restrict__ chrom, const uint32_t *__restrict__ js_, const uint32_t *__restrict__ je_,
+                                     const uint8_t *__restrict__ strand_, uint32_t *count, const uint32_t *__restrict__ base, uint32_t *flags, uint32_t *item_kind,
+                                     uint32_t *item_a, uint32_t *item_b, uint32_t *visit_each /* exon records of junction i's candidates (66,000 waves adding to
+                                     one counter took 0.57 of the pass's 0.82 ms) */) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;                                                     // (wave-uniform)
+    const int32_t ch = chrom[i];
+    const uint32_t js = js_[i], je = je_[i];
+    const char strand = (char)strand_[i];
+    uint32_t acc = 0, n_items = 0, ev = 0;                                  // wave-uniform: flags so far (bit 0 donor, 1 acceptor, 2 junction), items so far
+    if (ch >= 0 && (strand == '+' || strand == '-')) {                      // '?' matches no transcript (:322-323)
+        // the seven bin ranges (junction_scan, cse_core.h), one level per lane
+        uint32_t lo = 0, cnt = 0;
+        if (lane < 7) {
+            const uint32_t sb = (js >> 14) >> (3 * lane), eb = ((uint32_t)(je - 1) >> 14) >> (3 * lane);
+            if (sb <= eb) {
+                const uint32_t off = bin_offset((int)lane);
+                uint32_t hi;
+                bin_range(g, (uint32_t)ch, sb + off, eb + off, lo, hi);
+                cnt = hi - lo;
+            }
+        }
+        uint32_t l_lo[7], l_end[7], total = 0;                              // level l holds candidates [l_end[l-1], l_end[l])
+#pragma unroll
+        for (int l = 0; l < 7; ++l) { l_lo[l] = __shfl(lo, l, 64); total += __shfl(cnt, l, 64); l_end[l] = total; }
+        const uint32_t out0 = FILL ? base[i] : 0u;
+        for (uint32_t c0 = 0; c0 < total; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            bool mine = c < total;
+            uint32_t t = 0, nex = 0;
+            if (mine) {
+                uint32_t j = 0, before = 0;
+#pragma unroll
+                for (int l = 6; l >= 0; --l) if (c < l_end[l]) { before = l ? l_end[l - 1] : 0u; j = l_lo[l] + (c - before); }
+                t = g.bin_tx[j];
+                mine = (char)g.tx_strand[t] == strand;
+                if (mine) { nex = g.tx_n_exons[t]; ev += nex; }
+            }
+            const uint32_t *es = g.es + (mine ? g.tx_exon_off[t] : 0u), *ee = g.ee + (mine ? g.tx_exon_off[t] : 0u);
+            // pass A: the transcript's own flags, its item count, whether its loop ran to the end (an early return lists nothing)
+            JunctionFlags f{0, 0, 0};
+            uint32_t k = 0;
+            bool reached = false;
+            if (mine && nex > 1) {
+                const bool outside = strand == '+' ? (es[0] > je || ee[nex - 1] < js) : (ee[0] < js || es[nex - 1] > je);
+                if (!outside) { reached = true; (void)junction_vs_transcript(strand, es, ee, nex, js, je, f, [&](uint32_t, uint32_t, uint32_t) { ++k; }); }
+            }
+            const uint32_t own = f.known_donor | f.known_acceptor << 1 | f.known_junction << 2;
+            const uint32_t seen = wave_scan_or(own, lane) | acc;           // flags of everything visited up to and including this transcript
+            const bool listed = reached && seen != 0;
+            k += listed ? 1u : 0u;
+            const uint32_t incl = wave_scan_add(k, lane);
+            if (FILL && k) {
+                uint32_t w = out0 + n_items + incl - k;
+                if (k > (listed ? 1u : 0u)) {
+                    JunctionFlags f2{0, 0, 0};
+                    (void)junction_vs_transcript(strand, es, ee, nex, js, je, f2, [&](uint32_t kind, uint32_t a, uint32_t b) { item_kind[w] = kind; item_a[w] = a; item_b[w] = b; ++w; });
+                }
+                if (listed) { item_kind[w] = ITEM_TX; item_a[w] = t; item_b[w] = 0u; }
+            }
+            acc = __shfl(seen, 63, 64);
+            n_items += __shfl(incl, 63, 64);
+        }
+    }
+    if (!FILL) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) ev += __shfl_xor(ev, d, 64);
+        if (lane == 0) { count[i] = n_items; flags[i] = acc; if (visit_each) visit_each[i] = ev; }
+    }
 }
 
 // longest reference span of a read that supports an event: bounds how far before a window its overlapping reads can start
@@ -141,8 +234,16 @@ void launch_variant_scan(bool fill, GtfView g, uint32_t n, const int32_t *chrom,
     else hipLaunchKernelGGL(k_variant_scan<false>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, pos0, o, count, base, ces, cee, hit_tx, hit_ad, visits);
 }
 void launch_junction_scan(bool fill, GtfView g, uint32_t n, const int32_t *chrom, const uint32_t *js, const uint32_t *je, const uint8_t *strand, uint32_t *count,
-                          const uint32_t *base, uint32_t *flags, uint32_t *item_kind, uint32_t *item_a, uint32_t *item_b, unsigned long long *visits, hipStream_t stream) {
+                          const uint32_t *base, uint32_t *flags, uint32_t *item_kind, uint32_t *item_a, uint32_t *item_b, unsigned long long *visits, uint32_t *visit_each,
+                          hipStream_t stream) {
     if (!n) return;
+    static const bool lane_form = [] { const char *e = getenv("REGTOOLS_AMD_JSCAN"); return e && !strcmp(e, "lane"); }();   // (tests: the one-lane-per-junction form, against which the wave form is checked)
+    if (!lane_form) {
+        if (fill) hipLaunchKernelGGL(k_junction_scan_wave<true>, dim3((n + 3) / 4), dim3(256), 0, stream, g, n, chrom, js, je, strand, count, base, flags, item_kind, item_a, item_b, visit_each);
+        else hipLaunchKernelGGL(k_junction_scan_wave<false>, dim3((n + 3) / 4), dim3(256), 0, stream, g, n, chrom, js, je, strand, count, base, flags, item_kind, item_a, item_b, visit_each);
+        return;
+    }
+    if (visit_each && !fill) (void)hipMemsetAsync(visit_each, 0, (size_t)n * 4, stream);            // (the lane form counts into *visits)
     if (fill) hipLaunchKernelGGL(k_junction_scan<true>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, js, je, strand, count, base, flags, item_kind, item_a, item_b, visits);
     else hipLaunchKernelGGL(k_junction_scan<false>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, js, je, strand, count, base, flags, item_kind, item_a, item_b, visits);
 }

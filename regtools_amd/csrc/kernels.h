@@ -216,7 +216,7 @@ void launch_variant_scan(bool fill, GtfView g, uint32_t n, const int32_t *chrom,
 // count pass: count[i], flags[i] = known_donor | known_acceptor<<1 | known_junction<<2; fill pass: items (kind,a,b) in visitation order
 void launch_junction_scan(bool fill, GtfView g, uint32_t n, const int32_t *chrom, const uint32_t *js, const uint32_t *je, const uint8_t *strand, uint32_t *count,
                           const uint32_t *base, uint32_t *flags, uint32_t *item_kind, uint32_t *item_a, uint32_t *item_b, unsigned long long *visits,
-                          hipStream_t stream);
+                          uint32_t *visit_each /* wave form: exon records per junction */, hipStream_t stream);
 void launch_max_span(EventSoA ev, uint32_t n, uint32_t *out /* zeroed by the caller */, hipStream_t stream);
 void launch_window_pairs(bool fill, EventSoA ev, uint32_t n_events, uint32_t n_win, const int32_t *w_tid, const int32_t *w_beg, const int32_t *w_end,
                          const uint32_t *max_span, uint32_t *count, const uint32_t *base, uint32_t *pair_ev, uint32_t *pair_win, hipStream_t stream);

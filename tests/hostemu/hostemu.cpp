@@ -169,6 +169,15 @@ extern "C" int emu_gtf_dump(const char *gtf_path, const char *out_path, char *er
         fputc('\n', f);
     }
     for (size_t i = 0; i < m.bin_key.size(); ++i) fprintf(f, "bin %llu %u %u\n", (unsigned long long)(m.bin_key[i] >> 32), (unsigned)(m.bin_key[i] & 0xffffffffu), m.bin_tx[i]);
+    {   // the direct index must describe the table above exactly
+        bool ok = m.bin_start.size() == m.chroms.size() * (size_t)m.bin_stride + 1 && m.bin_start.back() == m.bin_key.size() && m.bin_start[0] == 0;
+        for (size_t k = 0; ok && k + 1 < m.bin_start.size(); ++k) {
+            if (m.bin_start[k] > m.bin_start[k + 1]) ok = false;
+            for (uint32_t j = m.bin_start[k]; ok && j < m.bin_start[k + 1]; ++j)
+                if (m.bin_key[j] != ((uint64_t)(k / m.bin_stride) << 32 | (uint64_t)(k % m.bin_stride))) ok = false;
+        }
+        fprintf(f, "bin_start %s\n", ok ? "ok" : "BAD");
+    }
     fclose(f);
     return 0;
 }

@@ -228,3 +228,31 @@ def test_bcf_input(gpu_ctx, work):
             assert open(files[ext], "rb").read() == open(os.path.join(CSE, "%s.%s" % (case["name"], ext)), "rb").read(), (case["name"], ext)
         done += 1
     assert done == 3
+
+
+def test_junction_scan_wave_form_equals_the_lane_form(gpu_ctx, work):
+    """k_junction_scan_wave (one wave per junction, candidate transcripts dealt to the lanes, two wave scans for the order-dependent parts) against
+    the one-lane-per-junction kernel it replaced (REGTOOLS_AMD_JSCAN=lane), on an annotation dense enough that junctions see several turns of 64
+    candidate transcripts: `identify` and `junctions annotate`, every output file."""
+    from regtools_amd import synth
+    exe = os.path.join(ROOT, "bin", "regtools-amd")
+    pre = os.path.join(str(work), "dense")
+    synth.write(pre + ".bam", 400_000, shape="short", seed=11, n_genes=30_000)
+    ann = synth.annotation(pre, 30_000, 20_000, seed=11, fasta=True)
+    outs = {}
+    for form in ("wave", "lane"):
+        env = dict(os.environ)
+        if form == "lane":
+            env["REGTOOLS_AMD_JSCAN"] = "lane"
+        o = pre + "." + form
+        r = subprocess.run([exe, "cis-splice-effects", "identify", "-s", "XS", "-o", o + ".tsv", "-v", o + ".vcf", "-j", o + ".bed", ann["vcf"], pre + ".bam", ann["fasta"], ann["gtf"]],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr
+        r = subprocess.run([exe, "junctions", "annotate", "-o", o + ".ja", o + ".bed", ann["fasta"], ann["gtf"]], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr
+        outs[form] = [open(o + e, "rb").read() for e in (".tsv", ".vcf", ".bed", ".ja")]
+    assert outs["wave"] == outs["lane"]
+    rows = outs["wave"][0].decode().splitlines()
+    assert len(rows) > 200
+    # (the test is about junctions with many candidates: some row lists more than 64 transcripts' worth of skipped elements or transcripts)
+    assert max(len(r.split("\t")[16].split(",")) for r in rows[1:]) >= 3

@@ -71,6 +71,7 @@ def restate(text):
         out.append("tx %s %s %s %d %s %d" % (tid, x["gn"], x["gi"], ci, x["strand"], b) + "".join(" %d-%d" % e for e in ex))
         bins.append((ci, b, t))
     out += ["bin %d %d %d" % k for k in sorted(bins)]
+    out.append("bin_start ok")
     return "\n".join(out) + "\n"
 
 
