@@ -172,25 +172,50 @@ __device__ __forceinline__ uint32_t ev_lower_bound(const EventSoA &ev, uint32_t 
 
 // Window w = reads with tid == t, pos < end, endpos > beg (hts.c:1946-1957).  Pairs (window, event) are produced window-major
 // and in event (file) order inside a window, so the later stable group-by sees every window's reads in file order.
-template <bool FILL>
-__global__ __launch_bounds__(64) void k_window_pairs(EventSoA ev, uint32_t n_events, uint32_t n_win, const int32_t *__restrict__ w_tid,
-                                                     const int32_t *__restrict__ w_beg, const int32_t *__restrict__ w_end, const uint32_t *__restrict__ max_span,
-                                                     uint32_t *count, const uint32_t *__restrict__ base, uint32_t *pair_ev, uint32_t *pair_win) {
-    const uint32_t w = blockIdx.x, lane = threadIdx.x;
+// A window's candidate range -- events whose read starts in [beg - longest read span, end) -- is found once per window (k_window_ranges, the fill pass reuses it) and cut into kWinSlices slices,
+// one workgroup of four waves each: a window over a highly expressed gene has orders of magnitude more candidates than the median one.  count / base are indexed
+// [window * kWinSlices + slice]; a window's pairs are its slices' pairs in slice order.
+// the candidate range of every window, one lane each (two binary searches over the events: ~50 dependent loads, done once per window here
+// instead of once per workgroup of the pair kernel)
+__global__ void k_window_ranges(EventSoA ev, uint32_t n_events, uint32_t n_win, const int32_t *__restrict__ w_tid, const int32_t *__restrict__ w_beg,
+                                const int32_t *__restrict__ w_end, const uint32_t *__restrict__ max_span, uint32_t *w_lo, uint32_t *w_hi) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_win) return;
     const int32_t t = w_tid[w], beg = w_beg[w], end = w_end[w];
     const uint32_t span = *max_span;
     const int32_t lo_pos = beg > (int32_t)span ? beg - (int32_t)span : 0;
-    const uint32_t lo = ev_lower_bound(ev, n_events, (uint32_t)t, (uint32_t)lo_pos), hi = ev_lower_bound(ev, n_events, (uint32_t)t, (uint32_t)end);
-    uint32_t out = FILL ? base[w] : 0u, total = 0;
-    for (uint32_t e0 = lo; e0 < hi; e0 += 64) {
-        const uint32_t e = e0 + lane;
-        const bool keep = e < hi && (int32_t)ev.rend[e] > beg;          // pos < end holds for the whole range
+    w_lo[w] = ev_lower_bound(ev, n_events, (uint32_t)t, (uint32_t)lo_pos);
+    w_hi[w] = ev_lower_bound(ev, n_events, (uint32_t)t, (uint32_t)end);
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_window_pairs(EventSoA ev, uint32_t n_win, const int32_t *__restrict__ w_beg, const uint32_t *__restrict__ w_lo,
+                                                      const uint32_t *__restrict__ w_hi, uint32_t *count, const uint32_t *__restrict__ base, uint32_t *pair_ev,
+                                                      uint32_t *pair_win) {
+    __shared__ uint32_t wave_cnt[4];
+    const uint32_t w = blockIdx.x, sl = blockIdx.y, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if (w >= n_win) return;
+    const int32_t beg = w_beg[w];
+    const uint32_t lo = w_lo[w], hi = w_hi[w];
+    const uint64_t len = hi - lo;
+    const uint32_t a = lo + (uint32_t)(len * sl / kWinSlices), b = lo + (uint32_t)(len * (sl + 1) / kWinSlices);
+    uint32_t out = FILL ? base[(size_t)w * kWinSlices + sl] : 0u, total = 0;
+    for (uint32_t e0 = a; e0 < b; e0 += 256) {                                // (block-uniform trip count)
+        const uint32_t e = e0 + threadIdx.x;
+        const bool keep = e < b && (int32_t)ev.rend[e] > beg;               // pos < end holds for the whole range
         const uint64_t m = __ballot(keep);
-        if (FILL && keep) { const uint32_t k = out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); pair_ev[k] = e; pair_win[k] = w; }
-        out += (uint32_t)__popcll(m); total += (uint32_t)__popcll(m);
+        if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        const uint32_t c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
+        if (FILL && keep) {
+            const uint32_t before = wv == 0 ? 0u : wv == 1 ? c0 : wv == 2 ? c0 + c1 : c0 + c1 + c2;
+            const uint32_t k = out + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            pair_ev[k] = e; pair_win[k] = w;
+        }
+        out += c0 + c1 + c2 + c3; total += c0 + c1 + c2 + c3;
+        __syncthreads();
     }
-    if (!FILL && lane == 0) count[w] = total;
+    if (!FILL && threadIdx.x == 0) count[(size_t)w * kWinSlices + sl] = total;
 }
 
 // `cis-splice-effects associate` (cis_splice_effects_associator.cc:261-272): window w keeps every junction of its contig whose start
@@ -253,10 +278,14 @@ void launch_max_span(EventSoA ev, uint32_t n, uint32_t *out, hipStream_t stream)
     hipLaunchKernelGGL(k_max_span, dim3(blocks), dim3(256), 0, stream, ev, n, out);
 }
 void launch_window_pairs(bool fill, EventSoA ev, uint32_t n_events, uint32_t n_win, const int32_t *w_tid, const int32_t *w_beg, const int32_t *w_end,
-                         const uint32_t *max_span, uint32_t *count, const uint32_t *base, uint32_t *pair_ev, uint32_t *pair_win, hipStream_t stream) {
+                         const uint32_t *max_span, uint32_t *w_lo, uint32_t *w_hi, uint32_t *count, const uint32_t *base, uint32_t *pair_ev, uint32_t *pair_win,
+                         hipStream_t stream) {
     if (!n_win) return;
-    if (fill) hipLaunchKernelGGL(k_window_pairs<true>, dim3(n_win), dim3(64), 0, stream, ev, n_events, n_win, w_tid, w_beg, w_end, max_span, count, base, pair_ev, pair_win);
-    else hipLaunchKernelGGL(k_window_pairs<false>, dim3(n_win), dim3(64), 0, stream, ev, n_events, n_win, w_tid, w_beg, w_end, max_span, count, base, pair_ev, pair_win);
+    if (fill) hipLaunchKernelGGL(k_window_pairs<true>, dim3(n_win, kWinSlices), dim3(256), 0, stream, ev, n_win, w_beg, w_lo, w_hi, count, base, pair_ev, pair_win);
+    else {
+        hipLaunchKernelGGL(k_window_ranges, dim3((n_win + 63) / 64), dim3(64), 0, stream, ev, n_events, n_win, w_tid, w_beg, w_end, max_span, w_lo, w_hi);
+        hipLaunchKernelGGL(k_window_pairs<false>, dim3(n_win, kWinSlices), dim3(256), 0, stream, ev, n_win, w_beg, w_lo, w_hi, count, base, pair_ev, pair_win);
+    }
 }
 void launch_assoc_pairs(bool fill, uint32_t n_win, const int32_t *w_chrom, const uint32_t *w_ces, const uint32_t *w_cee, const uint32_t *chrom_off,
                         const uint32_t *j_start, const uint32_t *j_end, uint32_t *count, const uint32_t *base, uint32_t *pair_j, uint32_t *pair_win, hipStream_t stream) {

@@ -218,8 +218,10 @@ void launch_junction_scan(bool fill, GtfView g, uint32_t n, const int32_t *chrom
                           const uint32_t *base, uint32_t *flags, uint32_t *item_kind, uint32_t *item_a, uint32_t *item_b, unsigned long long *visits,
                           uint32_t *visit_each /* wave form: exon records per junction */, hipStream_t stream);
 void launch_max_span(EventSoA ev, uint32_t n, uint32_t *out /* zeroed by the caller */, hipStream_t stream);
+constexpr uint32_t kWinSlices = 4;      // workgroups per variant window (k_window_pairs); count / base arrays hold n_win x kWinSlices entries
 void launch_window_pairs(bool fill, EventSoA ev, uint32_t n_events, uint32_t n_win, const int32_t *w_tid, const int32_t *w_beg, const int32_t *w_end,
-                         const uint32_t *max_span, uint32_t *count, const uint32_t *base, uint32_t *pair_ev, uint32_t *pair_win, hipStream_t stream);
+                         const uint32_t *max_span, uint32_t *w_lo, uint32_t *w_hi /* the windows' candidate ranges: written by the count pass (fill = false), read by the fill pass */,
+                         uint32_t *count, const uint32_t *base, uint32_t *pair_ev, uint32_t *pair_win, hipStream_t stream);
 // associate: (window, junction) pairs; junction arrays are bucketed by contig, chrom_off has n_chrom + 1 entries
 void launch_assoc_pairs(bool fill, uint32_t n_win, const int32_t *w_chrom, const uint32_t *w_ces, const uint32_t *w_cee, const uint32_t *chrom_off,
                         const uint32_t *j_start, const uint32_t *j_end, uint32_t *count, const uint32_t *base, uint32_t *pair_j, uint32_t *pair_win, hipStream_t stream);
