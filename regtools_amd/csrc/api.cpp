@@ -1528,7 +1528,7 @@ extern "C" int rgx_k_inflate(const void *d_comp, const rgx_member *d_members, ui
 }
 
 extern "C" int rgx_k_inflate_form(int form, const void *d_comp, const rgx_member *d_members, uint32_t n_members, void *d_arena, uint32_t *d_status, void *stream) {
-    if (form < 0 || form > 4) return RGX_ERR_ARG;
+    if (form < 0 || form > 5) return RGX_ERR_ARG;                    // 5 = k_inflate with up to four literals per trip
     static_assert(sizeof(rgx_member) == sizeof(Member), "rgx_member layout");
     // stage entry point: the code-length scratch is a process-lifetime buffer grown on demand
     static void *scratch = nullptr; static size_t scratch_cap = 0;

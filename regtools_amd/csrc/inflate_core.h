@@ -409,7 +409,10 @@ constexpr uint32_t kCopyBatch = 128;   // bytes moved per memory round trip (8 i
 //   C. push the copied bytes, then the decoded literal, through the output stage (OutStage), or arm the next copy.
 // In a 64-lane wavefront every lane is at a different point of a different member; a lane in the middle of a long
 // match therefore no longer stalls the 63 others for a whole copy loop -- each trip costs one round trip for all.
-template <class Tab>
+// LITS: literals a trip may take (1, or up to 4: a literal whose successors are literals too and still lie in the bit buffer are decoded in the same
+// trip -- the trip's memory wait and output logic are paid once for them.  For payloads that are mostly literals: random bases and qualities;
+// the host picks per launch, inflate_plan_for).  The symbols decoded and their order are the same for every LITS.
+template <int LITS = 1, class Tab>
 RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len, Tab &T, uint32_t *in_used = nullptr) {
     BitReader br; br.init(in, in_len);
     OutStage S; S.init(out, out_cap);
@@ -444,6 +447,9 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
         }
         // ---- B: next symbol (only when the copy, if any, ends with this batch) -------------------------------------
         uint32_t lit = 256, new_len = 0, new_dist = 0;
+        uint32_t more[LITS > 1 ? LITS - 1 : 1];                 // the literals behind `lit` taken in this trip (256 = none)
+#pragma unroll
+        for (int q = 0; q < (LITS > 1 ? LITS - 1 : 1); ++q) more[q] = 256;
         if (pend_len == n && !done) {
             if (in_symbols) {
                 const uint32_t v = rev15(br.peek(15));         // >= 48 valid bits here: the whole trip is fed from the buffer
@@ -452,8 +458,22 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
                 if (l == 0 || idx >= 288) { status = INF_BAD_CODE; break; }
                 const uint32_t sym = T.get_ll_sym(idx);
                 br.drop(l);
-                if (sym < 256) lit = sym;
-                else if (sym == 256) {
+                if (sym < 256) {
+                    lit = sym;
+                    if (LITS > 1) {
+                        bool run = true;                        // (no break: the lanes of a wave leave the unrolled steps together)
+#pragma unroll
+                        for (int q = 0; q < LITS - 1; ++q) {
+                            // a code is at most 15 bits: with 15 in the buffer the next symbol can be looked at; anything but a literal stays where it is
+                            // and is the next trip's symbol (also a code that is no code: that trip reports it)
+                            run = run && br.cnt >= 15;
+                            uint32_t l2 = 0, idx2 = 0, sym2 = 256;
+                            if (run) { idx2 = code_lookup(LL, rev15(br.peek(15)), l2); run = l2 != 0 && idx2 < 288; }
+                            if (run) { sym2 = T.get_ll_sym(idx2); run = sym2 < 256; }
+                            if (run) { br.drop(l2); more[q] = sym2; }
+                        }
+                    }
+                } else if (sym == 256) {
                     in_symbols = false;
                     if (br.overran()) { status = INF_IN_OVERRUN; break; }
                     if (last) done = true;
@@ -506,6 +526,13 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
         if (lit < 256) {
             if (o >= out_cap) { status = INF_OUT_OVERFLOW; break; }
             S.put_byte(o, lit); ++o;
+            if (LITS > 1) {
+                bool over = false;
+#pragma unroll
+                for (int q = 0; q < LITS - 1; ++q)
+                    if (more[q] < 256 && !over) { if (o >= out_cap) over = true; else { S.put_byte(o, more[q]); ++o; } }
+                if (over) { status = INF_OUT_OVERFLOW; break; }
+            }
         } else if (new_len) {
             if (new_dist > o) { status = INF_BAD_DIST; break; }
             if (o + new_len > out_cap) { status = INF_OUT_OVERFLOW; break; }

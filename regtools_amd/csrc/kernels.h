@@ -86,7 +86,8 @@ struct SegGeom {
 // seg_start[s] = guessed (or, for a chain's first segment, exact) first record start >= segment begin; seg_exit[s] = first record
 // start >= segment end reached by the chain from seg_start[s]; seg_cnt[s] = records that start inside the segment.
 void launch_seg_walk(const uint8_t *arena, SegGeom g, uint32_t n_seg, int32_t n_ref,
-                     uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, uint16_t *seg_cp /* n_seg * kSegCpSlots */, hipStream_t stream);
+                     uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, uint16_t *seg_cp /* n_seg * kSegCpSlots */, hipStream_t stream,
+                     uint32_t s_begin = 0 /* only segments [s_begin, n_seg): the guesses of a range can be made as soon as its bytes are inflated */);
 // One verification sweep: segment s re-walks from seg_exit_in[s-1] when that differs from seg_start_in[s].
 // *changed is incremented when anything changed. Reads *_in, writes *_out (all segments).
 void launch_seg_verify(const uint8_t *arena, SegGeom g, uint32_t n_seg,

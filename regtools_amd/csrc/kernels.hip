@@ -96,7 +96,7 @@ struct LdsTab {
 // block is as long as zlib says): every member into its own 64 KiB slot, true length (or ~0 = does not inflate) to sizes[m].
 // PIECE: the same code under a second symbol -- the launches of rgx_extract_mem's overlapped upload cover a third of a file each and
 // run side by side; a profiler's per-kernel statistics keep them apart from the whole-range launches the roofline is quoted on.
-template <bool PROBE, bool PIECE = false>
+template <bool PROBE, bool PIECE = false, int LITS = 1 /* literals per trip (inflate_core.h): 4 for payloads that are mostly literals */>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_inflate(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
                                                 uint32_t n_members, uint8_t *__restrict__ arena, uint64_t upos_bias, uint32_t *len_scratch,
                                                 uint32_t *status, uint32_t ignore_below, uint32_t index_bias, uint8_t *bad) {
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     int st;
     if (mb.isize > kBgzfMaxBlock) st = mb.isize == 0xffffffffu ? INF_IN_OVERRUN : INF_OUT_OVERFLOW;
     else {
-        st = inflate_raw(comp + mb.cpos, mb.clen, arena + (mb.upos - upos_bias), mb.isize, &out_len, T);
+        st = inflate_raw<LITS>(comp + mb.cpos, mb.clen, arena + (mb.upos - upos_bias), mb.isize, &out_len, T);
         if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
     }
     if (st != INF_OK) {
@@ -437,6 +437,8 @@ static void inflate_attrs() {
     (void)hipFuncSetAttribute((const void *)k_inflate<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate_coop<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+    (void)hipFuncSetAttribute((const void *)k_inflate<false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
+    (void)hipFuncSetAttribute((const void *)k_inflate<false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate_coop<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate_coop<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
     (void)hipFuncSetAttribute((const void *)k_inflate_coop<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
@@ -475,9 +477,15 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
 #undef RGX_COOP
         break;
     }
-    default:
-        if (piece) hipLaunchKernelGGL((k_inflate<false, true>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad);
-        else hipLaunchKernelGGL((k_inflate<false, false>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad);
+    default: {
+        // plan bit 1 = a payload of mostly literals (< 8 x): up to four of them per trip
+        static const int env_lits = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE_LITS"); return e ? atoi(e) : -1; }();      // (lab / tests) 1 or 4
+        const bool lits4 = form == 5 || (env_lits >= 0 ? env_lits > 1 : (plan & 2) != 0);          // (form 5: the stage entry point's way to ask for it)
+#define RGX_LANE(PIECE_, LITS_) hipLaunchKernelGGL((k_inflate<false, PIECE_, LITS_>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad)
+        if (piece) { if (lits4) RGX_LANE(true, 4); else RGX_LANE(true, 1); }
+        else { if (lits4) RGX_LANE(false, 4); else RGX_LANE(false, 1); }
+#undef RGX_LANE
+    }
     }
 }
 void launch_inflate_probe(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *slots, uint32_t *len_scratch, uint32_t *sizes,
@@ -529,8 +537,8 @@ __device__ __forceinline__ void seg_of(const SegGeom &g, uint32_t s, uint64_t &a
 }
 
 __global__ void k_seg_walk(const uint8_t *__restrict__ arena, SegGeom g, uint32_t n_seg, int32_t n_ref,
-                           uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, uint16_t *seg_cp) {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+                           uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, uint16_t *seg_cp, uint32_t s_begin) {
+    uint32_t s = s_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seg) return;
     uint16_t *cp = seg_cp + (size_t)s * kSegCpSlots;
     uint64_t a, b, lim; bool first;
@@ -641,9 +649,9 @@ __global__ void k_seg_truncate(SegGeom g, uint32_t n_seg, uint32_t last, uint64_
 }
 
 void launch_seg_walk(const uint8_t *arena, SegGeom g, uint32_t n_seg, int32_t n_ref, uint64_t *seg_start,
-                     uint64_t *seg_exit, uint32_t *seg_cnt, uint16_t *seg_cp, hipStream_t stream) {
-    if (!n_seg) return;
-    hipLaunchKernelGGL(k_seg_walk, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, g, n_seg, n_ref, seg_start, seg_exit, seg_cnt, seg_cp);
+                     uint64_t *seg_exit, uint32_t *seg_cnt, uint16_t *seg_cp, hipStream_t stream, uint32_t s_begin) {
+    if (n_seg <= s_begin) return;
+    hipLaunchKernelGGL(k_seg_walk, dim3((n_seg - s_begin + 63) / 64), dim3(64), 0, stream, arena, g, n_seg, n_ref, seg_start, seg_exit, seg_cnt, seg_cp, s_begin);
 }
 void launch_seg_verify(const uint8_t *arena, SegGeom g, uint32_t n_seg, const uint64_t *seg_start_in,
                        const uint64_t *seg_exit_in, const uint32_t *seg_cnt_in, uint64_t *seg_start_out, uint64_t *seg_exit_out,

@@ -7,6 +7,10 @@ extern "C" int emu_inflate(const uint8_t *in, uint32_t in_len, uint8_t *out, uin
     rgx::HostTab T;
     return rgx::inflate_raw(in, in_len, out, cap, out_len, T);
 }
+extern "C" int emu_inflate_lits(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t cap, uint32_t *out_len) {
+    rgx::HostTab T;
+    return rgx::inflate_raw<4>(in, in_len, out, cap, out_len, T);
+}
 
 // the round-2 decoder (inflate_ring.h: per-lane LDS window, cooperative line flush) with a one-lane wave.  The member is inflated into
 // a private buffer at destination phase `phase` (address % 128) with guard bytes around it: returns -100 / -101 if a byte in front of /

@@ -149,7 +149,7 @@ def test_cli_binary_writes_identical_file(gpu_ctx, tmp_path):
     assert subprocess.run([exe, "junctions", "extract", "-s", "XS", "missing.bam"], stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode == 1
 
 
-FORMS = [(1, "lane"), (2, "wave"), (3, "ring"), (4, "coop")]       # rgx_k_inflate_form: k_inflate, k_inflate_wave, k_inflate_ring, k_inflate_coop
+FORMS = [(1, "lane"), (2, "wave"), (3, "ring"), (4, "coop"), (5, "lane4")]       # rgx_k_inflate_form: k_inflate, k_inflate_wave, k_inflate_ring, k_inflate_coop, k_inflate<.., 4 literals per trip>
 
 
 @pytest.mark.parametrize("form", [f for f, _ in FORMS], ids=[n for _, n in FORMS])

@@ -44,6 +44,11 @@ def inflate(emu, payload, cap=65536):
     assert (st3 == 0) == (st == 0), (st, st3)
     if st == 0:
         assert out3.raw[:n3.value] == got, "wave decoder differs"
+    # ... and the lane decoder taking up to four literals per trip (same symbols in the same order, same status)
+    out5 = ctypes.create_string_buffer(cap + 64)
+    n5 = ctypes.c_uint32(0)
+    st5 = emu.emu_inflate_lits(buf, len(payload), out5, cap, ctypes.byref(n5))
+    assert st5 == st and n5.value == n.value and out5.raw[:n5.value] == got, (st, st5, n.value, n5.value)
     # ... and round 3's decoder (inflate_coop.h): long matches split into head / wave-copied aligned body / tail
     for pairs in (0, 1, 2, 3):                         # with and without the second symbol of a trip (bit 0), plain / windowed bit reader (bit 1)
         out4 = ctypes.create_string_buffer(cap + 64)
