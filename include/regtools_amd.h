@@ -240,6 +240,11 @@ void rgx_identify_params_default(rgx_identify_params *p);   /* CisSpliceEffectsI
 /* Whole command: reads the four files, runs the interval kernels and the extraction on the device, writes -o/-v/-j.
  * Error texts and the exit-code mapping are the reference's (nonzero return == exit 1). */
 int  rgx_identify(rgx_ctx *ctx, const rgx_identify_params *p, rgx_identify_stats *stats, char *err, size_t errlen);
+/* The same over several devices: the BAM's extraction is sharded over `devices` the way rgx_extract_multi shards it (contiguous member
+ * ranges cut at record starts from the index), the junction events are gathered onto devices[0] in file order with device-to-device copies, and the
+ * join, the annotation and the outputs run there.  Contexts come from the process-wide cache rgx_extract_multi uses; a device may be listed more than
+ * once.  Outputs are byte-identical to rgx_identify's whatever the list. */
+int  rgx_identify_multi(const int *devices, int n_devices, const rgx_identify_params *p, rgx_identify_stats *stats, char *err, size_t errlen);
 
 /* SURVEY 8(f) rows f2/f3 -- the three sibling commands over the same kernels.
  * `cis-splice-effects associate` (CisSpliceEffectsAssociator::associate, cis_splice_effects_associator.cc:234-276): the junctions come

@@ -8,8 +8,10 @@ from .extractor import Context, RegtoolsError, STRANDNESS
 
 
 class CisSpliceEffectsIdentifier(object):
-    def __init__(self, ctx=None, device=0):
-        self._ctx, self._device = ctx, device
+    def __init__(self, ctx=None, device=0, devices=None):
+        """devices = [d0, d1, ...]: the BAM's extraction is sharded over these GPUs (rgx_identify_multi; a device may be listed twice), everything
+        behind it runs on d0.  The outputs do not depend on the list."""
+        self._ctx, self._device, self._devices = ctx, device, list(devices) if devices else None
         self.p = _ffi.IdentifyParams()
         _ffi.lib().rgx_identify_params_default(C.byref(self.p))
         self.stats = {}
@@ -59,6 +61,15 @@ class CisSpliceEffectsIdentifier(object):
 
     # cis_splice_effects_identifier.cc:256-312
     def identify(self):
+        if self._devices and len(self._devices) > 1:
+            st = _ffi.IdentifyStats()
+            err = C.create_string_buffer(512)
+            dev = (C.c_int * len(self._devices))(*self._devices)
+            rc = _ffi.lib().rgx_identify_multi(dev, len(self._devices), C.byref(self.p), C.byref(st), err, len(err))
+            if rc != 0:
+                raise RegtoolsError(rc, err.value.decode())
+            self.stats = {n: getattr(st, n) for n, _ in st._fields_}
+            return 0
         return self._run(_ffi.lib().rgx_identify)
 
     def _run(self, fn):

@@ -291,10 +291,18 @@ int cse_identify(int argc, char **argv, bool associate = false) {
         char err[512] = {0};
         rgx_ctx *ctx = nullptr;
         int dev = 0; if (const char *d = getenv("REGTOOLS_AMD_DEVICE")) dev = atoi(d);
-        if (rgx_ctx_create(dev, &ctx, err, sizeof err) != RGX_OK) throw std::runtime_error(err);
+        // REGTOOLS_AMD_DEVICES=0,1,...: identify's extraction is sharded over these GPUs (rgx_identify_multi); the outputs do not depend on the list
+        std::vector<int> devices;
+        if (const char *d = getenv("REGTOOLS_AMD_DEVICES")) {
+            for (const char *q = d; *q;) { char *e; long v = strtol(q, &e, 10); if (e == q) break; devices.push_back((int)v); q = *e == ',' ? e + 1 : e; if (*e && *e != ',') break; }
+        }
+        if (devices.size() == 1) dev = devices[0];
+        const bool multi = !associate && devices.size() > 1;
+        if (!multi && rgx_ctx_create(dev, &ctx, err, sizeof err) != RGX_OK) throw std::runtime_error(err);
         rgx_identify_stats st;
-        int rc = associate ? rgx_associate(ctx, &p, &st, err, sizeof err) : rgx_identify(ctx, &p, &st, err, sizeof err);
-        rgx_ctx_destroy(ctx);
+        int rc = associate ? rgx_associate(ctx, &p, &st, err, sizeof err)
+                           : multi ? rgx_identify_multi(devices.data(), (int)devices.size(), &p, &st, err, sizeof err) : rgx_identify(ctx, &p, &st, err, sizeof err);
+        if (ctx) rgx_ctx_destroy(ctx);
         if (rc != RGX_OK) throw std::runtime_error(err);
         if (barcodes != "NA") {
             // identify's extractor is built without a barcode file (identifier.cc:288 -> junctions_extractor.h:197-205), so every junction's map

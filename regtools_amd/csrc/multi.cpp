@@ -105,6 +105,11 @@ rgx_ctx *context_for(int device, int nth, char *err, size_t errlen, int &rc) {
     return c;
 }
 
+}  // namespace
+// (for rgx_identify_multi, cse_api.inc: the same cache)
+rgx_ctx *rgx_multi_context(int device, int nth, char *err, size_t errlen, int *rc) { int r = RGX_OK; rgx_ctx *c = context_for(device, nth, err, errlen, r); if (rc) *rc = r; return c; }
+namespace {
+
 // What the exchange needs besides the contexts, per device LIST: RCCL communicators (ncclCommInitAll on an 8-GPU node takes hundreds of
 // milliseconds -- once, not per call), one stream and one send buffer per entry, the receive block on the first device.  Buffers grow,
 // nothing is handed back before the process ends (rgx_extract_multi calls take turns: call_mu).

@@ -256,3 +256,40 @@ def test_junction_scan_wave_form_equals_the_lane_form(gpu_ctx, work):
     assert len(rows) > 200
     # (the test is about junctions with many candidates: some row lists more than 64 transcripts' worth of skipped elements or transcripts)
     assert max(len(r.split("\t")[16].split(",")) for r in rows[1:]) >= 3
+
+
+def test_identify_over_several_device_listings_gives_the_same_files(gpu_ctx, work):
+    """rgx_identify_multi: the extraction sharded over the listed devices, the events gathered on the first, the rest as on one device.
+    One GPU is visible here, so the list names it two and five times (its shards take turns on it): the shard cuts, the per-shard extraction, the
+    gather in file order and the join over the gathered events are the real ones, the copies are device-local.  Through the Python mirror and the
+    CLI (REGTOOLS_AMD_DEVICES), with -s XS and with the window option."""
+    import regtools_amd
+    from regtools_amd import synth
+    from regtools_amd.cse import CisSpliceEffectsIdentifier
+    pre = os.path.join(str(work), "multi")
+    st = synth.write(pre + ".bam", 1_500_000, shape="short", seed=23, n_genes=6_000)
+    assert os.path.getsize(pre + ".bam") > (8 << 20)                  # (smaller files are not sharded)
+    ann = synth.annotation(pre, 6_000, 30_000, seed=23, fasta=True)
+
+    def run(tag, devices, extra):
+        ci = CisSpliceEffectsIdentifier(ctx=gpu_ctx if not devices else None, devices=devices)
+        o = pre + "." + tag
+        ci.parse_options(["-s", "XS"] + extra + ["-o", o + ".tsv", "-v", o + ".vcf", "-j", o + ".bed", ann["vcf"], pre + ".bam", ann["fasta"], ann["gtf"]])
+        ci.identify()
+        return [open(o + e, "rb").read() for e in (".tsv", ".vcf", ".bed")], ci.stats
+
+    for extra in ([], ["-w", "5000"]):
+        one, s1 = run("one", None, extra)
+        assert len(one[0].splitlines()) > 500
+        for devices in ([0, 0], [0, 0, 0, 0, 0]):
+            got, sm = run("m%d" % len(devices), devices, extra)
+            assert got == one, (devices, extra)
+            assert sm["n_records"] == s1["n_records"] == st["n_reads"] and sm["n_events"] == s1["n_events"]
+    exe = os.path.join(ROOT, "bin", "regtools-amd")
+    o = pre + ".cli"
+    r = subprocess.run([exe, "cis-splice-effects", "identify", "-s", "XS", "-o", o + ".tsv", "-v", o + ".vcf", "-j", o + ".bed", ann["vcf"], pre + ".bam", ann["fasta"], ann["gtf"]],
+                       env=dict(os.environ, REGTOOLS_AMD_DEVICES="0,0,0", REGTOOLS_AMD_TRACE="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count(b"launch inflate") == 3, r.stderr[-3000:]             # (three shards were extracted, not one file)
+    base, _ = run("one", None, [])
+    assert [open(o + e, "rb").read() for e in (".tsv", ".vcf", ".bed")] == base
