@@ -26,14 +26,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # the whole-file launch of the DEFLATE kernel the pipeline runs above 2048 members (kernels.hip launch_inflate; REGTOOLS_AMD_INFLATE overrides)
-INFLATE_KERNEL = {"lane": "rgx::k_inflate<false, false>", "ring": "rgx::k_inflate_ring<false>", "wave": "rgx::k_inflate_wave"}.get(
+INFLATE_KERNEL = {"lane": "rgx::k_inflate<false, false, 1>", "ring": "rgx::k_inflate_ring<false>", "wave": "rgx::k_inflate_wave"}.get(
     os.environ.get("REGTOOLS_AMD_INFLATE", ""), "rgx::k_inflate_coop<false, false, true>")
 
 
 def inflate_kernel_for(compressed, inflated):
-    """kernels.h inflate_plan_for: a payload that compresses less than 8x takes the round-1 lane form"""
+    """kernels.h inflate_plan_for: a payload that compresses less than 8x takes the round-1 lane form, up to four literals per trip"""
     if not os.environ.get("REGTOOLS_AMD_INFLATE") and compressed * 8 > inflated:
-        return "rgx::k_inflate<false, false>"
+        return "rgx::k_inflate<false, false, 4>" if os.environ.get("REGTOOLS_AMD_INFLATE_LITS", "4") != "1" else "rgx::k_inflate<false, false, 1>"
     if not os.environ.get("REGTOOLS_AMD_INFLATE") and compressed * 32 <= inflated:
         return "rgx::k_inflate_coop<false, false, false>"       # run-length payloads: plain bit reader, file-order lanes
     return INFLATE_KERNEL
