@@ -1641,6 +1641,13 @@ extern "C" int rgx_table_merge_barcodes(const rgx_junction_table *const *parts, 
     for (uint64_t i = 0; i < t->n; ++i) row_of[Key{t->tid[i], t->start[i], t->end[i], cls(t->strand[i])}] = i;
     struct Ent { const char *s; uint32_t len; uint32_t count; };
     std::vector<std::vector<Ent>> per_row((size_t)t->n);
+    // a junction of a single-cell library carries thousands of barcodes, times the shards: rows that grow past a few entries get an index
+    // (barcode bytes -> entry) instead of the linear scan the common few-barcode rows keep
+    struct SvHash { size_t operator()(const std::pair<const char *, uint32_t> &k) const { uint64_t h = 1469598103934665603ull; for (uint32_t i = 0; i < k.second; ++i) h = (h ^ (uint8_t)k.first[i]) * 1099511628211ull; return (size_t)h; } };
+    struct SvEq { bool operator()(const std::pair<const char *, uint32_t> &a, const std::pair<const char *, uint32_t> &b) const { return a.second == b.second && !memcmp(a.first, b.first, a.second); } };
+    typedef std::unordered_map<std::pair<const char *, uint32_t>, uint32_t, SvHash, SvEq> RowIndex;
+    std::unordered_map<uint64_t, RowIndex> row_index;
+    constexpr size_t kScanRows = 16;
     std::vector<uint64_t> order;
     for (int g = 0; g < n_parts; ++g) {
         const rgx_junction_table *p = parts[g];
@@ -1655,9 +1662,12 @@ extern "C" int rgx_table_merge_barcodes(const rgx_junction_table *const *parts, 
                 const char *str = p->bc_text + p->bc_str_begin[k];
                 const uint32_t len = (uint32_t)(p->bc_str_begin[k + 1] - p->bc_str_begin[k]);
                 bool found = false;
-                if (dst.size() > 16) {                                                            // many barcodes on one junction: a set, not a scan
-                    // (built lazily per call site would cost more than it saves for the common few-barcode rows)
-                    for (Ent &x : dst) if (x.len == len && !memcmp(x.s, str, len)) { x.count += p->bc_count[k]; found = true; break; }
+                if (dst.size() > kScanRows) {
+                    RowIndex &ix = row_index[it->second];
+                    if (ix.empty()) for (uint32_t q = 0; q < dst.size(); ++q) ix.emplace(std::make_pair(dst[q].s, dst[q].len), q);     // (the row just outgrew the scan)
+                    auto f = ix.find(std::make_pair(str, len));
+                    if (f != ix.end()) { dst[f->second].count += p->bc_count[k]; found = true; }
+                    else ix.emplace(std::make_pair(str, len), (uint32_t)dst.size());
                 } else for (Ent &x : dst) if (x.len == len && !memcmp(x.s, str, len)) { x.count += p->bc_count[k]; found = true; break; }
                 if (!found) dst.push_back(Ent{str, len, p->bc_count[k]});
             }
