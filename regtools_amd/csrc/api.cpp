@@ -620,7 +620,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     std::vector<VChunk> chunks;
     bool chunked = false;
     const bool geom_chunked_hint = !whole;                    // (region queries keep the checked path: their chunk table wants the members' verdicts)
-    if (!whole && p->n_shards <= 1 && p->region) {
+    if (!whole && p->region) {
         const size_t head_len = std::min<size_t>(bam_len, (size_t)8 << 20);
         std::vector<uint8_t> head_copy;
         const uint8_t *head = h_bam;
@@ -630,6 +630,19 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         if (host_bam_header(head, head_len, hh) && parse_region(hh, p->region, tid, beg, end) && tid < bi.n_ref && end >= beg &&
             region_chunks(bai, bai_len, tid, beg, end, chunks)) {
             chunked = true;
+            if (p->n_shards > 1) {
+                // a region query over several shards: the iterator's chunk list is dealt out in order, in runs of about equal compressed size;
+                // shard g follows its run as an iterator of its own, and the one that meets the record that ends the iteration says so
+                // (stream_ended): the merge ignores the shards behind it, as it does behind damage
+                std::vector<uint64_t> before(chunks.size() + 1, 0);
+                for (size_t k = 0; k < chunks.size(); ++k) before[k + 1] = before[k] + std::max<uint64_t>(1, (chunks[k].v >> 16) - (chunks[k].u >> 16));
+                const uint64_t W = std::max<uint64_t>(1, before[chunks.size()]);
+                std::vector<VChunk> mine;
+                for (size_t k = 0; k < chunks.size(); ++k)
+                    if ((int)std::min<uint64_t>((uint64_t)p->n_shards - 1, before[k] * (uint64_t)p->n_shards / W) == p->shard) mine.push_back(chunks[k]);
+                chunks.swap(mine);
+                cut_lo = seek ? seek_voff : 0; cut_hi = UINT64_MAX;     // (the byte cuts above were for a whole-file read)
+            }
             if (!chunks.empty()) {
                 // like the iterator's bgzf_seek: reading starts at the first chunk whatever the state of the members in front of it
                 uint64_t hi = 0;
@@ -901,8 +914,10 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         const uint64_t cut_lim = arena_of(cut_hi, h_sc[26], q_upos[2]);
         const uint32_t mh = h_sc[26];
         const uint32_t hi_wanted = (mh < n_members_all && (cut_hi & 0xffff)) ? mh + 1 : mh;
-        if (h_sc[0] != 0xffffffffu && lim < cut_lim) P.stream_ended = true;        // a member in front of the cut does not inflate
-        if (stop < std::min(hi_wanted, n_members_all)) P.stream_ended = true;      // an empty / unusable member in front of the cut (bgzf.c:548-578)
+        // (a region's chunks are seeks of their own: what lies between two of them ends nothing, and a chunk whose reader does run into such a
+        //  member reports it through its chain, below)
+        if (!chunked && h_sc[0] != 0xffffffffu && lim < cut_lim) P.stream_ended = true;        // a member in front of the cut does not inflate
+        if (!chunked && stop < std::min(hi_wanted, n_members_all)) P.stream_ended = true;      // an empty / unusable member in front of the cut (bgzf.c:548-578)
         lim = std::min(lim, cut_lim);
     } else if (h_sc[0] != 0xffffffffu) P.stream_ended = true;
     if (pos0 > lim) pos0 = lim;
@@ -1134,6 +1149,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         }
         n_events = h_sc[4]; n_long = h_sc[5];
         n_iterated = h_sc[8];
+        if (geom.chunks && p->n_shards > 1 && h_sc[80] != 0xffffffffu) P.stream_ended = true;      // this shard read the record that ends the iteration (hts.c:1946-1950)
         if (n_long) launch_long_fill(n_seg, seg_base, seg_cnt[cur], seg_long_base, cfg, soa, long_list, st);
     }
     HIP_TRY(hipEventRecord(c->ev[4], st));

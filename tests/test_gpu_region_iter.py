@@ -30,6 +30,24 @@ def gpu_extract(ctx, bam, args):
     return 0, je.bed12(), je
 
 
+def gpu_extract_sharded(ctx, bam, args, n_shards):
+    """The same query with the iterator's chunk list dealt to n_shards shards (api.cpp: runs of the list, in order) and the shard tables merged:
+    what several ranks / devices would do with a region query.  (0, bed12) or (1, b"")."""
+    import regtools_amd
+    from regtools_amd import distributed
+    keep, parts = [], []
+    for g in range(n_shards):
+        je = regtools_amd.JunctionsExtractor(ctx=ctx, shard=g, n_shards=n_shards)
+        try:
+            je.parse_options(list(args) + [bam])
+            je.identify_junctions_from_BAM()
+        except regtools_amd.RegtoolsError:
+            return 1, b""
+        keep.append(je)
+        parts.append(distributed.pack_table(je.table))
+    return 0, distributed.merge_packed(parts, keep[0].table, 8).bed12()
+
+
 @pytest.fixture(scope="module")
 def bams(tmp_path_factory):
     d = tmp_path_factory.mktemp("unsorted_gpu")
@@ -40,7 +58,10 @@ def bams(tmp_path_factory):
 def test_out_of_order_record_equals_reference(gpu_ctx, bams, kind, region):
     rc, out, _ = gpu_extract(gpu_ctx, bams[kind], ["-s", "XS", "-r", region])
     assert rc == 0
-    assert out == open(os.path.join(GOLD, uc.golden_name(kind, region)), "rb").read()
+    want = open(os.path.join(GOLD, uc.golden_name(kind, region)), "rb").read()
+    assert out == want
+    for n in (2, 5):
+        assert gpu_extract_sharded(gpu_ctx, bams[kind], ["-s", "XS", "-r", region], n) == (0, want), n
 
 
 @pytest.mark.parametrize("shape,n,seed", sc.SHAPES)
@@ -60,6 +81,7 @@ def test_stale_index_region_queries_equal_oracle(gpu_ctx, tmp_path, shape, n, se
             assert (rc != 0) == (orc_rc != 0), (case, region)
             if rc == 0:
                 assert out == orc_out, (case, region)
+                assert gpu_extract_sharded(gpu_ctx, path, args, 3) == (0, orc_out), (case, region)
             checked += 1
     assert checked == 2 * sc.N_VARIANTS
 
@@ -85,3 +107,4 @@ def test_empty_member_between_chunks_ends_one_chunk_only(gpu_ctx, tmp_path):
             assert (rc != 0) == (orc_rc != 0), (case, region)
             if rc == 0:
                 assert out == orc_out, (case, region)
+                assert gpu_extract_sharded(gpu_ctx, path, args, 2) == (0, orc_out), (case, region)
