@@ -79,6 +79,7 @@ struct rgx_ctx {
     // host input (rgx_extract_mem / rgx_extract): the file goes up in chunks on its own stream while the members that have arrived are
     // being inflated on the side streams (prepare_events)
     hipStream_t copy_stream = nullptr, side[kSideStreams] = {};
+    bool one_shot = false;                             // REGTOOLS_AMD_ONE_SHOT at creation: no streams besides `stream` (ensure_upload_streams)
     std::vector<hipEvent_t> chunk_ev;
     hipEvent_t ev_ready = nullptr, ev_side[kSideStreams] = {};
     hipEvent_t ev[8] = {};
@@ -155,6 +156,7 @@ extern "C" int rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errle
     rgx_ctx *c = new rgx_ctx();
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    { const char *e = getenv("REGTOOLS_AMD_ONE_SHOT"); c->one_shot = e && strcmp(e, "0") != 0; }
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
     c->pinned_cap = 4096;
@@ -165,7 +167,11 @@ extern "C" int rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errle
 // the copy stream and the side streams of the overlapped upload: made when a call first takes that path (a one-shot process that reads a
 // small file never pays for them; eight stream creations are ~100 ms of a cold start)
 static hipError_t ensure_upload_streams(rgx_ctx *c) {
-    if (c->copy_stream) return hipSuccess;
+    if (c->copy_stream || c->ev_ready) return hipSuccess;
+    // A process that makes one call (bin/regtools-amd: REGTOOLS_AMD_ONE_SHOT, set by its main()) does without streams of its own: creating
+    // the copy stream and two side streams costs 24-30 ms (8-10 ms per hardware queue), the overlap they buy -- upload under inflate, three inflate
+    // launches side by side -- 5 ms of a call: the file goes up in one piece on the context's stream, one inflate launch follows it.
+    if (c->one_shot) return hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
     hipError_t e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     if (e != hipSuccess) return e;
     // the runtime maps the streams of one priority onto four hardware queues; streams of another priority come from another pool of queues
@@ -389,6 +395,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     if (p->strandness == 3 && !p->fasta_path) return fail(err, errlen, RGX_ERR_ARG, "Strandness mode 'intron-motif' requires a fasta file!\n\n");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    hipStream_t copy_q = c->copy_stream ? c->copy_stream : c->stream;     // where the file's upload goes (a one-shot context: its only stream)
     const double t_begin = now_ms();
     const bool trace = getenv("REGTOOLS_AMD_TRACE") != nullptr;
     double t_last = t_begin;
@@ -425,9 +432,12 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         DevBuf &b = c->buf("bam");
         HIP_TRY(b.ensure(bam_len + 64));
         d_bam = b.as<uint8_t>();
+        mark("file buffer in HBM");
         static const bool no_overlap = getenv("REGTOOLS_AMD_NO_OVERLAP") != nullptr;
         if (allow_overlap && !d_true_sizes && !no_overlap && bam_len >= ((size_t)8 << 20)) {
             HIP_TRY(ensure_upload_streams(c));
+            if (c->copy_stream) copy_q = c->copy_stream;
+            mark("upload streams");
             // A shard of a file whose members the caller scanned: only the bytes this shard reads go up -- the header's members and the
             // range between its two cuts (the same cuts as below, from the index) -- N shards then move the file once, not N times.
             size_t up_lo = 0, up_hi = bam_len, hdr_hi = 0;
@@ -459,6 +469,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             // (tools/lab/pieces.sh): the concurrent launches share the chip, finer pieces do not end sooner.
             // REGTOOLS_AMD_PIECES="33,67" = the cuts in %, or "N" = N equal pieces, for experiments.
             std::vector<unsigned> cuts = {33, 67};
+            if (c->one_shot) cuts.clear();                            // (one stream: pieces would only take turns on it)
             if (const char *e = getenv("REGTOOLS_AMD_PIECES")) {
                 unsigned a = 0, b = 0;
                 if (sscanf(e, "%u,%u", &a, &b) == 2) { if (a > 0 && a < b && b < 100) cuts = {a, b}; }
@@ -472,14 +483,14 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             up.lo = up_lo; up.hi = up_hi; up.hdr_hi = hdr_hi;
             while (c->chunk_ev.size() < up.end.size()) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->chunk_ev.push_back(e); }
             uint8_t *dst = b.as<uint8_t>();
-            up.copy_stream = c->copy_stream;
-            up.th = std::thread([c, dst, h_bam, hdr_hi, up_lo, &up] {
+            up.copy_stream = copy_q;
+            up.th = std::thread([c, dst, h_bam, hdr_hi, up_lo, copy_q, &up] {
                 if (hipSetDevice(c->device) != hipSuccess) { up.err = 1; up.recorded = (uint32_t)up.end.size(); return; }
-                if (hdr_hi && hipMemcpyAsync(dst, h_bam, hdr_hi, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) up.err = 1;
+                if (hdr_hi && hipMemcpyAsync(dst, h_bam, hdr_hi, hipMemcpyHostToDevice, copy_q) != hipSuccess) up.err = 1;
                 size_t o = up_lo;
                 for (size_t j = 0; j < up.end.size(); ++j) {
-                    if ((up.end[j] > o && hipMemcpyAsync(dst + o, h_bam + o, up.end[j] - o, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) ||
-                        hipEventRecord(c->chunk_ev[j], c->copy_stream) != hipSuccess) up.err = 1;
+                    if ((up.end[j] > o && hipMemcpyAsync(dst + o, h_bam + o, up.end[j] - o, hipMemcpyHostToDevice, copy_q) != hipSuccess) ||
+                        hipEventRecord(c->chunk_ev[j], copy_q) != hipSuccess) up.err = 1;
                     o = up.end[j];
                     up.recorded.store((uint32_t)j + 1, std::memory_order_release);
                 }
@@ -491,9 +502,9 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
                 up.th.join();
                 if (up.err) return fail(err, errlen, RGX_ERR_DEVICE, "regtools_amd: upload failed\n");
                 if (up_lo || up_hi < bam_len) {                 // (only a range went up: the rest before the device looks at the file)
-                    if (up_lo > hdr_hi) HIP_TRY(hipMemcpyAsync(dst + hdr_hi, h_bam + hdr_hi, up_lo - hdr_hi, hipMemcpyHostToDevice, c->copy_stream));
-                    if (up_hi < bam_len) HIP_TRY(hipMemcpyAsync(dst + up_hi, h_bam + up_hi, bam_len - up_hi, hipMemcpyHostToDevice, c->copy_stream));
-                    HIP_TRY(hipEventRecord(c->chunk_ev[up.end.size() - 1], c->copy_stream));
+                    if (up_lo > hdr_hi) HIP_TRY(hipMemcpyAsync(dst + hdr_hi, h_bam + hdr_hi, up_lo - hdr_hi, hipMemcpyHostToDevice, copy_q));
+                    if (up_hi < bam_len) HIP_TRY(hipMemcpyAsync(dst + up_hi, h_bam + up_hi, bam_len - up_hi, hipMemcpyHostToDevice, copy_q));
+                    HIP_TRY(hipEventRecord(c->chunk_ev[up.end.size() - 1], copy_q));
                 }
                 HIP_TRY(hipStreamWaitEvent(st, c->chunk_ev[up.end.size() - 1], 0));
             }
@@ -503,7 +514,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     auto complete_upload = [&]() -> hipError_t {
         if (!h_bam || !(up.lo || (up.hi && up.hi < bam_len))) return hipSuccess;
         if (up.th.joinable()) up.th.join();
-        hipError_t e = hipStreamSynchronize(c->copy_stream);
+        hipError_t e = hipStreamSynchronize(copy_q);
         uint8_t *dst = c->buf("bam").as<uint8_t>();
         if (e == hipSuccess && up.lo > up.hdr_hi) e = hipMemcpy(dst + up.hdr_hi, h_bam + up.hdr_hi, up.lo - up.hdr_hi, hipMemcpyHostToDevice);
         if (e == hipSuccess && up.hi < bam_len) e = hipMemcpy(dst + up.hi, h_bam + up.hi, bam_len - up.hi, hipMemcpyHostToDevice);
@@ -689,7 +700,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         // the index points at something that is no member of this (well-formed) file: the device's discovery decides what that means
         up.th.join();
         HIP_TRY(complete_upload());
-        HIP_TRY(hipStreamSynchronize(c->copy_stream));
+        HIP_TRY(hipStreamSynchronize(copy_q));
         HIP_TRY(hipStreamSynchronize(st));
         const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, nullptr, false, region_to_file_end);
         P.t_begin = t_begin;
@@ -736,7 +747,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         if (need_lo < up.lo || need_hi > up.hi) {
             mark("shard range does not cover its members: whole-file upload");
             up.th.join();
-            HIP_TRY(hipStreamSynchronize(c->copy_stream));
+            HIP_TRY(hipStreamSynchronize(copy_q));
             HIP_TRY(hipStreamSynchronize(st));
             const int rc2 = prepare_events(c, d_bam_in, h_bam, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, d_true_sizes, allow_overlap, region_to_file_end, nullptr);
             P.t_begin = t_begin;
@@ -1063,7 +1074,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
                 // some member did not inflate to its footer's length: nothing enqueued since is worth anything
                 mark("inflate verdict: not clean, starting over device-resident");
                 HIP_TRY(complete_upload());
-                HIP_TRY(hipStreamSynchronize(c->copy_stream));
+                HIP_TRY(hipStreamSynchronize(copy_q));
                 const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, nullptr, false, region_to_file_end);
                 P.t_begin = t_begin;
                 return rc2;
@@ -1090,7 +1101,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         HIP_TRY(hipStreamSynchronize(st));
         if (h_sc[0] != 0xffffffffu || h_sc[kStatusEarly] != 0xffffffffu) {
             HIP_TRY(complete_upload());
-            HIP_TRY(hipStreamSynchronize(c->copy_stream));
+            HIP_TRY(hipStreamSynchronize(copy_q));
             const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, nullptr, false, region_to_file_end);
             P.t_begin = t_begin;
             return rc2;
@@ -1101,7 +1112,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         // a chunk's chain stopped -- possibly only because a record runs past the members the index asked for (an index that does not
         // describe this file): once more with everything up to the end of the file inflated
         mark("region: chain ended, re-reading to the end of the file");
-        if (overlap) { HIP_TRY(complete_upload()); HIP_TRY(hipStreamSynchronize(c->copy_stream)); }
+        if (overlap) { HIP_TRY(complete_upload()); HIP_TRY(hipStreamSynchronize(copy_q)); }
         const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, d_true_sizes, false, true);
         P.t_begin = t_begin;
         return rc2;

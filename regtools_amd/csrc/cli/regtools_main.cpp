@@ -395,6 +395,7 @@ int cse_main(int argc, char **argv) {
 
 // regtools.cc:36-74
 int main(int argc, char **argv) {
+    setenv("REGTOOLS_AMD_ONE_SHOT", "1", 0);                   // this process makes one library call: the context does without streams of its own (api.cpp ensure_upload_streams)
     std::cerr << "\nProgram:\tregtools (MI355X build)\nVersion:\t" << rgx_version() << std::endl;
     if (argc > 1) {
         std::string sub = argv[1];
