@@ -54,16 +54,24 @@ uint32_t bitlen(uint32_t v) { uint32_t b = 0; while (v) { ++b; v >>= 1; } return
 // growable device buffer that survives across calls (workspace reuse: no hipMalloc in steady state)
 // Every buffer starts kFront bytes into its allocation: k_inflate_ring's far copies load their source from up to 15 bytes in front of it
 // (inflate_ring.h, kArenaFrontPad), and for the first member of an arena that is in front of the buffer.
+struct AllocStats { double ms = 0; uint64_t calls = 0, bytes = 0; };
+static AllocStats g_alloc_stats;                                   // (REGTOOLS_AMD_TRACE: what growing the device buffers cost a call)
 struct DevBuf {
     static constexpr size_t kFront = 256;
     void *p = nullptr; size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
+        static const bool trace = getenv("REGTOOLS_AMD_TRACE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         release();
-        size_t want = bytes + bytes / 8 + 256;
+        // (growth slack, so that a context which sees files of slowly growing size does not reallocate per call; a one-shot process gets what it asks
+        //  for: device memory is cleared when it is handed out, 15.6 GB cost such a process 60-360 ms -- 1.7 GB of that was slack)
+        static const bool no_slack = [] { const char *e = getenv("REGTOOLS_AMD_ONE_SHOT"); return e && strcmp(e, "0") != 0; }();      // (first use: after main() said so)
+        size_t want = bytes + (no_slack ? 0 : bytes / 8) + 256;
         void *raw = nullptr;
         hipError_t e = hipMalloc(&raw, want + kFront);
         if (e == hipSuccess) { p = (uint8_t *)raw + kFront; cap = want; }
+        if (trace) { g_alloc_stats.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++g_alloc_stats.calls; g_alloc_stats.bytes += want; }
         return e;
     }
     void release() { if (p) (void)hipFree((uint8_t *)p - kFront); p = nullptr; cap = 0; }
@@ -1509,7 +1517,10 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     (void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); t->ms_scan = ms;
     (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); t->ms_reduce = ms;
     t->ms_total = now_ms() - P.t_begin;
-    if (getenv("REGTOOLS_AMD_TRACE")) fprintf(stderr, "[rgx trace] total %.3f ms\n", t->ms_total);
+    if (getenv("REGTOOLS_AMD_TRACE")) {
+        fprintf(stderr, "[rgx trace] total %.3f ms; device buffers grown so far: %llu allocations, %.1f MB, %.3f ms\n", t->ms_total, (unsigned long long)g_alloc_stats.calls,
+                (double)g_alloc_stats.bytes / 1e6, g_alloc_stats.ms);
+    }
     *out = t;
     return RGX_OK;
 }
