@@ -78,7 +78,7 @@ VARIANTS = {
     "hotlaneload": [HOT_LANE_LOADS],
     "bitwin": BITWIN,
     "bitwin_loadsonly": BITWIN + SINK + [NO_STAGE_STORES],
-    "onesym": [P("inflate_coop.h", "#define RGX_TWO_SYMBOLS 1", "#define RGX_TWO_SYMBOLS 0")],
+    # ("onesym" -- one symbol per trip -- is a run-time choice now: REGTOOLS_AMD_INFLATE_PAIRS=0 with the base build)
     "ntstage": [NT_STAGE],
     "ntcoop": [NT_COOP],
     "ntall": [NT_STAGE, NT_COOP],

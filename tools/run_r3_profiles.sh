@@ -13,5 +13,5 @@ bash tools/timeline.sh gpurun_out/r3/prof/tl --steps 2 --warmup 2 --no-extras > 
 # 4. the plain default line (all workloads)
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 # 5. the lab's ablations of k_inflate_coop on this box
-tools/lab/run_coop.sh base onesym noload loadsonly decode_only nostore > $O/inflate_coop_lab.txt 2>&1
+tools/lab/run_coop.sh base noload loadsonly decode_only nostore > $O/inflate_coop_lab.txt 2>&1
 ls -la $O; tail -3 $O/pmc_inflate.txt
