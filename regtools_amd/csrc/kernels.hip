@@ -818,6 +818,82 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
     }
 }
 
+// Long records (k_decode_seg<false>'s workload: two or three records per 16 KiB segment), one LANE per segment.  A wave per segment is a workgroup
+// per two records there -- 4 M workgroups of which one lane works, each a chain of dependent gathers (checkpoint, the records' lengths, head, CIGAR, aux):
+// 10.6 ms for config 5's 10 M records.  Here a lane follows its own segment's records from the verified start; sixty-four chains per wave.
+// Same rows, same counts: the per-record part restates k_decode_seg's with every read from the arena.
+__global__ __launch_bounds__(64) void k_decode_sparse(const uint8_t *__restrict__ arena, uint32_t n_seg, const uint64_t *__restrict__ seg_start,
+                                                      const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt, ExtractCfg cfg, ReadSoA soa,
+                                                      uint32_t *seg_iter, uint32_t *seg_long) {
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    uint32_t first_stop = 0xffffffffu, last_in = 0;
+    if (s < n_seg) {
+        const uint32_t cnt = seg_cnt[s];
+        uint32_t n_iter = 0, n_long = 0;
+        if (cnt) {
+            uint64_t o = seg_start[s];
+            const uint32_t base = seg_base[s];
+            for (uint32_t k = 0; k < cnt; ++k) {
+                RecHead h;
+                rec_head(arena + o, h);
+                const uint8_t *g_data = arena + o + 36;
+                auto cigar_at = [&](uint32_t q) -> uint32_t { return ld32(g_data + h.l_qname + 4 * (size_t)q); };
+                const uint32_t i = base + k;
+                soa.tid[i] = h.tid; soa.pos[i] = h.pos;
+                soa.flag_nc[i] = h.flag << 16 | h.n_cigar;
+                soa.cig_off[i] = o + 36 + h.l_qname;
+                if (soa.rec_off) soa.rec_off[i] = o;
+                bool in_region = true;
+                if (cfg.region_tid != -2) {
+                    in_region = h.tid == cfg.region_tid && h.pos < cfg.region_end;
+                    if (cfg.stop_out) {                                // hts_itr_next's end rule (hts.c:1946-1950), see ExtractCfg
+                        if (i >= cfg.stop_index) in_region = false;
+                        else if (!in_region) first_stop = min(first_stop, i);
+                    }
+                    if (in_region) {                                   // bam_endpos (sam.c:336-342)
+                        int32_t endpos = h.pos + 1;
+                        if (!(h.flag & 4) && h.n_cigar > 0) {
+                            int32_t l = 0;
+                            for (uint32_t q = 0; q < h.n_cigar; ++q) l += (int32_t)cig_ref_len(cigar_at(q));
+                            endpos = h.pos + l;
+                        }
+                        in_region = endpos > cfg.region_beg;
+                    }
+                }
+                n_iter += in_region ? 1u : 0u;
+                if (in_region) last_in = i + 1;
+                uint32_t nev = 0;
+                char strand = '?';
+                if (in_region && h.n_cigar > 1 && h.tid >= 0 && h.tid < cfg.n_ref) {
+                    for (uint32_t q = 0; q < h.n_cigar; ++q) {
+                        const uint32_t c = cigar_at(q);
+                        if (cig_is_N(c)) { const uint32_t len = c >> 4; nev += !(len < cfg.min_intron || len > cfg.max_intron); }
+                    }
+                    if (nev) {
+                        if (cfg.strandness == 0) {
+                            const int64_t l_data = (int64_t)h.block_len - 32;
+                            strand = strand_from_tag(g_data + h.aux_off, g_data + l_data, cfg.tag0, cfg.tag1);
+                        } else strand = strand_from_flag(h.flag, cfg.strandness);
+                        n_long += h.n_cigar > cfg.long_threshold ? 1u : 0u;
+                    }
+                }
+                soa.strand[i] = (uint8_t)strand;
+                soa.n_ev[i] = nev;
+                o += 4 + (uint64_t)(uint32_t)h.block_len;
+            }
+        }
+        seg_iter[s] = n_iter; seg_long[s] = n_long;
+    }
+    if (cfg.stop_out) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { first_stop = min(first_stop, (uint32_t)__shfl_xor((int)first_stop, d, 64)); last_in = max(last_in, (uint32_t)__shfl_xor((int)last_in, d, 64)); }
+        if (threadIdx.x == 0) {
+            if (first_stop < *(volatile uint32_t *)&cfg.stop_out[0]) atomicMin(&cfg.stop_out[0], first_stop);
+            if (last_in > *(volatile uint32_t *)&cfg.stop_out[1]) atomicMax(&cfg.stop_out[1], last_in);
+        }
+    }
+}
+
 // list of the reads that go to the wave-per-read kernel, built without atomics: one wave per segment, positions from the
 // exclusive scan of the per-segment counts
 __global__ __launch_bounds__(64) void k_long_fill(uint32_t n_seg, const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
@@ -839,7 +915,11 @@ void launch_decode_seg(const uint8_t *arena, SegGeom g, uint32_t n_seg, const ui
                        const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, const uint16_t *seg_cp, bool staged, hipStream_t stream) {
     if (!n_seg) return;
     if (staged) hipLaunchKernelGGL(k_decode_seg<true>, dim3(n_seg), dim3(64), kSegBytes + kSegTail + 48, stream, arena, g, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
-    else hipLaunchKernelGGL(k_decode_seg<false>, dim3(n_seg), dim3(64), 0, stream, arena, g, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
+    else {
+        static const bool wave_form = [] { const char *e = getenv("REGTOOLS_AMD_DECODE_SPARSE"); return e && !strcmp(e, "wave"); }();     // (tests / lab: the workgroup-per-segment form it replaced)
+        if (wave_form) hipLaunchKernelGGL(k_decode_seg<false>, dim3(n_seg), dim3(64), 0, stream, arena, g, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
+        else hipLaunchKernelGGL(k_decode_sparse, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long);
+    }
 }
 void launch_long_fill(uint32_t n_seg, const uint32_t *seg_base, const uint32_t *seg_cnt, const uint32_t *seg_long_base, ExtractCfg cfg, ReadSoA soa,
                       uint32_t *long_list, hipStream_t stream) {
