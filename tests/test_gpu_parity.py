@@ -554,3 +554,23 @@ def test_bench_multi_rank_path_on_one_gpu(gpu_ctx, tmp_path):
     je = regtools_amd.JunctionsExtractor(strandness=0, ctx=gpu_ctx)
     je.identify_junctions_from_BAM(bam_bytes=bam, bai_bytes=bai)
     assert open(bedc, "rb").read() == je.bed12()
+
+
+def test_long_record_decode_lane_form_equals_the_wave_form(gpu_ctx, synth_dir):
+    """k_decode_sparse (long records: one lane follows a segment's two or three records) against k_decode_seg<false> (a workgroup per segment,
+    REGTOOLS_AMD_DECODE_SPARSE=wave), through the CLI: whole file, a region query (the end rule's stop / last-in reduction), intron limits; and
+    against the oracle."""
+    from regtools_amd import synth
+    p = os.path.join(str(synth_dir), "sparse_long.bam")
+    synth.write(p, 30000, shape="long", seed=77)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "regtools-amd")
+    for args in (["-s", "XS"], ["-s", "RF", "-m", "200", "-M", "20000"], ["-s", "XS", "-r", "chr2:1000000-90000000"], ["-s", "FR", "-r", "chr1"]):
+        outs = []
+        for form in ("lane", "wave"):
+            o = p + "." + form + ".bed"
+            r = subprocess.run([exe, "junctions", "extract"] + args + ["-o", o, p], env=dict(os.environ, REGTOOLS_AMD_DECODE_SPARSE=form), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0, r.stderr
+            outs.append(open(o, "rb").read())
+        assert outs[0] == outs[1], args
+        assert outs[0] == run_oracle(args + [p])[1], args
+    assert len(outs[0]) > 1000
