@@ -835,7 +835,8 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // the stages behind the inflate are enqueued on the assumption that every member inflates to its footer's length (what a well-formed file
     // does), and the launch's verdict is read with the framing's counts: anything else starts over on the device-resident path below.
     BamHeader hdr_host;
-    const bool spec = overlap && !d_true_sizes && !geom_chunked_hint && host_bam_header(h_bam, std::min<size_t>(bam_len, (size_t)8 << 20), hdr_host);
+    uint32_t mean_rec = 0;                                    // mean size of the file's first records (0 = unknown: 16 KiB segments)
+    const bool spec = overlap && !d_true_sizes && !geom_chunked_hint && host_bam_header(h_bam, std::min<size_t>(bam_len, (size_t)8 << 20), hdr_host, nullptr, &mean_rec);
     if (spec) { h_sc[0] = h_sc[1] = 0xffffffffu; h_sc[kStatusEarly] = h_sc[kStatusEarly + 1] = 0xffffffffu; }
     else {
         HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 8, hipMemcpyDeviceToHost, st));
@@ -902,7 +903,18 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             if (bad_h != 0xffffffffu && bad_h < used) have = hmem[bad_h].upos;          // a corrupt member ends the header read
             uint64_t need = 0;
             int r = parse_bam_header(hbuf.data(), have, hdr, need);
-            if (r == 0) break;
+            if (r == 0) {
+                // how long the file's records are, from the first ones behind the header in the bytes at hand (the host's estimate on the spec path):
+                // files of long records are framed in long segments
+                uint64_t o = hdr.end, sum = 0; uint32_t cnt = 0;
+                while (o + 4 <= have) {
+                    uint32_t bl; memcpy(&bl, hbuf.data() + o, 4);
+                    if (bl < 32 || bl > (1u << 27) || o + 4 + bl > have) break;
+                    sum += 4 + (uint64_t)bl; ++cnt; o += 4 + (uint64_t)bl;
+                }
+                if (cnt >= 4) mean_rec = (uint32_t)(sum / cnt);
+                break;
+            }
             if (r == 2 || used < n_h || n_h == n_members_all || (bad_h != 0xffffffffu && bad_h < used))
                 return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion);   // sam_hdr_read == NULL (cc:519-522)
             n_h = std::min(n_members_all, n_h * 4);
@@ -987,6 +999,9 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // chunk c = virtual offsets [u, v): a seek to u (bgzf_seek: the member at u >> 16, the offset inside it clipped to its length; no such
     // member = the read fails and the iteration is over), then records while the position in front of the next one is below v.
     SegGeom geom; memset(&geom, 0, sizeof geom);
+    static const int env_seg = [] { const char *e = getenv("REGTOOLS_AMD_SEG_BYTES"); return e ? atoi(e) : 0; }();      // (tests / lab) 16384 or 131072
+    const uint32_t seg_bytes = env_seg == (int)kSegBytes || env_seg == (int)kSegBytesLong ? (uint32_t)env_seg : (mean_rec >= kLongRecordBytes ? kSegBytesLong : kSegBytes);
+    geom.seg_bytes = seg_bytes;
     std::vector<SegChunk> seg_chunks;
     if (chunked && chunks.empty()) lim = pos0;                // an iterator without chunks returns nothing
     if (chunked && !chunks.empty() && !empty_stream) {
@@ -1019,7 +1034,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             const uint32_t nb = next_bad[k];
             sc.dlim = nb < n_range ? rm[nb].upos - upos_lo : total;
             sc.seg_base = seg_total;
-            const uint64_t ns = (sc.b - sc.a + kSegBytes - 1) / kSegBytes;
+            const uint64_t ns = (sc.b - sc.a + seg_bytes - 1) / seg_bytes;
             if (seg_total + ns > 0x7fffffffull) return fail(err, errlen, RGX_ERR_FORMAT, "regtools_amd: region too large\n");
             seg_total += (uint32_t)ns;
             seg_chunks.push_back(sc);
@@ -1037,13 +1052,13 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // -- record framing ------------------------------------------------------------------------------------------------
     const uint8_t *arena = b_arena.as<uint8_t>();
     uint64_t span = lim - pos0;
-    uint32_t n_seg = (uint32_t)((span + kSegBytes - 1) / kSegBytes);
-    geom.pos0 = pos0; geom.lim = lim; geom.data_end = lim;
+    uint32_t n_seg = (uint32_t)((span + seg_bytes - 1) / seg_bytes);
+    geom.pos0 = pos0; geom.lim = lim; geom.data_end = lim; geom.seg_bytes = seg_bytes;
     if (geom.chunks) {
         span = 0;
         for (const SegChunk &sc : seg_chunks) span += sc.b - sc.a;
         const SegChunk &lastc = seg_chunks.back();
-        n_seg = lastc.seg_base + (uint32_t)((lastc.b - lastc.a + kSegBytes - 1) / kSegBytes);
+        n_seg = lastc.seg_base + (uint32_t)((lastc.b - lastc.a + seg_bytes - 1) / seg_bytes);
         geom.data_end = total;
     }
     uint32_t n_rec = 0;

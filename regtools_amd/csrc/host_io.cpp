@@ -290,27 +290,49 @@ bool bai_region_span(const uint8_t *d, size_t len, int32_t tid, int32_t beg, int
     return true;
 }
 
-bool host_bam_header(const uint8_t *d, size_t n, BamHeader &h, size_t *consumed) {
+bool host_bam_header(const uint8_t *d, size_t n, BamHeader &h, size_t *consumed, uint32_t *mean_record_bytes) {
     std::string plain;
     size_t off = 0;
+    if (mean_record_bytes) *mean_record_bytes = 0;
+    bool have_header = false;
+    int extra = 0;
+    auto estimate = [&]() -> bool {                                   // records that lie whole in what is inflated so far; true = enough of them
+        uint64_t o = h.end, sum = 0; uint32_t cnt = 0;
+        while (o + 4 <= plain.size()) {
+            const uint32_t bl = h32((const uint8_t *)plain.data() + o);
+            if (bl < 32 || bl > (1u << 27) || o + 4 + bl > plain.size()) break;
+            sum += 4 + (uint64_t)bl; ++cnt; o += 4 + (uint64_t)bl;
+        }
+        if (mean_record_bytes && cnt) *mean_record_bytes = (uint32_t)(sum / cnt);
+        return cnt >= 4;
+    };
     for (int members = 0; off + 18 <= n && members < 4096; ++members) {
-        if (d[off] != 31 || d[off + 1] != 139 || d[off + 2] != 8 || !(d[off + 3] & 4) || d[off + 10] != 6 || d[off + 11] != 0 || d[off + 12] != 'B' || d[off + 13] != 'C') return false;
+        if (d[off] != 31 || d[off + 1] != 139 || d[off + 2] != 8 || !(d[off + 3] & 4) || d[off + 10] != 6 || d[off + 11] != 0 || d[off + 12] != 'B' || d[off + 13] != 'C') return have_header;
         const size_t bl = (size_t)h16(d + off + 16) + 1;
-        if (bl < 26 || off + bl + 16 > n) return false;                    // (the decoder may look 16 bytes past a payload)
+        if (bl < 26 || off + bl + 16 > n) return have_header;                    // (the decoder may look 16 bytes past a payload)
         const uint32_t isz = h32(d + off + bl - 4);
-        if (isz == 0 || isz > 65536) return false;                         // an empty member ends the header read upstream: let the device path judge
+        if (isz == 0 || isz > 65536) return have_header;                         // an empty member ends the header read upstream: let the device path judge
         const size_t base = plain.size();
         plain.resize(base + isz + 64);
         HostTab T; uint32_t got = 0;
-        if (inflate_raw(d + off + 18, (uint32_t)(bl - 26), (uint8_t *)&plain[base], isz, &got, T) != INF_OK || got != isz) return false;
+        if (inflate_raw(d + off + 18, (uint32_t)(bl - 26), (uint8_t *)&plain[base], isz, &got, T) != INF_OK || got != isz) { plain.resize(base); return have_header; }
         plain.resize(base + isz);
         off += bl;
+        if (have_header) {                                                 // (only here for the record-size estimate)
+            if (estimate() || ++extra >= 2) return true;
+            continue;
+        }
         uint64_t need = 0;
         const int r = parse_bam_header((const uint8_t *)plain.data(), plain.size(), h, need);
-        if (r == 0) { if (consumed) *consumed = off; return true; }
+        if (r == 0) {
+            if (consumed) *consumed = off;
+            if (!mean_record_bytes || estimate()) return true;
+            have_header = true;                                            // a few more bytes of the stream, to see some records
+            continue;
+        }
         if (r == 2) return false;
     }
-    return false;
+    return have_header;
 }
 
 static bool readable(const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (!f) return false; fclose(f); return true; }

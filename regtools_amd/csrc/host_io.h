@@ -55,7 +55,8 @@ constexpr uint32_t kCsiMeta = 0xffffffffu;  // the pseudo-bin in the block of re
 // The BAM header from the head of the file, inflated on the host (the product's own decoder): region queries need the contig names
 // BEFORE the device launch to turn the region into a member range.  false = not available this way (the device path will say why).
 struct BamHeader;
-bool host_bam_header(const uint8_t *bam_head, size_t len, BamHeader &h, size_t *consumed = nullptr /* compressed bytes of the members the header spans */);
+bool host_bam_header(const uint8_t *bam_head, size_t len, BamHeader &h, size_t *consumed = nullptr /* compressed bytes of the members the header spans */,
+                     uint32_t *mean_record_bytes = nullptr /* of the first records behind the header (up to two more members are inflated for it); 0 = none seen */);
 
 // hts.c:2009-2042 index file name resolution: "<fn>.csi", "<fn minus extension>.csi", then the same two for ".bai".
 // returns 0 found, 1 none

@@ -82,7 +82,11 @@ struct SegGeom {
     uint64_t pos0, lim;
     uint64_t data_end;             // end of the inflated bytes (k_decode_seg's staging window may reach past a chunk's end)
     const SegChunk *chunks; uint32_t n_chunks;
+    uint32_t seg_bytes;            // kSegBytes, or kSegBytesLong for files of long records (the checkpoints and k_decode_seg only exist for kSegBytes)
 };
+constexpr uint32_t kSegBytesLong = 131072;     // a lane's first-record search reads, on average, half a record of sequence and quality: with records of
+                                               // kilobytes (long reads) 16 KiB segments spend their time there (config 5: k_seg_walk 11.9 ms of a 47 ms tail)
+constexpr uint32_t kLongRecordBytes = 2048;    // mean record size (estimated on the host from the file's first records) from which the long segments are used
 // seg_start[s] = guessed (or, for a chain's first segment, exact) first record start >= segment begin; seg_exit[s] = first record
 // start >= segment end reached by the chain from seg_start[s]; seg_cnt[s] = records that start inside the segment.
 void launch_seg_walk(const uint8_t *arena, SegGeom g, uint32_t n_seg, int32_t n_ref,

@@ -525,14 +525,14 @@ __device__ __forceinline__ uint64_t walk_chain(const uint8_t *arena, uint64_t o,
 // the bytes segment s covers: [a, b), where its chain's readable bytes end (lim), and whether s is the first segment of its chain
 __device__ __forceinline__ void seg_of(const SegGeom &g, uint32_t s, uint64_t &a, uint64_t &b, uint64_t &lim, bool &first) {
     if (!g.chunks) {
-        a = g.pos0 + (uint64_t)s * kSegBytes; b = a + kSegBytes; lim = g.lim; first = s == 0;
+        a = g.pos0 + (uint64_t)s * g.seg_bytes; b = a + g.seg_bytes; lim = g.lim; first = s == 0;
         if (b > lim) b = lim;
         return;
     }
     uint32_t lo = 0, hi = g.n_chunks;                    // the last chunk whose seg_base is <= s (few chunks, the table stays in the caches)
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g.chunks[mid].seg_base <= s) lo = mid; else hi = mid; }
     const SegChunk c = g.chunks[lo];
-    a = c.a + (uint64_t)(s - c.seg_base) * kSegBytes; b = a + kSegBytes; lim = c.dlim; first = s == c.seg_base;
+    a = c.a + (uint64_t)(s - c.seg_base) * g.seg_bytes; b = a + g.seg_bytes; lim = c.dlim; first = s == c.seg_base;
     if (b > c.b) b = c.b;
 }
 
@@ -540,7 +540,7 @@ __global__ void k_seg_walk(const uint8_t *__restrict__ arena, SegGeom g, uint32_
                            uint64_t *seg_start, uint64_t *seg_exit, uint32_t *seg_cnt, uint16_t *seg_cp, uint32_t s_begin) {
     uint32_t s = s_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seg) return;
-    uint16_t *cp = seg_cp + (size_t)s * kSegCpSlots;
+    uint16_t *cp = g.seg_bytes == kSegBytes ? seg_cp + (size_t)s * kSegCpSlots : nullptr;     // (checkpoints: 16-bit offsets, 16 KiB segments only)
     uint64_t a, b, lim; bool first;
     seg_of(g, s, a, b, lim, first);
     uint64_t o = a, ex = kChainEnd;
@@ -632,7 +632,7 @@ __global__ void k_seg_verify(const uint8_t *__restrict__ arena, SegGeom g, uint3
             const bool left_settled = first1 || (ex_in[s - 2] != kChainUnknown && seg_consistent(b1, ex_in[s - 2], st_in[s - 1], expect, cnt_in[s - 1]));
             if (placeholder || left_settled) {
                 if (expect >= b) { st = b; ex = expect; cnt = 0; }
-                else { st = expect; ex = walk_chain(arena, st, b, lim, cnt, seg_cp + (size_t)s * kSegCpSlots, a); }
+                else { st = expect; ex = walk_chain(arena, st, b, lim, cnt, g.seg_bytes == kSegBytes ? seg_cp + (size_t)s * kSegCpSlots : nullptr, a); }
             }
         }
     }
@@ -914,10 +914,10 @@ __global__ __launch_bounds__(64) void k_long_fill(uint32_t n_seg, const uint32_t
 void launch_decode_seg(const uint8_t *arena, SegGeom g, uint32_t n_seg, const uint64_t *seg_start, const uint32_t *seg_base,
                        const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, const uint16_t *seg_cp, bool staged, hipStream_t stream) {
     if (!n_seg) return;
-    if (staged) hipLaunchKernelGGL(k_decode_seg<true>, dim3(n_seg), dim3(64), kSegBytes + kSegTail + 48, stream, arena, g, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
+    if (staged && g.seg_bytes == kSegBytes) hipLaunchKernelGGL(k_decode_seg<true>, dim3(n_seg), dim3(64), kSegBytes + kSegTail + 48, stream, arena, g, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
     else {
         static const bool wave_form = [] { const char *e = getenv("REGTOOLS_AMD_DECODE_SPARSE"); return e && !strcmp(e, "wave"); }();     // (tests / lab: the workgroup-per-segment form it replaced)
-        if (wave_form) hipLaunchKernelGGL(k_decode_seg<false>, dim3(n_seg), dim3(64), 0, stream, arena, g, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
+        if (wave_form && g.seg_bytes == kSegBytes) hipLaunchKernelGGL(k_decode_seg<false>, dim3(n_seg), dim3(64), 0, stream, arena, g, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
         else hipLaunchKernelGGL(k_decode_sparse, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long);
     }
 }

@@ -566,11 +566,12 @@ def test_long_record_decode_lane_form_equals_the_wave_form(gpu_ctx, synth_dir):
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "regtools-amd")
     for args in (["-s", "XS"], ["-s", "RF", "-m", "200", "-M", "20000"], ["-s", "XS", "-r", "chr2:1000000-90000000"], ["-s", "FR", "-r", "chr1"]):
         outs = []
-        for form in ("lane", "wave"):
-            o = p + "." + form + ".bed"
-            r = subprocess.run([exe, "junctions", "extract"] + args + ["-o", o, p], env=dict(os.environ, REGTOOLS_AMD_DECODE_SPARSE=form), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        for form, seg in (("lane", "16384"), ("wave", "16384"), ("lane", "131072")):      # (the last: the segment size files of long records get, api.cpp seg_bytes)
+            o = p + "." + form + seg + ".bed"
+            r = subprocess.run([exe, "junctions", "extract"] + args + ["-o", o, p], env=dict(os.environ, REGTOOLS_AMD_DECODE_SPARSE=form, REGTOOLS_AMD_SEG_BYTES=seg),
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             assert r.returncode == 0, r.stderr
             outs.append(open(o, "rb").read())
-        assert outs[0] == outs[1], args
+        assert outs[0] == outs[1] == outs[2], args
         assert outs[0] == run_oracle(args + [p])[1], args
     assert len(outs[0]) > 1000
