@@ -351,8 +351,11 @@ def main():
             if n_reads == 50_000_000 and args.shape == "short" and not args.realistic and world == 1 and pm.get("kernel") == inflate_kernel_for(s["compressed_bytes"], s["inflated_bytes"]):
                 traffic = (pm["FETCH_SIZE_KiB"] + pm["WRITE_SIZE_KiB"]) * 1024.0
                 traffic_source = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel on this workload, tools/pmc_inflate.sh; a committed measurement, not taken in this run)"
-                traffic_note = ("(FETCH_SIZE + WRITE_SIZE) KiB, uncorrected: the guide's x2 FETCH correction is for wide coalesced streams; this kernel's reads are "
-                                "8-byte bit-stream words and 16-byte copy sources of 64 lanes in 64 different lines (DESIGN.md 5.2 splits the figure by source)")
+                traffic_note = ("(FETCH_SIZE + WRITE_SIZE) KiB, uncorrected = %.1f x the algorithmic bytes; with the guide's x2 on FETCH_SIZE = %.1f x.  In-situ calibration, same "
+                                "passes (profiles/r03_pmc_tail_kernels.json): k_decode_seg, a coalesced 16 B/lane read of the whole 11.7 GB arena, shows FETCH_SIZE 6.0 GB (x 1.95 "
+                                "missing) and its 1.45 GB of rows WRITE_SIZE 1.41 GB (exact) -- the x2 is real for wide streams; this kernel's reads are 8-byte bit-stream words and "
+                                "16-byte copy sources of 64 lanes in 64 different lines, for which it is not calibrated: the truth lies between the two figures"
+                                % (traffic / alg_bytes, ((2 * pm["FETCH_SIZE_KiB"] + pm["WRITE_SIZE_KiB"]) * 1024.0) / alg_bytes))
         except Exception:
             pass
         line = {
