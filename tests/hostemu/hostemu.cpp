@@ -185,3 +185,36 @@ extern "C" int emu_gtf_dump(const char *gtf_path, const char *out_path, char *er
     fclose(f);
     return 0;
 }
+
+// worker_pool.h / bigvec.h on their own: parallel_sort against std::sort, the pool's every-task-once contract, huge-page vectors
+#include "../../regtools_amd/csrc/worker_pool.h"
+#include "../../regtools_amd/csrc/bigvec.h"
+extern "C" int emu_pool_selftest(uint32_t seed, uint32_t n, uint32_t threads) {
+    rgx::WorkerPool pool(threads);
+    uint64_t x = seed * 0x9e3779b97f4a7c15ull + 1;
+    auto rnd = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    rgx::BigVec<uint64_t> a(n), b;
+    for (auto &v : a) v = rnd() % (n / 3 + 2);                     // plenty of equal keys
+    b.assign(a.begin(), a.end());
+    std::sort(b.begin(), b.end());
+    rgx::parallel_sort(pool, a.begin(), a.end(), [](uint64_t p, uint64_t q) { return p < q; });
+    if (a.size() != b.size() || !std::equal(a.begin(), a.end(), b.begin())) return 1;
+    // every task exactly once, whatever the task count
+    for (size_t tasks : {(size_t)0, (size_t)1, (size_t)2, (size_t)threads, (size_t)threads * 7 + 3}) {
+        std::vector<std::atomic<int>> hit(tasks);
+        for (auto &h : hit) h = 0;
+        pool.run(tasks, [&](size_t k) { hit[k].fetch_add(1); });
+        for (auto &h : hit) if (h.load() != 1) return 2;
+    }
+    // a block above the huge-page threshold: aligned, writable end to end, survives growth
+    rgx::BigVec<uint32_t> big;
+    big.resize((3u << 20) / 4 + 5);
+    if (((uintptr_t)big.data() & ((2u << 20) - 1)) != 0) return 3;
+    for (size_t i = 0; i < big.size(); ++i) big[i] = (uint32_t)i;
+    big.resize((9u << 20) / 4 + 1);
+    for (size_t i = 0; i < (3u << 20) / 4 + 5; ++i) if (big[i] != (uint32_t)i) return 4;
+    big.back() = 7;
+    rgx::BigVec<std::string> names(1000);
+    for (auto &s : names) if (!s.empty()) return 5;                 // strings ARE constructed (only trivial types are left untouched)
+    return 0;
+}

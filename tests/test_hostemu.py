@@ -267,3 +267,11 @@ def test_parallel_member_scan_equals_the_serial_walk(emu):
         big = got[len(got) // 3]
         foot = big[0] + big[2] - 4                                                              # ISIZE footer of that member
         assert scan(bam[:foot] + (70000).to_bytes(4, "little") + bam[foot + 4:], 4)[0] == -1   # claims more than a BGZF block holds
+
+
+@pytest.mark.parametrize("threads", [1, 2, 5, 16])
+def test_worker_pool_parallel_sort_and_huge_page_vectors(emu, threads):
+    """worker_pool.h (every task once; parallel_sort == std::sort, 5 .. 300,000 keys with many ties) and bigvec.h (2 MiB-aligned blocks, growth keeps
+    the contents, class types are constructed)."""
+    for seed, n in ((1, 5), (2, 1000), (3, 16384), (4, 100_001), (5, 300_000)):
+        assert emu.emu_pool_selftest(seed, n, threads) == 0, (seed, n, threads)
