@@ -71,7 +71,10 @@ struct DevBuf {
         void *raw = nullptr;
         hipError_t e = hipMalloc(&raw, want + kFront);
         if (e == hipSuccess) { p = (uint8_t *)raw + kFront; cap = want; }
-        if (trace) { g_alloc_stats.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++g_alloc_stats.calls; g_alloc_stats.bytes += want; }
+        if (trace) {                                                 // (shards of a multi-device call grow their buffers on their own threads)
+            static std::mutex mu; std::lock_guard<std::mutex> lock(mu);
+            g_alloc_stats.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++g_alloc_stats.calls; g_alloc_stats.bytes += want;
+        }
         return e;
     }
     void release() { if (p) (void)hipFree((uint8_t *)p - kFront); p = nullptr; cap = 0; }
