@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <charconv>
 #include <chrono>
 #include <map>
 #include <mutex>
