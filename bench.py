@@ -31,11 +31,7 @@ INFLATE_KERNEL = {"lane": "rgx::k_inflate<false, false, 1>", "ring": "rgx::k_inf
 
 
 def inflate_kernel_for(compressed, inflated):
-    """kernels.h inflate_plan_for: a payload that compresses less than 8x takes the round-1 lane form, up to four literals per trip"""
-    if not os.environ.get("REGTOOLS_AMD_INFLATE") and compressed * 8 > inflated:
-        return "rgx::k_inflate<false, false, 4>" if os.environ.get("REGTOOLS_AMD_INFLATE_LITS", "4") != "1" else "rgx::k_inflate<false, false, 1>"
-    if not os.environ.get("REGTOOLS_AMD_INFLATE") and compressed * 32 <= inflated:
-        return "rgx::k_inflate_coop<false, false, false>"       # run-length payloads: plain bit reader, file-order lanes
+    """kernels.h inflate_plan_for / launch_inflate: k_inflate_coop with the windowed bit reader for every payload class (round 4)"""
     return INFLATE_KERNEL
 
 

@@ -193,8 +193,9 @@ int  rgx_k_inflate(const void *d_comp, const rgx_member *d_members, uint32_t n_m
  * member in ~1.5 ms; above that one member per LANE -- ~8 ms per launch whatever its size, 196,608 members at a time; REGTOOLS_AMD_INFLATE=
  * lane|wave|ring|coop overrides), 1 = lane (k_inflate), 2 = wave (k_inflate_wave), 3 = lane with an LDS window and whole-line output
  * (k_inflate_ring; needs 16 readable bytes in front of d_arena), 4 = lane with the long matches copied by the wave (k_inflate_coop: what the
- * pipeline runs above 2048 members for payloads that compress 8 x and more; the members of a launch must lie in the arena in the order of the
- * list), 5 = lane taking up to four literals per trip (k_inflate<.., 4>: what the pipeline runs for payloads that compress less than 8 x). */
+ * pipeline runs above 2048 members; the members of a launch must lie in the arena in the order of the list, a group of 1024 of them within
+ * 4 GiB -- a list that does not is refused by forms 0 and 4: d_status[0] = the first offending member, d_status[1] = 10, nothing written),
+ * 5 = lane taking up to four literals per trip (k_inflate<.., 4>). */
 int  rgx_k_inflate_form(int form, const void *d_comp, const rgx_member *d_members, uint32_t n_members,
                         void *d_arena, uint32_t *d_status, void *stream);
 

@@ -1595,7 +1595,7 @@ extern "C" int rgx_k_inflate_form(int form, const void *d_comp, const rgx_member
         if (hipMalloc(&scratch, need) != hipSuccess) { scratch = nullptr; scratch_cap = 0; return RGX_ERR_DEVICE; }
         scratch_cap = need;
     }
-    launch_inflate((const uint8_t *)d_comp, (const Member *)d_members, n_members, (uint8_t *)d_arena, 0, (uint32_t *)scratch, d_status, (hipStream_t)stream, 0, 0, false, form);
+    launch_inflate((const uint8_t *)d_comp, (const Member *)d_members, n_members, (uint8_t *)d_arena, 0, (uint32_t *)scratch, d_status, (hipStream_t)stream, 0, 0, false, form, nullptr, 1, true);
     return hipGetLastError() == hipSuccess ? RGX_OK : RGX_ERR_DEVICE;
 }
 

@@ -8,7 +8,9 @@
 #include <hip/hip_runtime.h>
 #define RGX_HD __host__ __device__ __forceinline__
 #define RGX_D __device__ __forceinline__
+#define RGX_COLD __host__ __device__ __attribute__((noinline))      // rare and heavy: out of line, so that the hot loop around the call keeps its registers
 #else
+#define RGX_COLD __attribute__((noinline))
 #define RGX_HD inline
 #define RGX_D inline
 #endif

@@ -14,6 +14,12 @@
 // The owner lane only completes the chunk its stage holds (the copy's first 1..15 bytes) and keeps the copy's last partial chunk as its new
 // stage: the invariant "every output byte reaches memory once, in an aligned 16-byte store" survives.  Shorter copies stay per-lane.
 //
+// Round 4: the block header is a CALL (block_header_cold below): inlined, its tables' registers were the symbol loop's too and the allocator
+// spilled copy registers inside the trip -- a load waited for on the spot, then stored to scratch.  With the header out of line the loop needs
+// 167 registers and spills none, and its only wait for memory is the one spelled out at (R).  Two further designs were built on top of this,
+// exact, measured and not kept (tools/lab/r4_deferred_cold_and_group_head_tail.patch): cold symbol-list entries read without
+// blocking the trip, and the head / tail pieces of a long copy loaded by the group's spare lanes and handed over through LDS.
+//
 // The per-lane part is plain C++ over two accessors -- Tab (symbol lists) and Coop (the wave) -- so that tests/hostemu runs it on the
 // host against zlib with a one-lane "wave" (HostCopy below).
 #pragma once
@@ -34,11 +40,17 @@ struct HostCopy {
     RGX_HD void end() {}
 };
 
+#ifdef RGX_LAB_TRIPS
+static __device__ uint32_t rgx_lab_trips_total;      // (lab builds: wave trips of a launch)
+#endif
 // Every lane of the wave must call this together (Coop::any / begin / end are wave-wide); `active` = false: the lane has no member and
 // only serves the others' copies.  Returns an InflateStatus; *out_len = bytes produced (all of them in memory on return, also after an error).
 template <class BR, class Tab, class Coop>
 RGX_HD int inflate_coop(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len, Tab &T, Coop &C, bool active,
                         bool pairs /* a literal and the symbol behind it in one trip (same for every lane of the wave) */, uint32_t *in_used = nullptr) {
+#ifdef RGX_LAB_TRIPS
+    uint32_t rgx_lab_trips = 0;
+#endif
     BR br;                                                     // BitReader, or BitReaderWin where trips are memory-bound (inflate_core.h)
     br.p = in; br.in = in; br.in_len = in_len; br.buf = 0; br.cnt = 0; br.idle();
     if (active) br.init(in, in_len);
@@ -54,6 +66,9 @@ RGX_HD int inflate_coop(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
     u32x4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;   // copy registers: loaded (A) and consumed (C) under the same predicate; never re-initialised
 
     for (;;) {
+#ifdef RGX_LAB_TRIPS
+        ++rgx_lab_trips;
+#endif
         // ---- A: loads of the pending copy -----------------------------------------------------------------------
         const bool copying = !fin && pend_len != 0;
         uint32_t n = 0, head = 0, nb = 0, tail = 0;
@@ -124,7 +139,7 @@ RGX_HD int inflate_coop(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
                 }
             } else if (!copying) {
                 // block header (rare, heavy): only with no copy in flight, so that it may write output itself
-                const int r = block_header(br, T, LL, DD, in, in_len, out, o, out_cap, last, status, S);
+                const int r = block_header_call(br, T, LL, DD, in, in_len, out, o, out_cap, last, status, S);
                 if (status != INF_OK) { fin = true; break; }
                 if (r) in_symbols = true;
                 else if (last) { if (br.overran()) { status = INF_IN_OVERRUN; fin = true; break; } done = true; }
@@ -180,6 +195,9 @@ RGX_HD int inflate_coop(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
         }
         if (!C.any(!fin)) break;
     }
+#ifdef RGX_LAB_TRIPS
+    if (threadIdx.x == 0) atomicAdd(&rgx_lab_trips_total, rgx_lab_trips);
+#endif
     if (active) S.flush_partial(o);                                 // the tail chunk (also on errors: what was produced is in memory)
     if (in_used) *in_used = (uint32_t)(((uint64_t)(br.p - br.in) * 8 - br.cnt + 7) / 8);
     *out_len = o;

@@ -28,6 +28,7 @@ enum InflateStatus : int {
 // per CU) and the code-length scratch (needed only while a block header is parsed) in a global, lane-interleaved buffer.
 struct HostTab {
     uint16_t ll_sym[288]; uint8_t d_sym[32]; uint32_t len_words[40];
+    static constexpr bool kIsHandle = false;               // the tables themselves (the device's Tab is a handle: pointers into LDS and scratch)
     RGX_HD uint32_t get_ll_sym(uint32_t i) const { return ll_sym[i]; }
     RGX_HD void set_ll_sym(uint32_t i, uint32_t v) { ll_sym[i] = (uint16_t)v; }
     RGX_HD uint32_t get_d_sym(uint32_t i) const { return d_sym[i]; }
@@ -155,20 +156,27 @@ struct BitReaderWin {
     uint32_t in_len;
     uint64_t buf;
     uint32_t cnt;
-    uint64_t w0, w1;       // the 16 bytes at p - off
+    u32x4 win;             // the 16 bytes at p - off, kept as loaded: the load lands in these registers and nothing touches them before the next refill
+                           // (as two 64-bit words put together on arrival, every window load was waited for on the spot -- a second memory
+                           //  round trip in the middle of most wave trips)
     uint32_t off;          // <= 8 between refills, so the 8 bytes at p are always inside the window
     RGX_HD void load_window() {
         // a corrupt stream may ask for bits that do not exist: never read more than 16 bytes past the payload
         const uint8_t *wp = (size_t)(p - in) > (size_t)in_len ? in + in_len : p;
         off = (uint32_t)(p - wp);
-        const u32x4 v = ld128(wp);
-        w0 = (uint64_t)v[0] | (uint64_t)v[1] << 32; w1 = (uint64_t)v[2] | (uint64_t)v[3] << 32;
+        win = ld128(wp);
     }
     RGX_HD void init(const uint8_t *i, uint32_t n) { in = i; in_len = n; p = i; buf = 0; cnt = 0; load_window(); }
     RGX_HD void refill() {
         const uint32_t sh = 8 * off;
+        const uint64_t w0 = (uint64_t)win[0] | (uint64_t)win[1] << 32, w1 = (uint64_t)win[2] | (uint64_t)win[3] << 32;
         const uint64_t next = (sh >= 64 ? 0 : w0 >> sh) | (sh == 0 ? 0 : w1 << ((64 - sh) & 63));      // the 8 bytes at p
         buf |= next << cnt;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (the window's new load must not be scheduled in front of these last uses of its old bytes: it would then need registers of its own,
+        //  and the copy into `win` a wait)
+        asm volatile("" : "+v"(buf) : : "memory");
+#endif
         const uint32_t adv = (63u - cnt) >> 3;
         p += adv; off += adv;
         cnt |= 56u;
@@ -183,7 +191,7 @@ struct BitReaderWin {
     RGX_HD bool overran() const { return (uint64_t)(p - in) * 8 > (uint64_t)in_len * 8 + cnt; }
     RGX_HD const uint8_t *byte_ptr() const { return p; }
     RGX_HD void restart_at(const uint8_t *q) { p = q; buf = 0; cnt = 0; load_window(); }
-    RGX_HD void idle() { w0 = 0; w1 = 0; off = 0; }
+    RGX_HD void idle() { win = u32x4{0, 0, 0, 0}; off = 0; }
 };
 
 RGX_HD uint32_t rev15(uint32_t v) {
@@ -218,6 +226,9 @@ struct OutStage {
             u32x4 v = {(uint32_t)l, (uint32_t)(l >> 32), (uint32_t)h, (uint32_t)(h >> 32)};
             *(u32x4 *)(out + cb) = v;                                      // 16-byte aligned by construction
         } else {
+            // (only the two chunks cut by the member's ends get here: kept a LOOP -- unrolled, sixteen predicated byte stores were inlined at every site
+            //  that can complete a chunk)
+#pragma nounroll
             for (int i = 0; i < 16; ++i) {
                 const int32_t m = cb + i;
                 if (m >= 0 && (uint32_t)m < cap) out[m] = (uint8_t)((i < 8 ? l >> (8 * i) : h >> (8 * (i - 8))) & 0xff);
@@ -398,6 +409,27 @@ RGX_HD int block_header(BR &br, Tab &T, Code &LL, Code &DD, const uint8_t *in, u
     return build_block_codes(br, T, LL, DD, btype, status);
 }
 
+// The block header (once or a few times per member, thousands of instructions, its own long-lived tables) as a CALL.  The loop's state goes in
+// and out by value, so that nothing of it has its address taken where it matters.
+template <class BR> struct HeaderState { BR br; Code LL, DD; OutStage S; uint32_t o, last; int status; };
+template <class BR, class Tab>
+RGX_COLD int block_header_cold(HeaderState<BR> &h, Tab &T, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap) {
+    return block_header(h.br, T, h.LL, h.DD, in, in_len, out, h.o, out_cap, h.last, h.status, h.S);
+}
+// (callers: the symbol loops of inflate_raw below and of inflate_coop, inflate_coop.h)
+template <class BR, class Tab>
+RGX_HD int block_header_call(BR &br, Tab &T, Code &LL, Code &DD, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t &o, uint32_t out_cap,
+                             uint32_t &last, int &status, OutStage &S) {
+    HeaderState<BR> h{br, LL, DD, S, o, last, status};
+    int r;
+    if constexpr (Tab::kIsHandle) { Tab Tc = T; r = block_header_cold(h, Tc, in, in_len, out, out_cap); }      // (a handle: the copy's address escapes, not T's)
+    else r = block_header_cold(h, T, in, in_len, out, out_cap);
+    // (pointers that went through memory come back without their address space: rebuilt from the arguments)
+    { const size_t pofs = (size_t)(h.br.p - h.br.in); br = h.br; br.in = in; br.p = in + pofs; }
+    LL = h.LL; DD = h.DD; S = h.S; S.out = out; o = h.o; last = h.last; status = h.status;
+    return r;
+}
+
 constexpr uint32_t kCopyBatch = 128;   // bytes moved per memory round trip (8 independent 16-byte loads in flight)
 
 // Inflate one raw-DEFLATE stream. Returns an InflateStatus; *out_len = bytes produced.
@@ -495,7 +527,7 @@ RGX_HD int inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_
                 }
             } else if (!copying) {
                 // block header (rare, heavy): only with no copy in flight, so that it may write output itself
-                const int r = block_header(br, T, LL, DD, in, in_len, out, o, out_cap, last, status, S);
+                const int r = block_header_call(br, T, LL, DD, in, in_len, out, o, out_cap, last, status, S);      // (out of line: round 4, inflate_coop.h)
                 if (status != INF_OK) break;
                 if (r) in_symbols = true;
                 else if (last) { if (br.overran()) { status = INF_IN_OVERRUN; break; } done = true; }

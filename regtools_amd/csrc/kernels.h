@@ -24,17 +24,18 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
                     bool piece = false /* one of several concurrent launches over a range (own kernel symbol, same code) */,
                     int form = 0 /* 0 = chosen by member count / REGTOOLS_AMD_INFLATE; 1 = k_inflate, 2 = k_inflate_wave, 3 = k_inflate_ring */,
                     uint8_t *bad_flags = nullptr /* optional, zeroed by the caller: [index in the caller's range] = 1 for every member that did not inflate */,
-                    int plan = 1 /* inflate_plan_for */);
-// Which lane form suits a payload, from how well the file compresses (measured on 50 M-read files, all byte-equal to zlib):
-//   inflated / compressed > 32  (long reads: run-length copies)        k_inflate_coop: one symbol per trip, plain bit reader, lanes in file order
-//                                                                      126.7 ms against k_inflate's 135.6 (windowed reader + sorted lanes: 141)
-//   8 .. 32                     (the bench payload: 21)                 k_inflate_coop: literal pairs, windowed bit reader, lanes sorted by
-//                                                                      compressed length per 1024 members: 14.1 ms against 20.0
-//   < 8                         (random bases + binned qualities: 3.6)  k_inflate: 49.2 against 51-52 -- few matches are long enough for the wave
-//                                                                      to move, and the cooperative rounds' bookkeeping is paid by every trip
-// bit 0 = the middle class's options, bit 1 = the lane form is k_inflate.
+                    int plan = 1 /* inflate_plan_for */,
+                    bool check_layout = false /* a caller's own member list (stage entry point): k_inflate_coop only runs when the list's layout suits it */);
+// Which options suit a payload, from how well the file compresses (round 4, 50 M-read files / 10 M long reads on one box, ms, all byte-equal to zlib;
+// tools/lab/forms_r4.sh, profiles/r04_inflate_forms.txt):
+//   inflated / compressed > 32  (long reads: run-length copies)        k_inflate_coop, windowed bit reader, one symbol per trip, lanes in file order:
+//                                                                      117.5-118.7 (round 3's choice -- plain reader -- 120.7-122.2; pairs + sorted lanes 122; k_inflate 131)
+//   <= 32                       (the bench payload: 21;                 k_inflate_coop, windowed bit reader, literal pairs, lanes sorted by compressed length
+//                                random bases + binned qualities: 3.6)  per 1024 members: bench payload 14.5-15.2 (k_inflate 19.9-21.3); random bases 44.9-47.5
+//                                                                      (k_inflate with four literals per trip, round 3's choice for them: 53.1-54.1)
+// bit 0 = literal pairs + sorted lanes.  (k_inflate stays selectable: REGTOOLS_AMD_INFLATE=lane, form 1 / 5 of the stage entry point.)
 inline int inflate_plan_for(uint64_t compressed_bytes, uint64_t inflated_bytes) {
-    return (compressed_bytes * 32 > inflated_bytes ? 1 : 0) | (compressed_bytes * 8 > inflated_bytes ? 2 : 0);
+    return compressed_bytes * 32 > inflated_bytes ? 1 : 0;
 }
 
 // ---- a1 (container): BGZF member discovery on the device --------------------------------------------------

@@ -46,10 +46,12 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 constexpr uint32_t kHotSyms = 160;
 constexpr uint32_t kLdsLL = 0, kLdsD = (kHotSyms * 9 + 31) / 32, kLdsDwordsPerLane = kLdsD + 6;
 constexpr uint32_t kInflateLdsBytes = kLdsDwordsPerLane * 64 * 4;
-constexpr uint32_t kScratchLenWords = 40, kScratchColdWords = ((288 - kHotSyms) * 9 + 31) / 32 + 1;
+// (round 4: the cold end of the list is 16 bits per symbol -- ONE request per lookup, no read-modify-write when the list is built)
+constexpr uint32_t kScratchLenWords = 40, kScratchColdWords = (288 - kHotSyms + 1) / 2;
 constexpr uint32_t kScratchWordsPerLane = kScratchLenWords + kScratchColdWords;
 
 struct LdsTab {
+    static constexpr bool kIsHandle = true;     // (pointers into LDS and scratch: block_header_call copies the handle, not tables)
     uint32_t *base;       // LDS, already offset by lane
     uint32_t *scratch;    // global, already offset by global lane
     uint32_t stride;      // lanes in the grid (dword stride of the scratch)
@@ -70,17 +72,10 @@ struct LdsTab {
         wr(dw, (uint32_t)w);
         if (sh + width > 32) wr(dw + 1, (uint32_t)(w >> 32));
     }
-    __device__ __forceinline__ uint32_t get_cold(uint32_t i) const {
-        const uint32_t bit = i * 9, dw = kScratchLenWords + (bit >> 5), sh = bit & 31;
-        const uint64_t w = (uint64_t)grd(dw) | (uint64_t)grd(dw + 1) << 32;
-        return (uint32_t)(w >> sh) & 0x1ffu;
-    }
-    __device__ __forceinline__ void set_cold(uint32_t i, uint32_t v) {
-        const uint32_t bit = i * 9, dw = kScratchLenWords + (bit >> 5), sh = bit & 31;
-        uint64_t w = (uint64_t)grd(dw) | (uint64_t)grd(dw + 1) << 32;
-        w = (w & ~((uint64_t)0x1ffu << sh)) | ((uint64_t)v << sh);
-        gwr(dw, (uint32_t)w);
-        if (sh + 9 > 32) gwr(dw + 1, (uint32_t)(w >> 32));
+    // cold symbols: two per dword of the lane's scratch column
+    __device__ __forceinline__ uint32_t get_cold(uint32_t c) const { return (grd(kScratchLenWords + (c >> 1)) >> (16u * (c & 1u))) & 0x1ffu; }
+    __device__ __forceinline__ void set_cold(uint32_t c, uint32_t v) {
+        ((uint16_t *)(scratch + (size_t)(kScratchLenWords + (c >> 1)) * stride))[c & 1u] = (uint16_t)v;
     }
     __device__ __forceinline__ uint32_t get_ll_sym(uint32_t i) const { return i < kHotSyms ? get_bits(kLdsLL, i * 9, 9) : get_cold(i - kHotSyms); }
     __device__ __forceinline__ void set_ll_sym(uint32_t i, uint32_t v) { if (i < kHotSyms) set_bits(kLdsLL, i * 9, 9, v); else set_cold(i - kHotSyms, v); }
@@ -320,13 +315,27 @@ __global__ __launch_bounds__(256) void k_member_sort(const Member *__restrict__ 
     for (uint32_t t = threadIdx.x; t < kSortGroup; t += 256) if (g0 + t < n_members) perm[g0 + t] = g0 + (key[t] & 1023u);
 }
 
+// What k_inflate_coop asks of a member list the PIPELINE did not make (rgx_k_inflate / rgx_k_inflate_form): its wave copies address the arena with
+// 32-bit offsets from the first member of a group of kSortGroup, so upos must not decrease along the list and a group (plus one member's
+// 64 KiB) must span less than 4 GiB.  A list that does not is refused: status[0] = the first offending member, status[1] = INF_OUT_OVERFLOW.
+__global__ void k_members_check(const Member *__restrict__ members, uint32_t n_members, uint32_t *status, uint32_t *veto) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_members) return;
+    const uint32_t first = (m / kSortGroup) * kSortGroup;
+    const bool bad = (m > 0 && members[m].upos < members[m - 1].upos) || members[m].upos < members[first].upos ||
+                     members[m].upos - members[first].upos > 0xfffe0000ull;
+    if (bad) { *veto = 1; const uint32_t prev = atomicMin(&status[0], m); if (m < prev) status[1] = (uint32_t)INF_OUT_OVERFLOW; }
+}
+
 // one lane per member like k_inflate; no lane leaves before the wave is done (the lanes without a member serve the others' copies)
 template <bool PROBE, bool PIECE = false, bool WIN = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_inflate_coop(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
                                                 uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
                                                 uint32_t *status, uint32_t ignore_below, uint32_t index_bias, uint8_t *bad, uint32_t pairs,
-                                                const uint32_t *__restrict__ perm) {
+                                                const uint32_t *__restrict__ perm, const uint32_t *veto) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // (stage entry point only: k_members_check found the list's layout unfit for 32-bit offsets -- nothing may be written)
+    if (veto && *veto) return;
     const uint32_t lane = threadIdx.x;
     const uint32_t slot = blockIdx.x * 64 + lane;
     const bool have = slot < n_members;
@@ -449,7 +458,7 @@ static void inflate_attrs() {
     done = true;
 }
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
-                    uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias, bool piece, int form, uint8_t *bad, int plan) {
+                    uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias, bool piece, int form, uint8_t *bad, int plan, bool check_layout) {
     if (!n_members) return;
     inflate_attrs();
     static const int env_pairs = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE_PAIRS"); return e ? atoi(e) != 0 : -1; }();
@@ -465,13 +474,19 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
         hipLaunchKernelGGL(k_inflate_ring<false>, dim3(blocks), dim3(64), kRingLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad);
         break;
     case 4: {
-        // plan bit 0 set = the payload class of the bench file (8 .. 32 x): lanes sorted by compressed length and the windowed bit reader
-        // (14.1 ms against 16.0); long reads (> 32 x) lose with both (141 against 127 ms) and keep file order and the plain reader
+        // plan bit 0 set (payloads that compress up to 32 x): literal pairs and lanes sorted by compressed length; the windowed bit reader always
+        // (round 4: its loads are no longer waited for on the spot -- long reads 117.5 ms with it against 120.7 without, kernels.h)
         static const int env_tune = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE_TUNE"); return e ? atoi(e) : -1; }();      // (lab) bit 0 sort, bit 1 window
-        const bool sort = env_tune >= 0 ? (env_tune & 1) != 0 : (plan & 1) != 0, win = env_tune >= 0 ? (env_tune & 2) != 0 : (plan & 1) != 0;
+        const bool sort = env_tune >= 0 ? (env_tune & 1) != 0 : (plan & 1) != 0, win = env_tune >= 0 ? (env_tune & 2) != 0 : true;
         uint32_t *perm = sort ? len_scratch + inflate_scratch_words(n_members) : nullptr;
         if (perm) hipLaunchKernelGGL(k_member_sort, dim3((n_members + kSortGroup - 1) / kSortGroup), dim3(256), 0, stream, members, n_members, perm);
-#define RGX_COOP(PIECE_, WIN_) hipLaunchKernelGGL((k_inflate_coop<false, PIECE_, WIN_>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad, two, perm)
+        // (the veto word: behind the lane assignment in the scratch; only the stage entry point asks for the check)
+        uint32_t *veto = check_layout ? len_scratch + inflate_scratch_words(n_members) + ((size_t)n_members + 63) / 64 * 64 + kSortGroup - 1 : nullptr;
+        if (check_layout) {
+            (void)hipMemsetAsync(veto, 0, 4, stream);
+            hipLaunchKernelGGL(k_members_check, dim3((n_members + 255) / 256), dim3(256), 0, stream, members, n_members, status, veto);
+        }
+#define RGX_COOP(PIECE_, WIN_) hipLaunchKernelGGL((k_inflate_coop<false, PIECE_, WIN_>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad, two, perm, veto)
         if (piece) { if (win) RGX_COOP(true, true); else RGX_COOP(true, false); }
         else { if (win) RGX_COOP(false, true); else RGX_COOP(false, false); }
 #undef RGX_COOP
@@ -495,7 +510,7 @@ void launch_inflate_probe(const uint8_t *comp, const Member *members, uint32_t n
     const int form = inflate_form_env() ? inflate_form_env() : kDefaultLaneForm;
     const uint32_t blocks = (n_members + 63) / 64;
     if (form == 3) hipLaunchKernelGGL(k_inflate_ring<true>, dim3(blocks), dim3(64), kRingLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr);
-    else if (form == 4) hipLaunchKernelGGL(k_inflate_coop<true>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr, 1u, (const uint32_t *)nullptr);
+    else if (form == 4) hipLaunchKernelGGL(k_inflate_coop<true>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr, 1u, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     else hipLaunchKernelGGL(k_inflate<true>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr);
 }
 

@@ -179,6 +179,40 @@ def test_inflate_kernel_against_zlib(gpu_ctx, form):
     assert bytes(d_arena[256:256 + upos].cpu().numpy().tobytes()) == b"".join(expect)
 
 
+def test_coop_form_refuses_a_member_list_out_of_arena_order(gpu_ctx):
+    """k_inflate_coop addresses the arena with 32-bit offsets from a group's first member: a caller's own list whose members do not lie in the
+    arena in list order is refused by the stage entry point (status = first offending member, INF_OUT_OVERFLOW) and nothing is written;
+    the lane form takes the same list."""
+    import torch
+    from regtools_amd import _ffi, synth
+    bam, _, _ = synth.generate(3000, shape="short", seed=5)
+    members, upos, expect = [], 0, []
+    for off, payload, isize in bamio.bgzf_members(bam):
+        members.append([off + 18, upos, len(payload), isize])
+        expect.append(zlib.decompress(payload, -15))
+        upos += isize
+    assert len(members) >= 3
+    # swap the places of the first two members in the arena (the list keeps its order)
+    members[0][1], members[1][1] = members[1][3], 0
+    want = expect[1] + expect[0] + b"".join(expect[2:])
+    arr = (_ffi.Member * len(members))(*[_ffi.Member(*m) for m in members])
+    d_comp = torch.zeros(len(bam) + 64, dtype=torch.uint8, device="cuda")
+    d_comp[: len(bam)].copy_(torch.frombuffer(bytearray(bam), dtype=torch.uint8))
+    d_mem = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    for form, ok in ((4, False), (1, True)):
+        d_arena = torch.zeros(upos + 512, dtype=torch.uint8, device="cuda")
+        d_status = torch.tensor([0xffffffff, 0], dtype=torch.int64).to(torch.uint32).cuda()
+        torch.cuda.synchronize()
+        assert _ffi.lib().rgx_k_inflate_form(form, d_comp.data_ptr(), d_mem.data_ptr(), len(members), d_arena.data_ptr() + 256, d_status.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        st = d_status.cpu().tolist()
+        got = bytes(d_arena[256:256 + upos].cpu().numpy().tobytes())
+        if ok:
+            assert st[0] == 0xffffffff and got == want
+        else:
+            assert st == [1, 10] and got == bytes(upos), st
+
+
 def test_multi_million_read_properties(gpu_ctx, synth_dir):
     """Size-independent properties at a multi-million-read scale (the 50M-read identity check lives in bench.py)."""
     from regtools_amd import synth
