@@ -287,11 +287,33 @@ def main():
     rank_report = None
     if world > 1:
         mine = torch.tensor([je.stats["ms_inflate"], je.stats["ms_records"], je.stats["ms_scan"], je.stats["ms_reduce"], je.stats["ms_total"],
-                             sum(merge_ms) / max(1, len(merge_ms)), float(n_reads), float(je.stats["n_junctions"])], dtype=torch.float64, device=coll_dev)
+                             sum(merge_ms) / max(1, len(merge_ms)), float(n_reads), float(je.stats["n_junctions"]), float(je.stats["n_records"])], dtype=torch.float64, device=coll_dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         rank_report = [dict(rank=r, inflate_ms=round(v[0].item(), 3), records_ms=round(v[1].item(), 3), scan_ms=round(v[2].item(), 3), reduce_ms=round(v[3].item(), 3),
-                            extract_total_ms=round(v[4].item(), 3), gather_and_merge_ms=round(v[5].item(), 3), reads=int(v[6].item()), rows=int(v[7].item())) for r, v in enumerate(allr)]
+                            extract_total_ms=round(v[4].item(), 3), gather_and_merge_ms=round(v[5].item(), 3), reads=int(v[6].item()), rows=int(v[7].item()),
+                            n_records=int(v[8].item())) for r, v in enumerate(allr)]
+        # The N > 1 line checks itself (outside the timed region; the driver runs this path on hardware nobody else has seen it on):
+        #  (i) every rank decoded its whole slice: sum of n_records == N x reads;
+        #  (ii) the table the collective + device merge produced == an INDEPENDENT merge of the same per-rank tables -- every rank's packed rows
+        #       go to rank 0 as plain objects (no RCCL), rgx_table_merge (the host merge, its own code path) merges them, and the two tables
+        #       must have the same rows and print the same BED12 bytes; (iii) supporting reads are conserved: sum of the merged counts == sum
+        #       of the ranks' counts.
+        assert sum(r["n_records"] for r in rank_report) == world * n_reads, ("records lost", [r["n_records"] for r in rank_report], world, n_reads)
+        payload, nrows = rdist.pack_table(je.table)
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object((payload, nrows, int(je.table.contents.stream_ended)), parts, dst=0)
+        if rank == 0:
+            ref = rdist.merge_packed([(b, n) for b, n, _ in parts], je.table, 8, ended=[bool(e) for _, _, e in parts])
+            import numpy as np
+            cnt_parts = sum(int(np.frombuffer(b, dtype=np.uint32).reshape(-1, 12)[:, 5].sum()) for b, n, _ in parts if n)
+            mt = last.table.contents
+            cnt_merged = int(np.ctypeslib.as_array(mt.read_count, shape=(int(mt.n),)).astype(np.int64).sum()) if mt.n else 0
+            multi_checks = dict(records_conserved=True, merged_rows=int(last.n), independent_host_merge_rows=int(ref.n),
+                                bed12_equals_independent_merge=bool(last.bed12() == ref.bed12()), counts_conserved=bool(cnt_parts == cnt_merged),
+                                supporting_reads=cnt_merged)
+            assert multi_checks["merged_rows"] == multi_checks["independent_host_merge_rows"] and multi_checks["bed12_equals_independent_merge"], multi_checks
+            assert multi_checks["counts_conserved"], (cnt_parts, cnt_merged)
 
     # Second, untimed-for-the-headline pass with the file ALREADY RESIDENT in HBM: one k_inflate launch over the whole file, which is what
     # the roofline of the dominant kernel is quoted on (HIP events on the pipeline's stream), and the per-stage times.
@@ -371,7 +393,7 @@ def main():
             "multi_gpu": None if world == 1 else {"host": "one process per GPU (torchrun), torch.distributed backend %s" % backend, "rccl_ranks": world if backend == "nccl" else 0,
                                                   "exchange": "all_gather_into_tensor of the ranks' packed 48-byte rows into HBM + rgx_table_merge_device on every rank" if backend == "nccl"
                                                               else "all_gather of packed rows on the host + rgx_table_merge (test backend)",
-                                                  "merge_ms": round(max(r["gather_and_merge_ms"] for r in rank_report), 3), "per_rank": rank_report},
+                                                  "merge_ms": round(max(r["gather_and_merge_ms"] for r in rank_report), 3), "checks": multi_checks, "per_rank": rank_report},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "input_generation_s": round(t_gen, 2),
             "roofline": {"bound": "hbm", "kernel": inflate_kernel_for(s["compressed_bytes"], s["inflated_bytes"]), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -460,6 +482,18 @@ def main_cpp_host(args):
         with open(args.dump_bed, "wb") as f:
             f.write(m.bed12())
     tc = m.table.contents
+    # the line checks itself (outside the timed region): every record of the file was decoded by some shard, and the merged table is the table
+    # ONE device makes of the same file (one more extraction, on the first device, of the whole file)
+    from regtools_amd import _ffi
+    exchange = _ffi.lib().rgx_multi_exchange_kind().decode()
+    assert int(tc.n_records) == st["n_reads"], ("records lost", int(tc.n_records), st["n_reads"])
+    ctx1 = regtools_amd.Context(devices[0])
+    je1 = regtools_amd.JunctionsExtractor(strandness=0, ctx=ctx1)
+    je1.identify_junctions_from_BAM(bai_bytes=bai, host_ptr=pin.ptr, host_len=len(bam))
+    checks = dict(records_conserved=True, merged_rows=int(tc.n), single_device_rows=int(je1.stats["n_junctions"]), bed12_equals_single_device=bool(m.bed12() == je1.bed12()))
+    assert checks["merged_rows"] == checks["single_device_rows"] and checks["bed12_equals_single_device"], checks
+    del je1
+    ctx1.close()
     line = {"metric": "alignments/sec + junctions/sec, junctions extract, 1/2/4/8 MI355X", "value": st["n_reads"] * args.steps / dt, "unit": "alignments/s",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
@@ -467,7 +501,7 @@ def main_cpp_host(args):
                        "distinct_devices": len(set(devices)) == n},
             "junction_events_per_s": tc.n_events * args.steps / dt, "junction_rows": int(tc.n),
             "multi_gpu": {"host": "one process, a thread and a context per device (multi.cpp)", "rccl_ranks": n if len(set(devices)) == n else 0,
-                          "exchange": "ncclSend / ncclRecv gather of packed rows to the first device + rgx_table_merge_device" if len(set(devices)) == n else "device copies (one GPU listed several times)",
+                          "exchange": exchange + " -> rgx_table_merge_device on the first device", "checks": checks,
                           "max_stage_ms": {"inflate": tc.ms_inflate, "records": tc.ms_records, "scan": tc.ms_scan, "reduce": tc.ms_reduce, "shard_total": tc.ms_total}}}
     print(json.dumps(line), flush=True)
     pin.close()

@@ -126,8 +126,9 @@ int  rgx_extract_device(rgx_ctx *ctx, const void *d_bam, size_t bam_len,
 
 /* The same over several GPUs of one node from ONE host process: shard g of n_devices -- a contiguous BGZF member range
  * cut at record starts the index lists -- runs the whole pipeline on devices[g] from its own host thread; the shards' unique rows
- * (48 bytes each, still in HBM) are exchanged with one ncclAllGather (RCCL over xGMI; librccl.so.1 is loaded at run time) and merged on
- * devices[0] (rgx_table_merge_device).  Shard order is file order: the table is the single-GPU table whatever n_devices is.  A device
+ * (48 bytes each, packed in HBM on the shard's own stream) are gathered to devices[0] with ncclSend / ncclRecv in one group (RCCL over xGMI;
+ * librccl.so.1 is loaded at run time; peer access is switched on per device pair) and merged there (rgx_table_merge_device).  Where RCCL cannot
+ * be loaded, initialised or reports an error, the same rows travel as hipMemcpyPeerAsync copies and rgx_multi_exchange_kind() says so.  Shard order is file order: the table is the single-GPU table whatever n_devices is.  A device
  * may be listed more than once: those shards take turns on it and the exchange is a device copy (how a one-GPU box tests this path).
  * Replaces the call junctions_extract() makes into JunctionsExtractor (junctions_main.cc:45-59) on a multi-GPU node.  -b works across shards
  * (rgx_table_merge_barcodes).  The per-device contexts (workspace, streams) are created on first use and kept for the life of the process;
@@ -136,6 +137,10 @@ int  rgx_extract_multi(const int *devices, int n_devices, const char *bam_path, 
                        rgx_junction_table **out, char *err, size_t errlen);
 int  rgx_extract_multi_mem(const int *devices, int n_devices, const void *bam, size_t bam_len, const void *bai, size_t bai_len,
                            const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen);
+/* How the last rgx_extract_multi* call of this process moved the shards' rows to the first device: "rccl grouped send/recv, N ranks, ...",
+ * "hipMemcpyPeerAsync ... (RCCL not used: why)", "device copies (a device is listed more than once)", "none (one shard)".  The reference has
+ * no counterpart (junctions_main.cc:45-59 is one process on one core); callers that report a multi-GPU run quote it (bench.py multi_gpu.exchange). */
+const char *rgx_multi_exchange_kind(void);
 
 void rgx_table_free(rgx_junction_table *t);
 

@@ -46,7 +46,7 @@ EXPORTS = ["rgx_extract_params_default", "rgx_ctx_create", "rgx_ctx_destroy", "r
            "rgx_identify_params_default", "rgx_identify", "rgx_gtf_load", "rgx_gtf_free", "rgx_gtf_info", "rgx_gtf_transcript_bin",
            "rgx_gtf_transcript_id", "rgx_variant_windows", "rgx_variant_hits_free", "rgx_annotate_junctions", "rgx_junction_annot_free",
            "rgx_associate", "rgx_variants_annotate", "rgx_junctions_annotate", "rgx_table_merge_device", "rgx_window_join", "rgx_window_rows_free", "rgx_last_table_pack_device",
-           "rgx_host_alloc", "rgx_host_free", "rgx_extract_multi", "rgx_extract_multi_mem", "rgx_k_inflate_form", "rgx_table_merge_barcodes",
+           "rgx_host_alloc", "rgx_host_free", "rgx_extract_multi", "rgx_extract_multi_mem", "rgx_multi_exchange_kind", "rgx_k_inflate_form", "rgx_table_merge_barcodes",
            "rgx_table_pack_barcodes", "rgx_table_unpack_barcodes", "rgx_identify_multi"]
 
 
@@ -119,6 +119,8 @@ def lib():
                                          P(ExtractParams), P(P(JunctionTable)), C.c_char_p, C.c_size_t]
         L.rgx_table_free.argtypes = [P(JunctionTable)]
         L.rgx_extract_multi.argtypes = [P(C.c_int), C.c_int, C.c_char_p, P(ExtractParams), P(P(JunctionTable)), C.c_char_p, C.c_size_t]
+        L.rgx_multi_exchange_kind.restype = C.c_char_p
+        L.rgx_multi_exchange_kind.argtypes = []
         L.rgx_extract_multi_mem.argtypes = [P(C.c_int), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, P(ExtractParams), P(P(JunctionTable)), C.c_char_p, C.c_size_t]
         L.rgx_host_alloc.argtypes = [C.c_size_t]
         L.rgx_host_alloc.restype = C.c_void_p

@@ -31,6 +31,8 @@
 
 using namespace rgx;
 
+bool rgx_enable_peer(int a, int b);         // (below; also multi.cpp)
+
 namespace {
 
 int fail(char *err, size_t errlen, int code, const char *fmt, ...) {
@@ -38,11 +40,22 @@ int fail(char *err, size_t errlen, int code, const char *fmt, ...) {
     return code;
 }
 
+// Every checked HIP call also answers for the kernel launches queued since the last one (round 4): a launch whose configuration is refused
+// returns its error from hipLaunchKernel, which the launch_* wrappers do not look at -- it stays with the thread until hipGetLastError reads
+// it.  The pipeline synchronises (HIP_TRY(hipStreamSynchronize)) before it reads anything a kernel wrote, so a refused launch is an
+// RGX_ERR_DEVICE at the next such point instead of an untouched buffer read as data.
 #define HIP_TRY(expr)                                                                                       \
     do {                                                                                                    \
         hipError_t e_ = (expr);                                                                             \
         if (e_ != hipSuccess) return fail(err, errlen, RGX_ERR_DEVICE, "HIP error %s at %s:%d (%s)\n", hipGetErrorString(e_), __FILE__, __LINE__, #expr); \
+        e_ = rgx::pending_launch_error();                                                                   \
+        if (e_ != hipSuccess) return fail(err, errlen, RGX_ERR_DEVICE, "HIP error %s from a kernel launch before %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+// First HIP call of an entry point: errors other code left with this host thread (another library's polling of an event, an ignored return
+// of a clean-up call) are not this call's launches' -- drop them, then select the device.
+#define HIP_ENTER(dev)                                                                                      \
+    do { (void)rgx::pending_launch_error(); HIP_TRY(hipSetDevice(dev)); } while (0)
 
 const char *kMsgOpen = "Unable to open BAM/SAM file.\n\n";
 const char *kMsgIndex = "Unable to open BAM/SAM index. Make sure alignments are indexed\n\n";
@@ -93,7 +106,7 @@ struct rgx_ctx {
     hipStream_t copy_stream = nullptr, side[kSideStreams] = {};
     bool one_shot = false;                             // REGTOOLS_AMD_ONE_SHOT at creation: no streams besides `stream` (ensure_upload_streams)
     std::vector<hipEvent_t> chunk_ev;
-    hipEvent_t ev_ready = nullptr, ev_side[kSideStreams] = {};
+    hipEvent_t ev_ready = nullptr, ev_side[kSideStreams] = {}, ev_packed = nullptr;
     hipEvent_t ev[8] = {};
     std::map<std::string, DevBuf> bufs;
     void *pinned = nullptr; size_t pinned_cap = 0;     // small pinned staging for scalar readbacks
@@ -209,6 +222,7 @@ extern "C" void rgx_ctx_destroy(rgx_ctx *c) {
     for (auto &e : c->kfree) (void)hipEventDestroy(e);
     for (auto &e : c->ev_side) if (e) (void)hipEventDestroy(e);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+    if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
     for (auto &q : c->side) if (q) (void)hipStreamDestroy(q);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c->fasta;
@@ -405,7 +419,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
                           bool allow_overlap = true, bool region_to_file_end = false, const SharedMembers *shared = nullptr) {
     if (!p || p->strandness < 0 || p->strandness > 3) return fail(err, errlen, RGX_ERR_ARG, "Please supply strandness mode with '-s' option!\n\n");
     if (p->strandness == 3 && !p->fasta_path) return fail(err, errlen, RGX_ERR_ARG, "Strandness mode 'intron-motif' requires a fasta file!\n\n");
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_ENTER(c->device);
     hipStream_t st = c->stream;
     hipStream_t copy_q = c->copy_stream ? c->copy_stream : c->stream;     // where the file's upload goes (a one-shot context: its only stream)
     const double t_begin = now_ms();
@@ -1815,6 +1829,47 @@ extern "C" int rgx_table_merge(const rgx_junction_table *const *parts, int n_par
     return RGX_OK;
 }
 
+// Peer access between two devices, both directions, once per pair and process (round 4): without it hipMemcpyPeer* between two GPUs is a bounce
+// through host memory instead of a copy over xGMI.  Returns whether the pair is peer-accessible (a copy still works when it is not).
+bool rgx_enable_peer(int a, int b) {
+    if (a == b) return true;
+    static std::mutex mu; static std::map<std::pair<int, int>, bool> done;
+    std::lock_guard<std::mutex> lk(mu);
+    const std::pair<int, int> key{std::min(a, b), std::max(a, b)};
+    auto it = done.find(key);
+    if (it != done.end()) return it->second;
+    int prev = 0; (void)hipGetDevice(&prev);
+    bool ok = true;
+    for (int dir = 0; dir < 2; ++dir) {
+        const int self = dir ? b : a, peer = dir ? a : b;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, self, peer) != hipSuccess || !can) { ok = false; continue; }
+        if (hipSetDevice(self) != hipSuccess) { ok = false; continue; }
+        const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
+    }
+    (void)hipSetDevice(prev);
+    (void)hipGetLastError();                                        // ("already enabled" is not an error of anybody's launch)
+    done[key] = ok;
+    return ok;
+}
+
+// the rows of the context's last extraction, packed (48 bytes per row) into a buffer of the CONTEXT on its own stream, no host wait: *done is
+// recorded behind the kernel, for the exchange stream of rgx_extract_multi to wait on (multi.cpp; not part of the C ABI)
+int rgx_last_table_pack_async(rgx_ctx *c, const rgx_junction_table *t, void **d_packed, hipEvent_t *done, char *err, size_t errlen) {
+    if (!c || !t || !d_packed || !done) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
+    if (!c->last_rows_valid || t->n != c->last_rows || t->n_records != c->last_records || t->n_events != c->last_events || t->inflated_bytes != c->last_bytes)
+        return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: the table is not the result of the last extraction on this context\n");
+    HIP_ENTER(c->device);
+    DevBuf &b = c->buf("rows_packed");
+    HIP_TRY(b.ensure((size_t)std::max<uint64_t>(1, t->n) * RGX_PACKED_ROW_BYTES));
+    if (!c->ev_packed) HIP_TRY(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+    if (t->n) launch_cols_to_packed(c->buf("rows_out").as<uint32_t>(), (uint32_t)t->n, b.as<uint32_t>(), c->stream);
+    HIP_TRY(hipEventRecord(c->ev_packed, c->stream));
+    *d_packed = b.p; *done = c->ev_packed;
+    return RGX_OK;
+}
+
 // the rows of the context's last extraction, packed for the all-gather without leaving HBM
 extern "C" int rgx_last_table_pack_device(rgx_ctx *c, const rgx_junction_table *t, void *d_dst, uint64_t cap_rows, char *err, size_t errlen) {
     if (!c || !t) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
@@ -1822,7 +1877,7 @@ extern "C" int rgx_last_table_pack_device(rgx_ctx *c, const rgx_junction_table *
         return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: the table is not the result of the last extraction on this context\n");
     if (!t->n) return RGX_OK;
     if (!d_dst || cap_rows < t->n) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: destination holds %llu rows, %llu needed\n", (unsigned long long)cap_rows, (unsigned long long)t->n);
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_ENTER(c->device);
     launch_cols_to_packed(c->buf("rows_out").as<uint32_t>(), (uint32_t)t->n, (uint32_t *)d_dst, c->stream);
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RGX_OK;
@@ -1833,7 +1888,7 @@ extern "C" int rgx_table_merge_device(rgx_ctx *c, const void *d_rows, uint64_t s
                                       const rgx_junction_table *names_from, rgx_junction_table **out, char *err, size_t errlen) {
     if (!c || !d_rows || !part_rows || n_parts <= 0 || n_parts > 255 || !names_from || !out) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
     *out = nullptr;
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_ENTER(c->device);
     hipStream_t st = c->stream;
     const bool trace = getenv("REGTOOLS_AMD_TRACE") != nullptr;
     double t_last = now_ms();

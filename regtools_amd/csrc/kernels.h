@@ -17,6 +17,8 @@ constexpr uint64_t kChainUnknown = ~0ull - 1;   // exit of a segment in which th
 // member m writes its bytes at arena + (members[m].upos - upos_bias)
 // len_scratch: inflate_scratch_bytes(n_members) bytes of device memory (code-length scratch of the block headers)
 size_t inflate_scratch_bytes(uint32_t n_members);
+// an error of a kernel launch (refused configuration) or of a launch's set-up since this host thread last asked; hipSuccess = none (clears it)
+hipError_t pending_launch_error();
 constexpr uint32_t kStatusEarly = 76;   // status[kStatusEarly..+1]: the same pair for members below ignore_below (only written when that is > 0)
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
                     uint32_t *status /* [0]=first bad member (min), [1]=its status */, hipStream_t stream, uint32_t ignore_below = 0 /* failures of members below this index are not reported */,

@@ -434,28 +434,41 @@ static int inflate_form_env() {
 }
 // (the attribute belongs to the current device's copy of the function: once per device, and the shard threads of rgx_extract_multi
 // may get here together)
+// A configuration step that failed (hipFuncSetAttribute on this device's copy of a kernel) must not pass silently: the launch behind it
+// would fail or run with too little LDS, the arena would stay untouched and the stages behind it would read it.  The error is kept per host
+// thread until the caller's next checked HIP call (api.cpp HIP_TRY -> pending_launch_error) turns it into RGX_ERR_DEVICE.
+static thread_local hipError_t tl_launch_error = hipSuccess;
+hipError_t pending_launch_error() {
+    hipError_t e = tl_launch_error; tl_launch_error = hipSuccess;
+    const hipError_t last = hipGetLastError();                    // (a launch whose configuration was refused: sticky until read)
+    return e != hipSuccess ? e : last;
+}
 static void inflate_attrs() {
     static std::mutex mu;
     static bool done_dev[64] = {};
+    static hipError_t err_dev[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     std::lock_guard<std::mutex> lk(mu);
     bool &done = done_dev[dev];
-    if (done) return;
-    (void)hipFuncSetAttribute((const void *)k_inflate<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
-    (void)hipFuncSetAttribute((const void *)k_inflate<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
-    (void)hipFuncSetAttribute((const void *)k_inflate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
-    (void)hipFuncSetAttribute((const void *)k_inflate_coop<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
-    (void)hipFuncSetAttribute((const void *)k_inflate<false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
-    (void)hipFuncSetAttribute((const void *)k_inflate<false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
-    (void)hipFuncSetAttribute((const void *)k_inflate_coop<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
-    (void)hipFuncSetAttribute((const void *)k_inflate_coop<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
-    (void)hipFuncSetAttribute((const void *)k_inflate_coop<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
-    (void)hipFuncSetAttribute((const void *)k_inflate_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLdsBytes);
-    (void)hipFuncSetAttribute((const void *)k_inflate_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WaveShared));
-    (void)hipFuncSetAttribute((const void *)k_inflate_ring<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRingLdsBytes);
-    (void)hipFuncSetAttribute((const void *)k_inflate_ring<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRingLdsBytes);
-    done = true;
+    if (done) { if (err_dev[dev] != hipSuccess) tl_launch_error = err_dev[dev]; return; }
+    hipError_t first = hipSuccess;
+    auto set = [&](const void *fn, uint32_t bytes) { const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess && first == hipSuccess) first = e; };
+    set((const void *)k_inflate<false, false>, kInflateLdsBytes);
+    set((const void *)k_inflate<false, true>, kInflateLdsBytes);
+    set((const void *)k_inflate<true>, kInflateLdsBytes);
+    set((const void *)k_inflate_coop<false, false, false>, kInflateLdsBytes);
+    set((const void *)k_inflate<false, false, 4>, kInflateLdsBytes);
+    set((const void *)k_inflate<false, true, 4>, kInflateLdsBytes);
+    set((const void *)k_inflate_coop<false, true, false>, kInflateLdsBytes);
+    set((const void *)k_inflate_coop<false, false, true>, kInflateLdsBytes);
+    set((const void *)k_inflate_coop<false, true, true>, kInflateLdsBytes);
+    set((const void *)k_inflate_coop<true>, kInflateLdsBytes);
+    set((const void *)k_inflate_wave, (uint32_t)sizeof(WaveShared));
+    set((const void *)k_inflate_ring<false>, kRingLdsBytes);
+    set((const void *)k_inflate_ring<true>, kRingLdsBytes);
+    err_dev[dev] = first; done = true;
+    if (first != hipSuccess) tl_launch_error = first;
 }
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
                     uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias, bool piece, int form, uint8_t *bad, int plan, bool check_layout) {

@@ -34,6 +34,9 @@
 
 #include "host_io.h"
 
+// api.cpp (not part of the C ABI): the rows of a context's last extraction packed on ITS stream, an event behind the kernel; peer access per pair
+int rgx_last_table_pack_async(rgx_ctx *c, const rgx_junction_table *t, void **d_packed, hipEvent_t *done, char *err, size_t errlen);
+bool rgx_enable_peer(int a, int b);
 // api.cpp: rgx_extract_mem with the member list the caller scanned (not part of the C ABI)
 int rgx_extract_mem_scanned(rgx_ctx *ctx, const void *bam, size_t bam_len, const void *bai, size_t bai_len, const rgx_extract_params *p,
                             const std::vector<rgx::Member> *members, uint64_t total_inflated, rgx_junction_table **out, char *err, size_t errlen);
@@ -81,6 +84,7 @@ struct Rccl {
 };
 Rccl g_rccl;
 const int kNcclUint8 = 1;
+char g_exchange_kind[160] = "none";      // how the last rgx_extract_multi call moved its rows (rgx_multi_exchange_kind)
 
 struct Shard {
     int device = 0, nth = 0;                 // nth: which of the listings of this device
@@ -89,6 +93,8 @@ struct Shard {
     int rc = RGX_OK;
     char err[512] = {0};
     double ms_extract = 0;
+    void *d_packed = nullptr;                // the shard's rows, 48 bytes each, in a buffer of its context (packed on the shard's thread and stream)
+    hipEvent_t ev_packed = nullptr;          // ... recorded behind the pack kernel: the exchange waits for it on the device, no host wait per shard
 };
 
 // Contexts are kept for the life of the process, one per (device, how many times the device is listed): a second call finds its HBM
@@ -115,14 +121,16 @@ namespace {
 // nothing is handed back before the process ends (rgx_extract_multi calls take turns: call_mu).
 struct Exchange {
     std::vector<int> devices;
-    std::vector<nccl_comm> comms;            // empty while the list repeats a device (no collective then)
+    std::vector<nccl_comm> comms;            // empty while the list repeats a device (no collective then) or when RCCL could not be set up
+    std::string rccl_error;                  // why comms is empty on a list of distinct devices
+    std::vector<char> peer;                  // [g]: peer access between devices[0] and devices[g] is on (xGMI copies; else they go through the host)
     std::vector<hipStream_t> streams;
     std::vector<void *> d_send; std::vector<size_t> send_cap;
     void *d_recv = nullptr; size_t recv_cap = 0;
 };
 std::map<std::vector<int>, Exchange> g_exchange;
 
-int exchange_for(const int *devices, int n, bool distinct, size_t block, Exchange *&out, char *err, size_t errlen) {
+int exchange_for(const int *devices, int n, bool distinct, size_t block, const std::vector<char> &need_send, Exchange *&out, char *err, size_t errlen) {
     std::vector<int> key(devices, devices + n);
     Exchange &x = g_exchange[key];
     if (x.devices.empty()) {
@@ -130,15 +138,24 @@ int exchange_for(const int *devices, int n, bool distinct, size_t block, Exchang
         for (int g = 0; g < n; ++g)
             if (hipSetDevice(devices[g]) != hipSuccess || hipStreamCreateWithFlags(&x.streams[(size_t)g], hipStreamNonBlocking) != hipSuccess)
                 return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no stream for the row exchange on device %d\n", devices[g]);
+        x.peer.assign((size_t)n, 1);
         if (distinct && n > 1) {
-            if (!g_rccl.load(err, errlen)) return RGX_ERR_DEVICE;
-            x.comms.assign((size_t)n, nullptr);
-            const int r = g_rccl.CommInitAll(x.comms.data(), n, devices);
-            if (r != 0) { x.comms.clear(); return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: ncclCommInitAll failed: %s\n", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); }
+            // peer access first (RCCL's own transports and the fall-back copies both want it), then the communicators.  RCCL that cannot be
+            // loaded or initialised is not the end of the call: the gather then is peer copies (reported: rgx_multi_exchange_kind)
+            for (int g = 1; g < n; ++g) x.peer[(size_t)g] = rgx_enable_peer(devices[0], devices[g]) ? 1 : 0;
+            char why[256] = {0};
+            if (!g_rccl.load(why, sizeof why)) x.rccl_error = why;
+            else if (!g_rccl.Send || !g_rccl.Recv) x.rccl_error = "this librccl has no ncclSend / ncclRecv";
+            else {
+                x.comms.assign((size_t)n, nullptr);
+                const int r = g_rccl.CommInitAll(x.comms.data(), n, devices);
+                if (r != 0) { x.comms.clear(); x.rccl_error = std::string("ncclCommInitAll failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); }
+            }
+            while (!x.rccl_error.empty() && (x.rccl_error.back() == '\n' || x.rccl_error.back() == ' ')) x.rccl_error.pop_back();
         }
     }
     for (int g = 0; g < n; ++g) {
-        if (x.send_cap[(size_t)g] >= block) continue;
+        if (!need_send[(size_t)g] || x.send_cap[(size_t)g] >= block) continue;
         if (hipSetDevice(devices[g]) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: device %d\n", devices[g]);
         if (x.d_send[(size_t)g]) (void)hipFree(x.d_send[(size_t)g]);
         x.d_send[(size_t)g] = nullptr; x.send_cap[(size_t)g] = 0;
@@ -194,6 +211,13 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
         rgx_extract_params q = *p;
         q.shard = g; q.n_shards = n;
         s.rc = rgx_extract_mem_scanned(s.ctx, bam, bam_len, bai, bai_len, &q, &members, total_inflated, &s.table, s.err, sizeof s.err);
+        // the shard's rows are still in HBM: packed for the exchange right here, on the shard's own thread and stream (round 3 packed the shards
+        // one after the other on the calling thread, a host wait each).  A shard whose rows are not its context's last any more (several
+        // listings of one device share nothing, so this does not happen today) is packed from the host table below.
+        if (s.rc == RGX_OK && n > 1 && s.table->n) {
+            char e2[256];
+            if (rgx_last_table_pack_async(s.ctx, s.table, &s.d_packed, &s.ev_packed, e2, sizeof e2) != RGX_OK) { s.d_packed = nullptr; s.ev_packed = nullptr; }
+        }
         s.ms_extract = now_ms() - t0;
     };
     if (distinct) {
@@ -206,7 +230,7 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
     // (REGTOOLS_AMD_RCCL_SELFTEST: a one-device list goes through pack, ncclCommInitAll / ncclAllGather of one rank and the device merge
     // as well -- the collective's call sequence on the real library where only one GPU is visible)
     const bool selftest = getenv("REGTOOLS_AMD_RCCL_SELFTEST") != nullptr;
-    if (n == 1 && !selftest) { *out = S[0].table; S[0].table = nullptr; return RGX_OK; }
+    if (n == 1 && !selftest) { snprintf(g_exchange_kind, sizeof g_exchange_kind, "none (one shard)"); *out = S[0].table; S[0].table = nullptr; return RGX_OK; }
     if (n == 1) {
         // one rank through ncclCommInitAll / ncclAllGather on the real library (no peer to send to)
         if (!g_rccl.load(err, errlen)) return RGX_ERR_DEVICE;
@@ -233,55 +257,79 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
         return RGX_OK;
     }
 
-    // -- pack: every shard's rows, still in HBM on its device, into a block of `stride` rows ----------------------------------------------
+    // -- what every shard sends: its packed rows where they lie (d_packed, ready when ev_packed fires), or -- no device copy of them left --
+    //    a block uploaded from the host table ---------------------------------------------------------------------------------------------
     const double t_extract = now_ms();
     uint64_t stride = 1;
     std::vector<uint64_t> part_rows((size_t)n);
-    for (int g = 0; g < n; ++g) { part_rows[(size_t)g] = S[(size_t)g].table->n; stride = std::max<uint64_t>(stride, S[(size_t)g].table->n); }
+    std::vector<char> need_send((size_t)n, 0);
+    for (int g = 0; g < n; ++g) {
+        part_rows[(size_t)g] = S[(size_t)g].table->n; stride = std::max<uint64_t>(stride, S[(size_t)g].table->n);
+        need_send[(size_t)g] = S[(size_t)g].table->n && !S[(size_t)g].d_packed;
+    }
     const size_t block = (size_t)stride * RGX_PACKED_ROW_BYTES;
     Exchange *X = nullptr;
-    { const int rcx = exchange_for(devices, n, distinct, block, X, err, errlen); if (rcx != RGX_OK) return rcx; }
+    { const int rcx = exchange_for(devices, n, distinct, block, need_send, X, err, errlen); if (rcx != RGX_OK) return rcx; }
+    std::vector<const void *> src((size_t)n, nullptr);
     for (int g = 0; g < n; ++g) {
         Shard &s = S[(size_t)g];
+        if (!s.table->n) continue;
         if (hipSetDevice(s.device) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: device %d\n", s.device);
-        if (s.table->n) {
-            // the rows of a context's LAST extraction are still on its device; with several shards on one device only the last one's are,
-            // the others go up from the host table
-            if (rgx_last_table_pack_device(s.ctx, s.table, X->d_send[(size_t)g], stride, s.err, sizeof s.err) != RGX_OK) {
-                std::vector<uint8_t> h((size_t)s.table->n * RGX_PACKED_ROW_BYTES);
-                rgx_table_pack(s.table, h.data(), h.size());
-                if (hipMemcpy(X->d_send[(size_t)g], h.data(), h.size(), hipMemcpyHostToDevice) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: row upload failed\n");
-            }
+        if (s.d_packed) {
+            // the exchange stream of this shard waits for the pack ON THE DEVICE
+            if (hipStreamWaitEvent(X->streams[(size_t)g], s.ev_packed, 0) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no wait on the rows of device %d\n", s.device);
+            src[(size_t)g] = s.d_packed;
+        } else {
+            std::vector<uint8_t> h((size_t)s.table->n * RGX_PACKED_ROW_BYTES);
+            rgx_table_pack(s.table, h.data(), h.size());
+            if (hipMemcpy(X->d_send[(size_t)g], h.data(), h.size(), hipMemcpyHostToDevice) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: row upload failed\n");
+            src[(size_t)g] = X->d_send[(size_t)g];
         }
     }
 
-    // -- the one exchange of the job: every shard's block to the first device ------------------------------------------------------------------
-    if (distinct) {
+    // -- the one exchange of the job: every shard's rows to the first device (shard g's at d_recv + g x block; it sends exactly its rows) ---------
+    auto bytes_of = [&](int g) { return (size_t)part_rows[(size_t)g] * RGX_PACKED_ROW_BYTES; };
+    bool by_rccl = false;
+    std::string rccl_note = distinct ? X->rccl_error : std::string();
+    // (REGTOOLS_AMD_NO_RCCL: the fall-back on purpose -- how a multi-GPU box tests it)
+    if (distinct && getenv("REGTOOLS_AMD_NO_RCCL")) rccl_note = "REGTOOLS_AMD_NO_RCCL is set";
+    if (distinct && !X->comms.empty() && !getenv("REGTOOLS_AMD_NO_RCCL")) {
+        // a gather: rank g sends its rows, rank 0 receives n - 1 blocks, all in one group (its own rows are a device copy on its stream)
         int r = g_rccl.GroupStart();
-        if (g_rccl.Send && g_rccl.Recv) {
-            // a gather: rank g sends its block, rank 0 receives n of them (its own as a device copy inside the group)
-            for (int g = 0; g < n && r == 0; ++g) {
-                if (hipSetDevice(devices[g]) != hipSuccess) { r = -1; break; }
-                if (g > 0) r = g_rccl.Send(X->d_send[(size_t)g], block, kNcclUint8, 0, X->comms[(size_t)g], X->streams[(size_t)g]);
-            }
-            if (r == 0 && hipSetDevice(devices[0]) != hipSuccess) r = -1;
-            for (int g = 1; g < n && r == 0; ++g) r = g_rccl.Recv((uint8_t *)X->d_recv + (size_t)g * block, block, kNcclUint8, g, X->comms[0], X->streams[0]);
-            if (r == 0 && hipMemcpyAsync(X->d_recv, X->d_send[0], block, hipMemcpyDeviceToDevice, X->streams[0]) != hipSuccess) r = -1;
-        } else r = -1;                                        // (a library without point-to-point calls: reported below)
-        const int r2 = g_rccl.GroupEnd();
-        if (r != 0 || r2 != 0) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: the RCCL row gather failed: %s\n",
-                                            !(g_rccl.Send && g_rccl.Recv) ? "this librccl has no ncclSend / ncclRecv" : g_rccl.GetErrorString ? g_rccl.GetErrorString(r > 0 ? r : r2) : "?");
-        for (int g = 0; g < n; ++g) {
-            if (hipSetDevice(devices[g]) != hipSuccess || hipStreamSynchronize(X->streams[(size_t)g]) != hipSuccess)
-                return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: the row exchange did not complete on device %d\n", devices[g]);
+        for (int g = 1; g < n && r == 0; ++g) {
+            if (!bytes_of(g)) continue;
+            if (hipSetDevice(devices[g]) != hipSuccess) { r = -1; break; }
+            r = g_rccl.Send(src[(size_t)g], bytes_of(g), kNcclUint8, 0, X->comms[(size_t)g], X->streams[(size_t)g]);
         }
-    } else {
-        if (hipSetDevice(S[0].device) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: device %d\n", S[0].device);
-        for (int g = 0; g < n; ++g)
-            if (hipMemcpyPeer((uint8_t *)X->d_recv + (size_t)g * block, S[0].device, X->d_send[(size_t)g], S[(size_t)g].device, block) != hipSuccess)
-                return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: row copy from device %d failed\n", S[(size_t)g].device);
-        // a device-to-device copy may return before it is done, and the merge runs on the context's own (non-blocking) stream
-        if (hipDeviceSynchronize() != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: the row copies did not complete\n");
+        if (r == 0 && hipSetDevice(devices[0]) != hipSuccess) r = -1;
+        for (int g = 1; g < n && r == 0; ++g) if (bytes_of(g)) r = g_rccl.Recv((uint8_t *)X->d_recv + (size_t)g * block, bytes_of(g), kNcclUint8, g, X->comms[0], X->streams[0]);
+        const int r2 = g_rccl.GroupEnd();
+        by_rccl = r == 0 && r2 == 0;
+        if (by_rccl) {
+            for (int g = 0; g < n && by_rccl; ++g)
+                if (hipSetDevice(devices[g]) != hipSuccess || hipStreamSynchronize(X->streams[(size_t)g]) != hipSuccess) by_rccl = false;
+            if (!by_rccl) rccl_note = "the grouped ncclSend / ncclRecv did not complete";
+        } else rccl_note = std::string("the grouped ncclSend / ncclRecv failed: ") + (r < 0 ? "device selection" : g_rccl.GetErrorString ? g_rccl.GetErrorString(r > 0 ? r : r2) : "?");
+        (void)hipGetLastError();
+    }
+    if (hipSetDevice(devices[0]) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: device %d\n", devices[0]);
+    // rows that did not travel by RCCL: copies on the first device's exchange stream, each behind its shard's pack (peer copies between distinct
+    // devices -- the fall-back when RCCL is missing or failed, said so in rgx_multi_exchange_kind --, device copies when a device is listed twice)
+    for (int g = 0; g < n; ++g) {
+        if (!bytes_of(g) || (by_rccl && g > 0)) continue;
+        const Shard &s = S[(size_t)g];
+        if (s.d_packed && hipStreamWaitEvent(X->streams[0], s.ev_packed, 0) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no wait on the rows of device %d\n", s.device);
+        const hipError_t e = s.device == devices[0] ? hipMemcpyAsync((uint8_t *)X->d_recv + (size_t)g * block, src[(size_t)g], bytes_of(g), hipMemcpyDeviceToDevice, X->streams[0])
+                                                    : hipMemcpyPeerAsync((uint8_t *)X->d_recv + (size_t)g * block, devices[0], src[(size_t)g], s.device, bytes_of(g), X->streams[0]);
+        if (e != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: row copy from device %d failed: %s\n", s.device, hipGetErrorString(e));
+    }
+    // (the merge runs on the context's own stream: the rows must be there before it is enqueued)
+    if (hipStreamSynchronize(X->streams[0]) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: the row copies did not complete\n");
+    {
+        bool all_peer = true; for (int g = 1; g < n; ++g) if (!X->peer[(size_t)g]) all_peer = false;
+        if (!distinct) snprintf(g_exchange_kind, sizeof g_exchange_kind, "device copies (a device is listed more than once)");
+        else if (by_rccl) snprintf(g_exchange_kind, sizeof g_exchange_kind, "rccl grouped send/recv, %d ranks%s", n, all_peer ? ", peer access on" : ", peer access NOT available");
+        else snprintf(g_exchange_kind, sizeof g_exchange_kind, "hipMemcpyPeerAsync%s (RCCL not used: %.90s)", all_peer ? " over peer access" : " WITHOUT peer access", rccl_note.c_str());
     }
     const double t_exchange = now_ms();
 
@@ -294,7 +342,7 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
     if (rc != RGX_OK) return rc;
     const double t_merge = now_ms();
     if (getenv("REGTOOLS_AMD_TRACE")) {
-        fprintf(stderr, "[rgx trace] multi: %d shards (%s), member scan %.3f ms, shards %.3f ms (", n, distinct ? (g_rccl.Send ? "RCCL send/recv gather" : "RCCL") : "one device, copies",
+        fprintf(stderr, "[rgx trace] multi: %d shards (%s), member scan %.3f ms, shards %.3f ms (", n, g_exchange_kind,
                 t_scan - t_begin, t_extract - t_scan);
         for (int g = 0; g < n; ++g) fprintf(stderr, "%s%.1f", g ? " " : "", S[(size_t)g].ms_extract);
         fprintf(stderr, "), pack + exchange %.3f ms, merge %.3f ms\n", t_exchange - t_extract, t_merge - t_exchange);
@@ -317,6 +365,9 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
     *out = m;
     return RGX_OK;
 }
+
+// how the last rgx_extract_multi / rgx_extract_multi_mem call of this process moved the shards' rows to the first device
+extern "C" const char *rgx_multi_exchange_kind(void) { return g_exchange_kind; }
 
 extern "C" int rgx_extract_multi(const int *devices, int n_devices, const char *bam_path, const rgx_extract_params *p, rgx_junction_table **out,
                                  char *err, size_t errlen) {

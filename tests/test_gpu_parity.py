@@ -495,10 +495,23 @@ def test_multi_device_host_equals_single_gpu(gpu_ctx, synth_dir):
     lists = [[0], [0, 0], [0, 0, 0, 0, 0]]
     if n_gpu >= 2:
         lists += [list(range(n_gpu)), list(range(n_gpu - 1, -1, -1))[:2]]
+    from regtools_amd import _ffi
+    kind = lambda: _ffi.lib().rgx_multi_exchange_kind().decode()
     for devs in lists:
         m = regtools_amd.extract_multi(devs, bam=p, strandness=0)
         assert m.bed12() == single, devs
         assert m.table.contents.n_records == je.stats["n_records"] and m.table.contents.n_events == je.stats["n_events"], devs
+        # how the rows travelled: nothing to move, device copies when a device is listed twice, RCCL between distinct devices
+        want = "none" if len(devs) == 1 else "device copies" if len(set(devs)) < len(devs) else "rccl grouped send/recv, %d ranks" % len(devs)
+        assert kind().startswith(want), (devs, kind())
+    if n_gpu >= 2:
+        # the fall-back a node without a working RCCL takes: the same rows as peer copies, and the call says so
+        os.environ["REGTOOLS_AMD_NO_RCCL"] = "1"
+        try:
+            assert regtools_amd.extract_multi(list(range(n_gpu)), bam=p, strandness=0).bed12() == single
+            assert kind().startswith("hipMemcpyPeerAsync") and "REGTOOLS_AMD_NO_RCCL" in kind(), kind()
+        finally:
+            del os.environ["REGTOOLS_AMD_NO_RCCL"]
     for args, kw in ((["-s", "RF", "-a", "20"], dict(strandness=1, min_anchor_length=20)), (["-s", "XS", "-r", "chr3"], dict(strandness=0, region="chr3"))):
         exp = gpu_extract(gpu_ctx, p, args)[1]
         assert regtools_amd.extract_multi(lists[-1], bam=p, **kw).bed12() == exp, args
@@ -568,6 +581,9 @@ def test_bench_multi_rank_path_on_one_gpu(gpu_ctx, tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["multi_gpu"]["per_rank"][1]["reads"] == 200000 and line["multi_gpu"]["merge_ms"] > 0
+    ck = line["multi_gpu"]["checks"]                 # the line's own assertions (bench.py): records, an independent host merge, supporting reads
+    assert ck["records_conserved"] and ck["bed12_equals_independent_merge"] and ck["counts_conserved"] and ck["merged_rows"] == line["junction_rows"] == ck["independent_host_merge_rows"]
+    assert sum(r["n_records"] for r in line["multi_gpu"]["per_rank"]) == 400000
     # the same two slices, one rank each, merged here
     import regtools_amd
     from regtools_amd import distributed
@@ -584,6 +600,8 @@ def test_bench_multi_rank_path_on_one_gpu(gpu_ctx, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--multi-host", "cpp", "--steps", "1", "--warmup", "1", "--reads", "200000", "--dump-bed", bedc],
                        env=os.environ, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
+    linec = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert linec["multi_gpu"]["checks"]["bed12_equals_single_device"] and linec["multi_gpu"]["exchange"].startswith("device copies"), linec["multi_gpu"]
     bam, bai, _ = synth.generate(400000, shape="short", seed=1)
     je = regtools_amd.JunctionsExtractor(strandness=0, ctx=gpu_ctx)
     je.identify_junctions_from_BAM(bam_bytes=bam, bai_bytes=bai)
