@@ -106,6 +106,7 @@ struct rgx_ctx {
     hipStream_t copy_stream = nullptr, side[kSideStreams] = {};
     bool one_shot = false;                             // REGTOOLS_AMD_ONE_SHOT at creation: no streams besides `stream` (ensure_upload_streams)
     std::vector<hipEvent_t> chunk_ev;
+    uint32_t gate_epoch = 0;                           // arrival gate of the overlapped upload (kernels.h InflateGate): this context's call counter
     hipEvent_t ev_ready = nullptr, ev_side[kSideStreams] = {}, ev_packed = nullptr;
     hipEvent_t ev[8] = {};
     std::map<std::string, DevBuf> bufs;
@@ -451,7 +452,8 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         // may free or reuse that buffer as soon as the call returns)
         ~Upload() { if (th.joinable()) th.join(); if (copy_stream) (void)hipStreamSynchronize(copy_stream); }
     } up;
-    bool overlap = false;
+    bool overlap = false, gated = false;
+    size_t gate_chunk = 0;
     std::vector<Member> hm;                                  // the host scan's member list (overlap only)
     uint64_t hm_total = 0;
     if (!d_bam) {
@@ -460,7 +462,9 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         d_bam = b.as<uint8_t>();
         mark("file buffer in HBM");
         static const bool no_overlap = getenv("REGTOOLS_AMD_NO_OVERLAP") != nullptr;
-        if (allow_overlap && !d_true_sizes && !no_overlap && bam_len >= ((size_t)8 << 20)) {
+        // (REGTOOLS_AMD_OVERLAP_MIN: tests send small files through the overlapped path)
+        static const size_t overlap_min = [] { const char *e = getenv("REGTOOLS_AMD_OVERLAP_MIN"); return e ? (size_t)atoll(e) : (size_t)8 << 20; }();
+        if (allow_overlap && !d_true_sizes && !no_overlap && bam_len >= overlap_min) {
             HIP_TRY(ensure_upload_streams(c));
             if (c->copy_stream) copy_q = c->copy_stream;
             mark("upload streams");
@@ -489,6 +493,14 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
                     if (up_lo < hdr_hi) { up_lo = 0; hdr_hi = 0; }
                 }
             }
+            // Round 4: ONE inflate launch for the whole range, its waves gated by the arrival of their upload chunk (kernels.h InflateGate):
+            // the file goes up in kGateChunks equal chunks, a 4-byte copy of this call's epoch into the chunk's flag word queued right behind each.
+            // The members of the early chunks start ~0.6 ms into the upload; only those of the last chunk pay the lane-serial floor behind it
+            // (round 3: three launches, each ~10 ms for a third of the members, the last one started when the last third had arrived).
+            // REGTOOLS_AMD_GATE=0, REGTOOLS_AMD_PIECES or a one-shot context: round 3's pieces.
+            static const bool gate_off = [] { const char *e = getenv("REGTOOLS_AMD_GATE"); return e && !strcmp(e, "0"); }();
+            static const unsigned gate_chunks = [] { const char *e = getenv("REGTOOLS_AMD_GATE_CHUNKS"); const int v = e ? atoi(e) : 16; return (unsigned)std::min(std::max(v, 2), 64); }();
+            gated = !gate_off && !c->one_shot && !getenv("REGTOOLS_AMD_PIECES") && up_hi - up_lo >= std::min(overlap_min, (size_t)8 << 20) && up_hi - up_lo >= 2 * 4096 * (size_t)gate_chunks;
             // three pieces, each its own launch on its own hardware queue (two side streams + the pipeline's own; a launch takes ~8 ms however
             // small -- one lane per member).  Equal thirds measured best: 31.6 ms per step against 32.4-33.3 ms for pieces that shrink towards
             // the end, and 30.9-31.5 ms for four to six equal pieces on side streams of other priorities (= other queue pools), 32.6 for seven
@@ -501,6 +513,13 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
                 if (sscanf(e, "%u,%u", &a, &b) == 2) { if (a > 0 && a < b && b < 100) cuts = {a, b}; }
                 else if (sscanf(e, "%u", &a) == 1 && a >= 1 && a <= (unsigned)kSideStreams + 1) { cuts.clear(); for (unsigned k = 1; k < a; ++k) cuts.push_back(100 * k / a); }
             }
+            if (gated) {
+                gate_chunk = (((up_hi - up_lo) + gate_chunks - 1) / gate_chunks + 4095) & ~(size_t)4095;
+                for (size_t e = up_lo + gate_chunk; e < up_hi; e += gate_chunk) up.end.push_back(e);
+                DevBuf &bg = c->buf("gate_flags");
+                if (!bg.p) { HIP_TRY(bg.ensure(4 * 64)); HIP_TRY(hipMemset(bg.p, 0, 4 * 64)); c->gate_epoch = 0; }
+                ++c->gate_epoch;
+            } else
             for (unsigned pc : cuts) {
                 const size_t e = (up_lo + (size_t)((double)(up_hi - up_lo) * pc / 100.0) + 4095) & ~(size_t)4095;
                 if (e < up_hi && e > up_lo && (up.end.empty() || e > up.end.back())) up.end.push_back(e);
@@ -510,13 +529,16 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             while (c->chunk_ev.size() < up.end.size()) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->chunk_ev.push_back(e); }
             uint8_t *dst = b.as<uint8_t>();
             up.copy_stream = copy_q;
-            up.th = std::thread([c, dst, h_bam, hdr_hi, up_lo, copy_q, &up] {
+            uint32_t *gate_flags = gated ? c->buf("gate_flags").as<uint32_t>() : nullptr;
+            const uint32_t gate_epoch = c->gate_epoch;
+            up.th = std::thread([c, dst, h_bam, hdr_hi, up_lo, copy_q, gate_flags, gate_epoch, &up] {
                 if (hipSetDevice(c->device) != hipSuccess) { up.err = 1; up.recorded = (uint32_t)up.end.size(); return; }
                 if (hdr_hi && hipMemcpyAsync(dst, h_bam, hdr_hi, hipMemcpyHostToDevice, copy_q) != hipSuccess) up.err = 1;
                 size_t o = up_lo;
                 for (size_t j = 0; j < up.end.size(); ++j) {
                     if ((up.end[j] > o && hipMemcpyAsync(dst + o, h_bam + o, up.end[j] - o, hipMemcpyHostToDevice, copy_q) != hipSuccess) ||
                         hipEventRecord(c->chunk_ev[j], copy_q) != hipSuccess) up.err = 1;
+                    if (gate_flags) launch_gate_set(gate_flags + j, gate_epoch, copy_q);
                     o = up.end[j];
                     up.recorded.store((uint32_t)j + 1, std::memory_order_release);
                 }
@@ -815,6 +837,20 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         HIP_TRY(hipEventRecord(c->ev_ready, st));
         for (auto &q : c->side) if (q) HIP_TRY(hipStreamWaitEvent(q, c->ev_ready, 0));
         uint32_t g_lo = m_lo; size_t scratch_off = 0; unsigned used_side = 0;
+        if (gated) {
+            // one launch on the pipeline's stream, now: its waves wait for their chunk's flag themselves (k_inflate_coop; a range the wave form
+            // takes -- a few thousand members -- is one launch behind the last chunk)
+            if (inflate_takes_coop(n_range)) {
+                InflateGate gate;
+                gate.flags = c->buf("gate_flags").as<uint32_t>(); gate.epoch = c->gate_epoch; gate.n_chunks = (uint32_t)up.end.size(); gate.lo = up.lo; gate.chunk_bytes = gate_chunk;
+                launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below, 0, /*piece=*/true, 0, d_bad, pairs, false, gate);
+            } else {
+                while (up.recorded.load(std::memory_order_acquire) < up.end.size()) std::this_thread::yield();
+                HIP_TRY(hipStreamWaitEvent(st, c->chunk_ev[up.end.size() - 1], 0));
+                launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below, 0, false, 0, d_bad, pairs);
+            }
+            g_lo = m_hi;
+        }
         for (size_t j = 0; j < up.end.size() && g_lo < m_hi; ++j) {
             uint32_t g_hi = m_hi;
             if (j + 1 < up.end.size()) {     // first member of [g_lo, m_hi) that needs bytes beyond this chunk
@@ -837,12 +873,12 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             g_lo = g_hi;
         }
         up.th.join();
-        if (up.err) return fail(err, errlen, RGX_ERR_DEVICE, "regtools_amd: upload failed\n");
+        if (up.err) { (void)hipStreamSynchronize(st); return fail(err, errlen, RGX_ERR_DEVICE, "regtools_amd: upload failed\n"); }      // (gated waves give up after ~2 s)
         for (unsigned k = 0; k < (unsigned)kSideStreams; ++k) if (used_side >> k & 1) { HIP_TRY(hipEventRecord(c->ev_side[k], c->side[k])); HIP_TRY(hipStreamWaitEvent(st, c->ev_side[k], 0)); }
         HIP_TRY(hipStreamWaitEvent(st, c->chunk_ev[up.end.size() - 1], 0));      // (later stages read the file too: barcodes, header)
     }
     HIP_TRY(hipEventRecord(c->ev[1], st));
-    mark("launch inflate");
+    mark(gated && overlap && inflate_takes_coop(n_range) ? "launch inflate (gated)" : "launch inflate");
 
     // -- files whose ISIZE footers lie ------------------------------------------------------------------------------------------
     // The arena was laid out from the footers; the reference never reads them (inflate_block, bgzf.c:292-316: a block is as long as

@@ -4,6 +4,7 @@
 // codes as /root/reference/src/junctions/junctions_extractor.cc:42-143 (parse_options/usage),
 // src/junctions/junctions_main.cc:45-107 (dispatch, exception -> exit code) and src/regtools.cc:36-74
 // (banner, top-level usage).  Everything data-parallel happens behind the C ABI (include/regtools_amd.h).
+#include <errno.h>
 #include <getopt.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -120,16 +121,20 @@ int junctions_extract(int argc, char **argv) {
         if (n > text.size()) { text.resize(n + 1); n = rgx_table_format_bed12(t, 1, text.data(), text.size()); }
         const double t_format = wall_ms();
         FILE *f = o.output == "NA" ? stdout : fopen(o.output.c_str(), "w");
-        if (f) { fwrite(text.data(), 1, n, f); if (f != stdout) fclose(f); }
+        // (an output file that cannot be opened is skipped as upstream's ofstream would; a write that comes up SHORT -- full disk, closed pipe --
+        //  is an error here: the process ends with _exit below, nothing later could report it)
+        bool short_write = false;
+        if (f) { short_write = fwrite(text.data(), 1, n, f) != n; if (f != stdout) short_write |= fclose(f) != 0; else short_write |= fflush(f) != 0; }
         const double t_write = wall_ms();
         if (p.barcodes) {                                                  // print_all_junctions: an unopenable file is skipped silently (cc:255-256, :272)
             if (FILE *b = fopen(o.barcodes.c_str(), "w")) {
                 const size_t nb = rgx_table_format_barcodes(t, 1, nullptr, 0);
                 std::vector<char> bt(nb + 1);
                 rgx_table_format_barcodes(t, 1, bt.data(), nb);
-                fwrite(bt.data(), 1, nb, b); fclose(b);
+                short_write |= fwrite(bt.data(), 1, nb, b) != nb; short_write |= fclose(b) != 0;
             }
         }
+        if (short_write) { fprintf(stderr, "regtools-amd: writing the output failed (%s)\n", strerror(errno)); fflush(stderr); _exit(1); }
         if (getenv("REGTOOLS_AMD_STATS"))
             fprintf(stderr, "[regtools_amd] records=%llu events=%llu junctions=%llu inflate=%.3fms records=%.3fms scan=%.3fms reduce=%.3fms total=%.3fms\n",
                     (unsigned long long)t->n_records, (unsigned long long)t->n_events, (unsigned long long)t->n, t->ms_inflate, t->ms_records,

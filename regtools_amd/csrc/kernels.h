@@ -19,6 +19,15 @@ constexpr uint64_t kChainUnknown = ~0ull - 1;   // exit of a segment in which th
 size_t inflate_scratch_bytes(uint32_t n_members);
 // an error of a kernel launch (refused configuration) or of a launch's set-up since this host thread last asked; hipSuccess = none (clears it)
 hipError_t pending_launch_error();
+// Arrival gate of the overlapped upload (round 4): ONE k_inflate_coop launch covers the whole range while the file is still on the bus; a wave
+// starts once the upload chunk holding the last byte its members need has landed -- flags[k] == epoch, written by a 4-byte copy queued on the
+// copy stream right behind chunk k (api.cpp prepare_events).  flags = nullptr: no gate.
+struct InflateGate {
+    const uint32_t *flags = nullptr;   // device memory, one word per upload chunk
+    uint32_t epoch = 0;                // this call's value (the words keep earlier calls' values: smaller)
+    uint32_t n_chunks = 0;
+    uint64_t lo = 0, chunk_bytes = 1;  // chunk k = bytes [lo + k * chunk_bytes, lo + (k + 1) * chunk_bytes) of the file (the last one to the range's end)
+};
 constexpr uint32_t kStatusEarly = 76;   // status[kStatusEarly..+1]: the same pair for members below ignore_below (only written when that is > 0)
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
                     uint32_t *status /* [0]=first bad member (min), [1]=its status */, hipStream_t stream, uint32_t ignore_below = 0 /* failures of members below this index are not reported */,
@@ -27,7 +36,11 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
                     int form = 0 /* 0 = chosen by member count / REGTOOLS_AMD_INFLATE; 1 = k_inflate, 2 = k_inflate_wave, 3 = k_inflate_ring */,
                     uint8_t *bad_flags = nullptr /* optional, zeroed by the caller: [index in the caller's range] = 1 for every member that did not inflate */,
                     int plan = 1 /* inflate_plan_for */,
-                    bool check_layout = false /* a caller's own member list (stage entry point): k_inflate_coop only runs when the list's layout suits it */);
+                    bool check_layout = false /* a caller's own member list (stage entry point): k_inflate_coop only runs when the list's layout suits it */,
+                    InflateGate gate = InflateGate() /* k_inflate_coop only: waves wait for their upload chunk */);
+// whether launch_inflate would pick k_inflate_coop for a range of this size (the gate needs it)
+bool inflate_takes_coop(uint32_t n_members);
+void launch_gate_set(uint32_t *flag, uint32_t epoch, hipStream_t stream);      // flags[k] = epoch, in stream order behind chunk k's copy
 // Which options suit a payload, from how well the file compresses (round 4, 50 M-read files / 10 M long reads on one box, ms, all byte-equal to zlib;
 // tools/lab/forms_r4.sh, profiles/r04_inflate_forms.txt):
 //   inflated / compressed > 32  (long reads: run-length copies)        k_inflate_coop, windowed bit reader, one symbol per trip, lanes in file order:

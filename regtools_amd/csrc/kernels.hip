@@ -332,7 +332,7 @@ template <bool PROBE, bool PIECE = false, bool WIN = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_inflate_coop(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
                                                 uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
                                                 uint32_t *status, uint32_t ignore_below, uint32_t index_bias, uint8_t *bad, uint32_t pairs,
-                                                const uint32_t *__restrict__ perm, const uint32_t *veto) {
+                                                const uint32_t *__restrict__ perm, const uint32_t *veto, InflateGate gate) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // (stage entry point only: k_members_check found the list's layout unfit for 32-bit offsets -- nothing may be written)
     if (veto && *veto) return;
@@ -343,6 +343,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // lanes of a wave need about the same number of trips (a wave runs as long as its longest lane: 93.5 -> 98.6 % of the lanes busy)
     const uint32_t m = have ? (perm ? perm[slot] : slot) : n_members - 1;
     const Member mb = members[m];
+    if (PIECE && gate.flags) {
+        // the upload chunk with the last byte any lane of this wave reads (payload + footer + the bit reader's look-ahead); one lane polls,
+        // seldom (every waiting wave's poll is a request to the fabric the running waves share), an acquire then drops what this CU's L1 may
+        // hold.  A chunk that never comes (the host gave up): after ~2 s the wave's members are reported as not inflated.
+        uint64_t end_b = mb.cpos + mb.clen + 24;
+        end_b = end_b > gate.lo ? end_b - gate.lo : 0;
+        uint32_t need = (uint32_t)min((uint64_t)(gate.n_chunks - 1), end_b / gate.chunk_bytes);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) need = max(need, (uint32_t)__shfl_xor((int)need, d, 64));
+        bool arrived = true;
+        if (lane == 0) {
+            uint32_t spins = 0;
+            while (__hip_atomic_load(gate.flags + need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != gate.epoch) {
+                if (++spins > 100000u) { arrived = false; break; }
+                for (int k = 0; k < 5; ++k) __builtin_amdgcn_s_sleep(127);
+            }
+        }
+        arrived = __builtin_amdgcn_ballot_w64(!arrived) == 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!arrived) {
+            if (have) {
+                const uint32_t mi = m + index_bias;
+                if (bad) bad[mi] = 1;
+                uint32_t *sl = mi >= ignore_below ? status : status + kStatusEarly;
+                const uint32_t prev = atomicMin(&sl[0], mi);
+                if (mi < prev) sl[1] = (uint32_t)INF_IN_OVERRUN;
+            }
+            return;
+        }
+    }
     LdsTab T{lds + lane, len_scratch + (have ? slot : 0), gridDim.x * 64};
     // the lowest output address the wave's lanes can have: the first member of the wave's group (upos grows with the member index; PROBE: slot m)
     const uint32_t first = perm ? (blockIdx.x * 64 / kSortGroup) * kSortGroup : blockIdx.x * 64;
@@ -470,8 +500,17 @@ static void inflate_attrs() {
     err_dev[dev] = first; done = true;
     if (first != hipSuccess) tl_launch_error = first;
 }
+// The gate's flag word, written ON THE DEVICE (a one-lane kernel queued on the copy stream behind the chunk's copy): a word the copy engine
+// wrote was seen by the polling waves only hundreds of microseconds later (their system-scope loads are served by an L2 that the engine's
+// write does not reach; measured: 604 ms per step); a store from a wave is coherent with them.
+__global__ void k_gate_set(uint32_t *flag, uint32_t epoch) { __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+void launch_gate_set(uint32_t *flag, uint32_t epoch, hipStream_t stream) { hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(1), 0, stream, flag, epoch); }
+bool inflate_takes_coop(uint32_t n_members) {
+    const int f = inflate_form_env();
+    return f ? f == 4 : n_members > kWaveFormMaxMembers && kDefaultLaneForm == 4;
+}
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
-                    uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias, bool piece, int form, uint8_t *bad, int plan, bool check_layout) {
+                    uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias, bool piece, int form, uint8_t *bad, int plan, bool check_layout, InflateGate gate) {
     if (!n_members) return;
     inflate_attrs();
     static const int env_pairs = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE_PAIRS"); return e ? atoi(e) != 0 : -1; }();
@@ -499,7 +538,7 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
             (void)hipMemsetAsync(veto, 0, 4, stream);
             hipLaunchKernelGGL(k_members_check, dim3((n_members + 255) / 256), dim3(256), 0, stream, members, n_members, status, veto);
         }
-#define RGX_COOP(PIECE_, WIN_) hipLaunchKernelGGL((k_inflate_coop<false, PIECE_, WIN_>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad, two, perm, veto)
+#define RGX_COOP(PIECE_, WIN_) hipLaunchKernelGGL((k_inflate_coop<false, PIECE_, WIN_>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad, two, perm, veto, gate)
         if (piece) { if (win) RGX_COOP(true, true); else RGX_COOP(true, false); }
         else { if (win) RGX_COOP(false, true); else RGX_COOP(false, false); }
 #undef RGX_COOP
@@ -523,7 +562,7 @@ void launch_inflate_probe(const uint8_t *comp, const Member *members, uint32_t n
     const int form = inflate_form_env() ? inflate_form_env() : kDefaultLaneForm;
     const uint32_t blocks = (n_members + 63) / 64;
     if (form == 3) hipLaunchKernelGGL(k_inflate_ring<true>, dim3(blocks), dim3(64), kRingLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr);
-    else if (form == 4) hipLaunchKernelGGL(k_inflate_coop<true>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr, 1u, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+    else if (form == 4) hipLaunchKernelGGL(k_inflate_coop<true>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr, 1u, (const uint32_t *)nullptr, (const uint32_t *)nullptr, InflateGate());
     else hipLaunchKernelGGL(k_inflate<true>, dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, slots, (uint64_t)0, len_scratch, sizes, 0u, 0u, (uint8_t *)nullptr);
 }
 
