@@ -265,6 +265,11 @@ int  rgx_variants_annotate(rgx_ctx *ctx, const rgx_identify_params *p, rgx_ident
  * a malformed line ends the run with the reference's message after the rows before it were written. */
 int  rgx_junctions_annotate(rgx_ctx *ctx, const char *bed_path, const char *fasta_path, const char *gtf_path, const char *out_path,
                             uint64_t *n_rows, char *err, size_t errlen);
+/* The same with -S (junctions_annotator.cc:392-393, consumed at :131 / :231): include_single_exon != 0 lets single-exon transcripts take part
+ * in the scan (they can make a junction's donor or acceptor known, never skip anything).  The reference's one unchecked read on this path
+ * (exons[i + 1] behind a transcript's last exon, with or without -S) is "no match" here, as in the default mode. */
+int  rgx_junctions_annotate_opts(rgx_ctx *ctx, const char *bed_path, const char *fasta_path, const char *gtf_path, const char *out_path,
+                                 int include_single_exon, uint64_t *n_rows, char *err, size_t errlen);
 
 /* Stage entry points over a loaded annotation (flat exon/transcript/bin arrays in HBM). */
 typedef struct rgx_gtf rgx_gtf;

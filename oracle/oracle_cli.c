@@ -56,15 +56,15 @@ int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "identify")) return identify_main(argc, argv, 0);
     if (argc >= 2 && !strcmp(argv[1], "associate")) return identify_main(argc, argv, 1);
     if (argc >= 2 && !strcmp(argv[1], "junctions-annotate")) {          /* junctions_annotator.cc:385-428 */
-        const char *out = NULL; int c; optind = 2;
+        const char *out = NULL; int c, keep_single = 0; optind = 2;
         while ((c = getopt(argc, argv, "So:")) != -1) {
             if (c == 'o') out = optarg;
-            else if (c == 'S') { fprintf(stderr, "oracle: -S is not restated (the reference reads past the exon vector there)\n"); return 1; }
+            else if (c == 'S') keep_single = 1;
             else { fprintf(stderr, "Error parsing inputs!(1)\n\n"); return 1; }
         }
         if (argc - optind != 3) { fprintf(stderr, "Error parsing inputs!(2)\n\n"); return 1; }
         char err[512] = "";
-        if (orc_junctions_annotate(argv[optind], argv[optind + 1], argv[optind + 2], out, err, sizeof err)) { fputs(err, stderr); return 1; }
+        if (orc_junctions_annotate_opts(argv[optind], argv[optind + 1], argv[optind + 2], out, keep_single, err, sizeof err)) { fputs(err, stderr); return 1; }
         return 0;
     }
     if (argc >= 2 && !strcmp(argv[1], "variants-annotate")) {           /* variants_annotator.cc:48-110 */

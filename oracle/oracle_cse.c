@@ -270,9 +270,11 @@ static void set_anchor(jann *j) {   /* annotate_anchor :295-308 */
 }
 
 /* overlap_ps / overlap_ns :128-201, :228-292; js = junction.start, je = junction.end (= Junction.end + 1) */
+/* skip_single_exon_genes_ (junctions_annotator.cc:131, :231): cleared only by `junctions annotate -S` (:392-393); identify / associate keep it (h:209-214) */
+static int g_keep_single_exon = 0;
 static int overlap(const gtf_tx *t, uint32_t js, uint32_t je, jann *j) {
     const uint32_t *s = t->es, *e = t->ee; uint32_t n = t->n_exons;
-    if (n == 1) return 0;                                   /* skip_single_exon_genes_ is always true here (h:209-214) */
+    if (n == 1 && !g_keep_single_exon) return 0;
     int junction_start = 0;
     if (t->strand == '+') {
         if (s[0] > je || e[n - 1] < js) return 0;
@@ -663,6 +665,12 @@ int orc_identify(const orc_cse_params *p, char *err, size_t errlen) {
 /* ==================================================================================================
  * `junctions annotate` (junctions_main.cc:62-93)
  * ================================================================================================ */
+int orc_junctions_annotate_opts(const char *bed, const char *fasta_path, const char *gtf, const char *out, int include_single_exon, char *err, size_t errlen) {
+    g_keep_single_exon = include_single_exon;
+    const int rc = orc_junctions_annotate(bed, fasta_path, gtf, out, err, errlen);
+    g_keep_single_exon = 0;
+    return rc;
+}
 int orc_junctions_annotate(const char *bed, const char *fasta_path, const char *gtf, const char *out, char *err, size_t errlen) {
     gtf_model gm;
     if (gtf_load(gtf, &gm, err, errlen)) return 1;

@@ -45,7 +45,7 @@ EXPORTS = ["rgx_extract_params_default", "rgx_ctx_create", "rgx_ctx_destroy", "r
            "rgx_table_format_bed12", "rgx_table_format_barcodes", "rgx_version", "rgx_k_inflate",
            "rgx_identify_params_default", "rgx_identify", "rgx_gtf_load", "rgx_gtf_free", "rgx_gtf_info", "rgx_gtf_transcript_bin",
            "rgx_gtf_transcript_id", "rgx_variant_windows", "rgx_variant_hits_free", "rgx_annotate_junctions", "rgx_junction_annot_free",
-           "rgx_associate", "rgx_variants_annotate", "rgx_junctions_annotate", "rgx_table_merge_device", "rgx_window_join", "rgx_window_rows_free", "rgx_last_table_pack_device",
+           "rgx_associate", "rgx_variants_annotate", "rgx_junctions_annotate", "rgx_junctions_annotate_opts", "rgx_table_merge_device", "rgx_window_join", "rgx_window_rows_free", "rgx_last_table_pack_device",
            "rgx_host_alloc", "rgx_host_free", "rgx_extract_multi", "rgx_extract_multi_mem", "rgx_multi_exchange_kind", "rgx_k_inflate_form", "rgx_table_merge_barcodes",
            "rgx_table_pack_barcodes", "rgx_table_unpack_barcodes", "rgx_identify_multi"]
 
@@ -146,6 +146,7 @@ def lib():
         L.rgx_associate.argtypes = L.rgx_identify.argtypes
         L.rgx_identify_multi.argtypes = [P(C.c_int), C.c_int, P(IdentifyParams), P(IdentifyStats), C.c_char_p, C.c_size_t]
         L.rgx_variants_annotate.argtypes = L.rgx_identify.argtypes
+        L.rgx_junctions_annotate_opts.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, P(C.c_uint64), C.c_char_p, C.c_size_t]
         L.rgx_junctions_annotate.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, P(C.c_uint64), C.c_char_p, C.c_size_t]
         L.rgx_gtf_load.argtypes = [C.c_void_p, C.c_char_p, P(C.c_void_p), C.c_char_p, C.c_size_t]
         L.rgx_gtf_free.argtypes = [C.c_void_p]

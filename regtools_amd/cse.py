@@ -161,7 +161,7 @@ class JunctionsAnnotator(object):
         for k, v in opts:
             if k == "-h": raise RegtoolsError(0, "help")
             elif k == "-o": self.output_file = v
-            elif k == "-S": raise RegtoolsError(1, "regtools_amd: -S is outside the accelerated path\n\n")
+            elif k == "-S": self.skip_single_exon_genes = False
         if len(args) != 3:
             raise RegtoolsError(1, "Error parsing inputs!(2)\n\n")
         self.bed, self.ref, self.gtf = args
@@ -171,8 +171,9 @@ class JunctionsAnnotator(object):
             self._ctx = Context(self._device)
         err = C.create_string_buffer(512)
         n = C.c_uint64(0)
-        rc = _ffi.lib().rgx_junctions_annotate(self._ctx._h, self.bed.encode(), self.ref.encode(), self.gtf.encode(),
-                                               self.output_file.encode() if self.output_file else None, C.byref(n), err, len(err))
+        rc = _ffi.lib().rgx_junctions_annotate_opts(self._ctx._h, self.bed.encode(), self.ref.encode(), self.gtf.encode(),
+                                                    self.output_file.encode() if self.output_file else None,
+                                                    0 if getattr(self, "skip_single_exon_genes", True) else 1, C.byref(n), err, len(err))
         self.n_rows = n.value
         if rc != 0:
             raise RegtoolsError(rc, err.value.decode())

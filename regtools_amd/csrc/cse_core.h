@@ -18,6 +18,7 @@ struct GtfView {
     // b < bin_stride (= the largest bin any transcript has, + 1).  nullptr: binary search (annotations with absurdly many contigs x bins)
     const uint32_t *bin_start;
     uint32_t bin_stride;
+    uint32_t keep_single;         // `junctions annotate -S` (junctions_annotator.cc:392-393): single-exon transcripts take part in the junction scan
 };
 
 // bedFile.h:49-63: 7 levels, offsets with the upstream 32678 typo, first shift 14, next shift 3
@@ -140,8 +141,10 @@ RGX_HD bool anchor_not_N(const JunctionFlags &f) { return f.known_junction || f.
 // overlap_ps / overlap_ns (:128-201, :228-292); js = junction.start, je = junction.end (= Junction.end + 1).
 // item(kind, a, b) reports skipped exons / donors / acceptors (duplicates allowed; the caller makes them unique).
 template <class Item>
-RGX_HD bool junction_vs_transcript(char strand, const uint32_t *s, const uint32_t *e, uint32_t n, uint32_t js, uint32_t je, JunctionFlags &f, Item &&item) {
-    if (n == 1) return false;                                  // skip_single_exon_genes_ is always true on this path (junctions_annotator.h:209-214)
+RGX_HD bool junction_vs_transcript(char strand, const uint32_t *s, const uint32_t *e, uint32_t n, uint32_t js, uint32_t je, JunctionFlags &f, Item &&item, bool keep_single = false) {
+    // skip_single_exon_genes_ (:131, :231): true unless `junctions annotate -S`; identify / associate never clear it (junctions_annotator.h:209-214).
+    // A single exon can only end up a known donor / acceptor (every "skipped" test wants a neighbour); upstream's unchecked exons[i + 1] is "no match".
+    if (n == 1 && !keep_single) return false;
     bool started = false;
     if (strand == '+') {
         if (s[0] > je || e[n - 1] < js) return false;
@@ -194,7 +197,7 @@ RGX_HD void junction_scan(const GtfView &g, int32_t chrom, uint32_t js, uint32_t
                 const uint32_t t = g.bin_tx[j];
                 if ((char)g.tx_strand[t] != strand) continue;
                 exon_visits += g.tx_n_exons[t];
-                if (junction_vs_transcript(strand, g.es + g.tx_exon_off[t], g.ee + g.tx_exon_off[t], g.tx_n_exons[t], js, je, f, item)) item(ITEM_TX, t, 0u);
+                if (junction_vs_transcript(strand, g.es + g.tx_exon_off[t], g.ee + g.tx_exon_off[t], g.tx_n_exons[t], js, je, f, item, g.keep_single != 0)) item(ITEM_TX, t, 0u);
             }
         }
         sb >>= 3; eb >>= 3;

@@ -119,9 +119,9 @@ __global__ __launch_bounds__(256) void k_junction_scan_wave(GtfView g, uint32_t 
             JunctionFlags f{0, 0, 0};
             uint32_t k = 0;
             bool reached = false;
-            if (mine && nex > 1) {
+            if (mine && (nex > 1 || g.keep_single)) {        // (single-exon transcripts: `junctions annotate -S` only)
                 const bool outside = strand == '+' ? (es[0] > je || ee[nex - 1] < js) : (ee[0] < js || es[nex - 1] > je);
-                if (!outside) { reached = true; (void)junction_vs_transcript(strand, es, ee, nex, js, je, f, [&](uint32_t, uint32_t, uint32_t) { ++k; }); }
+                if (!outside) { reached = true; (void)junction_vs_transcript(strand, es, ee, nex, js, je, f, [&](uint32_t, uint32_t, uint32_t) { ++k; }, g.keep_single != 0); }
             }
             const uint32_t own = f.known_donor | f.known_acceptor << 1 | f.known_junction << 2;
             const uint32_t seen = wave_scan_or(own, lane) | acc;           // flags of everything visited up to and including this transcript
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_junction_scan_wave(GtfView g, uint32_t 
                 uint32_t w = out0 + n_items + incl - k;
                 if (k > (listed ? 1u : 0u)) {
                     JunctionFlags f2{0, 0, 0};
-                    (void)junction_vs_transcript(strand, es, ee, nex, js, je, f2, [&](uint32_t kind, uint32_t a, uint32_t b) { item_kind[w] = kind; item_a[w] = a; item_b[w] = b; ++w; });
+                    (void)junction_vs_transcript(strand, es, ee, nex, js, je, f2, [&](uint32_t kind, uint32_t a, uint32_t b) { item_kind[w] = kind; item_a[w] = a; item_b[w] = b; ++w; }, g.keep_single != 0);
                 }
                 if (listed) { item_kind[w] = ITEM_TX; item_a[w] = t; item_b[w] = 0u; }
             }

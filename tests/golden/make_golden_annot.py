@@ -39,6 +39,11 @@ def main():
             name = "ja_s%d" % seed
             r = subprocess.run([REF, "junctions", "annotate", "-o", os.path.join(out, name + ".tsv"), bed, q["fasta"], q["gtf"]], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             cases.append(dict(name=name, cmd="junctions-annotate", seed=seed, n_genes=10 + 2 * seed, args=[], rc=r.returncode))
+            # -S (junctions_annotator.cc:392-393): single-exon transcripts take part (the synthetic annotations have some, made of an exon that
+            # ends where annotated junctions start)
+            name = "ja_s%d_S" % seed
+            r = subprocess.run([REF, "junctions", "annotate", "-S", "-o", os.path.join(out, name + ".tsv"), bed, q["fasta"], q["gtf"]], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            cases.append(dict(name=name, cmd="junctions-annotate", seed=seed, n_genes=10 + 2 * seed, args=["-S"], rc=r.returncode))
             for k, a in enumerate(VA_ARGS):
                 name = "va_s%d_%d" % (seed, k)
                 r = subprocess.run([REF, "variants", "annotate"] + a + ["-o", os.path.join(out, name + ".vcf"), q["vcf"], q["gtf"]], stdout=subprocess.PIPE, stderr=subprocess.PIPE)

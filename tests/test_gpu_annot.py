@@ -64,7 +64,7 @@ def test_equals_reference_outputs(gpu_ctx, case, work, oracle_cli):
     q = ac.quartet(case["seed"], case["n_genes"], work, oracle_cli)
     pre = os.path.join(str(work), case["name"])
     if case["cmd"] == "junctions-annotate":
-        rc, msg = run_mirror(regtools_amd.JunctionsAnnotator(ctx=gpu_ctx), ["-o", pre + ".tsv", q["bed"], q["fasta"], q["gtf"]], "annotate")
+        rc, msg = run_mirror(regtools_amd.JunctionsAnnotator(ctx=gpu_ctx), case["args"] + ["-o", pre + ".tsv", q["bed"], q["fasta"], q["gtf"]], "annotate")      # ([] or ["-S"])
         exts = ["tsv"]
     elif case["cmd"] == "variants-annotate":
         rc, msg = run_mirror(regtools_amd.VariantsAnnotator(ctx=gpu_ctx), case["args"] + ["-o", pre + ".vcf", q["vcf"], q["gtf"]], "annotate_vcf")
