@@ -35,6 +35,25 @@ def inflate_kernel_for(compressed, inflated):
     return INFLATE_KERNEL
 
 
+def committed_traffic(key, kernel, alg_bytes):
+    """HBM-side traffic of a workload's DEFLATE launch from the round's committed rocprofv3 PMC passes (profiles/r04_pmc_traffic.json, made by
+    tools/pmc_traffic_r4.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of the launch alone on the same file).  A committed measurement, not
+    one of this run -- only quoted when kernel and algorithmic bytes are this run's."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))[key]
+        if pm.get("kernel") != kernel or abs(pm["algorithmic_bytes"] - alg_bytes) > 1e-3 * alg_bytes:
+            return {"traffic": None}
+        t = (pm["FETCH_SIZE_KiB"] + pm["WRITE_SIZE_KiB"]) * 1024.0
+        return {"traffic": t,
+                "traffic_source": "profiles/r04_pmc_traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel on this workload, tools/pmc_traffic_r4.sh; "
+                                  "a committed measurement, not taken in this run)" % key,
+                "traffic_note": "(FETCH_SIZE + WRITE_SIZE) KiB, uncorrected = %.1f x the algorithmic bytes; with the guide's x2 on FETCH_SIZE = %.1f x (the x2 is calibrated for wide "
+                                "coalesced streams -- profiles/r03_pmc_tail_kernels.json -- not for this kernel's 16-byte requests of 64 lanes in 64 lines: the truth lies between)"
+                                % (t / alg_bytes, ((2 * pm["FETCH_SIZE_KiB"] + pm["WRITE_SIZE_KiB"]) * 1024.0) / alg_bytes)}
+    except Exception:
+        return {"traffic": None}
+
+
 def cpu_baseline(bam_path, n_reads, n_events):
     """Time the reference (or the oracle port) on the host cores: single thread, because the reference has
     no threads at all."""
@@ -125,6 +144,7 @@ def extra_extract(regtools_amd, synth, ctx, label, shape, realistic, n_reads, sa
            "bytes_per_alignment": {"compressed": s["compressed_bytes"] / st["n_reads"], "inflated": s["inflated_bytes"] / st["n_reads"]},
            "roofline": {"bound": "hbm", "kernel": inflate_kernel_for(s["compressed_bytes"], s["inflated_bytes"]), "kernel_ms": min(k_ms), "algorithmic_bytes": alg,
                         "achieved": alg / (min(k_ms) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (min(k_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    out["roofline"].update(committed_traffic("long10M" if shape == "long" else "realistic" if realistic else "default", out["roofline"]["kernel"], alg))
     del d_bam, bam
     pin.close()
     # the reference on a bounded sample of the same shape (the full file would take it minutes)
@@ -139,6 +159,8 @@ def extra_extract(regtools_amd, synth, ctx, label, shape, realistic, n_reads, sa
             out["reference"] = {"sample": "%d reads of the same shape (seed %d), reference regtools, 1 thread" % (ss["n_reads"], seed + 1), "seconds": round(dt, 3),
                                 "alignments_per_s": ss["n_reads"] / dt if rc == 0 else None,
                                 "bed12_identical_to_gpu": bool(rc == 0 and open(bed, "rb").read() == jx.bed12())}
+            if rc == 0 and shape == "short":     # what all the host's cores do with the reference on this payload (one process per contig)
+                out["reference"]["all_host_cores"] = reference_on_all_cores(os.path.join(ROOT, "oracle", "_ref", "regtools_ref"), p, ss["n_reads"])
     return out
 
 
@@ -362,20 +384,9 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         # HBM-side traffic of the same kernel from rocprofv3 PMC passes (tools/pmc_traffic.sh; separate --pmc runs of this
         # very command).  Only quoted when the committed measurement was taken on this exact workload.
-        traffic, traffic_note, traffic_source = None, None, None
-        try:
-            pm_path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-            pm = json.load(open(pm_path))
-            if n_reads == 50_000_000 and args.shape == "short" and not args.realistic and world == 1 and pm.get("kernel") == inflate_kernel_for(s["compressed_bytes"], s["inflated_bytes"]):
-                traffic = (pm["FETCH_SIZE_KiB"] + pm["WRITE_SIZE_KiB"]) * 1024.0
-                traffic_source = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel on this workload, tools/pmc_inflate.sh; a committed measurement, not taken in this run)"
-                traffic_note = ("(FETCH_SIZE + WRITE_SIZE) KiB, uncorrected = %.1f x the algorithmic bytes; with the guide's x2 on FETCH_SIZE = %.1f x.  In-situ calibration, same "
-                                "passes (profiles/r03_pmc_tail_kernels.json): k_decode_seg, a coalesced 16 B/lane read of the whole 11.7 GB arena, shows FETCH_SIZE 6.0 GB (x 1.95 "
-                                "missing) and its 1.45 GB of rows WRITE_SIZE 1.41 GB (exact) -- the x2 is real for wide streams; this kernel's reads are 8-byte bit-stream words and "
-                                "16-byte copy sources of 64 lanes in 64 different lines, for which it is not calibrated: the truth lies between the two figures"
-                                % (traffic / alg_bytes, ((2 * pm["FETCH_SIZE_KiB"] + pm["WRITE_SIZE_KiB"]) * 1024.0) / alg_bytes))
-        except Exception:
-            pass
+        tr = committed_traffic("long10M" if args.shape == "long" else "realistic" if args.realistic else "default", inflate_kernel_for(s["compressed_bytes"], s["inflated_bytes"]), alg_bytes) \
+            if world == 1 else {"traffic": None}
+        traffic, traffic_note, traffic_source = tr.get("traffic"), tr.get("traffic_note"), tr.get("traffic_source")
         line = {
             "metric": "alignments/sec + junctions/sec, junctions extract, 1/2/4/8 MI355X",
             "value": aln_per_s, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -420,10 +431,10 @@ def main():
                 try:
                     sys.path.insert(0, os.path.join(ROOT, "tools"))
                     import cli_wall
-                    cw = cli_wall.measure(path, runs=3, with_reference=False)
+                    cw = cli_wall.measure(path, runs=5, with_reference=False)
                     cli_bed = open(path + ".cli.bed", "rb").read()
                     line["cli"] = {"command": "bin/regtools-amd junctions extract -s XS -o out.bed bench.bam (cold process, file in the page cache)",
-                                   "wall_s": cw["wall_s"], "runs": cw["runs"], "reference_wall_s": cb.get("seconds") if cb.get("kind") == "reference" else None,
+                                   "wall_s": cw["wall_s"], "wall_s_is": "median of 5 cold processes, 0.5 s apart", "best_wall_s": cw["best_wall_s"], "runs": cw["runs"], "reference_wall_s": cb.get("seconds") if cb.get("kind") == "reference" else None,
                                    "identical_file": cli_bed == ref_bed,
                                    "ratio_process": round(cb["seconds"] / cw["wall_s"], 1) if cb.get("kind") == "reference" else None,
                                    "ratio_pipeline": round(cb["seconds"] / (ms_step * 1e-3), 1) if cb.get("kind") == "reference" else None,

@@ -195,3 +195,19 @@ def synth():
         L.rgx_synth_annotation.argtypes = [P(SynthParams), C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p]
         _synth = L
     return _synth
+
+
+def format_bed12(table_ptr, only_anchored=True):
+    """BED12 text of a table in ONE formatting pass (rgx_table_format_bed12 formats every row even for its size query): a row is its contig's
+    name and at most 160 bytes of numbers (Junction::print, junctions_extractor.h:90-98), so n x (longest name + 160) bytes hold it; the exact
+    two-call protocol only if that bound were ever short."""
+    L = lib()
+    t = table_ptr.contents
+    longest = max([len(t.ref_name[i]) for i in range(t.n_ref)] or [0])
+    cap = int(t.n) * (longest + 160) + 1
+    buf = C.create_string_buffer(cap)
+    n = L.rgx_table_format_bed12(table_ptr, 1 if only_anchored else 0, buf, cap)
+    if n > cap:
+        buf = C.create_string_buffer(n + 1)
+        L.rgx_table_format_bed12(table_ptr, 1 if only_anchored else 0, buf, n)
+    return buf.raw[:n]

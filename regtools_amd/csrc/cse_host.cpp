@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <set>
 #include <thread>
 #include <numeric>
 
@@ -454,7 +455,26 @@ std::string VcfText::load(const std::string &path) {
             if (n >= 2 && d[0] == 0x1f && d[1] == 0x8b) { if (gunzip_all(d, n, idx).empty()) { d = (const uint8_t *)idx.data(); n = idx.size(); } else n = 0; }
             if (n >= 36 && !memcmp(d, "TBI\1", 4)) {
                 int32_t n_ref, l_nm; memcpy(&n_ref, d + 4, 4); memcpy(&l_nm, d + 32, 4);
-                if (n_ref >= 0 && l_nm >= 0 && (size_t)l_nm <= n - 36) {
+                // the whole index must load, not only its names (tbx_index_load -> hts_idx_load_core, hts.c:1517-1567): per sequence the bins
+                // (number, chunk count, chunks; a bin number listed twice is an error) and the linear index, every read complete
+                bool body_ok = n_ref >= 0 && l_nm >= 0 && (size_t)l_nm <= n - 36;
+                if (body_ok) {
+                    size_t o = 36 + (size_t)l_nm;
+                    auto rd32 = [&](uint32_t &v) { if (n - o < 4) return false; memcpy(&v, d + o, 4); o += 4; return true; };
+                    for (int32_t k = 0; k < n_ref && body_ok; ++k) {
+                        uint32_t nb = 0, ni = 0;
+                        if (!rd32(nb)) { body_ok = false; break; }
+                        std::set<uint32_t> seen;
+                        for (uint32_t b = 0; b < nb && body_ok; ++b) {
+                            uint32_t key = 0, nc = 0;
+                            if (!rd32(key) || !seen.insert(key).second || !rd32(nc) || (n - o) / 16 < nc) { body_ok = false; break; }
+                            o += (size_t)nc * 16;
+                        }
+                        if (!body_ok || !rd32(ni) || (n - o) / 8 < ni) { body_ok = false; break; }
+                        o += (size_t)ni * 8;
+                    }
+                }
+                if (body_ok) {
                     const char *q = (const char *)d + 36, *e = q + l_nm;
                     for (int32_t k = 0; k < n_ref && q < e; ++k) {
                         const size_t ln = strnlen(q, (size_t)(e - q));

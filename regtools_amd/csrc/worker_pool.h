@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -25,23 +26,43 @@ class WorkerPool {
     WorkerPool(const WorkerPool &) = delete;
     WorkerPool &operator=(const WorkerPool &) = delete;
     size_t threads() const { return workers_.size() + 1; }
-    // f(k) for k in [0, n), each exactly once, on the pool's threads and the caller; returns when all are done
+    // f(k) for k in [0, n), each exactly once, on the pool's threads and the caller; returns when all are done.  An exception thrown by a task
+    // (bad_alloc from a task's vectors, say) is caught where it happens, the phase still runs to its end -- the workers hold pointers into the
+    // caller's frame until then -- and the first one is thrown again here.  A run() from inside a task of the same pool (or from a second thread
+    // while one is in flight) does not queue behind itself: it runs its tasks on the calling thread.
     void run(size_t n, const std::function<void(size_t)> &f) {
         if (n == 0) return;
-        if (n == 1 || workers_.empty()) { for (size_t k = 0; k < n; ++k) f(k); return; }
+        if (n == 1 || workers_.empty()) { serial(n, f); return; }
         {
-            std::lock_guard<std::mutex> g(m_);
+            std::unique_lock<std::mutex> g(m_);
+            if (in_run_) { g.unlock(); serial(n, f); return; }
+            in_run_ = true; error_ = nullptr;
             f_ = &f; n_ = n; next_.store(0, std::memory_order_relaxed); pending_ = workers_.size(); ++phase_;
         }
         wake_.notify_all();
         work();
-        std::unique_lock<std::mutex> g(m_);
-        done_.wait(g, [this] { return pending_ == 0; });
-        f_ = nullptr;
+        std::exception_ptr e;
+        {
+            std::unique_lock<std::mutex> g(m_);
+            done_.wait(g, [this] { return pending_ == 0; });
+            f_ = nullptr; in_run_ = false; e = error_; error_ = nullptr;
+        }
+        if (e) std::rethrow_exception(e);
     }
 
   private:
-    void work() { for (size_t k; (k = next_.fetch_add(1, std::memory_order_relaxed)) < n_;) (*f_)(k); }
+    // (the same contract without helpers: every task runs, the first exception is thrown at the end)
+    static void serial(size_t n, const std::function<void(size_t)> &f) {
+        std::exception_ptr e;
+        for (size_t k = 0; k < n; ++k) { try { f(k); } catch (...) { if (!e) e = std::current_exception(); } }
+        if (e) std::rethrow_exception(e);
+    }
+    void work() {
+        for (size_t k; (k = next_.fetch_add(1, std::memory_order_relaxed)) < n_;) {
+            try { (*f_)(k); }
+            catch (...) { std::lock_guard<std::mutex> g(m_); if (!error_) error_ = std::current_exception(); }      // (the other tasks still run: the counter drains)
+        }
+    }
     void loop() {
         uint64_t seen = 0;
         for (;;) {
@@ -62,7 +83,8 @@ class WorkerPool {
     size_t n_ = 0, pending_ = 0;
     std::atomic<size_t> next_{0};
     uint64_t phase_ = 0;
-    bool stop_ = false;
+    bool stop_ = false, in_run_ = false;
+    std::exception_ptr error_;
 };
 
 // std::sort's result on [b, e), by the pool: runs sorted side by side, then merged pairwise (a stable merge of sorted runs of distinct keys --

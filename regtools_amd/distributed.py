@@ -25,11 +25,7 @@ class MergedTable(object):
         return self._table.contents.n
 
     def bed12(self, only_anchored=True):
-        lib = _ffi.lib()
-        n = lib.rgx_table_format_bed12(self._table, 1 if only_anchored else 0, None, 0)
-        buf = C.create_string_buffer(n + 1)
-        lib.rgx_table_format_bed12(self._table, 1 if only_anchored else 0, buf, n)
-        return buf.raw[:n]
+        return _ffi.format_bed12(self._table, only_anchored)
 
     def barcodes_text(self, only_anchored=True):
         """Junction::print_barcodes per printed row (junctions_extractor.h:99-111) -- present when the shards were extracted with -b and merged by

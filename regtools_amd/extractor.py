@@ -210,11 +210,7 @@ class JunctionsExtractor(object):
 
     # -- print_all_junctions (junctions_extractor.cc:249-280): BED12 of the rows anchored on both sides ------------------
     def bed12(self, only_anchored=True):
-        lib = _ffi.lib()
-        n = lib.rgx_table_format_bed12(self._table, 1 if only_anchored else 0, None, 0)
-        buf = C.create_string_buffer(n + 1)
-        lib.rgx_table_format_bed12(self._table, 1 if only_anchored else 0, buf, n)
-        return buf.raw[:n]
+        return _ffi.format_bed12(self._table, only_anchored)
 
     # -- Junction::print_barcodes per printed row (junctions_extractor.h:99-111, cc:272-273) ---------------------------------
     def barcodes_text(self, only_anchored=True):

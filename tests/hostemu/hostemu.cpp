@@ -187,6 +187,7 @@ extern "C" int emu_gtf_dump(const char *gtf_path, const char *out_path, char *er
 }
 
 // worker_pool.h / bigvec.h on their own: parallel_sort against std::sort, the pool's every-task-once contract, huge-page vectors
+#include <stdexcept>
 #include "../../regtools_amd/csrc/worker_pool.h"
 #include "../../regtools_amd/csrc/bigvec.h"
 extern "C" int emu_pool_selftest(uint32_t seed, uint32_t n, uint32_t threads) {
@@ -205,6 +206,24 @@ extern "C" int emu_pool_selftest(uint32_t seed, uint32_t n, uint32_t threads) {
         for (auto &h : hit) h = 0;
         pool.run(tasks, [&](size_t k) { hit[k].fetch_add(1); });
         for (auto &h : hit) if (h.load() != 1) return 2;
+    }
+    // a task that throws: the phase still runs every other task once, the first exception comes out of run(), the pool stays usable
+    {
+        const size_t tasks = (size_t)threads * 5 + 2;
+        std::vector<std::atomic<int>> hit(tasks);
+        for (auto &h : hit) h = 0;
+        bool thrown = false;
+        try { pool.run(tasks, [&](size_t k) { hit[k].fetch_add(1); if (k == tasks / 2) throw std::runtime_error("task"); }); }
+        catch (const std::runtime_error &) { thrown = true; }
+        if (!thrown) return 6;
+        for (auto &h : hit) if (h.load() != 1) return 7;
+        std::atomic<int> sum{0};
+        pool.run(tasks, [&](size_t) { sum.fetch_add(1); });
+        if (sum.load() != (int)tasks) return 8;
+        // a run() from inside a task does its work on the calling thread instead of queueing behind itself
+        std::atomic<int> inner{0};
+        pool.run(4, [&](size_t) { pool.run(3, [&](size_t) { inner.fetch_add(1); }); });
+        if (inner.load() != 12) return 9;
     }
     // a block above the huge-page threshold: aligned, writable end to end, survives growth
     rgx::BigVec<uint32_t> big;

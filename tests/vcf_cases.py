@@ -207,14 +207,22 @@ def _line_cases():
     }
 
 
-def _tbi(names):
-    """a tabix index that lists these sequence names and no bins (BGZF-compressed, as tabix writes it)"""
+def _tbi(names, cut_body=False, bins=None):
+    """a tabix index that lists these sequence names and no bins (BGZF-compressed, as tabix writes it).  cut_body: the file ends behind the
+    names (hts_idx_load_core fails on the first n_bin it cannot read: no index); bins: per sequence, a list of bin numbers, one chunk each
+    (a number listed twice makes the load fail: "duplicate bin")."""
     import struct
     import bamio
     nm = b"".join(n.encode() + b"\0" for n in names)
     body = b"TBI\1" + struct.pack("<iiiiiii", len(names), 2, 1, 2, 0, ord("#"), 0) + struct.pack("<i", len(nm)) + nm
-    for _ in names:
-        body += struct.pack("<ii", 0, 0)
+    for k, _ in enumerate(names):
+        if cut_body:
+            break
+        bl = bins[k] if bins else []
+        body += struct.pack("<i", len(bl))
+        for b in bl:
+            body += struct.pack("<Ii", b, 1) + struct.pack("<QQ", 0, 1 << 16)
+        body += struct.pack("<i", 0)
     return bamio.bgzf_member(body) + bamio.EOF_MARKER
 
 
@@ -227,7 +235,11 @@ def companions():
     one that cannot be read is no index."""
     return {"tbi_contigs": {".vcf.tbi": _tbi(["1", "7", "chrUn", "2"])},
             "tbi_stem": {".tbi": _tbi(["zz", "7"])},
-            "tbi_broken": {".vcf.tbi": b"TBI\1 this is not a tabix index"}}
+            "tbi_broken": {".vcf.tbi": b"TBI\1 this is not a tabix index"},
+            # an index whose body cannot be loaded is no index at all, names or not (tbx_index_load -> hts_idx_load_core, hts.c:1517-1567)
+            "tbi_cut_body": {".vcf.tbi": _tbi(["1", "7", "chrUn"], cut_body=True)},
+            "tbi_dup_bin": {".vcf.tbi": _tbi(["1", "chrUn"], bins=[[4681, 4681], []])},
+            "tbi_with_bins": {".vcf.tbi": _tbi(["1", "chrUn"], bins=[[4681, 4682], [585]])}}
 
 
 def build(tmpdir):
