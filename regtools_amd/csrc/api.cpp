@@ -17,6 +17,7 @@
 #include <charconv>
 #include <chrono>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -215,6 +216,7 @@ static hipError_t ensure_upload_streams(rgx_ctx *c) {
 
 extern "C" void rgx_ctx_destroy(rgx_ctx *c) {
     if (!c) return;
+    Reaper::get().drain();                                  // (deferred teardown of finished calls may still hold memory of this device)
     (void)hipSetDevice(c->device);
     for (auto &kv : c->bufs) kv.second.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -501,6 +503,20 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             static const bool gate_off = [] { const char *e = getenv("REGTOOLS_AMD_GATE"); return e && !strcmp(e, "0"); }();
             static const unsigned gate_chunks = [] { const char *e = getenv("REGTOOLS_AMD_GATE_CHUNKS"); const int v = e ? atoi(e) : 16; return (unsigned)std::min(std::max(v, 2), 64); }();
             gated = !gate_off && !c->one_shot && !getenv("REGTOOLS_AMD_PIECES") && up_hi - up_lo >= std::min(overlap_min, (size_t)8 << 20) && up_hi - up_lo >= 2 * 4096 * (size_t)gate_chunks;
+            if (gated) {
+                // ... for payloads whose inflate is of the upload's order (measured: bench payload 27.5 -> 26.5 ms, random bases + qualities 98.2 ->
+                // 93.7); run-length payloads (long reads: 1 GB of file, 65 GB inflated, five rounds of waves) lose 5-6 ms of 158 to it and keep
+                // the pieces.  The class comes from the file's first members (BSIZE / ISIZE of up to 64 of them: what the host scan will find).
+                uint64_t cb = 0, ub = 0; size_t o = 0;
+                for (int k = 0; k < 64 && o + 28 <= bam_len; ++k) {
+                    if (!(h_bam[o] == 0x1f && h_bam[o + 1] == 0x8b && h_bam[o + 12] == 'B' && h_bam[o + 13] == 'C')) break;
+                    const size_t bl = (size_t)(h_bam[o + 16] | h_bam[o + 17] << 8) + 1;
+                    if (bl < 26 || o + bl > bam_len) break;
+                    uint32_t isz; memcpy(&isz, h_bam + o + bl - 4, 4);
+                    cb += bl; ub += isz; o += bl;
+                }
+                if (cb && !(inflate_plan_for(cb, ub) & 1)) gated = false;
+            }
             // three pieces, each its own launch on its own hardware queue (two side streams + the pipeline's own; a launch takes ~8 ms however
             // small -- one lane per member).  Equal thirds measured best: 31.6 ms per step against 32.4-33.3 ms for pieces that shrink towards
             // the end, and 30.9-31.5 ms for four to six equal pieces on side streams of other priorities (= other queue pools), 32.6 for seven

@@ -1,5 +1,6 @@
 // host_io.cpp -- see host_io.h.
 #include "host_io.h"
+#include "worker_pool.h"
 
 #include <thread>
 #include "inflate_core.h"
@@ -496,6 +497,10 @@ bool read_index(const std::string &path, std::vector<uint8_t> &out) {
 }
 
 FileBytes::~FileBytes() { release(); }
+void FileBytes::release_later() {
+    if (mapped && p && n) { uint8_t *q = const_cast<uint8_t *>(p); const size_t len = n; Reaper::get().later([q, len] { munmap(q, len); }); p = nullptr; n = 0; mapped = false; }
+    release();
+}
 void FileBytes::release() { if (mapped && p && n) munmap(const_cast<uint8_t *>(p), n); p = nullptr; n = 0; mapped = false; std::vector<uint8_t>().swap(own); }
 
 bool FileBytes::open(const std::string &path, bool populate) {

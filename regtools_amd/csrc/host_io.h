@@ -89,6 +89,7 @@ struct FileBytes {
     FileBytes &operator=(const FileBytes &) = delete;
     ~FileBytes();
     void release();
+    void release_later();      // the unmapping on the process's background thread (worker_pool.h Reaper): the caller's call ends without it
     // populate: fault the whole mapping in at once (text files that several threads are about to scan)
     bool open(const std::string &path, bool populate = false);
     const uint8_t *data() const { return p; }

@@ -4,6 +4,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <condition_variable>
 #include <exception>
 #include <functional>
@@ -104,5 +105,48 @@ void parallel_sort(WorkerPool &pool, It b, It e, Less less) {
         });
     }
 }
+
+
+// Things whose teardown is page-table or allocator work the caller need not wait for (unmapping a 500 MB file costs 8 ms, handing back the
+// tables of a 250 k-transcript annotation 4 ms): handed to ONE background thread of the process, in order.  drain() = wait until everything
+// handed over so far is gone (a context being destroyed; the process ending -- registered with atexit when the thread starts, which runs
+// before the HIP runtime's own exit handlers because it was registered after them).
+class Reaper {
+  public:
+    static Reaper &get() { static Reaper *r = new Reaper(); return *r; }      // (never destroyed: no static-destruction order to get wrong)
+    void later(std::function<void()> f) {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            if (!started_) { started_ = true; std::thread([this] { loop(); }).detach(); atexit([] { Reaper::get().drain(); }); }
+            q_.push_back(std::move(f)); ++queued_;
+        }
+        wake_.notify_one();
+    }
+    void drain() {
+        std::unique_lock<std::mutex> g(m_);
+        const uint64_t want = queued_;
+        idle_.wait(g, [&] { return done_ >= want; });
+    }
+
+  private:
+    void loop() {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                wake_.wait(g, [&] { return !q_.empty(); });
+                f = std::move(q_.front()); q_.erase(q_.begin());
+            }
+            try { f(); } catch (...) {}
+            { std::lock_guard<std::mutex> g(m_); ++done_; }
+            idle_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable wake_, idle_;
+    std::vector<std::function<void()>> q_;
+    uint64_t queued_ = 0, done_ = 0;
+    bool started_ = false;
+};
 
 }  // namespace rgx
