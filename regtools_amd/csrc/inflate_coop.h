@@ -43,11 +43,17 @@ struct HostCopy {
 #ifdef RGX_LAB_TRIPS
 static __device__ uint32_t rgx_lab_trips_total;      // (lab builds: wave trips of a launch)
 #endif
+#ifdef RGX_HOST_TRIPS
+static uint64_t rgx_host_trips;                      // (lab tools on the host: trips of the one-lane wave)
+#endif
 // Every lane of the wave must call this together (Coop::any / begin / end are wave-wide); `active` = false: the lane has no member and
 // only serves the others' copies.  Returns an InflateStatus; *out_len = bytes produced (all of them in memory on return, also after an error).
 template <class BR, class Tab, class Coop>
 RGX_HD int inflate_coop(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len, Tab &T, Coop &C, bool active,
-                        bool pairs /* a literal and the symbol behind it in one trip (same for every lane of the wave) */, uint32_t *in_used = nullptr) {
+                        uint32_t mode /* same for every lane of the wave.  bit 0: a literal and the symbol behind it in one trip; bit 1 (with bit 0): a
+                                         second literal may have a MATCH or the end of the block behind it in the same trip; bit 2: a match at a
+                                         distance of 16 or less is a run written from registers, 64 bytes a trip (expand_run, inflate_core.h) */, uint32_t *in_used = nullptr) {
+    const bool pairs = (mode & 1u) != 0, runs = (mode & 3u) == 3u, regruns = (mode & 4u) != 0;
 #ifdef RGX_LAB_TRIPS
     uint32_t rgx_lab_trips = 0;
 #endif
@@ -69,21 +75,29 @@ RGX_HD int inflate_coop(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
 #ifdef RGX_LAB_TRIPS
         ++rgx_lab_trips;
 #endif
+#ifdef RGX_HOST_TRIPS
+        ++rgx_host_trips;
+#endif
         // ---- A: loads of the pending copy -----------------------------------------------------------------------
         const bool copying = !fin && pend_len != 0;
         uint32_t n = 0, head = 0, nb = 0, tail = 0;
-        bool coop = false;
+        bool coop = false, rl = false;
         if (copying) {
             n = pend_len < kCoopCopyMax ? pend_len : kCoopCopyMax;
-            if (pend_dist < n) n = pend_dist;                       // only bytes that are already produced (any distance >= 1)
+            // a run: the period is in the 16 bytes at (o - distance), the trip writes 64 bytes of it instead of doubling 1, 2, 4 ... bytes a trip
+            rl = regruns && pend_dist <= 16 && pend_len > pend_dist;
+            if (rl) n = n < kLaneCopyMax ? n : kLaneCopyMax;
+            else if (pend_dist < n) n = pend_dist;                  // only bytes that are already produced (any distance >= 1)
             coop = n > kLaneCopyMax;
             if (pend_dist < n + 16) S.flush_partial(o);             // ... and the last < 16 of those may still be in the stage
             const uint8_t *s = out + o - pend_dist;
             if (!coop) {
                 v0 = ld128(s);
-                if (n > 16) v1 = ld128(s + 16);
-                if (n > 32) v2 = ld128(s + 32);
-                if (n > 48) v3 = ld128(s + 48);
+                if (!rl) {
+                    if (n > 16) v1 = ld128(s + 16);
+                    if (n > 32) v2 = ld128(s + 32);
+                    if (n > 48) v3 = ld128(s + 48);
+                }
             } else {
                 const uint32_t k = (S.a + o) & 15u;
                 head = k ? 16u - k : 0u;                            // completes the chunk the stage holds (this lane)
@@ -98,45 +112,60 @@ RGX_HD int inflate_coop(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
         uint32_t lit = 256, lit2 = 256, new_len = 0, new_dist = 0;
         if (!fin && pend_len == n && !done) do {
             if (in_symbols) {
-                uint32_t v = rev15(br.peek(15));               // >= 48 valid bits here: the whole trip is fed from the buffer
-                uint32_t l;
-                uint32_t idx = code_lookup(LL, v, l);
-                if (l == 0 || idx >= 288) { status = INF_BAD_CODE; fin = true; break; }
-                uint32_t sym = T.get_ll_sym(idx);
-                br.drop(l);
-                if (pairs && sym < 256 && br.cnt >= 48) {
-                    // a literal, and the buffer still holds a whole symbol (15 + 5 + 15 + 13 bits): take the next one in the same trip.
-                    // Pays where literals are frequent (random bases and qualities: 12 % off the kernel) and costs where the trips
-                    // are run-length copies that decode nothing (long reads: +11 %): the host decides per launch from the file's
-                    // compression ratio (launch_inflate)
-                    lit = sym;
-                    v = rev15(br.peek(15));
-                    idx = code_lookup(LL, v, l);
-                    if (l == 0 || idx >= 288) { status = INF_BAD_CODE; fin = true; break; }
-                    sym = T.get_ll_sym(idx);
+                // Up to three code lookups, ONE non-literal behind them.  The first symbol of a trip is covered by the >= 48 bits R leaves in the
+                // buffer (15 + 5 + 15 + 13).  mode bit 0: a literal and the symbol behind it in one trip when 48 bits are still there (pays where
+                // literals are frequent -- random bases and qualities: 12 % off the kernel -- and costs where the trips are run-length copies
+                // that decode nothing -- long reads: +11 %: the host decides per launch from the file's compression ratio, launch_inflate).
+                // mode bits 0 + 1 (round 4): symbols behind the first are taken when every bit of them is in the buffer, counted exactly
+                // instead of by the worst case, and a second literal may have a MATCH (or the end of the block) behind it: on BAM payloads
+                // two literals between two matches is the usual shape (bench file: two thirds of the literal runs are pairs), and that was
+                // two trips -- the pair, then the match alone, a trip that moves nothing (2,030 -> 1,628 trips per member).  A third
+                // literal, a code that is no code, bits that are not there yet: left where they are for the next trip, which reports errors.
+                uint32_t sym = 0x7fffffffu, l = 0, q = 0;
+                uint64_t sb; uint32_t sc;                         // the bit buffer in front of the symbol being looked at
+                for (;;) {
+                    sb = br.buf; sc = br.cnt;
+                    const uint32_t idx = code_lookup(LL, rev15(br.peek(15)), l);
+                    if (l == 0 || idx >= 288) { if (q == 0) { status = INF_BAD_CODE; fin = true; } break; }
+                    const uint32_t s1 = T.get_ll_sym(idx);
+                    if (s1 >= 256) { sym = s1; break; }
+                    if (q == 2) break;                             // (a third literal stays)
                     br.drop(l);
-                    if (sym < 256) { lit2 = sym; break; }
-                } else if (sym < 256) { lit = sym; break; }
+                    if (q == 0) lit = s1; else lit2 = s1;
+                    ++q;
+                    if (!(runs ? (q < 3 && br.cnt >= 15) : (pairs && q < 2 && br.cnt >= 48))) break;
+                }
+                if (sym == 0x7fffffffu) break;                     // literals only (or an error)
+                bool fits = true;                                  // (q > 0: the symbol is taken if all of it is in the buffer)
+                br.drop(l);
                 if (sym == 256) {
-                    in_symbols = false;
-                    if (br.overran()) { status = INF_IN_OVERRUN; fin = true; break; }
-                    if (last) done = true;
+                    if (q == 0 || sc >= l) {
+                        in_symbols = false;
+                        if (br.overran()) { status = INF_IN_OVERRUN; fin = true; break; }
+                        if (last) done = true;
+                    } else fits = false;
                 } else {
                     const uint32_t c = sym - 257;
-                    if (c > 28) { status = INF_BAD_CODE; fin = true; break; }
-                    if (c < 8) new_len = 3 + c;
-                    else if (c == 28) new_len = 258;
-                    else { const uint32_t e = (c >> 2) - 1; new_len = ((4 + (c & 3)) << e) + 3 + br.bits(e); }
-                    const uint32_t dv = rev15(br.peek(15));
-                    uint32_t dl;
-                    const uint32_t didx = code_lookup(DD, dv, dl);
-                    if (dl == 0 || didx >= 32) { status = INF_BAD_CODE; fin = true; break; }
-                    const uint32_t dsym = T.get_d_sym(didx);
-                    br.drop(dl);
-                    if (dsym > 29) { status = INF_BAD_CODE; fin = true; break; }
-                    if (dsym < 4) new_dist = 1 + dsym;
-                    else { const uint32_t e = (dsym >> 1) - 1; new_dist = ((2 + (dsym & 1)) << e) + 1 + br.bits(e); }
+                    if (c > 28) { if (q == 0) { status = INF_BAD_CODE; fin = true; break; } fits = false; }
+                    else {
+                        uint32_t e = 0;
+                        if (c < 8) new_len = 3 + c;
+                        else if (c == 28) new_len = 258;
+                        else { e = (c >> 2) - 1; new_len = ((4 + (c & 3)) << e) + 3 + br.bits(e); }
+                        uint32_t dl;
+                        const uint32_t didx = code_lookup(DD, rev15(br.peek(15)), dl);
+                        const uint32_t dsym = T.get_d_sym(didx & 31u);
+                        if (dl == 0 || didx >= 32 || dsym > 29) { if (q == 0) { status = INF_BAD_CODE; fin = true; break; } fits = false; }
+                        else {
+                            br.drop(dl);
+                            uint32_t de = 0;
+                            if (dsym < 4) new_dist = 1 + dsym;
+                            else { de = (dsym >> 1) - 1; new_dist = ((2 + (dsym & 1)) << de) + 1 + br.bits(de); }
+                            fits = q == 0 || sc >= l + e + dl + de;
+                        }
+                    }
                 }
+                if (!fits) { br.buf = sb; br.cnt = sc; new_len = 0; new_dist = 0; }
             } else if (!copying) {
                 // block header (rare, heavy): only with no copy in flight, so that it may write output itself
                 const int r = block_header_call(br, T, LL, DD, in, in_len, out, o, out_cap, last, status, S);
@@ -153,6 +182,7 @@ RGX_HD int inflate_coop(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
         if (!fin) br.ensure(48);
         // ---- C: output -------------------------------------------------------------------------------------------------
         if (copying) {                                              // (an error in B leaves the copy of this trip to be finished: its loads are done)
+            if (rl) expand_run(v0, v1, v2, v3, pend_dist);
             if (!coop) {
 #define RGX_PUT(J, V)                                                                                                            \
                 if (n > 16u * (J)) {                                                                                                 \
@@ -170,8 +200,12 @@ RGX_HD int inflate_coop(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
                 S.lo = tl; S.hi = th;
             }
             o += n; pend_len -= n;
-            // an overlapping copy is periodic with period pend_dist, so 2 * pend_dist is as good a distance for the rest
-            if (n == pend_dist) pend_dist += pend_dist;
+            // an overlapping copy is periodic with period pend_dist, so 2 * pend_dist is as good a distance for the rest (a run written from
+            // registers: the largest period x 2^k that the 64 bytes just written hold)
+            if (rl) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) if (pend_dist <= 32) pend_dist += pend_dist;
+            } else if (n == pend_dist) pend_dist += pend_dist;
         }
         // (an error met while decoding the trip's second symbol: the literal in front of it is not written -- what a failed member left
         //  behind is never read, the stream ends where the member starts)

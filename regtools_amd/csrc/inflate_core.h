@@ -215,6 +215,41 @@ RGX_HD uint32_t rev15(uint32_t v) {
 RGX_HD uint64_t shl64(uint64_t x, uint32_t s) { return s >= 64 ? 0 : x << s; }
 RGX_HD uint64_t shr64(uint64_t x, uint32_t s) { return s >= 64 ? 0 : x >> s; }
 
+// ---- runs from registers (round 4) -------------------------------------------------------------------------------------------------
+// A match whose distance d is at most 16 repeats the d bytes in front of it: given the 16 bytes at (o - d) -- of which the first d are
+// output already written, the rest anything -- the next 64 bytes of output are E[j] = P[j mod d], built here without touching memory again.
+// (The doubling rule of the symbol loop gets there in log2 steps, one trip -- one memory round trip and one partial-chunk store -- each:
+// long reads spend half their trips in such runs.)  x0 = E[0..16): P doubled up four times; chunk c = E[16c..16c+16): with r = 16c mod d,
+// bytes [0, d - r) come from x0 >> 8r and the rest from x0 << 8(d - r).
+RGX_HD void shl128(uint64_t &lo, uint64_t &hi, uint32_t s) {          // s in bits, any value (>= 128 gives 0)
+    const uint64_t nh = shl64(hi, s) | shr64(lo, 64u - s) | shl64(lo, s - 64u);      // (out-of-range counts, also the wrapped ones, give 0)
+    lo = shl64(lo, s); hi = nh;
+}
+RGX_HD void shr128(uint64_t &lo, uint64_t &hi, uint32_t s) {
+    const uint64_t nl = shr64(lo, s) | shl64(hi, 64u - s) | shr64(hi, s - 64u);
+    hi = shr64(hi, s); lo = nl;
+}
+RGX_HD void expand_run(u32x4 &v0, u32x4 &v1, u32x4 &v2, u32x4 &v3, uint32_t d /* 1..16 */) {
+    uint64_t xl = (uint64_t)v0[0] | (uint64_t)v0[1] << 32, xh = (uint64_t)v0[2] | (uint64_t)v0[3] << 32;
+    { const uint32_t mb = 8 * d; xl &= mb >= 64 ? ~0ull : ((1ull << (mb & 63)) - 1); xh &= mb >= 128 ? ~0ull : (mb <= 64 ? 0ull : ((1ull << ((mb - 64) & 63)) - 1)); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { uint64_t tl = xl, th = xh; shl128(tl, th, (8u * d) << k); xl |= tl; xh |= th; }
+    const uint32_t r1 = (uint32_t)(0x0123456702410100ull >> (4 * (d - 1))) & 15u;     // 16 mod d, d = 1..16
+    uint32_t r = 0;
+    u32x4 *dst[3] = {&v1, &v2, &v3};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        r += r1; if (r >= d) r -= d;                                                 // 16 (c + 1) mod d
+        uint64_t al = xl, ah = xh, bl = xl, bh = xh;
+        shr128(al, ah, 8 * r); shl128(bl, bh, 8 * (d - r));
+        const uint32_t mb = 8 * (d - r);                                              // 8..128 bits kept of a
+        al &= mb >= 64 ? ~0ull : ((1ull << (mb & 63)) - 1); ah &= mb >= 128 ? ~0ull : (mb <= 64 ? 0ull : ((1ull << ((mb - 64) & 63)) - 1));
+        al |= bl; ah |= bh;
+        *dst[c] = u32x4{(uint32_t)al, (uint32_t)(al >> 32), (uint32_t)ah, (uint32_t)(ah >> 32)};
+    }
+    v0 = u32x4{(uint32_t)xl, (uint32_t)(xl >> 32), (uint32_t)xh, (uint32_t)(xh >> 32)};
+}
+
 struct OutStage {
     uint8_t *out; uint32_t cap, a;
     uint64_t lo, hi;

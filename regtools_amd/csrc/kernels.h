@@ -49,6 +49,10 @@ void launch_gate_set(uint32_t *flag, uint32_t epoch, hipStream_t stream);      /
 //                                random bases + binned qualities: 3.6)  per 1024 members: bench payload 14.5-15.2 (k_inflate 19.9-21.3); random bases 44.9-47.5
 //                                                                      (k_inflate with four literals per trip, round 3's choice for them: 53.1-54.1)
 // bit 0 = literal pairs + sorted lanes.  (k_inflate stays selectable: REGTOOLS_AMD_INFLATE=lane, form 1 / 5 of the stage entry point.)
+// Second half of round 4 (k_inflate_coop's mode word, launch_inflate): runs at distances of 16 bytes or less are written from registers, 64 bytes a
+// trip, for every class (long reads 121.2 -> 79.8 ms: half their trips were such runs growing 1, 2, 4 ... bytes a trip, each with a partial-chunk
+// store); up to 32 x also a literal pair and the match behind it in one trip, bits counted exactly (bench payload 2,030 -> 1,463 trips per
+// member, 15.2 -> 14.1-15.0 ms: the launch follows its memory requests, not its trips).
 inline int inflate_plan_for(uint64_t compressed_bytes, uint64_t inflated_bytes) {
     return compressed_bytes * 32 > inflated_bytes ? 1 : 0;
 }

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     uint32_t out_len = 0;
     if (PROBE) {
         const bool run = have && mb.isize != 0xffffffffu;         // ~0: BSIZE runs past the end of the file (or is < 26): the read fails upstream
-        const int st = inflate_coop<BitReader>(comp + mb.cpos, mb.clen, arena + (uint64_t)(have ? m : first) * kBgzfMaxBlock, kBgzfMaxBlock, &out_len, T, C, run, pairs != 0);
+        const int st = inflate_coop<BitReader>(comp + mb.cpos, mb.clen, arena + (uint64_t)(have ? m : first) * kBgzfMaxBlock, kBgzfMaxBlock, &out_len, T, C, run, pairs);
         if (have) status[m] = run && st == INF_OK ? out_len : 0xffffffffu;
         return;
     }
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // range the host asked for.  ~0 = the member runs past the end of the file (k_member_link).
     const bool run = have && mb.isize <= kBgzfMaxBlock;
     typedef typename std::conditional<WIN, BitReaderWin, BitReader>::type BR;
-    int st = inflate_coop<BR>(comp + mb.cpos, mb.clen, run ? arena + (mb.upos - upos_bias) : C.wave_base, run ? mb.isize : 0, &out_len, T, C, run, pairs != 0);
+    int st = inflate_coop<BR>(comp + mb.cpos, mb.clen, run ? arena + (mb.upos - upos_bias) : C.wave_base, run ? mb.isize : 0, &out_len, T, C, run, pairs);
     if (!have) return;
     if (!run) st = mb.isize == 0xffffffffu ? INF_IN_OVERRUN : INF_OUT_OVERFLOW;
     else if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
@@ -513,8 +513,13 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
                     uint32_t *status, hipStream_t stream, uint32_t ignore_below, uint32_t index_bias, bool piece, int form, uint8_t *bad, int plan, bool check_layout, InflateGate gate) {
     if (!n_members) return;
     inflate_attrs();
-    static const int env_pairs = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE_PAIRS"); return e ? atoi(e) != 0 : -1; }();
-    const uint32_t two = env_pairs >= 0 ? (uint32_t)env_pairs : (plan & 1) != 0;
+    // k_inflate_coop's mode word (inflate_coop.h): bit 0 = a literal and the symbol behind it per trip, bits 0 + 1 = exact bit counts and a
+    // match behind a literal pair in the same trip, bit 2 = runs (distance <= 16) written from registers, 64 bytes a trip (round 4).
+    // Same box, interleaved, ms (tools/lab/runs_ab.sh, profiles/r04_inflate_modes.txt): bench payload mode 1 15.2-15.3 / 3 14.2-15.1 / 7 14.1-15.0;
+    // random bases + qualities 1: 48.2-48.4 / 3: 45.4-47.4; long reads 0: 121.2 / 1: 123.9-124.7 / 4: 79.8-79.9 / 5: 80.4-80.6 / 7: 80.5-80.9.
+    // REGTOOLS_AMD_INFLATE_PAIRS=<mode> overrides (lab / tests).
+    static const int env_pairs = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE_PAIRS"); return e ? atoi(e) : -1; }();
+    const uint32_t two = env_pairs >= 0 ? (uint32_t)env_pairs : (plan & 1) ? 7u : 4u;
     if (!form) form = inflate_form_env();
     if (!form) form = n_members <= kWaveFormMaxMembers ? 2 : (plan & 2) ? 1 : kDefaultLaneForm;
     const uint32_t blocks = (n_members + 63) / 64;

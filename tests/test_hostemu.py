@@ -50,7 +50,8 @@ def inflate(emu, payload, cap=65536):
     st5 = emu.emu_inflate_lits(buf, len(payload), out5, cap, ctypes.byref(n5))
     assert st5 == st and n5.value == n.value and out5.raw[:n5.value] == got, (st, st5, n.value, n5.value)
     # ... and round 3's decoder (inflate_coop.h): long matches split into head / wave-copied aligned body / tail
-    for pairs in (0, 1, 2, 3):                         # with and without the second symbol of a trip (bit 0), plain / windowed bit reader (bit 1)
+    # with and without the second symbol of a trip (bit 0), plain / windowed bit reader (bit 1), literal pair + match per trip (bit 2), runs written from registers (bit 3)
+    for pairs in (0, 1, 2, 3, 5, 7, 8, 10, 13, 15):
         out4 = ctypes.create_string_buffer(cap + 64)
         n4 = ctypes.c_uint32(0)
         st4 = emu.emu_inflate_coop(buf, len(payload), out4, cap, ctypes.byref(n4), _phase[0], pairs)
@@ -223,16 +224,16 @@ def test_coop_decoder_every_destination_phase_and_copy_split(emu):
     match, distances from runs to the window's end, at every destination phase of a 16-byte chunk; guard bytes around the member must stay
     untouched (emu_inflate_coop checks them)."""
     rnd = random.Random(29)
-    for dist in (1, 2, 3, 15, 16, 17, 63, 64, 65, 66, 79, 80, 81, 127, 128, 129, 221, 257, 258, 259, 300, 1000, 32768):
+    for dist in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 63, 64, 65, 66, 79, 80, 81, 127, 128, 129, 221, 257, 258, 259, 300, 1000, 32768):
         seed = bytes(rnd.randrange(256) for _ in range(dist))
-        for total in (dist + 3, dist + 64, dist + 65, dist + 80, dist + 130, dist + 258, dist + 259, dist + 700):
+        for total in (dist + 3, dist + 17, dist + 64, dist + 65, dist + 80, dist + 130, dist + 258, dist + 259, dist + 700):
             data = (seed * (total // dist + 2))[:total]
             c = zlib.compressobj(9, zlib.DEFLATED, -15, 9)
             p = c.compress(data) + c.flush()
             for phase in list(range(16)) + [31, 100, 127]:
                 out = ctypes.create_string_buffer(len(data) + 64)
                 n = ctypes.c_uint32(0)
-                st = emu.emu_inflate_coop(p, len(p), out, len(data), ctypes.byref(n), phase, phase & 3)
+                st = emu.emu_inflate_coop(p, len(p), out, len(data), ctypes.byref(n), phase, (phase & 3) | (4 if phase & 5 == 5 or phase > 16 else 0) | (8 if phase & 2 or dist <= 16 and phase & 1 else 0))
                 assert st == 0 and out.raw[:n.value] == data, (dist, total, phase, st)
 
 
