@@ -1317,8 +1317,31 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
     uint32_t *chrom_rank_rows = nullptr;
     R = HostRows();
     if (n_events) {
-        const size_t E = n_events;
-        const size_t rtmp = radix_tmp_words(n_events) + scan_tmp_words(n_events) + 64;
+        // Round 4: equal keys are grouped per tile of consecutive events first (k_preagg); what is sorted and reduced are the tiles' partial
+        // rows.  Callers that need every event's row (the -b pass: row_map) keep the event form.
+        static const int env_preagg = [] { const char *e = getenv("REGTOOLS_AMD_PREAGG"); return e ? atoi(e) : 1; }();
+        const bool preagg = env_preagg && !row_map;
+        PartialSoA pr; memset(&pr, 0, sizeof pr);
+        uint32_t *ev_flag = nullptr;           // preagg: one word per EVENT (first-seen flags, then their scan)
+        EventSoA sev = ev;                     // what is sorted: the events, or the partial rows
+        uint32_t n_s = n_events;
+        if (preagg) {
+            DevBuf &b_par = c->buf("partials");
+            const size_t Ev = n_events;
+            HIP_TRY(b_par.ensure(Ev * 4 * 9 + scan_tmp_words(n_events) * 4 + 512));
+            uint32_t *q = b_par.as<uint32_t>();
+            pr.tid = q; q += Ev; pr.start = q; q += Ev; pr.ilen_cls = q; q += Ev; pr.ts = q; q += Ev; pr.te = q; q += Ev;
+            pr.count = q; q += Ev; pr.first = q; q += Ev; pr.last = q; q += Ev; ev_flag = q;
+            HIP_TRY(hipMemsetAsync(d_sc + 7, 0, 4, st));
+            launch_preagg(ev, n_events, pr, d_sc + 7, st);
+            HIP_TRY(hipMemcpyAsync(h_sc + 7, d_sc + 7, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            n_s = h_sc[7];
+            memset(&sev, 0, sizeof sev);
+            sev.tid = pr.tid; sev.start = pr.start; sev.ilen_cls = pr.ilen_cls; sev.ts = pr.ts; sev.te = pr.te;
+        }
+        const size_t E = n_s;
+        const size_t rtmp = radix_tmp_words(n_s) + scan_tmp_words(n_s) + 64;
         HIP_TRY(b_sort.ensure(E * 4 * 6 + rtmp * 4 + 256));
         uint32_t *q = b_sort.as<uint32_t>();
         perm[0] = q; q += E; perm[1] = q; q += E;
@@ -1331,21 +1354,21 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
         auto sort_word = [&](const uint32_t *word, uint32_t nbits) {
             const uint32_t *kin = word;
             int kc = 0;
-            if (pc >= 0) { launch_gather_u32(n_events, word, perm[pc], key[0], st); kin = key[0]; kc = 1; }
+            if (pc >= 0) { launch_gather_u32(n_s, word, perm[pc], key[0], st); kin = key[0]; kc = 1; }
             for (uint32_t sh = 0; sh < nbits; sh += 8) {
                 const uint32_t bits = std::min<uint32_t>(8, nbits - sh);
                 const int nxt = pc < 0 ? 0 : pc ^ 1;
-                launch_radix_pass_keyed(kin, key[kc], sh, bits, pc < 0 ? nullptr : perm[pc], perm[nxt], n_events, tmp, st);
+                launch_radix_pass_keyed(kin, key[kc], sh, bits, pc < 0 ? nullptr : perm[pc], perm[nxt], n_s, tmp, st);
                 kin = key[kc]; kc ^= 1;
                 pc = nxt;
             }
         };
-        sort_word(ev.ilen_cls, ilen_bits);
-        sort_word(ev.start, 32);
-        sort_word(ev.tid, group_bits);
+        sort_word(sev.ilen_cls, ilen_bits);
+        sort_word(sev.start, 32);
+        sort_word(sev.tid, group_bits);
         const uint32_t *sorted = perm[pc];
-        launch_heads(ev, sorted, n_events, head, st);
-        launch_scan_u32(head, seg_excl, n_events, d_sc + 6, tmp, st);
+        launch_heads(sev, sorted, n_s, head, st);
+        launch_scan_u32(head, seg_excl, n_s, d_sc + 6, tmp, st);
         HIP_TRY(hipMemcpyAsync(h_sc + 6, d_sc + 6, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         n_unique = h_sc[6];
@@ -1362,19 +1385,31 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
         u.strand = (uint8_t *)w;
         launch_fill_u32(u.ts_min, 0xffffffffu, U, st);
         launch_fill_u32(u.te_max, 0u, U, st);
-        launch_reduce(ev, sorted, head, seg_excl, n_events, u, head_pos, st);
-        if (row_map) {
-            DevBuf &b_map = c->buf("row_map");
-            HIP_TRY(b_map.ensure((E + U) * 4 + 256));
-            row_map->ev_urow = b_map.as<uint32_t>(); row_map->urow_pos = row_map->ev_urow + E;
-            launch_event_urow(sorted, head, seg_excl, n_events, row_map->ev_urow, st);
+        if (preagg) {
+            launch_fill_u32(u.count, 0u, U, st);
+            launch_fill_u32(u.first_seen, 0xffffffffu, U, st);
+            launch_fill_u32(u.last_seen, 0u, U, st);
+            launch_reduce_partials(pr, sorted, head, seg_excl, n_s, u, st);
+            // first-seen naming (junctions_extractor.cc:152-157): rank of the key's first event among all keys -- flags over the EVENTS
+            HIP_TRY(hipMemsetAsync(ev_flag, 0, (size_t)n_events * 4, st));
+            launch_reduce_finish_partials(ev.strand, n_unique, u, ev_flag, st);
+            launch_scan_u32(ev_flag, ev_flag, n_events, nullptr, ev_flag + n_events, st);
+            launch_name_rank(n_unique, ev_flag, u, st);
+        } else {
+            launch_reduce(ev, sorted, head, seg_excl, n_events, u, head_pos, st);
+            if (row_map) {
+                DevBuf &b_map = c->buf("row_map");
+                HIP_TRY(b_map.ensure((E + U) * 4 + 256));
+                row_map->ev_urow = b_map.as<uint32_t>(); row_map->urow_pos = row_map->ev_urow + E;
+                launch_event_urow(sorted, head, seg_excl, n_events, row_map->ev_urow, st);
+            }
+            // first-seen naming (junctions_extractor.cc:152-157): rank of the key's first event among all keys
+            uint32_t *first_flag = head;       // reuse: head/seg_excl are dead after launch_reduce
+            HIP_TRY(hipMemsetAsync(first_flag, 0, E * 4, st));
+            launch_reduce_finish(ev, sorted, n_events, n_unique, head_pos, u, first_flag, st);
+            launch_scan_u32(first_flag, seg_excl, n_events, nullptr, tmp, st);
+            launch_name_rank(n_unique, seg_excl, u, st);
         }
-        // first-seen naming (junctions_extractor.cc:152-157): rank of the key's first event among all keys
-        uint32_t *first_flag = head;       // reuse: head/seg_excl are dead after launch_reduce
-        HIP_TRY(hipMemsetAsync(first_flag, 0, E * 4, st));
-        launch_reduce_finish(ev, sorted, n_events, n_unique, head_pos, u, first_flag, st);
-        launch_scan_u32(first_flag, seg_excl, n_events, nullptr, tmp, st);
-        launch_name_rank(n_unique, seg_excl, u, st);
 
         // output order (junctions_extractor.h:117-140): rank of the group (chrom string order), thick_start, thick_end, name
         uint32_t rk = 0;

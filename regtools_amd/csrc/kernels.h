@@ -188,6 +188,12 @@ struct UniqueSoA {
     uint32_t *tid, *start, *end, *ts_min, *te_max, *count, *first_seen, *last_seen, *name_rank;
     uint8_t  *strand;
 };
+// Partial rows (round 4, k_preagg): one row per distinct key of a tile of consecutive events; reduce_events sorts and reduces these instead of the events.
+struct PartialSoA { uint32_t *tid, *start, *ilen_cls, *ts, *te, *count, *first, *last; };
+void launch_preagg(EventSoA ev, uint32_t n, PartialSoA p, uint32_t *p_total /* device, zeroed by the caller: rows appended */, hipStream_t stream);
+// u.count / te_max / last_seen pre-filled with 0, u.ts_min / first_seen with 0xffffffff
+void launch_reduce_partials(PartialSoA p, const uint32_t *perm, const uint32_t *head, const uint32_t *seg_excl, uint32_t n, UniqueSoA u, hipStream_t stream);
+void launch_reduce_finish_partials(const uint8_t *ev_strand, uint32_t n_unique, UniqueSoA u, uint32_t *first_flag /* one word per EVENT, zeroed */, hipStream_t stream);
 // head[i] = 1 where sorted position i starts a new key
 void launch_heads(EventSoA ev, const uint32_t *perm, uint32_t n, uint32_t *head, hipStream_t stream);
 // seg_excl = exclusive scan of head. ts_min must be pre-filled with 0xffffffff, te_max with 0.

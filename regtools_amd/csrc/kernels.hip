@@ -328,7 +328,7 @@ __global__ void k_members_check(const Member *__restrict__ members, uint32_t n_m
 }
 
 // one lane per member like k_inflate; no lane leaves before the wave is done (the lanes without a member serve the others' copies)
-template <bool PROBE, bool PIECE = false, bool WIN = false>
+template <bool PROBE, bool PIECE = false, int WIN = 0 /* bit reader: 0 = 8 bytes a refill, 1 = 16-byte window */>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_inflate_coop(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
                                                 uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
                                                 uint32_t *status, uint32_t ignore_below, uint32_t index_bias, uint8_t *bad, uint32_t pairs,
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // a member whose claimed size is no BGZF block size owns no bytes of the arena (k_member_compact): it must not write any, whatever
     // range the host asked for.  ~0 = the member runs past the end of the file (k_member_link).
     const bool run = have && mb.isize <= kBgzfMaxBlock;
-    typedef typename std::conditional<WIN, BitReaderWin, BitReader>::type BR;
+    typedef typename std::conditional<WIN == 1, BitReaderWin, BitReader>::type BR;
     int st = inflate_coop<BR>(comp + mb.cpos, mb.clen, run ? arena + (mb.upos - upos_bias) : C.wave_base, run ? mb.isize : 0, &out_len, T, C, run, pairs);
     if (!have) return;
     if (!run) st = mb.isize == 0xffffffffu ? INF_IN_OVERRUN : INF_OUT_OVERFLOW;
@@ -455,6 +455,7 @@ __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t *__restrict__
 // The pipeline (form 0) takes the wave form up to kWaveFormMaxMembers members and kDefaultLaneForm beyond.
 constexpr uint32_t kWaveFormMaxMembers = 2048;
 constexpr int kDefaultLaneForm = 4;
+constexpr int kDefaultWindow = 1;     // k_inflate_coop's bit reader (its WIN parameter)
 static int inflate_form_env() {
     static const int f = [] {
         const char *e = getenv("REGTOOLS_AMD_INFLATE");
@@ -487,12 +488,12 @@ static void inflate_attrs() {
     set((const void *)k_inflate<false, false>, kInflateLdsBytes);
     set((const void *)k_inflate<false, true>, kInflateLdsBytes);
     set((const void *)k_inflate<true>, kInflateLdsBytes);
-    set((const void *)k_inflate_coop<false, false, false>, kInflateLdsBytes);
+    set((const void *)k_inflate_coop<false, false, 0>, kInflateLdsBytes);
     set((const void *)k_inflate<false, false, 4>, kInflateLdsBytes);
     set((const void *)k_inflate<false, true, 4>, kInflateLdsBytes);
-    set((const void *)k_inflate_coop<false, true, false>, kInflateLdsBytes);
-    set((const void *)k_inflate_coop<false, false, true>, kInflateLdsBytes);
-    set((const void *)k_inflate_coop<false, true, true>, kInflateLdsBytes);
+    set((const void *)k_inflate_coop<false, true, 0>, kInflateLdsBytes);
+    set((const void *)k_inflate_coop<false, false, 1>, kInflateLdsBytes);
+    set((const void *)k_inflate_coop<false, true, 1>, kInflateLdsBytes);
     set((const void *)k_inflate_coop<true>, kInflateLdsBytes);
     set((const void *)k_inflate_wave, (uint32_t)sizeof(WaveShared));
     set((const void *)k_inflate_ring<false>, kRingLdsBytes);
@@ -533,8 +534,9 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
     case 4: {
         // plan bit 0 set (payloads that compress up to 32 x): literal pairs and lanes sorted by compressed length; the windowed bit reader always
         // (round 4: its loads are no longer waited for on the spot -- long reads 117.5 ms with it against 120.7 without, kernels.h)
-        static const int env_tune = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE_TUNE"); return e ? atoi(e) : -1; }();      // (lab) bit 0 sort, bit 1 window
-        const bool sort = env_tune >= 0 ? (env_tune & 1) != 0 : (plan & 1) != 0, win = env_tune >= 0 ? (env_tune & 2) != 0 : true;
+        static const int env_tune = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE_TUNE"); return e ? atoi(e) : -1; }();      // (lab) bit 0 sort, bit 1 16-byte window
+        const bool sort = env_tune >= 0 ? (env_tune & 1) != 0 : (plan & 1) != 0;
+        const int win = env_tune >= 0 ? ((env_tune & 2) ? 1 : 0) : kDefaultWindow;
         uint32_t *perm = sort ? len_scratch + inflate_scratch_words(n_members) : nullptr;
         if (perm) hipLaunchKernelGGL(k_member_sort, dim3((n_members + kSortGroup - 1) / kSortGroup), dim3(256), 0, stream, members, n_members, perm);
         // (the veto word: behind the lane assignment in the scratch; only the stage entry point asks for the check)
@@ -544,8 +546,8 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
             hipLaunchKernelGGL(k_members_check, dim3((n_members + 255) / 256), dim3(256), 0, stream, members, n_members, status, veto);
         }
 #define RGX_COOP(PIECE_, WIN_) hipLaunchKernelGGL((k_inflate_coop<false, PIECE_, WIN_>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad, two, perm, veto, gate)
-        if (piece) { if (win) RGX_COOP(true, true); else RGX_COOP(true, false); }
-        else { if (win) RGX_COOP(false, true); else RGX_COOP(false, false); }
+        if (piece) { if (win) RGX_COOP(true, 1); else RGX_COOP(true, 0); }
+        else { if (win) RGX_COOP(false, 1); else RGX_COOP(false, 0); }
 #undef RGX_COOP
         break;
     }
@@ -1560,6 +1562,101 @@ __global__ void k_reduce(EventSoA ev, const uint32_t *__restrict__ perm, const u
     if (run_head) { atomicMin(&u.ts_min[row], ts); atomicMax(&u.te_max[row], te); }
 }
 
+// ---- round 4: pre-aggregation -------------------------------------------------------------------------------------------------------
+// The events of one junction come close together in file order (the reads that support it start within a read length of each other), so
+// most of the group-by can happen before anything is sorted: a workgroup takes kAggTile consecutive events, groups equal keys in an LDS hash
+// table (open addressing; a slot holds the tile-local index of the event that claimed it, keys are compared in the staged key columns) and
+// writes ONE partial row per distinct key of the tile -- key, number of events, min thick_start, max thick_end, first and last event index.
+// The radix sort, the head flags and the reduce then run on the partial rows (bench file 7.5 M events -> ~0.4 M rows, long reads 125 M ->
+// a few M) and combine them with sum / min / max, which do not care in which order the tiles appended their rows.  Exact for any input:
+// events that do not repeat inside a tile simply stay rows of one.
+constexpr uint32_t kAggTile = 2048, kAggSlots = 2 * kAggTile, kAggEmpty = 0xffffffffu;
+__global__ __launch_bounds__(256) void k_preagg(EventSoA ev, uint32_t n, PartialSoA p, uint32_t *p_total) {
+    __shared__ uint32_t s_tid[kAggTile], s_start[kAggTile], s_ilen[kAggTile], s_slot[kAggSlots];
+    __shared__ uint32_t s_cnt[kAggTile], s_ts[kAggTile], s_te[kAggTile], s_first[kAggTile], s_last[kAggTile];
+    __shared__ uint32_t s_wave[4], s_base;
+    const uint32_t base = blockIdx.x * kAggTile, t = threadIdx.x;
+#pragma unroll
+    for (uint32_t k = 0; k < kAggTile / 256; ++k) {
+        const uint32_t i = t + 256 * k, e = base + i;
+        if (e < n) { s_tid[i] = ev.tid[e]; s_start[i] = ev.start[e]; s_ilen[i] = ev.ilen_cls[e]; }
+        s_cnt[i] = 0; s_ts[i] = 0xffffffffu; s_te[i] = 0; s_first[i] = 0xffffffffu; s_last[i] = 0;
+        s_slot[i] = kAggEmpty; s_slot[i + kAggTile] = kAggEmpty;
+    }
+    __syncthreads();
+    uint32_t mine = 0;                                        // bit k: my event k claimed a slot (it writes the key's row)
+#pragma unroll
+    for (uint32_t k = 0; k < kAggTile / 256; ++k) {
+        const uint32_t i = t + 256 * k, e = base + i;
+        if (e < n) {
+            const uint32_t kt = s_tid[i], ks = s_start[i], kl = s_ilen[i];
+            uint32_t h = ks * 0x9E3779B1u ^ kl * 0x85EBCA6Bu ^ kt * 0xC2B2AE35u;
+            h = (h ^ h >> 15) & (kAggSlots - 1);
+            uint32_t leader;
+            for (;;) {
+                const uint32_t prev = atomicCAS(&s_slot[h], kAggEmpty, i);
+                if (prev == kAggEmpty) { leader = i; mine |= 1u << k; break; }
+                if (s_tid[prev] == kt && s_start[prev] == ks && s_ilen[prev] == kl) { leader = prev; break; }
+                h = (h + 1) & (kAggSlots - 1);
+            }
+            atomicAdd(&s_cnt[leader], 1u);
+            atomicMin(&s_ts[leader], ev.ts[e]); atomicMax(&s_te[leader], ev.te[e]);
+            atomicMin(&s_first[leader], i); atomicMax(&s_last[leader], i);
+        }
+    }
+    __syncthreads();
+    uint32_t tot;
+    uint32_t at = block_excl_scan_256((uint32_t)__popc(mine), s_wave, tot);
+    if (t == 0) s_base = tot ? atomicAdd(p_total, tot) : 0u;
+    __syncthreads();
+    at += s_base;
+#pragma unroll
+    for (uint32_t k = 0; k < kAggTile / 256; ++k) {
+        if (mine >> k & 1u) {
+            const uint32_t i = t + 256 * k;
+            p.tid[at] = s_tid[i]; p.start[at] = s_start[i]; p.ilen_cls[at] = s_ilen[i];
+            p.count[at] = s_cnt[i]; p.ts[at] = s_ts[i]; p.te[at] = s_te[i]; p.first[at] = base + s_first[i]; p.last[at] = base + s_last[i];
+            ++at;
+        }
+    }
+}
+
+// k_reduce for partial rows: per key the sum of the counts, min / max of the thick bounds, the earliest first and the latest last event.
+// u.count / te_max / last_seen must be pre-filled with 0, u.ts_min / first_seen with 0xffffffff.
+__global__ void k_reduce_partials(PartialSoA p, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ head,
+                                  const uint32_t *__restrict__ seg_excl, uint32_t n, UniqueSoA u) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    uint32_t row = 0, ts = 0xffffffffu, te = 0, cnt = 0, first = 0xffffffffu, last = 0;
+    if (valid) {
+        const uint32_t e = perm[i];
+        const uint32_t hd = head[i];
+        row = seg_excl[i] + hd - 1;
+        ts = p.ts[e]; te = p.te[e]; cnt = p.count[e]; first = p.first[e]; last = p.last[e];
+        if (hd) { u.tid[row] = p.tid[e]; u.start[row] = p.start[e]; u.end[row] = p.start[e] + (p.ilen_cls[e] >> 2); }
+    }
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t r2 = __shfl_down(row, d, 64), ts2 = __shfl_down(ts, d, 64), te2 = __shfl_down(te, d, 64), c2 = __shfl_down(cnt, d, 64);
+        const uint32_t f2 = __shfl_down(first, d, 64), l2 = __shfl_down(last, d, 64);
+        const bool v2 = __shfl_down((uint32_t)valid, d, 64) != 0;
+        if (lane + d < 64 && v2 && r2 == row) { ts = min(ts, ts2); te = max(te, te2); cnt += c2; first = min(first, f2); last = max(last, l2); }
+    }
+    const uint32_t prev_row = __shfl_up(row, 1, 64);
+    const bool run_head = valid && (lane == 0 || prev_row != row);
+    if (run_head) {
+        atomicMin(&u.ts_min[row], ts); atomicMax(&u.te_max[row], te); atomicAdd(&u.count[row], cnt);
+        atomicMin(&u.first_seen[row], first); atomicMax(&u.last_seen[row], last);
+    }
+}
+__global__ void k_reduce_finish_partials(const uint8_t *__restrict__ ev_strand, uint32_t n_unique, UniqueSoA u, uint32_t *first_flag) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_unique) return;
+    u.strand[r] = ev_strand[u.last_seen[r]];          // newest read's strand wins (junctions_extractor.cc:233)
+    first_flag[u.first_seen[r]] = 1;
+}
+
 __global__ void k_reduce_finish(EventSoA ev, const uint32_t *__restrict__ perm, uint32_t n, uint32_t n_unique,
                                 const uint32_t *__restrict__ head_pos, UniqueSoA u, uint32_t *first_flag) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1640,6 +1737,15 @@ void launch_rows_out(UniqueSoA u, const uint32_t *order, uint32_t n, uint32_t *o
 }
 void launch_rows_table(UniqueSoA u, const uint32_t *order, uint32_t n, uint32_t min_anchor, uint8_t *out, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(k_rows_table, dim3((n + 255) / 256), dim3(256), 0, stream, u, order, n, min_anchor, out);
+}
+void launch_preagg(EventSoA ev, uint32_t n, PartialSoA p, uint32_t *p_total, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_preagg, dim3((n + kAggTile - 1) / kAggTile), dim3(256), 0, stream, ev, n, p, p_total);
+}
+void launch_reduce_partials(PartialSoA p, const uint32_t *perm, const uint32_t *head, const uint32_t *seg_excl, uint32_t n, UniqueSoA u, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(k_reduce_partials, dim3((n + 255) / 256), dim3(256), 0, stream, p, perm, head, seg_excl, n, u);
+}
+void launch_reduce_finish_partials(const uint8_t *ev_strand, uint32_t n_unique, UniqueSoA u, uint32_t *first_flag, hipStream_t stream) {
+    if (n_unique) hipLaunchKernelGGL(k_reduce_finish_partials, dim3((n_unique + 255) / 256), dim3(256), 0, stream, ev_strand, n_unique, u, first_flag);
 }
 void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, v, n);

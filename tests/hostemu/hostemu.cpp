@@ -34,16 +34,19 @@ extern "C" int emu_inflate_ring(const uint8_t *in, uint32_t in_len, uint8_t *out
 // the round-3 decoder (inflate_coop.h: long matches handed to the wave) with a one-lane wave; same guard bytes, every destination phase
 #include "../../regtools_amd/csrc/inflate_coop.h"
 extern "C" int emu_inflate_coop(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t cap, uint32_t *out_len, uint32_t phase, int pairs) {
-    std::vector<uint8_t> ibuf((size_t)in_len + 64, 0);
-    memcpy(ibuf.data(), in, in_len);
+    // (the payload at every phase of a 16-byte block too)
+    std::vector<uint8_t> ibuf((size_t)in_len + 64 + 64, 0xEE);
+    uint8_t *src = (uint8_t *)(((uintptr_t)ibuf.data() + 15) & ~(uintptr_t)15) + 16 + ((phase * 7u) & 15u);
+    memcpy(src, in, in_len);
+    memset(src + in_len, 0, 24);
     std::vector<uint8_t> obuf((size_t)cap + 1024, 0xA5);
     uint8_t *dst = (uint8_t *)(((uintptr_t)obuf.data() + 127) & ~(uintptr_t)127) + 256 + (phase & 127u);
     rgx::HostTab T; rgx::HostCopy C;
     // bit 0 of `pairs`: a literal and the symbol behind it per trip; bit 1 selects the windowed bit reader; bit 2 (with bit 0): two literals and a
     // match behind them per trip, bits counted exactly (the decoder's mode bit 1); bit 3: runs written from registers (mode bit 2)
     const uint32_t mode = (uint32_t)(pairs & 1) | ((pairs & 4) ? 2u : 0u) | ((pairs & 8) ? 4u : 0u);
-    const int st = (pairs & 2) ? rgx::inflate_coop<rgx::BitReaderWin>(ibuf.data(), in_len, dst, cap, out_len, T, C, true, mode)
-                               : rgx::inflate_coop<rgx::BitReader>(ibuf.data(), in_len, dst, cap, out_len, T, C, true, mode);
+    const int st = (pairs & 2) ? rgx::inflate_coop<rgx::BitReaderWin>(src, in_len, dst, cap, out_len, T, C, true, mode)
+                               : rgx::inflate_coop<rgx::BitReader>(src, in_len, dst, cap, out_len, T, C, true, mode);
     for (uint8_t *q = obuf.data(); q < dst; ++q) if (*q != 0xA5) return -100;
     for (uint8_t *q = dst + cap; q < obuf.data() + obuf.size(); ++q) if (*q != 0xA5) return -101;
     memcpy(out, dst, *out_len <= cap ? *out_len : cap);
