@@ -105,6 +105,7 @@ struct rgx_ctx {
     // host input (rgx_extract_mem / rgx_extract): the file goes up in chunks on its own stream while the members that have arrived are
     // being inflated on the side streams (prepare_events)
     hipStream_t copy_stream = nullptr, side[kSideStreams] = {};
+    bool walk_strict = false;             // set around the re-run of a call whose block_size-only framing met a record bam_read1 refuses (prepare_events)
     bool one_shot = false;                             // REGTOOLS_AMD_ONE_SHOT at creation: no streams besides `stream` (ensure_upload_streams)
     std::vector<hipEvent_t> chunk_ev;
     uint32_t gate_epoch = 0;                           // arrival gate of the overlapped upload (kernels.h InflateGate): this context's call counter
@@ -547,14 +548,21 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             up.copy_stream = copy_q;
             uint32_t *gate_flags = gated ? c->buf("gate_flags").as<uint32_t>() : nullptr;
             const uint32_t gate_epoch = c->gate_epoch;
-            up.th = std::thread([c, dst, h_bam, hdr_hi, up_lo, copy_q, gate_flags, gate_epoch, &up] {
+            static const int env_gate_side = [] { const char *e = getenv("REGTOOLS_AMD_GATE_SIDE"); return e ? atoi(e) : 1; }();
+            hipStream_t gate_q = env_gate_side && c->side[0] ? c->side[0] : copy_q;
+            up.th = std::thread([c, dst, h_bam, hdr_hi, up_lo, copy_q, gate_q, gate_flags, gate_epoch, &up] {
                 if (hipSetDevice(c->device) != hipSuccess) { up.err = 1; up.recorded = (uint32_t)up.end.size(); return; }
                 if (hdr_hi && hipMemcpyAsync(dst, h_bam, hdr_hi, hipMemcpyHostToDevice, copy_q) != hipSuccess) up.err = 1;
                 size_t o = up_lo;
                 for (size_t j = 0; j < up.end.size(); ++j) {
                     if ((up.end[j] > o && hipMemcpyAsync(dst + o, h_bam + o, up.end[j] - o, hipMemcpyHostToDevice, copy_q) != hipSuccess) ||
                         hipEventRecord(c->chunk_ev[j], copy_q) != hipSuccess) up.err = 1;
-                    if (gate_flags) launch_gate_set(gate_flags + j, gate_epoch, copy_q);
+                    // (the flag's one-lane kernel goes to a side stream behind the chunk's event: on the copy stream itself it sat between two
+                    //  copies, ~30 us of an idle bus per chunk)
+                    if (gate_flags) {
+                        if (gate_q != copy_q && hipStreamWaitEvent(gate_q, c->chunk_ev[j], 0) != hipSuccess) up.err = 1;
+                        launch_gate_set(gate_flags + j, gate_epoch, gate_q);
+                    }
                     o = up.end[j];
                     up.recorded.store((uint32_t)j + 1, std::memory_order_release);
                 }
@@ -1124,6 +1132,9 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     uint64_t span = lim - pos0;
     uint32_t n_seg = (uint32_t)((span + seg_bytes - 1) / seg_bytes);
     geom.pos0 = pos0; geom.lim = lim; geom.data_end = lim; geom.seg_bytes = seg_bytes;
+    static const int env_lite = [] { const char *e = getenv("REGTOOLS_AMD_LITE_WALK"); return e ? atoi(e) : 1; }();
+    const bool lite_walk = env_lite && !c->walk_strict;
+    geom.lite_walk = lite_walk ? 1u : 0u;
     if (geom.chunks) {
         span = 0;
         for (const SegChunk &sc : seg_chunks) span += sc.b - sc.a;
@@ -1239,6 +1250,8 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             HIP_TRY(hipMemsetAsync(d_sc + 80, 0xff, 4, st));
             HIP_TRY(hipMemsetAsync(d_sc + 81, 0, 4, st));
         }
+        cfg.insane_out = nullptr;
+        if (lite_walk) { cfg.insane_out = d_sc + 82; HIP_TRY(hipMemsetAsync(d_sc + 82, 0, 4, st)); h_sc[82] = 0; }
         for (int pass = 0; pass < 2; ++pass) {
             launch_decode_seg(arena, geom, n_seg, seg_start[cur], seg_base, seg_cnt[cur], cfg, soa, seg_iter, seg_long, seg_cp,
                               /*staged=*/span / n_rec <= kSparseRecordBytes, st);
@@ -1247,7 +1260,19 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             launch_scan_u32(seg_long, seg_long_base, n_seg, d_sc + 5, b_tmp.as<uint32_t>(), st);
             HIP_TRY(hipMemcpyAsync(h_sc + 4, d_sc + 4, 24, hipMemcpyDeviceToHost, st));
             if (cfg.stop_out) HIP_TRY(hipMemcpyAsync(h_sc + 80, d_sc + 80, 8, hipMemcpyDeviceToHost, st));
+            if (cfg.insane_out) HIP_TRY(hipMemcpyAsync(h_sc + 82, d_sc + 82, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
+            if (cfg.insane_out && h_sc[82]) {
+                // a record the reference's reader would not have accepted (sam.c:421-423) lies on the chain the block_size walk followed:
+                // the whole call again with the framing making the full test (damaged files only)
+                mark("decode: a record fails bam_read1's test, starting over with the full walk");
+                if (overlap) { HIP_TRY(complete_upload()); HIP_TRY(hipStreamSynchronize(copy_q)); }
+                c->walk_strict = true;
+                const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, d_true_sizes, false, region_to_file_end);
+                c->walk_strict = false;
+                P.t_begin = t_begin;
+                return rc2;
+            }
             if (pass || !cfg.stop_out || h_sc[80] == 0xffffffffu || h_sc[81] <= h_sc[80] + 1) break;
             cfg.stop_index = h_sc[80];
         }

@@ -103,6 +103,9 @@ struct SegGeom {
     uint64_t data_end;             // end of the inflated bytes (k_decode_seg's staging window may reach past a chunk's end)
     const SegChunk *chunks; uint32_t n_chunks;
     uint32_t seg_bytes;            // kSegBytes, or kSegBytesLong for files of long records (the checkpoints and k_decode_seg only exist for kSegBytes)
+    uint32_t lite_walk;            // round 4: the chain walk reads a record's block_size only (one request per record instead of seven dwords over
+                                   // two lines); bam_read1's other acceptance tests (sam.c:421-423) are then made by the decode pass on the head it
+                                   // reads anyway (ExtractCfg::insane_out), and a record that fails them sends the call through the full walk
 };
 constexpr uint32_t kSegBytesLong = 131072;     // a lane's first-record search reads, on average, half a record of sequence and quality: with records of
                                                // kilobytes (long reads) 16 KiB segments spend their time there (config 5: k_seg_walk 11.9 ms of a 47 ms tail)
@@ -146,6 +149,7 @@ struct ExtractCfg {
     // [1] = 1 + largest index of a record that passed the overlap test (preset 0); records at or behind stop_index are not iterated.
     uint32_t *stop_out;
     uint32_t stop_index;
+    uint32_t *insane_out;          // null = the framing made bam_read1's acceptance test itself; else [0] is set when a decoded record fails it (SegGeom::lite_walk)
 };
 
 // one wave per framing segment, segment bytes staged through LDS (replaces launch_seg_fill + launch_decode on the hot path)

@@ -581,12 +581,18 @@ void launch_inflate_probe(const uint8_t *comp, const Member *members, uint32_t n
 // cp (optional): cp[j] = offset of record 8j from seg_begin -- k_decode_seg's lanes re-walk eight records each from there instead of
 // one lane re-walking all of them.
 __device__ __forceinline__ uint64_t walk_chain(const uint8_t *arena, uint64_t o, uint64_t seg_end, uint64_t lim, uint32_t &cnt, uint16_t *cp = nullptr,
-                                               uint64_t seg_begin = 0) {
+                                               uint64_t seg_begin = 0, bool lite = false) {
     cnt = 0;
     while (o < seg_end) {
         if (o + 36 > lim) return kChainEnd;             // bam_read1: short read of the fixed part
-        RecHead h; rec_head(arena + o, h);
-        if (!rec_sane(h)) return kChainEnd;             // sam.c:421-423 -> iteration ends
+        RecHead h;
+        if (lite) {                                     // block_size alone: ONE request per record (the rest of the test: the decode pass, SegGeom::lite_walk)
+            h.block_len = (int32_t)ld32(arena + o);
+            if (h.block_len < 32) return kChainEnd;
+        } else {
+            rec_head(arena + o, h);
+            if (!rec_sane(h)) return kChainEnd;         // sam.c:421-423 -> iteration ends
+        }
         uint64_t nxt = o + 4 + (uint64_t)(uint32_t)h.block_len;
         if (nxt > lim) return kChainEnd;                // truncated record body
         if (cp && (cnt & 7u) == 0) cp[cnt >> 3] = (uint16_t)(o - seg_begin);
@@ -660,12 +666,12 @@ __global__ void k_seg_walk(const uint8_t *__restrict__ arena, SegGeom g, uint32_
                 c += 16;
             }
             if (cand == kChainEnd) break;
-            ex = walk_chain(arena, cand, b, lim, cnt, cp, a);
+            ex = walk_chain(arena, cand, b, lim, cnt, cp, a, g.lite_walk != 0);
             if (ex != kChainEnd) { o = cand; break; }
             c = cand + 1;
         }
         if (o == kChainEnd) { ex = kChainUnknown; o = b; cnt = 0; }  // nothing usable: a placeholder that claims nothing (see k_seg_verify)
-    } else ex = walk_chain(arena, o, b, lim, cnt, cp, a);
+    } else ex = walk_chain(arena, o, b, lim, cnt, cp, a, g.lite_walk != 0);
     seg_start[s] = o; seg_exit[s] = ex; seg_cnt[s] = cnt;
 }
 
@@ -706,7 +712,7 @@ __global__ void k_seg_verify(const uint8_t *__restrict__ arena, SegGeom g, uint3
             const bool left_settled = first1 || (ex_in[s - 2] != kChainUnknown && seg_consistent(b1, ex_in[s - 2], st_in[s - 1], expect, cnt_in[s - 1]));
             if (placeholder || left_settled) {
                 if (expect >= b) { st = b; ex = expect; cnt = 0; }
-                else { st = expect; ex = walk_chain(arena, st, b, lim, cnt, g.seg_bytes == kSegBytes ? seg_cp + (size_t)s * kSegCpSlots : nullptr, a); }
+                else { st = expect; ex = walk_chain(arena, st, b, lim, cnt, g.seg_bytes == kSegBytes ? seg_cp + (size_t)s * kSegCpSlots : nullptr, a, g.lite_walk != 0); }
             }
         }
     }
@@ -828,6 +834,7 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
             h.l_qseq = (int32_t)x[5]; h.mtid = (int32_t)x[6];
             h.aux_off = (int64_t)h.l_qname + 4 * (int64_t)h.n_cigar + (((int64_t)h.l_qseq + 1) >> 1) + h.l_qseq;
         }
+        if (cfg.insane_out && !rec_sane(h)) cfg.insane_out[0] = 1;   // (the framing only looked at block_size: the call starts over with the full walk)
         // body (CIGAR, aux) from the LDS window when the whole record is inside it, else straight from the arena
         const uint64_t rec_end = o + 4 + (uint64_t)(uint32_t)h.block_len;
         const bool in_win = STAGED && rec_end <= w1;
@@ -910,6 +917,7 @@ __global__ __launch_bounds__(64) void k_decode_sparse(const uint8_t *__restrict_
             for (uint32_t k = 0; k < cnt; ++k) {
                 RecHead h;
                 rec_head(arena + o, h);
+                if (cfg.insane_out && !rec_sane(h)) cfg.insane_out[0] = 1;
                 const uint8_t *g_data = arena + o + 36;
                 auto cigar_at = [&](uint32_t q) -> uint32_t { return ld32(g_data + h.l_qname + 4 * (size_t)q); };
                 const uint32_t i = base + k;
