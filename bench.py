@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # the whole-file launch of the DEFLATE kernel the pipeline runs above 2048 members (kernels.hip launch_inflate; REGTOOLS_AMD_INFLATE overrides)
 INFLATE_KERNEL = {"lane": "rgx::k_inflate<false, false, 1>", "ring": "rgx::k_inflate_ring<false>", "wave": "rgx::k_inflate_wave"}.get(
-    os.environ.get("REGTOOLS_AMD_INFLATE", ""), "rgx::k_inflate_coop<false, false, true>")
+    os.environ.get("REGTOOLS_AMD_INFLATE", ""), "rgx::k_inflate_coop<false, false, 1>")
 
 
 def inflate_kernel_for(compressed, inflated):

@@ -206,7 +206,10 @@ static hipError_t ensure_upload_streams(rgx_ctx *c) {
     int pr_least = 0, pr_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
     const int prio[kSideStreams] = {0, 0, pr_greatest, pr_greatest, pr_least, pr_least};
-    const unsigned want = 2;                                  // (three pieces: two side streams + the pipeline's own; REGTOOLS_AMD_PIECES may ask for more)
+    // (three pieces: two side streams + the pipeline's own; REGTOOLS_AMD_PIECES may ask for more.  The third one, of the greatest priority, takes the
+    //  early tail's second inflate launch: the members that arrive last are what the call waits for)
+    static const bool early_prio = [] { const char *e = getenv("REGTOOLS_AMD_EARLY_TAIL_PRIO"); return !e || atoi(e) != 0; }();
+    const unsigned want = early_prio ? 3 : 2;
     for (int k = 0; k < kSideStreams; ++k) {
         if ((unsigned)k >= want && !getenv("REGTOOLS_AMD_PIECES")) break;
         if ((e = hipStreamCreateWithPriority(&c->side[k], hipStreamNonBlocking, prio[k])) != hipSuccess) return e;
@@ -853,6 +856,14 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         HIP_TRY(hipMemsetAsync(d_bad, 0, n_range, st));
     }
     const int pairs = inflate_plan_for(bam_len, total_all);      // (the whole file's ratio: a range of it is the same kind of payload)
+    // (early tail: the second of two gated launches is still running on a side stream; whoever reads its part of the arena, or the launch's
+    //  verdict, first makes the pipeline's stream wait for it)
+    bool split_B = false; uint64_t split_upos = 0; hipEvent_t split_ev = nullptr;
+    auto join_B = [&]() -> hipError_t {
+        if (!split_B) return hipSuccess;
+        split_B = false;
+        return hipStreamWaitEvent(st, split_ev, 0);
+    };
     if (!overlap) launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below, 0, false, 0, d_bad, pairs);
     else {
         // one launch per upload chunk, on the side streams: the members whose bytes (plus the decoder's 16-byte look-ahead) have arrived with
@@ -867,6 +878,31 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             if (inflate_takes_coop(n_range)) {
                 InflateGate gate;
                 gate.flags = c->buf("gate_flags").as<uint32_t>(); gate.epoch = c->gate_epoch; gate.n_chunks = (uint32_t)up.end.size(); gate.lo = up.lo; gate.chunk_bytes = gate_chunk;
+                // Round 4, second half: the members of the last upload chunks are a launch of their own on a side stream (same gate, same time).
+                // They end ~6-9 ms behind the last chunk's arrival (a member's own chain) on a chip that is emptying; the launch with the members
+                // of the first three quarters of the file ends earlier, and the framing and the decode of ITS part of the arena then run
+                // under the other launch's lonely end instead of behind it (below: "early tail").  REGTOOLS_AMD_EARLY_TAIL=<sixteenths of
+                // the upload in the first launch>, 0 = one launch.
+                static const int env_split = [] { const char *e = getenv("REGTOOLS_AMD_EARLY_TAIL"); const int v = e ? atoi(e) : 12; return v > 0 && v < 16 ? v : 0; }();
+                static const uint32_t early_min = [] { const char *e = getenv("REGTOOLS_AMD_EARLY_TAIL_MIN"); return e ? (uint32_t)atoi(e) : 4096u; }();     // (tests: small files)
+                uint32_t mA = m_hi;
+                const int sB = c->side[2] ? 2 : 1;               // (side[0] carries the gate's flag kernels)
+                if (env_split && c->side[sB] && up.end.size() >= 8 && !d_bad && !d_true_sizes) {
+                    const size_t kA = std::max<size_t>(1, up.end.size() * (size_t)env_split / 16);
+                    const uint64_t lim_b = up.end[kA - 1];
+                    uint32_t lo = m_lo, hi = m_hi;                 // first member that reads bytes behind chunk kA - 1 (k_inflate_coop's own rule)
+                    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (hm[mid].cpos + hm[mid].clen + 24 <= lim_b) lo = mid + 1; else hi = mid; }
+                    if (lo - m_lo >= early_min && m_hi - lo >= early_min && inflate_takes_coop(lo - m_lo) && inflate_takes_coop(m_hi - lo)) mA = lo;
+                }
+                if (mA < m_hi) {
+                    const uint32_t nA = mA - m_lo, nB = m_hi - mA;
+                    HIP_TRY(b_lens.ensure(inflate_scratch_bytes(nA) + inflate_scratch_bytes(nB)));
+                    launch_inflate(d_bam, d_members + m_lo, nA, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below, 0, /*piece=*/true, 0, d_bad, pairs, false, gate);
+                    launch_inflate(d_bam, d_members + mA, nB, b_arena.as<uint8_t>(), upos_lo, (uint32_t *)(b_lens.as<uint8_t>() + inflate_scratch_bytes(nA)), d_sc, c->side[sB], ignore_below, nA, /*piece=*/true, 0, d_bad, pairs, false, gate);
+                    HIP_TRY(hipEventRecord(c->ev_side[sB], c->side[sB]));
+                    split_ev = c->ev_side[sB];
+                    split_B = true; split_upos = hm[mA].upos - upos_lo;
+                } else
                 launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below, 0, /*piece=*/true, 0, d_bad, pairs, false, gate);
             } else {
                 while (up.recorded.load(std::memory_order_acquire) < up.end.size()) std::this_thread::yield();
@@ -917,6 +953,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     const bool spec = overlap && !d_true_sizes && !geom_chunked_hint && host_bam_header(h_bam, std::min<size_t>(bam_len, (size_t)8 << 20), hdr_host, nullptr, &mean_rec);
     if (spec) { h_sc[0] = h_sc[1] = 0xffffffffu; h_sc[kStatusEarly] = h_sc[kStatusEarly + 1] = 0xffffffffu; }
     else {
+        HIP_TRY(join_B());
         HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(h_sc + kStatusEarly, d_sc + kStatusEarly, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -1147,26 +1184,20 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     HIP_TRY(hipEventRecord(c->ev[2], st));
     uint64_t *seg_start[2] = {nullptr, nullptr}, *seg_exit[2] = {nullptr, nullptr};
     uint32_t *seg_cnt[2] = {nullptr, nullptr}, *seg_base = nullptr;
+    uint32_t *seg_iter_e = nullptr, *seg_long_e = nullptr, *seg_long_base_e = nullptr;      // early tail: per-segment outputs of the decode that the second framing must not overwrite
     uint16_t *seg_cp = nullptr;
     int cur = 0;
-    if (n_seg) {
-        const size_t per = (size_t)n_seg;
-        HIP_TRY(b_seg.ensure(per * (8 + 8 + 4) * 2 + per * 4 + 64));
-        HIP_TRY(c->buf("seg_cp").ensure(per * kSegCpSlots * 2 + 64));
-        seg_cp = c->buf("seg_cp").as<uint16_t>();
-        uint8_t *q = b_seg.as<uint8_t>();
-        for (int k = 0; k < 2; ++k) { seg_start[k] = (uint64_t *)q; q += per * 8; seg_exit[k] = (uint64_t *)q; q += per * 8; }
-        for (int k = 0; k < 2; ++k) { seg_cnt[k] = (uint32_t *)q; q += per * 4; }
-        seg_base = (uint32_t *)q;
-        HIP_TRY(b_tmp.ensure(scan_tmp_words(n_seg) * 4 + 64));
-        launch_seg_walk(arena, geom, n_seg, n_ref, seg_start[0], seg_exit[0], seg_cnt[0], seg_cp, st);
+    // One framing: the walk of segments [walk_from, n_s), then verification sweeps over [0, n_s) until the chain agrees.  Returns -1 to go on,
+    // anything else is the call's result (a restart on another path has run, or an error).  `ended` = the chain ends inside [0, n_s).
+    auto frame = [&](uint32_t n_s, uint32_t walk_from, bool &ended) -> int {
+        launch_seg_walk(arena, geom, n_s, n_ref, seg_start[cur], seg_exit[cur], seg_cnt[cur], seg_cp, st, walk_from);
         // d_sc[10]: leftmost disagreeing segment, d_sc[11]: leftmost chain end, d_sc[3]: record total
         for (int iter = 0;; ++iter) {
             HIP_TRY(hipMemsetAsync(d_sc + 10, 0xff, 8, st));
-            launch_seg_verify(arena, geom, n_seg, seg_start[cur], seg_exit[cur], seg_cnt[cur], seg_start[cur ^ 1], seg_exit[cur ^ 1],
+            launch_seg_verify(arena, geom, n_s, seg_start[cur], seg_exit[cur], seg_cnt[cur], seg_start[cur ^ 1], seg_exit[cur ^ 1],
                               seg_cnt[cur ^ 1], d_sc + 10, seg_cp, st);
             cur ^= 1;
-            launch_scan_u32(seg_cnt[cur], seg_base, n_seg, d_sc + 3, b_tmp.as<uint32_t>(), st);
+            launch_scan_u32(seg_cnt[cur], seg_base, n_s, d_sc + 3, b_tmp.as<uint32_t>(), st);
             HIP_TRY(hipMemcpyAsync(h_sc + 3, d_sc + 3, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(h_sc + 10, d_sc + 10, 8, hipMemcpyDeviceToHost, st));
             if (spec && iter == 0) {
@@ -1177,19 +1208,21 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             if (spec && iter == 0 && (h_sc[0] != 0xffffffffu || h_sc[kStatusEarly] != 0xffffffffu)) {
                 // some member did not inflate to its footer's length: nothing enqueued since is worth anything
                 mark("inflate verdict: not clean, starting over device-resident");
+                HIP_TRY(join_B());
                 HIP_TRY(complete_upload());
                 HIP_TRY(hipStreamSynchronize(copy_q));
+                HIP_TRY(hipStreamSynchronize(st));
                 const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, nullptr, false, region_to_file_end);
                 P.t_begin = t_begin;
                 return rc2;
             }
             ++P.framing_sweeps;
-            if (h_sc[11] != 0xffffffffu) chain_ended = true;     // some segment's chain ends: an unreadable / cut-off record (sam.c:421-423)
+            if (h_sc[11] != 0xffffffffu) ended = true;           // some segment's chain ends: an unreadable / cut-off record (sam.c:421-423)
             // the chain ends inside the exact prefix (or everything is exact): nothing starts after that segment -- with one chain the
             // end already spread to the right by itself; the chains of later chunks would not know
             if (h_sc[11] != 0xffffffffu && (h_sc[11] < h_sc[10] || (h_sc[10] == 0xffffffffu && geom.chunks))) {
-                launch_seg_truncate(geom, n_seg, h_sc[11], seg_start[cur], seg_exit[cur], seg_cnt[cur], st);
-                launch_scan_u32(seg_cnt[cur], seg_base, n_seg, d_sc + 3, b_tmp.as<uint32_t>(), st);
+                launch_seg_truncate(geom, n_s, h_sc[11], seg_start[cur], seg_exit[cur], seg_cnt[cur], st);
+                launch_scan_u32(seg_cnt[cur], seg_base, n_s, d_sc + 3, b_tmp.as<uint32_t>(), st);
                 HIP_TRY(hipMemcpyAsync(h_sc + 3, d_sc + 3, 4, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 break;
@@ -1197,8 +1230,75 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             if (h_sc[10] == 0xffffffffu) break;
             if (iter > 1 << 20) return fail(err, errlen, RGX_ERR_FORMAT, "regtools_amd: record framing did not converge\n");
         }
+        return -1;
+    };
+    // Early tail (round 4): while the side stream's launch still inflates the members of the last upload chunks, the segments that lie wholly
+    // in front of their part of the arena (one member's margin: a walk only ever reads the 36 bytes behind its segment, a guess that
+    // reads further is only a guess) are framed, verified and decoded -- exact for the same reason the whole chain is: segment 0 starts at
+    // an exact offset.  Plain whole-file calls on 16 KiB segments only; anything unusual in the prefix (the chain ends there, sweeps beyond
+    // the usual one) drops back to the one-pass order.
+    uint32_t sA = 0, n_rec_A = 0;
+    size_t soa_cap = 0;                                       // rows the SoA columns are laid out for (early tail: an estimate made from the prefix)
+    DevBuf &b_soa = c->buf("soa");
+    ReadSoA soa; memset(&soa, 0, sizeof soa);
+    uint32_t *ev_base = nullptr, *long_list = nullptr;
+    auto soa_layout = [&](size_t R) -> hipError_t {
+        hipError_t e_ = b_soa.ensure(R * (4 + 4 + 4 + 8 + 1 + 4 + 4 + 4 + (p->barcodes ? 8 : 0)) + 256);
+        if (e_ != hipSuccess) return e_;
+        uint8_t *q = b_soa.as<uint8_t>();
+        soa.cig_off = (uint64_t *)q; q += R * 8;
+        if (p->barcodes) { soa.rec_off = (uint64_t *)q; q += R * 8; }
+        soa.tid = (int32_t *)q; q += R * 4; soa.pos = (int32_t *)q; q += R * 4; soa.flag_nc = (uint32_t *)q; q += R * 4;
+        soa.n_ev = (uint32_t *)q; q += R * 4; ev_base = (uint32_t *)q; q += R * 4; long_list = (uint32_t *)q; q += R * 4;
+        soa.strand = q;
+        soa_cap = R;
+        return hipSuccess;
+    };
+    if (n_seg) {
+        const size_t per = (size_t)n_seg;
+        HIP_TRY(b_seg.ensure(per * (8 + 8 + 4) * 2 + per * 4 + per * 12 + 64));
+        HIP_TRY(c->buf("seg_cp").ensure(per * kSegCpSlots * 2 + 64));
+        seg_cp = c->buf("seg_cp").as<uint16_t>();
+        uint8_t *q = b_seg.as<uint8_t>();
+        for (int k = 0; k < 2; ++k) { seg_start[k] = (uint64_t *)q; q += per * 8; seg_exit[k] = (uint64_t *)q; q += per * 8; }
+        for (int k = 0; k < 2; ++k) { seg_cnt[k] = (uint32_t *)q; q += per * 4; }
+        seg_base = (uint32_t *)q; q += per * 4;
+        seg_iter_e = (uint32_t *)q; q += per * 4; seg_long_e = (uint32_t *)q; q += per * 4; seg_long_base_e = (uint32_t *)q;
+        HIP_TRY(b_tmp.ensure(scan_tmp_words(n_seg) * 4 + 64));
+        if (split_B && spec && !geom.chunks && seg_bytes == kSegBytes && cut_hi == UINT64_MAX && !empty_stream && lim == total &&
+            split_upos > pos0 + 2 * (uint64_t)kBgzfMaxBlock) {
+            sA = (uint32_t)std::min<uint64_t>(n_seg, (split_upos - kBgzfMaxBlock - pos0) / seg_bytes);
+            static const bool small_ok = getenv("REGTOOLS_AMD_EARLY_TAIL_MIN") != nullptr;
+            if (small_ok ? (sA < 2 || n_seg - sA < 1) : (sA < 1024 || n_seg - sA < 64)) sA = 0;
+        }
+        if (trace && (split_B || sA)) fprintf(stderr, "[rgx trace] early tail: split %d spec %d chunks %d seg_bytes %u cut_hi_open %d empty %d lim==total %d split_upos %llu pos0 %llu n_seg %u -> %u segments\n",
+                                              (int)split_B, (int)spec, (int)(geom.chunks != nullptr), seg_bytes, (int)(cut_hi == UINT64_MAX), (int)empty_stream, (int)(lim == total),
+                                              (unsigned long long)split_upos, (unsigned long long)pos0, n_seg, sA);
+        if (sA) {
+            bool ended_A = false;
+            const uint32_t sweeps0 = P.framing_sweeps;
+            const int rcA = frame(sA, 0, ended_A);
+            if (rcA != -1) return rcA;
+            n_rec_A = h_sc[3];
+            const bool slow_A = P.framing_sweeps - sweeps0 > 2;
+            P.framing_sweeps = sweeps0;                               // (the sweeps over everything, below, are the call's count)
+            const uint64_t span_A = (uint64_t)sA * seg_bytes;
+            if (trace) fprintf(stderr, "[rgx trace] early tail: prefix of %u segments: %u records, chain ended %d, sweeps beyond two %d\n", sA, n_rec_A, (int)ended_A, (int)slow_A);
+            if (ended_A || slow_A || !n_rec_A || span_A / n_rec_A > kSparseRecordBytes) { sA = 0; n_rec_A = 0; }   // not the plain case: one pass over everything below
+            else {
+                // rows for the whole file, estimated from the prefix (+ 1/8); when the estimate turns out short the decode is simply made again below
+                HIP_TRY(soa_layout((size_t)((double)n_rec_A * ((double)n_seg / sA) * 1.125) + 65536));
+                cfg.insane_out = nullptr;
+                if (lite_walk) { cfg.insane_out = d_sc + 82; HIP_TRY(hipMemsetAsync(d_sc + 82, 0, 4, st)); h_sc[82] = 0; }
+                launch_decode_seg(arena, geom, sA, seg_start[cur], seg_base, seg_cnt[cur], cfg, soa, seg_iter_e, seg_long_e, seg_cp, /*staged=*/true, st);
+                mark("early tail: prefix framed and decoded");
+            }
+        }
+        HIP_TRY(join_B());
+        const int rcF = frame(n_seg, sA, chain_ended);
+        if (rcF != -1) return rcF;
         n_rec = h_sc[3];
-    }
+    } else HIP_TRY(join_B());
     if (spec && !n_seg) {                                     // (no framing, no sync yet: the inflate's verdict is still due)
         HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(h_sc + kStatusEarly, d_sc + kStatusEarly, 8, hipMemcpyDeviceToHost, st));
@@ -1225,23 +1325,18 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     mark("framing (sync)");
 
     // -- decode + count -----------------------------------------------------------------------------------------------------
-    DevBuf &b_soa = c->buf("soa");
-    ReadSoA soa; memset(&soa, 0, sizeof soa);
-    uint32_t *ev_base = nullptr, *long_list = nullptr;
     uint32_t n_events = 0, n_long = 0;
     uint64_t n_iterated = 0;
     if (n_rec) {
         const size_t R = n_rec;
-        HIP_TRY(b_soa.ensure(R * (4 + 4 + 4 + 8 + 1 + 4 + 4 + 4 + (p->barcodes ? 8 : 0)) + 256));
-        uint8_t *q = b_soa.as<uint8_t>();
-        soa.cig_off = (uint64_t *)q; q += R * 8;
-        if (p->barcodes) { soa.rec_off = (uint64_t *)q; q += R * 8; }
-        soa.tid = (int32_t *)q; q += R * 4; soa.pos = (int32_t *)q; q += R * 4; soa.flag_nc = (uint32_t *)q; q += R * 4;
-        soa.n_ev = (uint32_t *)q; q += R * 4; ev_base = (uint32_t *)q; q += R * 4; long_list = (uint32_t *)q; q += R * 4;
-        soa.strand = q;
+        // (early tail: the prefix is decoded already, into columns laid out for an estimate of the row count; when that was short, or the chain
+        //  ended after all, everything is decoded again)
+        uint32_t s_from = sA;
+        if (sA && (R > soa_cap || chain_ended)) s_from = 0;
+        if (!s_from) HIP_TRY(soa_layout(R));
         HIP_TRY(b_tmp.ensure(scan_tmp_words(n_rec) * 4 + 64));
         // per-segment outputs (no hot atomics): reuse the spare segment arrays as seg_iter / seg_long
-        uint32_t *seg_iter = seg_cnt[cur ^ 1], *seg_long = (uint32_t *)seg_start[cur ^ 1], *seg_long_base = (uint32_t *)seg_exit[cur ^ 1];
+        uint32_t *seg_iter = sA ? seg_iter_e : seg_cnt[cur ^ 1], *seg_long = sA ? seg_long_e : (uint32_t *)seg_start[cur ^ 1], *seg_long_base = sA ? seg_long_base_e : (uint32_t *)seg_exit[cur ^ 1];
         // the iterator's end rule only where the iterator's chunks are followed (hts_itr_next, hts.c:1946-1950): the first pass finds the
         // first record that ends the iteration and the last one that passed the overlap test; when one of those lies behind the other
         // (records out of order -- no indexer writes such a file) the pass is repeated with the stop in place
@@ -1250,11 +1345,13 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             HIP_TRY(hipMemsetAsync(d_sc + 80, 0xff, 4, st));
             HIP_TRY(hipMemsetAsync(d_sc + 81, 0, 4, st));
         }
-        cfg.insane_out = nullptr;
-        if (lite_walk) { cfg.insane_out = d_sc + 82; HIP_TRY(hipMemsetAsync(d_sc + 82, 0, 4, st)); h_sc[82] = 0; }
+        if (!s_from) {
+            cfg.insane_out = nullptr;
+            if (lite_walk) { cfg.insane_out = d_sc + 82; HIP_TRY(hipMemsetAsync(d_sc + 82, 0, 4, st)); h_sc[82] = 0; }
+        }
         for (int pass = 0; pass < 2; ++pass) {
             launch_decode_seg(arena, geom, n_seg, seg_start[cur], seg_base, seg_cnt[cur], cfg, soa, seg_iter, seg_long, seg_cp,
-                              /*staged=*/span / n_rec <= kSparseRecordBytes, st);
+                              /*staged=*/span / n_rec <= kSparseRecordBytes, st, s_from);
             launch_scan_u32(soa.n_ev, ev_base, n_rec, d_sc + 4, b_tmp.as<uint32_t>(), st);
             launch_scan_u32(seg_iter, seg_iter, n_seg, d_sc + 8, b_tmp.as<uint32_t>(), st);
             launch_scan_u32(seg_long, seg_long_base, n_seg, d_sc + 5, b_tmp.as<uint32_t>(), st);

@@ -156,7 +156,8 @@ struct ExtractCfg {
 // seg_iter[s] = records of segment s that pass the region filter; seg_long[s] = its reads for the wave-per-read kernel
 void launch_decode_seg(const uint8_t *arena, SegGeom g, uint32_t n_seg, const uint64_t *seg_start, const uint32_t *seg_base,
                        const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, const uint16_t *seg_cp,
-                       bool staged /* segment bytes through LDS (short records) or read in place (long records) */, hipStream_t stream);
+                       bool staged /* segment bytes through LDS (short records) or read in place (long records) */, hipStream_t stream,
+                       uint32_t s_begin = 0 /* only segments [s_begin, n_seg): the early tail decodes the file's front part first */);
 void launch_long_fill(uint32_t n_seg, const uint32_t *seg_base, const uint32_t *seg_cnt, const uint32_t *seg_long_base, ExtractCfg cfg, ReadSoA soa,
                       uint32_t *long_list, hipStream_t stream);
 

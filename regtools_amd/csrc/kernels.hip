@@ -761,10 +761,10 @@ template <bool STAGED>
 __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ arena, SegGeom g, uint32_t n_seg,
                                                    const uint64_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_base,
                                                    const uint32_t *__restrict__ seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter,
-                                                   uint32_t *seg_long, const uint16_t *__restrict__ seg_cp) {
+                                                   uint32_t *seg_long, const uint16_t *__restrict__ seg_cp, uint32_t s_begin) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_buf[];          // kSegBytes + kSegTail + 48 when STAGED, nothing otherwise
     __shared__ uint32_t s_off[kSegMaxRecs];
-    const uint32_t s = blockIdx.x, lane = threadIdx.x;
+    const uint32_t s = s_begin + blockIdx.x, lane = threadIdx.x;
     const uint32_t cnt = seg_cnt[s];
     if (cnt == 0) { if (lane == 0) { seg_iter[s] = 0; seg_long[s] = 0; } return; }
     uint64_t a, seg_b, seg_lim; bool seg_first;
@@ -905,8 +905,8 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
 // Same rows, same counts: the per-record part restates k_decode_seg's with every read from the arena.
 __global__ __launch_bounds__(64) void k_decode_sparse(const uint8_t *__restrict__ arena, uint32_t n_seg, const uint64_t *__restrict__ seg_start,
                                                       const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt, ExtractCfg cfg, ReadSoA soa,
-                                                      uint32_t *seg_iter, uint32_t *seg_long) {
-    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+                                                      uint32_t *seg_iter, uint32_t *seg_long, uint32_t s_begin) {
+    const uint32_t s = s_begin + blockIdx.x * 64 + threadIdx.x;
     uint32_t first_stop = 0xffffffffu, last_in = 0;
     if (s < n_seg) {
         const uint32_t cnt = seg_cnt[s];
@@ -994,13 +994,15 @@ __global__ __launch_bounds__(64) void k_long_fill(uint32_t n_seg, const uint32_t
 }
 
 void launch_decode_seg(const uint8_t *arena, SegGeom g, uint32_t n_seg, const uint64_t *seg_start, const uint32_t *seg_base,
-                       const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, const uint16_t *seg_cp, bool staged, hipStream_t stream) {
-    if (!n_seg) return;
-    if (staged && g.seg_bytes == kSegBytes) hipLaunchKernelGGL(k_decode_seg<true>, dim3(n_seg), dim3(64), kSegBytes + kSegTail + 48, stream, arena, g, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
+                       const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, const uint16_t *seg_cp, bool staged, hipStream_t stream,
+                       uint32_t s_begin) {
+    if (n_seg <= s_begin) return;
+    const uint32_t n = n_seg - s_begin;
+    if (staged && g.seg_bytes == kSegBytes) hipLaunchKernelGGL(k_decode_seg<true>, dim3(n), dim3(64), kSegBytes + kSegTail + 48, stream, arena, g, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp, s_begin);
     else {
         static const bool wave_form = [] { const char *e = getenv("REGTOOLS_AMD_DECODE_SPARSE"); return e && !strcmp(e, "wave"); }();     // (tests / lab: the workgroup-per-segment form it replaced)
-        if (wave_form && g.seg_bytes == kSegBytes) hipLaunchKernelGGL(k_decode_seg<false>, dim3(n_seg), dim3(64), 0, stream, arena, g, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp);
-        else hipLaunchKernelGGL(k_decode_sparse, dim3((n_seg + 63) / 64), dim3(64), 0, stream, arena, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long);
+        if (wave_form && g.seg_bytes == kSegBytes) hipLaunchKernelGGL(k_decode_seg<false>, dim3(n), dim3(64), 0, stream, arena, g, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp, s_begin);
+        else hipLaunchKernelGGL(k_decode_sparse, dim3((n + 63) / 64), dim3(64), 0, stream, arena, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, s_begin);
     }
 }
 void launch_long_fill(uint32_t n_seg, const uint32_t *seg_base, const uint32_t *seg_cnt, const uint32_t *seg_long_base, ExtractCfg cfg, ReadSoA soa,

@@ -38,7 +38,7 @@ json.dump(out, open(sys.argv[2], "w"))
 """
 
 
-@pytest.mark.parametrize("chunks", ["2", "7", "16"])
+@pytest.mark.parametrize("chunks", ["2", "7", "16", "16-early-tail"])
 def test_gated_launch_equals_the_oracle(gpu_ctx, tmp_path, chunks):
     from regtools_amd import synth
     jobs = []
@@ -56,10 +56,18 @@ def test_gated_launch_equals_the_oracle(gpu_ctx, tmp_path, chunks):
     jobs.append(dict(bam=os.path.join(cases.GOLD, "test_hcc1395.bam"), kw=dict(strandness=1, min_anchor_length=30), args=["-s", "RF", "-a", "30"]))
     jf, of = str(tmp_path / "jobs.json"), str(tmp_path / "out.json")
     json.dump(jobs, open(jf, "w"))
-    env = dict(os.environ, REGTOOLS_AMD_OVERLAP_MIN="0", REGTOOLS_AMD_INFLATE="coop", REGTOOLS_AMD_GATE_CHUNKS=chunks, REGTOOLS_AMD_TRACE="1", PYTHONPATH=ROOT)
+    # "16-early-tail": the members of the last upload chunks as a second launch, the front part of the arena framed and decoded under it (round 4;
+    # REGTOOLS_AMD_EARLY_TAIL_MIN lets files of a few hundred members take that path)
+    early = chunks.endswith("early-tail")
+    env = dict(os.environ, REGTOOLS_AMD_OVERLAP_MIN="0", REGTOOLS_AMD_INFLATE="coop", REGTOOLS_AMD_GATE_CHUNKS=chunks.split("-")[0], REGTOOLS_AMD_TRACE="1", PYTHONPATH=ROOT)
+    if early:
+        env["REGTOOLS_AMD_EARLY_TAIL_MIN"] = "4"
+    else:
+        env["REGTOOLS_AMD_EARLY_TAIL"] = "0"
     r = subprocess.run([sys.executable, "-c", CHILD, jf, of], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     assert b"gated" in r.stderr, "the calls did not take the gated launch:\n" + r.stderr.decode()[-2000:]
+    assert (b"early tail" in r.stderr) == early, "early tail taken / not taken against the test's intent:\n" + r.stderr.decode()[-2000:]
     got = json.load(open(of))
     for j, res in zip(jobs, got):
         rc, exp, _ = run_oracle(j["args"] + [j["bam"]])

@@ -1,8 +1,9 @@
 #!/bin/bash
-# tools/lab/step_ab.sh: the bench step (host bytes -> table, and device-resident) under environment switches, interleaved
+# tools/lab/step_ab.sh [VARIANTS...]: the bench step (host bytes -> table, and device-resident) under environment switches, interleaved
 cd "$(dirname "$0")/../.."
+if [ $# -eq 0 ]; then set -- "A=1" "REGTOOLS_AMD_EARLY_TAIL=0" "REGTOOLS_AMD_EARLY_TAIL=10" "REGTOOLS_AMD_EARLY_TAIL=13" "REGTOOLS_AMD_EARLY_TAIL=14"; fi
 for r in 1 2; do
-  for v in "A=1" "REGTOOLS_AMD_GATE_SIDE=0" "REGTOOLS_AMD_LITE_WALK=0" "REGTOOLS_AMD_PREAGG=0"; do
+  for v in "$@"; do
     echo -n "$v: "
     env $v python bench.py --steps 8 --warmup 2 --no-extras 2>/dev/null | python -c "
 import sys,json

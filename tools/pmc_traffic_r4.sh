@@ -8,7 +8,7 @@ R=$PWD; export TMPDIR=/tmp; mkdir -p $R/$OUT
 [ -f /tmp/labr50.bam ] || bin/synth_bam write /tmp/labr50.bam 50000000 --seed 1 --realistic > /dev/null
 [ -f /tmp/labl10.bam ] || bin/synth_bam write /tmp/labl10.bam 10000000 --seed 1 --shape long > /dev/null
 cd /tmp
-for w in default:lab50: realistic:labr50: long10M:labl10:"REGTOOLS_AMD_INFLATE_TUNE=2 REGTOOLS_AMD_INFLATE_PAIRS=0"; do
+for w in default:lab50: realistic:labr50: long10M:labl10:"REGTOOLS_AMD_INFLATE_TUNE=2 REGTOOLS_AMD_INFLATE_PAIRS=4"; do
   key=${w%%:*}; rest=${w#*:}; f=${rest%%:*}; envs=${rest#*:}
   env $envs $R/tools/lab/bin/coop_lab_cur /tmp/$f.bam 3 > $R/$OUT/$key.lab.json 2>/dev/null
   stat -c %s /tmp/$f.bam > $R/$OUT/$key.size
