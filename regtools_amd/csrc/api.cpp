@@ -206,9 +206,9 @@ static hipError_t ensure_upload_streams(rgx_ctx *c) {
     int pr_least = 0, pr_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
     const int prio[kSideStreams] = {0, 0, pr_greatest, pr_greatest, pr_least, pr_least};
-    // (three pieces: two side streams + the pipeline's own; REGTOOLS_AMD_PIECES may ask for more.  The third one, of the greatest priority, takes the
-    //  early tail's second inflate launch: the members that arrive last are what the call waits for)
-    static const bool early_prio = [] { const char *e = getenv("REGTOOLS_AMD_EARLY_TAIL_PRIO"); return !e || atoi(e) != 0; }();
+    // (three pieces: two side streams + the pipeline's own; REGTOOLS_AMD_PIECES may ask for more.  REGTOOLS_AMD_EARLY_TAIL_PRIO=1: a third one, of the
+    //  greatest priority, for the early tail's second inflate launch -- the members that arrive last are what the call waits for)
+    static const bool early_prio = [] { const char *e = getenv("REGTOOLS_AMD_EARLY_TAIL_PRIO"); return e && atoi(e) != 0; }();      // (measured: 26.8-26.9 ms per step with it, 26.0-26.1 without: off)
     const unsigned want = early_prio ? 3 : 2;
     for (int k = 0; k < kSideStreams; ++k) {
         if ((unsigned)k >= want && !getenv("REGTOOLS_AMD_PIECES")) break;
@@ -858,7 +858,9 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     const int pairs = inflate_plan_for(bam_len, total_all);      // (the whole file's ratio: a range of it is the same kind of payload)
     // (early tail: the second of two gated launches is still running on a side stream; whoever reads its part of the arena, or the launch's
     //  verdict, first makes the pipeline's stream wait for it)
-    bool split_B = false; uint64_t split_upos = 0; hipEvent_t split_ev = nullptr;
+    struct EarlyPart { uint32_t members, waves; uint64_t upos; };       // a part ends in front of member `members` of the range = workgroup `waves` = arena offset `upos`
+    std::vector<EarlyPart> early_parts;
+    bool split_B = false; hipEvent_t split_ev = nullptr;
     auto join_B = [&]() -> hipError_t {
         if (!split_B) return hipSuccess;
         split_B = false;
@@ -878,30 +880,43 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             if (inflate_takes_coop(n_range)) {
                 InflateGate gate;
                 gate.flags = c->buf("gate_flags").as<uint32_t>(); gate.epoch = c->gate_epoch; gate.n_chunks = (uint32_t)up.end.size(); gate.lo = up.lo; gate.chunk_bytes = gate_chunk;
-                // Round 4, second half: the members of the last upload chunks are a launch of their own on a side stream (same gate, same time).
-                // They end ~6-9 ms behind the last chunk's arrival (a member's own chain) on a chip that is emptying; the launch with the members
-                // of the first three quarters of the file ends earlier, and the framing and the decode of ITS part of the arena then run
-                // under the other launch's lonely end instead of behind it (below: "early tail").  REGTOOLS_AMD_EARLY_TAIL=<sixteenths of
-                // the upload in the first launch>, 0 = one launch.
-                static const int env_split = [] { const char *e = getenv("REGTOOLS_AMD_EARLY_TAIL"); const int v = e ? atoi(e) : 12; return v > 0 && v < 16 ? v : 0; }();
+                // Round 4, second half ("early tail"): the launch goes to a side stream and counts its finished waves per PART of the member list
+                // (parts cut where upload chunks end, at multiples of the lane-sorting group); the pipeline's stream waits for part after part
+                // (launch_wait_done) and frames, verifies and decodes the part of the arena behind it while the waves of the later parts still
+                // run -- what is left behind the launch's end is the last part's framing and decode, not the whole file's.  (A member's own
+                // chain puts the end of the launch 6-9 ms behind the last chunk's arrival, whatever the chip does meanwhile.)
+                // REGTOOLS_AMD_EARLY_TAIL="8,12,14" = the cuts in sixteenths of the upload (up to three), "0" = off.
+                static const std::vector<unsigned> env_cuts = [] {
+                    std::vector<unsigned> v; const char *e = getenv("REGTOOLS_AMD_EARLY_TAIL");
+                    unsigned a = 0, b2 = 0, c2 = 0; const int n = sscanf(e ? e : "8,12,14", "%u,%u,%u", &a, &b2, &c2);
+                    for (unsigned x : {a, b2, c2}) if ((int)v.size() < n && x > 0 && x < 16 && (v.empty() || x > v.back())) v.push_back(x);
+                    return v;
+                }();
                 static const uint32_t early_min = [] { const char *e = getenv("REGTOOLS_AMD_EARLY_TAIL_MIN"); return e ? (uint32_t)atoi(e) : 4096u; }();     // (tests: small files)
-                uint32_t mA = m_hi;
-                const int sB = c->side[2] ? 2 : 1;               // (side[0] carries the gate's flag kernels)
-                if (env_split && c->side[sB] && up.end.size() >= 8 && !d_bad && !d_true_sizes) {
-                    const size_t kA = std::max<size_t>(1, up.end.size() * (size_t)env_split / 16);
-                    const uint64_t lim_b = up.end[kA - 1];
-                    uint32_t lo = m_lo, hi = m_hi;                 // first member that reads bytes behind chunk kA - 1 (k_inflate_coop's own rule)
-                    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (hm[mid].cpos + hm[mid].clen + 24 <= lim_b) lo = mid + 1; else hi = mid; }
-                    if (lo - m_lo >= early_min && m_hi - lo >= early_min && inflate_takes_coop(lo - m_lo) && inflate_takes_coop(m_hi - lo)) mA = lo;
+                if (!env_cuts.empty() && c->side[1] && up.end.size() >= 8 && !d_bad && !d_true_sizes) {
+                    const uint32_t align = kInflateSortGroup;          // (a wave's members all come from one group of that many)
+                    for (unsigned cut : env_cuts) {
+                        const size_t kA = std::max<size_t>(1, up.end.size() * (size_t)cut / 16);
+                        const uint64_t lim_b = up.end[kA - 1];
+                        uint32_t lo = m_lo, hi = m_hi;             // first member that reads bytes behind chunk kA - 1 (k_inflate_coop's own rule)
+                        while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (hm[mid].cpos + hm[mid].clen + 24 <= lim_b) lo = mid + 1; else hi = mid; }
+                        uint32_t k = (lo - m_lo) / align * align;     // members of the range in front of the cut
+                        const uint32_t prev = early_parts.empty() ? 0u : early_parts.back().members;
+                        if (k >= prev + early_min && n_range - k >= early_min) early_parts.push_back(EarlyPart{k, k / 64, hm[m_lo + k].upos - upos_lo});
+                    }
                 }
-                if (mA < m_hi) {
-                    const uint32_t nA = mA - m_lo, nB = m_hi - mA;
-                    HIP_TRY(b_lens.ensure(inflate_scratch_bytes(nA) + inflate_scratch_bytes(nB)));
-                    launch_inflate(d_bam, d_members + m_lo, nA, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below, 0, /*piece=*/true, 0, d_bad, pairs, false, gate);
-                    launch_inflate(d_bam, d_members + mA, nB, b_arena.as<uint8_t>(), upos_lo, (uint32_t *)(b_lens.as<uint8_t>() + inflate_scratch_bytes(nA)), d_sc, c->side[sB], ignore_below, nA, /*piece=*/true, 0, d_bad, pairs, false, gate);
-                    HIP_TRY(hipEventRecord(c->ev_side[sB], c->side[sB]));
-                    split_ev = c->ev_side[sB];
-                    split_B = true; split_upos = hm[mA].upos - upos_lo;
+                if (!early_parts.empty()) {
+                    DevBuf &bd = c->buf("gate_done");
+                    HIP_TRY(bd.ensure(64));
+                    uint32_t *d_done = bd.as<uint32_t>();
+                    hipStream_t q = c->side[1];
+                    HIP_TRY(hipMemsetAsync(d_done, 0, 32, q));
+                    gate.done = d_done;
+                    for (size_t j = 0; j < early_parts.size(); ++j) gate.part_start[j] = early_parts[j].waves;
+                    launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, q, ignore_below, 0, /*piece=*/true, 0, d_bad, pairs, false, gate);
+                    HIP_TRY(hipEventRecord(c->ev_side[1], q));
+                    split_ev = c->ev_side[1];
+                    split_B = true;
                 } else
                 launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below, 0, /*piece=*/true, 0, d_bad, pairs, false, gate);
             } else {
@@ -1237,7 +1252,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // reads further is only a guess) are framed, verified and decoded -- exact for the same reason the whole chain is: segment 0 starts at
     // an exact offset.  Plain whole-file calls on 16 KiB segments only; anything unusual in the prefix (the chain ends there, sweeps beyond
     // the usual one) drops back to the one-pass order.
-    uint32_t sA = 0, n_rec_A = 0;
+    uint32_t sA = 0;                                          // early tail: segments [0, sA) are framed, verified and decoded
     size_t soa_cap = 0;                                       // rows the SoA columns are laid out for (early tail: an estimate made from the prefix)
     DevBuf &b_soa = c->buf("soa");
     ReadSoA soa; memset(&soa, 0, sizeof soa);
@@ -1265,34 +1280,41 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         seg_base = (uint32_t *)q; q += per * 4;
         seg_iter_e = (uint32_t *)q; q += per * 4; seg_long_e = (uint32_t *)q; q += per * 4; seg_long_base_e = (uint32_t *)q;
         HIP_TRY(b_tmp.ensure(scan_tmp_words(n_seg) * 4 + 64));
-        if (split_B && spec && !geom.chunks && seg_bytes == kSegBytes && cut_hi == UINT64_MAX && !empty_stream && lim == total &&
-            split_upos > pos0 + 2 * (uint64_t)kBgzfMaxBlock) {
-            sA = (uint32_t)std::min<uint64_t>(n_seg, (split_upos - kBgzfMaxBlock - pos0) / seg_bytes);
-            static const bool small_ok = getenv("REGTOOLS_AMD_EARLY_TAIL_MIN") != nullptr;
-            if (small_ok ? (sA < 2 || n_seg - sA < 1) : (sA < 1024 || n_seg - sA < 64)) sA = 0;
-        }
-        if (trace && (split_B || sA)) fprintf(stderr, "[rgx trace] early tail: split %d spec %d chunks %d seg_bytes %u cut_hi_open %d empty %d lim==total %d split_upos %llu pos0 %llu n_seg %u -> %u segments\n",
-                                              (int)split_B, (int)spec, (int)(geom.chunks != nullptr), seg_bytes, (int)(cut_hi == UINT64_MAX), (int)empty_stream, (int)(lim == total),
-                                              (unsigned long long)split_upos, (unsigned long long)pos0, n_seg, sA);
-        if (sA) {
-            bool ended_A = false;
+        bool early = split_B && spec && !geom.chunks && seg_bytes == kSegBytes && cut_hi == UINT64_MAX && !empty_stream && lim == total;
+        static const bool small_ok = getenv("REGTOOLS_AMD_EARLY_TAIL_MIN") != nullptr;
+        uint32_t waves_done = 0;
+        for (size_t j = 0; early && j < early_parts.size(); ++j) {
+            const EarlyPart &ep = early_parts[j];
+            if (ep.upos <= pos0 + 2 * (uint64_t)kBgzfMaxBlock) continue;
+            uint32_t sJ = (uint32_t)std::min<uint64_t>(n_seg, (ep.upos - kBgzfMaxBlock - pos0) / seg_bytes);
+            if (small_ok ? (sJ < sA + 2 || n_seg - sJ < 1) : (sJ < sA + 1024 || n_seg - sJ < 64)) continue;
+            // the stream waits until every wave of parts 0..j has finished (the counters of the parts are waited for in turn)
+            HIP_TRY(hipMemsetAsync(d_sc + 83, 0, 4, st));
+            for (size_t i = 0; i <= j; ++i) {
+                const uint32_t w_end = early_parts[i].waves, w_beg = i ? early_parts[i - 1].waves : 0u;
+                if (w_end > waves_done) { launch_wait_done(c->buf("gate_done").as<uint32_t>() + i, w_end - w_beg, d_sc + 83, st); waves_done = w_end; }
+            }
+            HIP_TRY(hipMemcpyAsync(h_sc + 83, d_sc + 83, 4, hipMemcpyDeviceToHost, st));      // (read behind the framing's first wait for the stream)
+            if (trace) fprintf(stderr, "[rgx trace] early tail: part %zu: members < %u, segments [%u, %u) of %u\n", j, ep.members, sA, sJ, n_seg);
+            bool ended_J = false;
             const uint32_t sweeps0 = P.framing_sweeps;
-            const int rcA = frame(sA, 0, ended_A);
-            if (rcA != -1) return rcA;
-            n_rec_A = h_sc[3];
-            const bool slow_A = P.framing_sweeps - sweeps0 > 2;
+            const int rcJ = frame(sJ, sA, ended_J);
+            if (rcJ != -1) return rcJ;
+            const uint32_t n_rec_J = h_sc[3];
+            const bool slow_J = P.framing_sweeps - sweeps0 > 2;
             P.framing_sweeps = sweeps0;                               // (the sweeps over everything, below, are the call's count)
-            const uint64_t span_A = (uint64_t)sA * seg_bytes;
-            if (trace) fprintf(stderr, "[rgx trace] early tail: prefix of %u segments: %u records, chain ended %d, sweeps beyond two %d\n", sA, n_rec_A, (int)ended_A, (int)slow_A);
-            if (ended_A || slow_A || !n_rec_A || span_A / n_rec_A > kSparseRecordBytes) { sA = 0; n_rec_A = 0; }   // not the plain case: one pass over everything below
-            else {
-                // rows for the whole file, estimated from the prefix (+ 1/8); when the estimate turns out short the decode is simply made again below
-                HIP_TRY(soa_layout((size_t)((double)n_rec_A * ((double)n_seg / sA) * 1.125) + 65536));
+            const uint64_t span_J = (uint64_t)sJ * seg_bytes;
+            if (h_sc[83] || ended_J || slow_J || !n_rec_J || span_J / n_rec_J > kSparseRecordBytes ||
+                (sA && n_rec_J > soa_cap)) { early = false; sA = 0; break; }     // not the plain case: one pass over everything below
+            if (!sA) {
+                // rows for the whole file, estimated from the first part (+ 1/8); when the estimate turns out short the decode is simply made again below
+                HIP_TRY(soa_layout((size_t)((double)n_rec_J * ((double)n_seg / sJ) * 1.125) + 65536));
                 cfg.insane_out = nullptr;
                 if (lite_walk) { cfg.insane_out = d_sc + 82; HIP_TRY(hipMemsetAsync(d_sc + 82, 0, 4, st)); h_sc[82] = 0; }
-                launch_decode_seg(arena, geom, sA, seg_start[cur], seg_base, seg_cnt[cur], cfg, soa, seg_iter_e, seg_long_e, seg_cp, /*staged=*/true, st);
-                mark("early tail: prefix framed and decoded");
             }
+            launch_decode_seg(arena, geom, sJ, seg_start[cur], seg_base, seg_cnt[cur], cfg, soa, seg_iter_e, seg_long_e, seg_cp, /*staged=*/true, st, sA);
+            sA = sJ;
+            mark("early tail: part framed and decoded");
         }
         HIP_TRY(join_B());
         const int rcF = frame(n_seg, sA, chain_ended);
@@ -1426,7 +1448,8 @@ struct RowMap { uint32_t *ev_urow = nullptr, *urow_pos = nullptr; };
 struct TableSink { const BamHeader *hdr = nullptr; uint32_t min_anchor = 0; rgx_junction_table *table = nullptr; };
 
 static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t group_bits, uint32_t ilen_bits, const uint32_t *rank_of_group_host,
-                         uint32_t n_groups, HostRows &R, char *err, size_t errlen, bool view_only = false, RowMap *row_map = nullptr, TableSink *sink = nullptr) {
+                         uint32_t n_groups, HostRows &R, char *err, size_t errlen, bool view_only = false, RowMap *row_map = nullptr, TableSink *sink = nullptr,
+                         bool allow_preagg = true /* identify's window pairs (a few million, one small sort) measured 0.3-0.4 ms slower with it */) {
     hipStream_t st = c->stream;
     uint32_t *d_sc = c->buf("scalars").as<uint32_t>();
     uint32_t *h_sc = (uint32_t *)c->pinned;
@@ -1442,7 +1465,7 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
         // Round 4: equal keys are grouped per tile of consecutive events first (k_preagg); what is sorted and reduced are the tiles' partial
         // rows.  Callers that need every event's row (the -b pass: row_map) keep the event form.
         static const int env_preagg = [] { const char *e = getenv("REGTOOLS_AMD_PREAGG"); return e ? atoi(e) : 1; }();
-        const bool preagg = env_preagg && !row_map;
+        const bool preagg = !row_map && (env_preagg > 1 || (env_preagg && allow_preagg));     // (REGTOOLS_AMD_PREAGG=2: also where it does not pay, tests)
         PartialSoA pr; memset(&pr, 0, sizeof pr);
         uint32_t *ev_flag = nullptr;           // preagg: one word per EVENT (first-seen flags, then their scan)
         EventSoA sev = ev;                     // what is sorted: the events, or the partial rows

@@ -27,7 +27,16 @@ struct InflateGate {
     uint32_t epoch = 0;                // this call's value (the words keep earlier calls' values: smaller)
     uint32_t n_chunks = 0;
     uint64_t lo = 0, chunk_bytes = 1;  // chunk k = bytes [lo + k * chunk_bytes, lo + (k + 1) * chunk_bytes) of the file (the last one to the range's end)
+    // Early tail (round 4): the launch's waves are counted as they finish, by part of the member list -- part j = the waves from part_start[j - 1]
+    // (workgroup index; part 0 starts at 0) up to part_start[j] -- so that the pipeline's stream can frame and decode the front parts of the arena
+    // (launch_wait_done) while the waves of the later parts still run.  done = null: nobody counts.
+    uint32_t *done = nullptr;          // device memory, kGateParts words, zeroed by the caller in front of the launch
+    uint32_t part_start[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
 };
+constexpr uint32_t kGateParts = 4;
+constexpr uint32_t kInflateSortGroup = 1024;   // k_inflate_coop: the lanes of a wave take their members from one group of that many consecutive ones (k_member_sort)
+// one lane on `stream` waits until done[0] reaches `expected` (a wave count); gives up after ~2 s and sets *timed_out
+void launch_wait_done(const uint32_t *done, uint32_t expected, uint32_t *timed_out, hipStream_t stream);
 constexpr uint32_t kStatusEarly = 76;   // status[kStatusEarly..+1]: the same pair for members below ignore_below (only written when that is > 0)
 void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
                     uint32_t *status /* [0]=first bad member (min), [1]=its status */, hipStream_t stream, uint32_t ignore_below = 0 /* failures of members below this index are not reported */,

@@ -291,7 +291,7 @@ struct WaveCopy {                     // (kCoopRounds = 4 rounds in flight: d0..
 
 // Lane assignment: per group of kSortGroup consecutive members, their indices sorted by compressed length (bitonic sort in LDS, one
 // workgroup per group).  A group spans at most kSortGroup x 64 KiB = 64 MiB of the arena: offsets relative to its first member fit 32 bits.
-constexpr uint32_t kSortGroup = 1024;
+constexpr uint32_t kSortGroup = kInflateSortGroup;
 __global__ __launch_bounds__(256) void k_member_sort(const Member *__restrict__ members, uint32_t n_members, uint32_t *perm) {
     __shared__ uint32_t key[kSortGroup];
     const uint32_t g0 = blockIdx.x * kSortGroup;
@@ -325,6 +325,27 @@ __global__ void k_members_check(const Member *__restrict__ members, uint32_t n_m
     const bool bad = (m > 0 && members[m].upos < members[m - 1].upos) || members[m].upos < members[first].upos ||
                      members[m].upos - members[first].upos > 0xfffe0000ull;
     if (bad) { *veto = 1; const uint32_t prev = atomicMin(&status[0], m); if (m < prev) status[1] = (uint32_t)INF_OUT_OVERFLOW; }
+}
+
+// early tail: this wave's bytes (and its members' verdicts) are out -- count it in its part of the launch (kernels.h InflateGate)
+__device__ __forceinline__ void gate_wave_done(const InflateGate &gate, uint32_t lane) {
+    if (!gate.done) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) {
+        const uint32_t b = blockIdx.x;
+        const uint32_t part = (b >= gate.part_start[0] ? 1u : 0u) + (b >= gate.part_start[1] ? 1u : 0u) + (b >= gate.part_start[2] ? 1u : 0u);
+        __hip_atomic_fetch_add(gate.done + part, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__global__ void k_wait_done(const uint32_t *done, uint32_t expected, uint32_t *timed_out) {
+    uint32_t spins = 0;
+    while (__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+        if (++spins > 120000u) { *timed_out = 1; break; }
+        for (int k = 0; k < 5; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+}
+void launch_wait_done(const uint32_t *done, uint32_t expected, uint32_t *timed_out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_wait_done, dim3(1), dim3(1), 0, stream, done, expected, timed_out);
 }
 
 // one lane per member like k_inflate; no lane leaves before the wave is done (the lanes without a member serve the others' copies)
@@ -370,6 +391,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 const uint32_t prev = atomicMin(&sl[0], mi);
                 if (mi < prev) sl[1] = (uint32_t)INF_IN_OVERRUN;
             }
+            gate_wave_done(gate, lane);
             return;
         }
     }
@@ -393,16 +415,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const bool run = have && mb.isize <= kBgzfMaxBlock;
     typedef typename std::conditional<WIN == 1, BitReaderWin, BitReader>::type BR;
     int st = inflate_coop<BR>(comp + mb.cpos, mb.clen, run ? arena + (mb.upos - upos_bias) : C.wave_base, run ? mb.isize : 0, &out_len, T, C, run, pairs);
-    if (!have) return;
-    if (!run) st = mb.isize == 0xffffffffu ? INF_IN_OVERRUN : INF_OUT_OVERFLOW;
-    else if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
-    if (st != INF_OK) {
-        const uint32_t mi = m + index_bias;
-        if (bad) bad[mi] = 1;
-        uint32_t *sl = mi >= ignore_below ? status : status + kStatusEarly;
-        uint32_t prev = atomicMin(&sl[0], mi);
-        if (mi < prev) sl[1] = (uint32_t)st;
+    if (have) {
+        if (!run) st = mb.isize == 0xffffffffu ? INF_IN_OVERRUN : INF_OUT_OVERFLOW;
+        else if (st == INF_OK && out_len != mb.isize) st = INF_SIZE_MISMATCH;
+        if (st != INF_OK) {
+            const uint32_t mi = m + index_bias;
+            if (bad) bad[mi] = 1;
+            uint32_t *sl = mi >= ignore_below ? status : status + kStatusEarly;
+            uint32_t prev = atomicMin(&sl[0], mi);
+            if (mi < prev) sl[1] = (uint32_t)st;
+        }
     }
+    if (PIECE) gate_wave_done(gate, lane);
 }
 
 // (the code-length / cold-symbol scratch of every lane, + the lane assignment of k_inflate_coop behind it)

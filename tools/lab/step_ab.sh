@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/lab/step_ab.sh [VARIANTS...]: the bench step (host bytes -> table, and device-resident) under environment switches, interleaved
 cd "$(dirname "$0")/../.."
-if [ $# -eq 0 ]; then set -- "A=1" "REGTOOLS_AMD_EARLY_TAIL=0" "REGTOOLS_AMD_EARLY_TAIL=10" "REGTOOLS_AMD_EARLY_TAIL=13" "REGTOOLS_AMD_EARLY_TAIL=14"; fi
+if [ $# -eq 0 ]; then set -- "A=1" "REGTOOLS_AMD_EARLY_TAIL=0" "REGTOOLS_AMD_EARLY_TAIL=12" "REGTOOLS_AMD_EARLY_TAIL=10,13" "REGTOOLS_AMD_EARLY_TAIL=6,10,13"; fi
 for r in 1 2; do
   for v in "$@"; do
     echo -n "$v: "
