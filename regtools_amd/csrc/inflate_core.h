@@ -258,6 +258,9 @@ struct OutStage {
     RGX_HD void store_chunk(uint32_t o, uint64_t l, uint64_t h) const {
         const int32_t cb = (int32_t)((a + o) & ~15u) - (int32_t)a;        // member offset of the chunk's byte 0 (< 0 for the head chunk)
         if (cb >= 0 && (uint32_t)cb + 16 <= cap) {
+#ifdef RGX_LAB_DROP_STAGE
+            if ((((a + o) >> 4) & 3u) != 3u) return;                       // (lab, WRONG OUTPUT: three of four stage stores dropped -- what whole-sector stores could save at most)
+#endif
             u32x4 v = {(uint32_t)l, (uint32_t)(l >> 32), (uint32_t)h, (uint32_t)(h >> 32)};
             *(u32x4 *)(out + cb) = v;                                      // 16-byte aligned by construction
         } else {

@@ -1604,8 +1604,10 @@ __global__ void k_reduce(EventSoA ev, const uint32_t *__restrict__ perm, const u
 // The radix sort, the head flags and the reduce then run on the partial rows (bench file 7.5 M events -> ~0.4 M rows, long reads 125 M ->
 // a few M) and combine them with sum / min / max, which do not care in which order the tiles appended their rows.  Exact for any input:
 // events that do not repeat inside a tile simply stay rows of one.
-constexpr uint32_t kAggTile = 2048, kAggSlots = 2 * kAggTile, kAggEmpty = 0xffffffffu;
+constexpr uint32_t kAggEmpty = 0xffffffffu;
+template <uint32_t kAggTile>
 __global__ __launch_bounds__(256) void k_preagg(EventSoA ev, uint32_t n, PartialSoA p, uint32_t *p_total) {
+    constexpr uint32_t kAggSlots = 2 * kAggTile;
     __shared__ uint32_t s_tid[kAggTile], s_start[kAggTile], s_ilen[kAggTile], s_slot[kAggSlots];
     __shared__ uint32_t s_cnt[kAggTile], s_ts[kAggTile], s_te[kAggTile], s_first[kAggTile], s_last[kAggTile];
     __shared__ uint32_t s_wave[4], s_base;
@@ -1773,7 +1775,10 @@ void launch_rows_table(UniqueSoA u, const uint32_t *order, uint32_t n, uint32_t 
     if (n) hipLaunchKernelGGL(k_rows_table, dim3((n + 255) / 256), dim3(256), 0, stream, u, order, n, min_anchor, out);
 }
 void launch_preagg(EventSoA ev, uint32_t n, PartialSoA p, uint32_t *p_total, hipStream_t stream) {
-    if (n) hipLaunchKernelGGL(k_preagg, dim3((n + kAggTile - 1) / kAggTile), dim3(256), 0, stream, ev, n, p, p_total);
+    if (!n) return;
+    static const int tile = [] { const char *e = getenv("REGTOOLS_AMD_AGG_TILE"); return e ? atoi(e) : 1024; }();      // (lab: 2048 events per tile = 80 KB of LDS, two workgroups per CU: reduce 1.52 ms on the bench file against 1.40-1.42 with 1024)
+    if (tile == 1024) hipLaunchKernelGGL(k_preagg<1024>, dim3((n + 1023) / 1024), dim3(256), 0, stream, ev, n, p, p_total);
+    else hipLaunchKernelGGL(k_preagg<2048>, dim3((n + 2047) / 2048), dim3(256), 0, stream, ev, n, p, p_total);
 }
 void launch_reduce_partials(PartialSoA p, const uint32_t *perm, const uint32_t *head, const uint32_t *seg_excl, uint32_t n, UniqueSoA u, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(k_reduce_partials, dim3((n + 255) / 256), dim3(256), 0, stream, p, perm, head, seg_excl, n, u);
