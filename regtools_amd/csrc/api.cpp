@@ -1253,6 +1253,17 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // an exact offset.  Plain whole-file calls on 16 KiB segments only; anything unusual in the prefix (the chain ends there, sweeps beyond
     // the usual one) drops back to the one-pass order.
     uint32_t sA = 0;                                          // early tail: segments [0, sA) are framed, verified and decoded
+    bool emit_parts_ok = false; uint32_t emit_parts = 0, emit_rows = 0; size_t ev_lay = 0;      // early tail: rows [0, emit_rows) have their events out, in emit_parts parts
+    EventSoA ev_e; memset(&ev_e, 0, sizeof ev_e);
+    auto ev_layout = [&](uint8_t *q, size_t E) {
+        EventSoA v; memset(&v, 0, sizeof v);
+        v.tid = (uint32_t *)q; q += E * 4; v.start = (uint32_t *)q; q += E * 4; v.ilen_cls = (uint32_t *)q; q += E * 4;
+        v.ts = (uint32_t *)q; q += E * 4; v.te = (uint32_t *)q; q += E * 4;
+        if (want_read_span) { v.rpos = (uint32_t *)q; q += E * 4; v.rend = (uint32_t *)q; q += E * 4; }
+        if (p->barcodes) { v.read = (uint32_t *)q; q += E * 4; }
+        v.strand = q;
+        return v;
+    };
     size_t soa_cap = 0;                                       // rows the SoA columns are laid out for (early tail: an estimate made from the prefix)
     DevBuf &b_soa = c->buf("soa");
     ReadSoA soa; memset(&soa, 0, sizeof soa);
@@ -1281,6 +1292,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         seg_iter_e = (uint32_t *)q; q += per * 4; seg_long_e = (uint32_t *)q; q += per * 4; seg_long_base_e = (uint32_t *)q;
         HIP_TRY(b_tmp.ensure(scan_tmp_words(n_seg) * 4 + 64));
         bool early = split_B && spec && !geom.chunks && seg_bytes == kSegBytes && cut_hi == UINT64_MAX && !empty_stream && lim == total;
+        static const bool env_early_emit = [] { const char *e = getenv("REGTOOLS_AMD_EARLY_EMIT"); return !e || atoi(e) != 0; }();
         static const bool small_ok = getenv("REGTOOLS_AMD_EARLY_TAIL_MIN") != nullptr;
         uint32_t waves_done = 0;
         for (size_t j = 0; early && j < early_parts.size(); ++j) {
@@ -1305,7 +1317,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             P.framing_sweeps = sweeps0;                               // (the sweeps over everything, below, are the call's count)
             const uint64_t span_J = (uint64_t)sJ * seg_bytes;
             if (h_sc[83] || ended_J || slow_J || !n_rec_J || span_J / n_rec_J > kSparseRecordBytes ||
-                (sA && n_rec_J > soa_cap)) { early = false; sA = 0; break; }     // not the plain case: one pass over everything below
+                (sA && n_rec_J > soa_cap)) { early = false; sA = 0; emit_parts_ok = false; emit_parts = 0; emit_rows = 0; break; }     // not the plain case: one pass over everything below
             if (!sA) {
                 // rows for the whole file, estimated from the first part (+ 1/8); when the estimate turns out short the decode is simply made again below
                 HIP_TRY(soa_layout((size_t)((double)n_rec_J * ((double)n_seg / sJ) * 1.125) + 65536));
@@ -1313,6 +1325,20 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
                 if (lite_walk) { cfg.insane_out = d_sc + 82; HIP_TRY(hipMemsetAsync(d_sc + 82, 0, 4, st)); h_sc[82] = 0; }
             }
             launch_decode_seg(arena, geom, sJ, seg_start[cur], seg_base, seg_cnt[cur], cfg, soa, seg_iter_e, seg_long_e, seg_cp, /*staged=*/true, st, sA);
+            // ... and its junction events emitted, into the events block the context's last call left (no count is known yet, so nothing can be
+            // sized: a first call, or a block that turns out too small, emits everything at the end as before).  ev_base counts from the part's
+            // first row; the totals of the parts stay on the device, k_emit_short adds those in front of its part.
+            if (!sA) {
+                DevBuf &b_ev0 = c->buf("events");
+                ev_lay = b_ev0.cap > 256 ? (b_ev0.cap - 256) / 33 : 0;
+                emit_parts_ok = env_early_emit && ev_lay >= 4096;
+                if (emit_parts_ok) { HIP_TRY(b_tmp.ensure(scan_tmp_words((uint32_t)std::min<size_t>(soa_cap, 0xffffffffu)) * 4 + 64)); ev_e = ev_layout(b_ev0.as<uint8_t>(), ev_lay); }
+            }
+            if (emit_parts_ok && emit_parts < 4) {
+                launch_scan_u32(soa.n_ev + emit_rows, ev_base + emit_rows, n_rec_J - emit_rows, d_sc + 84 + emit_parts, b_tmp.as<uint32_t>(), st);
+                launch_emit_short(arena, n_rec_J, cfg, soa, ev_base, ev_e, st, emit_rows, d_sc + 84, emit_parts, (uint32_t)std::min<size_t>(ev_lay, 0xffffffffu));
+                emit_rows = n_rec_J; ++emit_parts;
+            }
             sA = sJ;
             mark("early tail: part framed and decoded");
         }
@@ -1355,7 +1381,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         //  ended after all, everything is decoded again)
         uint32_t s_from = sA;
         if (sA && (R > soa_cap || chain_ended)) s_from = 0;
-        if (!s_from) HIP_TRY(soa_layout(R));
+        if (!s_from) { HIP_TRY(soa_layout(R)); emit_parts_ok = false; }
         HIP_TRY(b_tmp.ensure(scan_tmp_words(n_rec) * 4 + 64));
         // per-segment outputs (no hot atomics): reuse the spare segment arrays as seg_iter / seg_long
         uint32_t *seg_iter = sA ? seg_iter_e : seg_cnt[cur ^ 1], *seg_long = sA ? seg_long_e : (uint32_t *)seg_start[cur ^ 1], *seg_long_base = sA ? seg_long_base_e : (uint32_t *)seg_exit[cur ^ 1];
@@ -1374,7 +1400,12 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         for (int pass = 0; pass < 2; ++pass) {
             launch_decode_seg(arena, geom, n_seg, seg_start[cur], seg_base, seg_cnt[cur], cfg, soa, seg_iter, seg_long, seg_cp,
                               /*staged=*/span / n_rec <= kSparseRecordBytes, st, s_from);
-            launch_scan_u32(soa.n_ev, ev_base, n_rec, d_sc + 4, b_tmp.as<uint32_t>(), st);
+            if (emit_parts_ok && s_from) {
+                // the last part's events, emitted like the others'; the event total = the parts' totals
+                launch_scan_u32(soa.n_ev + emit_rows, ev_base + emit_rows, n_rec - emit_rows, d_sc + 84 + emit_parts, b_tmp.as<uint32_t>(), st);
+                launch_emit_short(arena, n_rec, cfg, soa, ev_base, ev_e, st, emit_rows, d_sc + 84, emit_parts, (uint32_t)std::min<size_t>(ev_lay, 0xffffffffu));
+                HIP_TRY(hipMemcpyAsync(h_sc + 84, d_sc + 84, 20, hipMemcpyDeviceToHost, st));
+            } else launch_scan_u32(soa.n_ev, ev_base, n_rec, d_sc + 4, b_tmp.as<uint32_t>(), st);
             launch_scan_u32(seg_iter, seg_iter, n_seg, d_sc + 8, b_tmp.as<uint32_t>(), st);
             launch_scan_u32(seg_long, seg_long_base, n_seg, d_sc + 5, b_tmp.as<uint32_t>(), st);
             HIP_TRY(hipMemcpyAsync(h_sc + 4, d_sc + 4, 24, hipMemcpyDeviceToHost, st));
@@ -1396,6 +1427,18 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             cfg.stop_index = h_sc[80];
         }
         n_events = h_sc[4]; n_long = h_sc[5];
+        if (emit_parts_ok && s_from) {
+            uint64_t tot = 0;
+            for (uint32_t k = 0; k <= emit_parts && k < 5; ++k) tot += h_sc[84 + k];
+            if (tot > ev_lay || tot > 0xffffffffull || n_long) {
+                // the recycled block was too small after all (or wave-per-read rows want their global slots): everything once more, the plain way
+                emit_parts_ok = false;
+                launch_scan_u32(soa.n_ev, ev_base, n_rec, d_sc + 4, b_tmp.as<uint32_t>(), st);
+                HIP_TRY(hipMemcpyAsync(h_sc + 4, d_sc + 4, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                n_events = h_sc[4];
+            } else n_events = (uint32_t)tot;
+        }
         n_iterated = h_sc[8];
         if (geom.chunks && p->n_shards > 1 && h_sc[80] != 0xffffffffu) P.stream_ended = true;      // this shard read the record that ends the iteration (hts.c:1946-1950)
         if (n_long) launch_long_fill(n_seg, seg_base, seg_cnt[cur], seg_long_base, cfg, soa, long_list, st);
@@ -1408,15 +1451,13 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     EventSoA ev; memset(&ev, 0, sizeof ev);
     if (n_events) {
         const size_t E = n_events;
-        HIP_TRY(b_ev.ensure(E * (4 * 8 + 1) + 256));
-        uint8_t *q = b_ev.as<uint8_t>();
-        ev.tid = (uint32_t *)q; q += E * 4; ev.start = (uint32_t *)q; q += E * 4; ev.ilen_cls = (uint32_t *)q; q += E * 4;
-        ev.ts = (uint32_t *)q; q += E * 4; ev.te = (uint32_t *)q; q += E * 4;
-        if (want_read_span) { ev.rpos = (uint32_t *)q; q += E * 4; ev.rend = (uint32_t *)q; q += E * 4; }
-        if (p->barcodes) { ev.read = (uint32_t *)q; q += E * 4; }
-        ev.strand = q;
-        launch_emit_short(arena, n_rec, cfg, soa, ev_base, ev, st);
-        launch_emit_long(arena, long_list, n_long, cfg, soa, ev_base, ev, st);
+        if (emit_parts_ok && n_rec) ev = ev_e;                  // (early tail: every part's rows are out already)
+        else {
+            HIP_TRY(b_ev.ensure(E * (4 * 8 + 1) + 256));
+            ev = ev_layout(b_ev.as<uint8_t>(), E);
+            launch_emit_short(arena, n_rec, cfg, soa, ev_base, ev, st);
+            launch_emit_long(arena, long_list, n_long, cfg, soa, ev_base, ev, st);
+        }
         if (cfg.fa_data) {
             HIP_TRY(hipMemcpyAsync(h_sc + 64, d_sc + 64, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));

@@ -179,7 +179,9 @@ struct EventSoA {
     uint32_t *read;                     // optional (may be null): index of the supporting read (-b barcodes)
 };
 void launch_emit_short(const uint8_t *arena, uint32_t n_rec, ExtractCfg cfg, ReadSoA soa, const uint32_t *ev_base,
-                       EventSoA ev, hipStream_t stream);
+                       EventSoA ev, hipStream_t stream, uint32_t row_begin = 0 /* rows [row_begin, n_rec) */,
+                       const uint32_t *part_totals = nullptr, uint32_t n_parts = 0 /* device words added to every ev_base (early tail: ev_base counts per part) */,
+                       uint32_t slot_cap = 0xffffffffu /* events at or behind this slot are counted, not written */);
 void launch_emit_long(const uint8_t *arena, const uint32_t *long_list, uint32_t n_long,
                       ExtractCfg cfg, ReadSoA soa, const uint32_t *ev_base, EventSoA ev, hipStream_t stream);
 

@@ -1048,9 +1048,11 @@ __device__ __forceinline__ void put_event(const EventSoA &ev, uint32_t slot, int
 }
 
 // short reads: one lane per read, the serial state machine (config 2: 1 or 3 ops)
+// (row_begin, part_totals, n_parts: the early tail emits the rows of one part of the file at a time; ev_base then counts from the part's first row, and the
+//  events of the parts in front of it -- their totals sit in device memory, nobody waited for them -- are added here)
 __global__ void k_emit_short(const uint8_t *__restrict__ arena, uint32_t n_rec, ExtractCfg cfg, ReadSoA soa,
-                             const uint32_t *__restrict__ ev_base, EventSoA ev) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+                             const uint32_t *__restrict__ ev_base, EventSoA ev, uint32_t row_begin, const uint32_t *__restrict__ part_totals, uint32_t n_parts, uint32_t slot_cap) {
+    uint32_t i = row_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rec) return;
     uint32_t nev = soa.n_ev[i];
     if (!nev) return;
@@ -1060,6 +1062,7 @@ __global__ void k_emit_short(const uint8_t *__restrict__ arena, uint32_t n_rec, 
     int32_t tid = soa.tid[i];
     char strand = (char)soa.strand[i];
     uint32_t slot = ev_base[i];
+    for (uint32_t k = 0; k < n_parts; ++k) slot += part_totals[k];
     const int32_t pos = soa.pos[i];
     const uint32_t rend = ev.rpos ? (uint32_t)rec_endpos(cig, n_cigar, fnc >> 16, pos) : 0u;     // bam_endpos of the supporting read
     char carried = 0;
@@ -1073,7 +1076,7 @@ __global__ void k_emit_short(const uint8_t *__restrict__ arena, uint32_t n_rec, 
             else { const char m = strand_from_motif(cfg.fa_data, fc, s, e, carried); if (m != '?') st = m; }
             carried = st;
         }
-        if (intron_ok(s, e, cfg.min_intron, cfg.max_intron)) put_event(ev, slot++, tid, s, e, ts, te, st, (uint32_t)pos, rend, i);
+        if (intron_ok(s, e, cfg.min_intron, cfg.max_intron)) { if (slot < slot_cap) put_event(ev, slot, tid, s, e, ts, te, st, (uint32_t)pos, rend, i); ++slot; }   // (slot_cap: a block sized before the count was known)
     });
 }
 
@@ -1185,9 +1188,9 @@ __global__ __launch_bounds__(256) void k_emit_long(const uint8_t *__restrict__ a
 }
 
 void launch_emit_short(const uint8_t *arena, uint32_t n_rec, ExtractCfg cfg, ReadSoA soa, const uint32_t *ev_base, EventSoA ev,
-                       hipStream_t stream) {
-    if (!n_rec) return;
-    hipLaunchKernelGGL(k_emit_short, dim3((n_rec + 255) / 256), dim3(256), 0, stream, arena, n_rec, cfg, soa, ev_base, ev);
+                       hipStream_t stream, uint32_t row_begin, const uint32_t *part_totals, uint32_t n_parts, uint32_t slot_cap) {
+    if (n_rec <= row_begin) return;
+    hipLaunchKernelGGL(k_emit_short, dim3((n_rec - row_begin + 255) / 256), dim3(256), 0, stream, arena, n_rec, cfg, soa, ev_base, ev, row_begin, part_totals, n_parts, slot_cap);
 }
 void launch_emit_long(const uint8_t *arena, const uint32_t *long_list, uint32_t n_long, ExtractCfg cfg,
                       ReadSoA soa, const uint32_t *ev_base, EventSoA ev, hipStream_t stream) {
