@@ -866,6 +866,9 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         split_B = false;
         return hipStreamWaitEvent(st, split_ev, 0);
     };
+    // (every way out of this function while the side stream's launch may still run -- an error in the prefix's framing, say: the next call on this
+    //  context must not meet it)
+    struct SideGuard { bool &pending; hipEvent_t &ev; ~SideGuard() { if (pending && ev) (void)hipEventSynchronize(ev); } } side_guard{split_B, split_ev};
     if (!overlap) launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below, 0, false, 0, d_bad, pairs);
     else {
         // one launch per upload chunk, on the side streams: the members whose bytes (plus the decoder's 16-byte look-ahead) have arrived with
