@@ -883,6 +883,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             if (inflate_takes_coop(n_range)) {
                 InflateGate gate;
                 gate.flags = c->buf("gate_flags").as<uint32_t>(); gate.epoch = c->gate_epoch; gate.n_chunks = (uint32_t)up.end.size(); gate.lo = up.lo; gate.chunk_bytes = gate_chunk;
+                { static const int env_prio = [] { const char *e = getenv("REGTOOLS_AMD_GATE_PRIO"); return e ? atoi(e) : 0; }(); gate.prio = (uint32_t)env_prio; }
                 // Round 4, second half ("early tail"): the launch goes to a side stream and counts its finished waves per PART of the member list
                 // (parts cut where upload chunks end, at multiples of the lane-sorting group); the pipeline's stream waits for part after part
                 // (launch_wait_done) and frames, verifies and decodes the part of the arena behind it while the waves of the later parts still

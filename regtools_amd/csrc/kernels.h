@@ -30,6 +30,7 @@ struct InflateGate {
     // Early tail (round 4): the launch's waves are counted as they finish, by part of the member list -- part j = the waves from part_start[j - 1]
     // (workgroup index; part 0 starts at 0) up to part_start[j] -- so that the pipeline's stream can frame and decode the front parts of the arena
     // (launch_wait_done) while the waves of the later parts still run.  done = null: nobody counts.
+    uint32_t prio = 0;                 // 1: a wave's issue priority (s_setprio 0..3) grows with the upload chunk it waits for
     uint32_t *done = nullptr;          // device memory, kGateParts words, zeroed by the caller in front of the launch
     uint32_t part_start[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
 };

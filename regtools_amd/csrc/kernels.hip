@@ -383,6 +383,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         }
         arrived = __builtin_amdgcn_ballot_w64(!arrived) == 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // (the members of the last chunks are what the call waits for -- their own chain behind the last arrival: their waves issue ahead of the
+        //  waves of earlier chunks that share their SIMD)
+        if (gate.prio) { const uint32_t q = need * 4u / gate.n_chunks; if (q >= 3) __builtin_amdgcn_s_setprio(3); else if (q == 2) __builtin_amdgcn_s_setprio(2); else if (q == 1) __builtin_amdgcn_s_setprio(1); }
         if (!arrived) {
             if (have) {
                 const uint32_t mi = m + index_bias;
