@@ -2,7 +2,7 @@
 # tools/lab/step_ab.sh [VARIANTS...]: the bench step (host bytes -> table, and device-resident) under environment switches, interleaved
 cd "$(dirname "$0")/../.."
 if [ $# -eq 0 ]; then set -- "A=1" "REGTOOLS_AMD_EARLY_TAIL=0" "REGTOOLS_AMD_EARLY_TAIL=12" "REGTOOLS_AMD_EARLY_TAIL=10,13" "REGTOOLS_AMD_EARLY_TAIL=6,10,13"; fi
-for r in 1 2; do
+for r in $(seq ${ROUNDS:-2}); do
   for v in "$@"; do
     echo -n "$v: "
     env $v python bench.py --steps 8 --warmup 2 --no-extras 2>/dev/null | python -c "
