@@ -105,6 +105,8 @@ struct rgx_ctx {
     // host input (rgx_extract_mem / rgx_extract): the file goes up in chunks on its own stream while the members that have arrived are
     // being inflated on the side streams (prepare_events)
     hipStream_t copy_stream = nullptr, side[kSideStreams] = {};
+    bool gate_distrust = false, early_distrust = false;   // a gated launch whose verdict was not clean / an early-tail wait that timed out on this context: not tried again (a stream layout in which
+                                                       // the waiting waves and the kernels that release them share a hardware queue would cost every call its 2 s time-out)
     bool walk_strict = false;             // set around the re-run of a call whose block_size-only framing met a record bam_read1 refuses (prepare_events)
     bool one_shot = false;                             // REGTOOLS_AMD_ONE_SHOT at creation: no streams besides `stream` (ensure_upload_streams)
     std::vector<hipEvent_t> chunk_ev;
@@ -506,7 +508,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             // REGTOOLS_AMD_GATE=0, REGTOOLS_AMD_PIECES or a one-shot context: round 3's pieces.
             static const bool gate_off = [] { const char *e = getenv("REGTOOLS_AMD_GATE"); return e && !strcmp(e, "0"); }();
             static const unsigned gate_chunks = [] { const char *e = getenv("REGTOOLS_AMD_GATE_CHUNKS"); const int v = e ? atoi(e) : 16; return (unsigned)std::min(std::max(v, 2), 64); }();
-            gated = !gate_off && !c->one_shot && !getenv("REGTOOLS_AMD_PIECES") && up_hi - up_lo >= std::min(overlap_min, (size_t)8 << 20) && up_hi - up_lo >= 2 * 4096 * (size_t)gate_chunks;
+            gated = !gate_off && !c->gate_distrust && !c->one_shot && !getenv("REGTOOLS_AMD_PIECES") && up_hi - up_lo >= std::min(overlap_min, (size_t)8 << 20) && up_hi - up_lo >= 2 * 4096 * (size_t)gate_chunks;
             if (gated) {
                 // ... for payloads whose inflate is of the upload's order (measured: bench payload 27.5 -> 26.5 ms, random bases + qualities 98.2 ->
                 // 93.7); run-length payloads (long reads: 1 GB of file, 65 GB inflated, five rounds of waves) lose 5-6 ms of 158 to it and keep
@@ -897,7 +899,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
                     return v;
                 }();
                 static const uint32_t early_min = [] { const char *e = getenv("REGTOOLS_AMD_EARLY_TAIL_MIN"); return e ? (uint32_t)atoi(e) : 4096u; }();     // (tests: small files)
-                if (!env_cuts.empty() && c->side[1] && up.end.size() >= 8 && !d_bad && !d_true_sizes) {
+                if (!env_cuts.empty() && !c->early_distrust && c->side[1] && up.end.size() >= 8 && !d_bad && !d_true_sizes) {
                     const uint32_t align = kInflateSortGroup;          // (a wave's members all come from one group of that many)
                     for (unsigned cut : env_cuts) {
                         const size_t kA = std::max<size_t>(1, up.end.size() * (size_t)cut / 16);
@@ -1227,6 +1229,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             if (spec && iter == 0 && (h_sc[0] != 0xffffffffu || h_sc[kStatusEarly] != 0xffffffffu)) {
                 // some member did not inflate to its footer's length: nothing enqueued since is worth anything
                 mark("inflate verdict: not clean, starting over device-resident");
+                if (gated) c->gate_distrust = true;
                 HIP_TRY(join_B());
                 HIP_TRY(complete_upload());
                 HIP_TRY(hipStreamSynchronize(copy_q));
@@ -1320,6 +1323,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             const bool slow_J = P.framing_sweeps - sweeps0 > 2;
             P.framing_sweeps = sweeps0;                               // (the sweeps over everything, below, are the call's count)
             const uint64_t span_J = (uint64_t)sJ * seg_bytes;
+            if (h_sc[83]) c->early_distrust = true;
             if (h_sc[83] || ended_J || slow_J || !n_rec_J || span_J / n_rec_J > kSparseRecordBytes ||
                 (sA && n_rec_J > soa_cap)) { early = false; sA = 0; emit_parts_ok = false; emit_parts = 0; emit_rows = 0; break; }     // not the plain case: one pass over everything below
             if (!sA) {

@@ -1094,20 +1094,39 @@ __global__ __launch_bounds__(256) void k_emit_long(const uint8_t *__restrict__ a
     __shared__ uint32_t s_ops[4][64];
     __shared__ uint32_t s_R[4][65];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    for (uint32_t w = blockIdx.x * 4 + wave; w < n_long; w += gridDim.x * 4) {
-        const uint32_t i = long_list[w];
-        const uint32_t n_cigar = soa.flag_nc[i] & 0xffff;
-        const uint8_t *cig = arena + soa.cig_off[i];
-        const int32_t tid = soa.tid[i];
-        const char strand = (char)soa.strand[i];
-        uint32_t slot = ev_base[i];
-        const uint32_t rpos = (uint32_t)soa.pos[i];
+    // (round 4: a read is three dependent round trips -- its index, its row, its CIGAR -- in front of ~200 instructions: the NEXT read's index and row are
+    //  requested while this one's CIGAR is in flight and its junctions are worked out, so that an iteration waits for one round trip, not three)
+    const uint32_t stride = gridDim.x * 4;
+    uint32_t w = blockIdx.x * 4 + wave;
+    if (w >= n_long) return;
+    uint32_t nx_i = long_list[w];
+    uint32_t nn_i = w + stride < n_long ? long_list[w + stride] : 0u;          // (the index of the read after the next: its row's loads must not wait for it)
+    uint32_t nx_fnc = soa.flag_nc[nx_i], nx_slot = ev_base[nx_i];
+    uint64_t nx_cig = soa.cig_off[nx_i];
+    int32_t nx_tid = soa.tid[nx_i], nx_pos = soa.pos[nx_i];
+    uint8_t nx_strand = soa.strand[nx_i];
+    for (; w < n_long; w += stride) {
+        const uint32_t i = nx_i, fnc = nx_fnc;
+        const uint32_t n_cigar = fnc & 0xffff;
+        const uint8_t *cig = arena + nx_cig;
+        const int32_t tid = nx_tid;
+        const char strand = (char)nx_strand;
+        uint32_t slot = nx_slot;
+        const uint32_t rpos = (uint32_t)nx_pos;
+        // this read's first CIGAR tile: requested now, looked at below
+        const uint32_t c_first = lane < n_cigar ? ld32(cig + 4 * (size_t)lane) : 0x5u /* 0H: inert */;
+        // ... the next read's row behind it (its index came with the last iteration), and the index of the one after
+        if (w + stride < n_long) {
+            nx_i = nn_i;
+            nx_fnc = soa.flag_nc[nx_i]; nx_slot = ev_base[nx_i]; nx_cig = soa.cig_off[nx_i]; nx_tid = soa.tid[nx_i]; nx_pos = soa.pos[nx_i]; nx_strand = soa.strand[nx_i];
+            if (w + 2 * stride < n_long) nn_i = long_list[w + 2 * stride];
+        }
         uint32_t rend = 0;
         if (ev.rpos) {                               // bam_endpos (sam.c:336-342): pos + reference span, or pos+1 for unmapped-flagged reads
             uint32_t span = 0;
             for (uint32_t t0 = lane; t0 < n_cigar; t0 += 64) span += cig_ref_len(ld32(cig + 4 * (size_t)t0));
             span = __shfl(wave_incl_scan(span), 63, 64);
-            rend = ((soa.flag_nc[i] >> 16) & 4u) ? rpos + 1 : rpos + span;
+            rend = ((fnc >> 16) & 4u) ? rpos + 1 : rpos + span;
         }
         uint32_t refpos = rpos;                      // R at the start of the tile
         uint32_t ts_carry = refpos;                  // R[pb+1] for an N with no breaker earlier in the tile
@@ -1116,7 +1135,7 @@ __global__ __launch_bounds__(256) void k_emit_long(const uint8_t *__restrict__ a
         char carried = 0;                            // intron-motif rule: strand of the read's previous junction
         for (uint32_t t0 = 0; t0 < n_cigar; t0 += 64) {
             const uint32_t k = t0 + lane;
-            const uint32_t c = k < n_cigar ? ld32(cig + 4 * (size_t)k) : 0x5u /* 0H: inert */;
+            const uint32_t c = t0 == 0 ? c_first : k < n_cigar ? ld32(cig + 4 * (size_t)k) : 0x5u /* 0H: inert */;
             s_ops[wave][lane] = c;
             const uint32_t adv = cig_advances_junction_state(c) ? (c >> 4) : 0u;
             const uint32_t incl = wave_incl_scan(adv);
