@@ -115,6 +115,7 @@ struct rgx_ctx {
     hipEvent_t ev[8] = {};
     std::map<std::string, DevBuf> bufs;
     void *pinned = nullptr; size_t pinned_cap = 0;     // small pinned staging for scalar readbacks
+    std::vector<Member> hm_scratch;
     void *pinned_members = nullptr; size_t pinned_members_cap = 0;      // the host scan's member list: kernels read it in place (grow-only)
     void *pinned_rows = nullptr; size_t pinned_rows_cap = 0;
     uint64_t last_rows = 0, last_records = 0, last_events = 0, last_bytes = 0; bool last_rows_valid = false;      // rows of the last rgx_extract* call, still in the "rows_out" block in HBM   // grow-only pinned staging for whole result tables (device merge)
@@ -462,7 +463,8 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     } up;
     bool overlap = false, gated = false;
     size_t gate_chunk = 0;
-    std::vector<Member> hm;                                  // the host scan's member list (overlap only)
+    std::vector<Member> &hm = c->hm_scratch;                 // the host scan's member list (overlap only; the context keeps its pages: a fresh 4 MB is a thousand page faults per call)
+    hm.clear();
     uint64_t hm_total = 0;
     if (!d_bam) {
         DevBuf &b = c->buf("bam");

@@ -66,7 +66,7 @@ bool scan_members_parallel(const uint8_t *bam, size_t len, int threads, std::vec
     int T = threads < 1 ? 1 : threads;
     // The walk is a chain of dependent cache misses (BSIZE of one member names the next): every thread walks several chains in turn, so that a
     // core keeps as many misses in flight as a dozen threads would -- the ranks of a multi-GPU job share the host's cores.
-    const int kChains = 8;
+    static const int kChains = [] { const char *e = getenv("REGTOOLS_AMD_SCAN_CHAINS"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 64 ? v : 8; }();     // (lab)
     size_t n_seg = (size_t)T * kChains;
     if (n_seg > len / (1u << 19) + 1) n_seg = len / (1u << 19) + 1;           // not worth a chain per few members
     if ((size_t)T > n_seg) T = (int)n_seg;
@@ -83,7 +83,15 @@ bool scan_members_parallel(const uint8_t *bam, size_t len, int threads, std::vec
         }
         start[t] = found;
     }
-    std::vector<std::vector<Member>> part(n_seg);
+    // (the chains' lists live across calls -- whoever holds the pool's lock below owns them: 4 MB of fresh vectors were a thousand page faults per call)
+    static std::mutex pool_mu;
+    static WorkerPool *pool = nullptr;
+    std::unique_lock<std::mutex> pool_lock(pool_mu, std::try_to_lock);       // (a second caller at the same time -- shards of different files -- walks on its own thread)
+    static std::vector<std::vector<Member>> part_keep;
+    std::vector<std::vector<Member>> part_own;
+    std::vector<std::vector<Member>> &part = pool_lock.owns_lock() ? part_keep : part_own;
+    if (part.size() < n_seg) part.resize(n_seg);
+    for (size_t k = 0; k < n_seg; ++k) part[k].clear();
     std::vector<char> ok(n_seg, 0);
     auto walk = [&](int t) {
         const size_t s0 = n_seg * (size_t)t / (size_t)T, s1 = n_seg * ((size_t)t + 1) / (size_t)T;
@@ -112,9 +120,6 @@ bool scan_members_parallel(const uint8_t *bam, size_t len, int threads, std::vec
     };
     // (round 4: the walkers are a pool that outlives the call -- starting two dozen threads was half of the scan's 1.8 ms, and the inflate launch waits
     //  for this list -- and the lists of the chains are put together by the same threads)
-    static std::mutex pool_mu;
-    static WorkerPool *pool = nullptr;
-    std::unique_lock<std::mutex> pool_lock(pool_mu, std::try_to_lock);       // (a second caller at the same time -- shards of different files -- walks on its own thread)
     if (pool_lock.owns_lock() && T > 1 && (!pool || pool->threads() < (size_t)T)) { delete pool; pool = new WorkerPool((size_t)T); }
     auto run = [&](size_t n_tasks, const std::function<void(size_t)> &f) {
         if (pool_lock.owns_lock() && pool && T > 1) pool->run(n_tasks, f);
