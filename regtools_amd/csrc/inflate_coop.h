@@ -27,7 +27,10 @@
 
 namespace rgx {
 
-constexpr uint32_t kLaneCopyMax = 64;     // bytes a lane copies itself per trip (4 chunk registers); longer pieces go to the wave
+#ifndef RGX_LAB_LANE_COPY_MAX
+#define RGX_LAB_LANE_COPY_MAX 64
+#endif
+constexpr uint32_t kLaneCopyMax = RGX_LAB_LANE_COPY_MAX;     // bytes a lane copies itself per trip (4 chunk registers); longer pieces go to the wave
 constexpr uint32_t kCoopCopyMax = 258;    // a whole match: head (< 16) + at most 16 aligned chunks + tail (< 16)
 
 // one-lane "wave" of the host build: the body chunks are copied on the spot
@@ -204,7 +207,7 @@ RGX_HD int inflate_coop(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
             // registers: the largest period x 2^k that the 64 bytes just written hold)
             if (rl) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) if (pend_dist <= 32) pend_dist += pend_dist;
+                for (int k = 0; k < 6; ++k) if (2 * pend_dist <= n) pend_dist += pend_dist;       // (n: the bytes this trip wrote -- all of them periods)
             } else if (n == pend_dist) pend_dist += pend_dist;
         }
         // (an error met while decoding the trip's second symbol: the literal in front of it is not written -- what a failed member left
