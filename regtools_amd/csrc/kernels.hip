@@ -43,7 +43,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 // the SIMD are what fills those gaps (measured with the output stage in place: 5 -> 7 waves per CU is 1.3x).
 // The canonical codes themselves (bounds, lengths, list offsets) are 2 x 16 REGISTER words (inflate_core.h Code); the
 // code-length scratch that only a block header needs is global too (40 dwords per lane, before the cold symbols).
-constexpr uint32_t kHotSyms = 160;
+#ifndef RGX_LAB_HOT_SYMS
+#define RGX_LAB_HOT_SYMS 160
+#endif
+constexpr uint32_t kHotSyms = RGX_LAB_HOT_SYMS;
 constexpr uint32_t kLdsLL = 0, kLdsD = (kHotSyms * 9 + 31) / 32, kLdsDwordsPerLane = kLdsD + 6;
 constexpr uint32_t kInflateLdsBytes = kLdsDwordsPerLane * 64 * 4;
 // (round 4: the cold end of the list is 16 bits per symbol -- ONE request per lookup, no read-modify-write when the list is built)
