@@ -1288,8 +1288,14 @@ void launch_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *to
 }
 
 // ---- radix pass ------------------------------------------------------------------------------------------
-constexpr uint32_t kRadixRows = 32;                   // one wave per workgroup, 64 x 32 = 2048 keys per tile
-constexpr uint32_t kRadixTile = 64 * kRadixRows;
+// one wave per workgroup, 64 x rows keys per tile.  Round 4: 8 rows for sorts of up to two million keys -- the partial rows of the group-by, the unique rows
+// of the output order: a few hundred thousand keys in 2,048-key tiles are 150 workgroups on 256 CUs, each a chain of 32 dependent rows (a pass 41 us); in
+// 512-key tiles four times as many workgroups walk a quarter of the rows each
+constexpr uint32_t kRadixRowsLarge = 32, kRadixRowsSmall = 8, kRadixSmallMax = 2u << 20;
+static inline uint32_t radix_rows(uint32_t n) {
+    static const uint32_t small = [] { const char *e = getenv("REGTOOLS_AMD_RADIX_ROWS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? (uint32_t)v : kRadixRowsSmall; }();     // (lab)
+    return n <= kRadixSmallMax ? small : kRadixRowsLarge;
+}
 
 __device__ __forceinline__ uint32_t radix_digit(const uint32_t *__restrict__ word, const uint32_t *__restrict__ perm_in, uint32_t i,
                                                 uint32_t shift, uint32_t mask, uint32_t &src) {
@@ -1311,12 +1317,12 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
 // KEYED = the key of position i is word[i] itself (it travels with the permutation: launch_radix_pass_keyed) instead of word[perm_in[i]]
 template <bool KEYED>
 __global__ __launch_bounds__(64) void k_radix_hist(const uint32_t *__restrict__ word, uint32_t shift, uint32_t mask,
-                                                   const uint32_t *__restrict__ perm_in, uint32_t n, uint32_t n_tiles, uint32_t *hist) {
+                                                   const uint32_t *__restrict__ perm_in, uint32_t n, uint32_t n_tiles, uint32_t *hist, uint32_t rows) {
     __shared__ uint32_t s_cnt[256];
     for (uint32_t k = threadIdx.x; k < 256; k += 64) s_cnt[k] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * kRadixTile;
-    for (uint32_t r = 0; r < kRadixRows; ++r) {
+    const uint32_t base = blockIdx.x * 64 * rows;
+    for (uint32_t r = 0; r < rows; ++r) {
         const uint32_t i = base + r * 64 + threadIdx.x;
         if (i < n) { uint32_t src; atomicAdd(&s_cnt[KEYED ? ((word[i] >> shift) & mask) : radix_digit(word, perm_in, i, shift, mask, src)], 1u); }
     }
@@ -1328,7 +1334,7 @@ template <bool KEYED>
 __global__ __launch_bounds__(64) void k_radix_scatter(const uint32_t *__restrict__ word, uint32_t shift, uint32_t mask,
                                                       const uint32_t *__restrict__ perm_in, uint32_t *perm_out, uint32_t n,
                                                       uint32_t n_tiles, const uint32_t *__restrict__ hist_scan, uint32_t *key_out,
-                                                      const uint32_t *__restrict__ digit_total) {
+                                                      const uint32_t *__restrict__ digit_total, uint32_t rows) {
     __shared__ uint32_t s_base[256];
     {
         // where digit d starts in the output = the totals of the digits below it: 256 numbers, scanned by every workgroup for itself
@@ -1343,8 +1349,8 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const uint32_t *__restrict
         s_base[k0 + 3] = run + hist_scan[(size_t)(k0 + 3) * n_tiles + blockIdx.x];
     }
     __syncthreads();
-    const uint32_t base = blockIdx.x * kRadixTile;
-    for (uint32_t r = 0; r < kRadixRows; ++r) {
+    const uint32_t base = blockIdx.x * 64 * rows;
+    for (uint32_t r = 0; r < rows; ++r) {
         const uint32_t i = base + r * 64 + threadIdx.x;
         const bool valid = i < n;
         uint32_t src = 0, key = 0;
@@ -1384,7 +1390,7 @@ __global__ __launch_bounds__(256) void k_radix_offsets(uint32_t *hist, uint32_t 
 }
 
 size_t radix_tmp_words(uint32_t n) {
-    const size_t tiles = ((size_t)n + kRadixTile - 1) / kRadixTile;
+    const size_t tile = 64 * (size_t)radix_rows(n), tiles = ((size_t)n + tile - 1) / tile;
     return 256 * tiles + 256 + 4;
 }
 
@@ -1392,22 +1398,22 @@ size_t radix_tmp_words(uint32_t n) {
 void launch_radix_pass(const uint32_t *word, uint32_t shift, uint32_t bits, const uint32_t *perm_in, uint32_t *perm_out, uint32_t n,
                        uint32_t *tmp, hipStream_t stream) {
     if (!n) return;
-    const uint32_t tiles = (n + kRadixTile - 1) / kRadixTile;
+    const uint32_t rows = radix_rows(n), tiles = (n + 64 * rows - 1) / (64 * rows);
     const uint32_t mask = (1u << bits) - 1u;
     uint32_t *hist = tmp, *totals = tmp + (size_t)256 * tiles;
-    hipLaunchKernelGGL(k_radix_hist<false>, dim3(tiles), dim3(64), 0, stream, word, shift, mask, perm_in, n, tiles, hist);
+    hipLaunchKernelGGL(k_radix_hist<false>, dim3(tiles), dim3(64), 0, stream, word, shift, mask, perm_in, n, tiles, hist, rows);
     hipLaunchKernelGGL(k_radix_offsets, dim3(256), dim3(256), 0, stream, hist, tiles, totals);
-    hipLaunchKernelGGL(k_radix_scatter<false>, dim3(tiles), dim3(64), 0, stream, word, shift, mask, perm_in, perm_out, n, tiles, hist, (uint32_t *)nullptr, totals);
+    hipLaunchKernelGGL(k_radix_scatter<false>, dim3(tiles), dim3(64), 0, stream, word, shift, mask, perm_in, perm_out, n, tiles, hist, (uint32_t *)nullptr, totals, rows);
 }
 void launch_radix_pass_keyed(const uint32_t *key_in, uint32_t *key_out, uint32_t shift, uint32_t bits, const uint32_t *perm_in, uint32_t *perm_out,
                              uint32_t n, uint32_t *tmp, hipStream_t stream) {
     if (!n) return;
-    const uint32_t tiles = (n + kRadixTile - 1) / kRadixTile;
+    const uint32_t rows = radix_rows(n), tiles = (n + 64 * rows - 1) / (64 * rows);
     const uint32_t mask = (1u << bits) - 1u;
     uint32_t *hist = tmp, *totals = tmp + (size_t)256 * tiles;
-    hipLaunchKernelGGL(k_radix_hist<true>, dim3(tiles), dim3(64), 0, stream, key_in, shift, mask, perm_in, n, tiles, hist);
+    hipLaunchKernelGGL(k_radix_hist<true>, dim3(tiles), dim3(64), 0, stream, key_in, shift, mask, perm_in, n, tiles, hist, rows);
     hipLaunchKernelGGL(k_radix_offsets, dim3(256), dim3(256), 0, stream, hist, tiles, totals);
-    hipLaunchKernelGGL(k_radix_scatter<true>, dim3(tiles), dim3(64), 0, stream, key_in, shift, mask, perm_in, perm_out, n, tiles, hist, key_out, totals);
+    hipLaunchKernelGGL(k_radix_scatter<true>, dim3(tiles), dim3(64), 0, stream, key_in, shift, mask, perm_in, perm_out, n, tiles, hist, key_out, totals, rows);
 }
 
 
