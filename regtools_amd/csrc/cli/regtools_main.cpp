@@ -148,10 +148,10 @@ int junctions_extract(int argc, char **argv) {
         rgx_table_free(t);
         if (ctx) rgx_ctx_destroy(ctx);
     } catch (const HelpRequested &h) {
-        std::cerr << h.text;
+        std::cerr << h.text << std::endl;
         return 0;
     } catch (const std::runtime_error &e) {
-        std::cerr << e.what();
+        std::cerr << e.what() << std::endl;
         return 1;
     }
     return 0;
@@ -183,12 +183,12 @@ int junctions_annotate(int argc, char **argv) {
                 case 'S': skip_single = false; break;
                 case 'o': out = optarg; break;
                 case 'h': { std::ostringstream ss; annotate_usage(ss); throw HelpRequested{ss.str()}; }
-                default: annotate_usage(std::cout); throw std::runtime_error("Error parsing inputs!(1)\n\n");
+                default: annotate_usage(std::cerr); throw std::runtime_error("Error parsing inputs!(1)\n\n");
             }
         }
         std::string bed, ref = "NA", gtf;
         if (argc - optind >= 3) { bed = argv[optind++]; ref = argv[optind++]; gtf = argv[optind++]; }
-        if (optind < argc || ref == "NA" || bed.empty() || gtf.empty()) { annotate_usage(std::cout); throw std::runtime_error("Error parsing inputs!(2)\n\n"); }
+        if (optind < argc || ref == "NA" || bed.empty() || gtf.empty()) { annotate_usage(std::cerr); throw std::runtime_error("Error parsing inputs!(2)\n\n"); }
         std::cerr << "Reference: " << ref << "\nGTF: " << gtf << "\nJunctions: " << bed << "\n" << (skip_single ? "Skipping single exon genes.\n" : "");
         if (out != "NA") std::cerr << "Output file: " << out << "\n";
         std::cerr << "\n";
@@ -200,17 +200,17 @@ int junctions_annotate(int argc, char **argv) {
         if (rc != RGX_OK) throw std::runtime_error(err);
         std::cerr << "\nAnnotated " << n << " lines.\n";
     } catch (const HelpRequested &h) {
-        std::cerr << h.text;
+        std::cerr << h.text << std::endl;
         return 0;
     } catch (const std::runtime_error &e) {
-        std::cerr << e.what();
+        std::cerr << e.what() << std::endl;
         return 1;
     }
     return 0;
 }
 
 int junctions_usage(std::ostream &out) {
-    out << "\nUsage:\t\tregtools junctions <command> [options]\n"
+    out << "Usage:\t\tregtools junctions <command> [options]\n"
         << "Command:\textract\t\tIdentify exon-exon junctions from alignments.\n"
         << "\t\tannotate\tAnnotate the junctions.\n\n";
     return 0;
@@ -223,24 +223,35 @@ int junctions_main(int argc, char **argv) {
         if (sub == "extract") return junctions_extract(argc - 1, argv + 1);
         if (sub == "annotate") return junctions_annotate(argc - 1, argv + 1);
     }
-    return junctions_usage(std::cerr);
+    return junctions_usage(std::cout);
 }
 
 // ---- cis-splice-effects identify (cis_splice_effects_identifier.cc:112-219, cis_splice_effects_main.cc:35-93) -------------
-void identify_usage(std::ostream &out) {
-    out << "Usage:\t\tregtools cis-splice-effects identify [options] variants.vcf alignments.bam ref.fa annotations.gtf\n"
+void space_options(std::ostream &out);
+
+void window_options(std::ostream &out) {
+    out << "\t\t-a INT\tMinimum anchor length. Junctions which satisfy a minimum \n\t\t\t anchor length on both sides are reported. [8]\n"
+        << "\t\t-m INT\tMinimum intron length. [70]\n\t\t-M INT\tMaximum intron length. [500000]\n"
+        << "\t\t-w INT\tWindow size in b.p to identify splicing events in.\n\t\t\t The tool identifies events in variant.start +/- w basepairs.\n"
+        << "\t\t\t Default behaviour is to look at the window between previous and next exons.\n";
+}
+
+void identify_usage(std::ostream &out, bool associate = false) {
+    out << "Usage:\t\tregtools cis-splice-effects " << (associate ? "associate [options] variants.vcf junctions.bed" : "identify [options] variants.vcf alignments.bam") << " ref.fa annotations.gtf\n"
         << "Options:\n"
         << "\t\t-o STR\tOutput file containing the aberrant splice junctions with annotations. [STDOUT]\n"
         << "\t\t-v STR\tOutput file containing variants annotated as splice relevant (VCF format).\n"
-        << "\t\t-j STR\tOutput file containing the aberrant junctions in BED12 format.\n"
-        << "\t\t-s INT\tStrandness mode \n\t\t\t XS, use XS tags provided by aligner; RF, first-strand; FR, second-strand. intron-motif, infer strand using canonical intron motifs. REQUIRED\n"
-        << "\t\t-C\tOverride strand assignments by inferring based on canonical motifs.\n"
-        << "\t\t-t STR\tTag used in bam to label strand. [XS]\n"
-        << "\t\t-a INT\tMinimum anchor length. [8]\n\t\t-m INT\tMinimum intron length. [70]\n\t\t-M INT\tMaximum intron length. [500000]\n"
-        << "\t\t-w INT\tWindow size in b.p to identify splicing events in.\n"
-        << "\t\t-e INT\tMaximum exonic distance from an exon edge. [3]\n\t\t-i INT\tMaximum intronic distance from an exon edge. [2]\n"
-        << "\t\t-I\tAnnotate variants in intronic space within a transcript.\n\t\t-E\tAnnotate variants in exonic space within a transcript.\n"
-        << "\t\t-S\tDon't skip single exon transcripts.\n\n";
+        << "\t\t-j STR\tOutput file containing the aberrant junctions in BED12 format.\n";
+    if (!associate)
+        out << "\t\t-s INT\tStrandness mode \n\t\t\t XS, use XS tags provided by aligner; RF, first-strand; FR, second-strand. intron-motif, infer strand using canonical intron motifs. REQUIRED\n"
+            << "\t\t-C\tOverride strand assignments by inferring based on canonical motifs. Does not need to be specified if passing '-s intron-motif'.\n"
+            << "\t\t-t STR\tTag used in bam to label strand. [XS]\n";
+    window_options(out);
+    space_options(out);
+    if (!associate)
+        out << "\t\t-b STR\tThe file containing the barcodes of interest for single cell data.\n"
+            << "\t\t-C\tTells cis-splice-effects identify that you want intron-motif method to take priority when assigning strand. i.e. decide strandedness based on the fasta rather than what is encoded in the alignment file.\n";
+    out << "\n";
 }
 
 bool file_exists(const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (!f) return false; fclose(f); return true; }
@@ -264,7 +275,7 @@ int cse_identify(int argc, char **argv, bool associate = false) {
                 case 'I': p.all_intronic = 1; break;
                 case 'E': p.all_exonic = 1; break;
                 case 'S': p.skip_single = 0; break;
-                case 'h': { std::ostringstream ss; identify_usage(ss); throw HelpRequested{ss.str()}; }
+                case 'h': { std::ostringstream ss; identify_usage(ss, associate); throw HelpRequested{ss.str()}; }
                 case 's': {
                     std::string s = optarg;
                     if (s == "XS") p.strandness = 0; else if (s == "RF") p.strandness = 1; else if (s == "FR") p.strandness = 2;
@@ -278,12 +289,12 @@ int cse_identify(int argc, char **argv, bool associate = false) {
                 case 'M': p.max_intron = (uint32_t)atoi(optarg); break;
                 case 'b': barcodes = optarg; break;
                 case 'C': p.override_motif = 1; break;
-                default: identify_usage(std::cerr); throw std::runtime_error("Error parsing inputs!(1)\n\n");
+                default: identify_usage(std::cerr, associate); throw std::runtime_error("Error parsing inputs!(1)\n\n");
             }
         }
         std::string vcf = "NA", bam = "NA", ref = "NA", gtf = "NA";
         if (argc - optind >= 4) { vcf = argv[optind++]; bam = argv[optind++]; ref = argv[optind++]; gtf = argv[optind++]; }
-        if (optind < argc || vcf == "NA" || bam == "NA" || ref == "NA" || gtf == "NA") { identify_usage(std::cerr); throw std::runtime_error("Error parsing inputs!(2)\n\n"); }
+        if (optind < argc || vcf == "NA" || bam == "NA" || ref == "NA" || gtf == "NA") { identify_usage(std::cerr, associate); throw std::runtime_error("Error parsing inputs!(2)\n\n"); }
         if (associate) p.strandness = 0;
         if (p.strandness == -1) { identify_usage(std::cerr); throw std::runtime_error("Please supply strand specificity with '-s' option!\n\n"); }
         if (!file_exists(vcf) || !file_exists(bam) || !file_exists(ref) || !file_exists(gtf)) throw std::runtime_error("Please make sure input files exist.\n\n");
@@ -321,24 +332,30 @@ int cse_identify(int argc, char **argv, bool associate = false) {
                     (unsigned long long)st.n_variants, (unsigned long long)st.n_relevant, (unsigned long long)st.n_windows, (unsigned long long)st.n_pairs,
                     (unsigned long long)st.n_junctions, st.ms_total, st.ms_gtf, st.ms_variants, st.ms_extract, st.ms_join, st.ms_annotate, st.ms_output);
     } catch (const HelpRequested &h) {
-        std::cerr << h.text;
+        std::cerr << h.text << std::endl;
         return 0;
     } catch (const std::runtime_error &e) {
-        std::cerr << e.what();
+        std::cerr << e.what() << std::endl;
         return 1;
     }
     return 0;
 }
 
 // ---- variants annotate (variants_annotator.cc:48-110, variants_main.cc) -------------------------------------------------------------
-void variants_usage(std::ostream &out) {
-    out << "Usage:\t\tregtools variants annotate [options] variants.vcf annotations.gtf\n"
-        << "Options:\t-e INT\tMaximum distance from the start/end of an exon to annotate a variant as relevant to splicing, the variant is in exonic space. [3]\n"
-        << "\t\t-i INT\tMaximum distance from the start/end of an exon to annotate a variant as relevant to splicing, the variant is in intronic space. [2]\n"
+void space_options(std::ostream &out) {
+    out << "\t\t-e INT\tMaximum distance from the start/end of an exon \n\t\t\t to annotate a variant as relevant to splicing, the variant \n\t\t\t is in exonic space, i.e a coding variant. [3]\n"
+        << "\t\t-i INT\tMaximum distance from the start/end of an exon \n\t\t\t to annotate a variant as relevant to splicing, the variant \n\t\t\t is in intronic space. [2]\n"
         << "\t\t-I\tAnnotate variants in intronic space within a transcript(not to be used with -i).\n"
         << "\t\t-E\tAnnotate variants in exonic space within a transcript(not to be used with -e).\n"
-        << "\t\t-S\tDon't skip single exon transcripts.\n"
-        << "\t\t-o\tFile to write output to. [STDOUT]\n\n";
+        << "\t\t-S\tDon't skip single exon transcripts.\n";
+}
+
+void variants_usage(std::ostream &out) {
+    out << "Usage:\t\tregtools variants annotate [options] variants.vcf annotations.gtf\n"
+        << "Options:\n"
+        << "\t\t-o FILE\tThe file to write output to. [STDOUT]\n";
+    space_options(out);
+    out << "\n";
 }
 
 int variants_annotate(int argc, char **argv) {
@@ -357,10 +374,10 @@ int variants_annotate(int argc, char **argv) {
                 case 'S': p.skip_single = 0; break;
                 case 'o': out = optarg; break;
                 case 'h': { std::ostringstream ss; variants_usage(ss); throw HelpRequested{ss.str()}; }
-                default: variants_usage(std::cerr); throw std::runtime_error("Error parsing inputs!(1)\n\n");
+                default: variants_usage(std::cout); throw std::runtime_error("Error parsing inputs!(1)\n\n");
             }
         }
-        if (argc - optind < 2) { variants_usage(std::cerr); throw std::runtime_error("Error parsing inputs!(2)\n\n"); }
+        if (argc - optind < 2) { variants_usage(std::cout); throw std::runtime_error("Error parsing inputs!(2)\n\n"); }
         const std::string vcf = argv[optind], gtf = argv[optind + 1];
         p.vcf_path = vcf.c_str(); p.gtf_path = gtf.c_str(); p.out_vcf = out == "NA" ? nullptr : out.c_str();
         std::cerr << "Variant file: " << vcf << "\nGTF file: " << gtf << "\n\n";
@@ -370,10 +387,10 @@ int variants_annotate(int argc, char **argv) {
         rgx_ctx_destroy(ctx);
         if (rc != RGX_OK) throw std::runtime_error(err);
     } catch (const HelpRequested &h) {
-        std::cerr << h.text;
+        std::cerr << h.text << std::endl;
         return 0;
     } catch (const std::runtime_error &e) {
-        std::cerr << e.what();
+        std::cerr << e.what() << std::endl;
         return 1;
     }
     return 0;
@@ -381,7 +398,7 @@ int variants_annotate(int argc, char **argv) {
 
 int variants_main(int argc, char **argv) {
     if (argc > 1 && std::string(argv[1]) == "annotate") return variants_annotate(argc - 1, argv + 1);
-    std::cerr << "\nUsage:\t\tregtools variants <command> [options]\nCommand:\tannotate\tAnnotate variants with splicing information.\n\n";
+    std::cout << "Usage:\t\tregtools variants <command> [options]\nCommand:\tannotate\t\tAnnotate variants with splicing information.\n\n";
     return 0;
 }
 
@@ -391,7 +408,7 @@ int cse_main(int argc, char **argv) {
         if (sub == "identify") return cse_identify(argc - 1, argv + 1);
         if (sub == "associate") return cse_identify(argc - 1, argv + 1, true);
     }
-    std::cerr << "\nUsage:\t\tregtools cis-splice-effects <command> [options]\nCommand:\tidentify\t\tIdentify cis splicing effects.\n\t\tassociate\tAssociate splice junctions (BED12) with cis splicing effects.\n\n";
+    std::cout << "Usage:\t\tregtools cis-splice-effects <command> [options]\nCommand:\tidentify\t\tIdentify cis splicing effects.\n\t\tassociate\tAssociate extracted junctions with variants\n\n";
     return 0;
 }
 

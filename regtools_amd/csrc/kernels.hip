@@ -1389,9 +1389,13 @@ __global__ __launch_bounds__(256) void k_radix_offsets(uint32_t *hist, uint32_t 
     if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
 }
 
+// an upper bound that is MONOTONE in n: a buffer sized for n keys is reused for sorts of fewer keys (the unique rows of a merge), and up to
+// kRadixSmallMax keys take the small tiles, which need four times the histogram words per key of the large ones
 size_t radix_tmp_words(uint32_t n) {
     const size_t tile = 64 * (size_t)radix_rows(n), tiles = ((size_t)n + tile - 1) / tile;
-    return 256 * tiles + 256 + 4;
+    const size_t n_small = std::min<size_t>(n, kRadixSmallMax), tile_small = 64 * (size_t)radix_rows((uint32_t)n_small);
+    const size_t tiles_small = (n_small + tile_small - 1) / tile_small;
+    return 256 * std::max(tiles, tiles_small) + 256 + 4;
 }
 
 // a pass = three launches: per-tile digit counts, per-digit scan over the tiles, scatter

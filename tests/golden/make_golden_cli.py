@@ -1,0 +1,19 @@
+"""Record what the REAL reference (oracle/_ref/regtools_ref = /root/reference/src compiled in place) writes to stdout and stderr for
+the argument lists of tests/test_cli_contract.py -> tests/golden/cli/cli_streams.json.  Run in the dev container:
+    python tests/golden/make_golden_cli.py"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import test_cli_contract as t  # noqa: E402
+
+out = {}
+for argv, rc in t.CASES[t.TOP_LEVEL:]:
+    r = t.run_full(t.REF, argv)
+    assert r[0] == rc, (argv, r)
+    out[t.case_id(argv)] = {"rc": r[0], "stdout": r[1].decode("latin-1"), "stderr": r[2].decode("latin-1")}
+os.makedirs(os.path.join(HERE, "cli"), exist_ok=True)
+json.dump(out, open(os.path.join(HERE, "cli", "cli_streams.json"), "w"), indent=1, sort_keys=True)
+print("%d argument lists recorded" % len(out))

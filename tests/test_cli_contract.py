@@ -1,6 +1,11 @@
-"""the host CLI keeps the reference's subcommands, option letters and exit codes.  Every argument list here
-ends before any device work, so the test runs without a GPU; where the real reference binary is present (dev container,
-oracle/_ref) the exit codes are compared with it directly, elsewhere with the codes recorded from it below."""
+"""the host CLI keeps the reference's subcommands, option letters, exit codes AND streams: which text goes to
+stdout and which to stderr (junctions_main.cc:35-41,96-107; variants_main.cc:33,64; variants_annotator.cc:80,92;
+junctions_annotator.h:235; cis_splice_effects_main.cc:73-93).  Every argument list here ends before any device work, so the test
+runs without a GPU; where the real reference binary is present (dev container, oracle/_ref) exit code, stdout and stderr are
+compared with it directly, and everywhere with the copies of its output committed under tests/golden/cli (made by
+tests/golden/make_golden_cli.py from that binary).  The product's three-line version banner (regtools.cc:36-42 prints upstream's;
+oracle/ref_driver.cc stands in for regtools.cc and prints none) is cut off before stderr is compared."""
+import json
 import os
 import subprocess
 
@@ -34,15 +39,56 @@ CASES = [
     (["cis-splice-effects", "associate", VCF, BED, FA], 1),
     (["cis-splice-effects", "associate", VCF, "/no/such.bed", FA, GTF], 1),
     (["cis-splice-effects", "associate", "-s", "XS", VCF, BED, FA, GTF], 1),            # -s is not an option of associate
+    # round 5: more ways of ending in a usage text, for the streams
+    (["junctions", "nonsense"], 0), (["variants", "nonsense"], 0), (["cis-splice-effects", "nonsense"], 0),
+    (["junctions", "annotate", "-Q", BED, FA, GTF], 1), (["junctions", "annotate", BED, FA, GTF, "extra"], 1),
+    (["variants", "annotate", "-Q", VCF, GTF], 1),
+    (["cis-splice-effects", "identify", "-Q", "-s", "XS", VCF, BAM, FA, GTF], 1),
+    (["cis-splice-effects", "identify", "-s", "XS", VCF, BAM, FA, GTF, "extra"], 1),
+    (["cis-splice-effects", "identify", "-s", "XS"], 1),
+    (["cis-splice-effects", "associate", VCF, BED, FA, GTF, "extra"], 1),
+    (["cis-splice-effects", "associate"], 1),
+    (["junctions", "extract", "-s", "XS", BAM, FA, "extra"], 1),
 ]
+TOP_LEVEL = 3                # the first three lists end in regtools.cc's own usage, which ref_driver.cc replaces: exit codes only
+
+
+def case_id(argv):
+    return " ".join(os.path.basename(a) for a in argv) or "(none)"
+
+
+def strip_banner(err):
+    """the product's banner: an empty line, Program:, Version:"""
+    lines = err.split(b"\n", 3)
+    assert lines[0] == b"" and lines[1].startswith(b"Program:\tregtools") and lines[2].startswith(b"Version:\t"), err[:120]
+    return lines[3] if len(lines) > 3 else b""
+
+
+def run_full(exe, argv):
+    r = subprocess.run([exe] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    return r.returncode, r.stdout.replace(ROOT.encode(), b"@ROOT@"), r.stderr.replace(ROOT.encode(), b"@ROOT@")
 
 
 def run(exe, argv):
-    return subprocess.run([exe] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120).returncode
+    return run_full(exe, argv)[0]
 
 
-@pytest.mark.parametrize("argv,ref_rc", CASES, ids=[" ".join(os.path.basename(a) for a in c[0]) or "(none)" for c in CASES])
+@pytest.mark.parametrize("argv,ref_rc", CASES, ids=[case_id(c[0]) for c in CASES])
 def test_exit_codes_match_the_reference(built, argv, ref_rc):
     if os.path.exists(REF):
         assert run(REF, argv) == ref_rc, "the recorded reference exit code is stale"
     assert run(EXE, argv) == ref_rc
+
+
+@pytest.mark.parametrize("k", range(TOP_LEVEL, len(CASES)), ids=[case_id(c[0]) for c in CASES[TOP_LEVEL:]])
+def test_stdout_and_stderr_bytes_match_the_reference(built, k):
+    argv, ref_rc = CASES[k]
+    gold = json.load(open(os.path.join(GOLD, "cli", "cli_streams.json")))[case_id(argv)]
+    want_out, want_err = gold["stdout"].encode("latin-1"), gold["stderr"].encode("latin-1")
+    if os.path.exists(REF):
+        rc, out, err = run_full(REF, argv)
+        assert (rc, out, err) == (ref_rc, want_out, want_err), "tests/golden/cli is stale: run tests/golden/make_golden_cli.py"
+    rc, out, err = run_full(EXE, argv)
+    assert rc == ref_rc
+    assert out == want_out
+    assert strip_banner(err) == want_err
