@@ -569,6 +569,9 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
                     if (gate_flags) {
                         if (gate_q != copy_q && hipStreamWaitEvent(gate_q, c->chunk_ev[j], 0) != hipSuccess) up.err = 1;
                         launch_gate_set(gate_flags + j, gate_epoch, gate_q);
+                        // (a refused launch is only in THIS thread's hipGetLastError: unread, the flag would never be set and every gated wave
+                        //  would wait out its time-out)
+                        if (hipGetLastError() != hipSuccess) up.err = 1;
                     }
                     o = up.end[j];
                     up.recorded.store((uint32_t)j + 1, std::memory_order_release);
@@ -1231,7 +1234,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             if (spec && iter == 0 && (h_sc[0] != 0xffffffffu || h_sc[kStatusEarly] != 0xffffffffu)) {
                 // some member did not inflate to its footer's length: nothing enqueued since is worth anything
                 mark("inflate verdict: not clean, starting over device-resident");
-                if (gated) c->gate_distrust = true;
+                if (gated) { c->gate_distrust = true; if (trace) fprintf(stderr, "[rgx trace] arrival gate: verdict not clean, this context no longer uses it\n"); }
                 HIP_TRY(join_B());
                 HIP_TRY(complete_upload());
                 HIP_TRY(hipStreamSynchronize(copy_q));
@@ -1322,11 +1325,20 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             const int rcJ = frame(sJ, sA, ended_J);
             if (rcJ != -1) return rcJ;
             const uint32_t n_rec_J = h_sc[3];
+            // Where the last record that STARTS in the prefix ends = the verified chain's exit from its last segment.  The margin between the prefix
+            // and the part of the arena still being inflated is one member; a record that reaches past it (a CIGAR of tens of thousands of
+            // operations, a read of tens of kilobases) would be decoded from bytes that may not be there yet: such a file takes the one-pass order.
+            uint64_t exit_J = 0;
+            HIP_TRY(hipMemcpyAsync(h_sc + 92, seg_exit[cur] + (sJ - 1), 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            memcpy(&exit_J, h_sc + 92, 8);
+            const bool reaches_J = exit_J > ep.upos;
+            if (reaches_J && trace) fprintf(stderr, "[rgx trace] early tail: a record of the prefix ends at %llu, behind the inflated part (%llu): one pass\n", (unsigned long long)exit_J, (unsigned long long)ep.upos);
             const bool slow_J = P.framing_sweeps - sweeps0 > 2;
             P.framing_sweeps = sweeps0;                               // (the sweeps over everything, below, are the call's count)
             const uint64_t span_J = (uint64_t)sJ * seg_bytes;
-            if (h_sc[83]) c->early_distrust = true;
-            if (h_sc[83] || ended_J || slow_J || !n_rec_J || span_J / n_rec_J > kSparseRecordBytes ||
+            if (h_sc[83]) { c->early_distrust = true; if (trace) fprintf(stderr, "[rgx trace] early tail: a wait for a part's waves timed out, this context no longer uses it\n"); }
+            if (h_sc[83] || ended_J || slow_J || reaches_J || !n_rec_J || span_J / n_rec_J > kSparseRecordBytes ||
                 (sA && n_rec_J > soa_cap)) { early = false; sA = 0; emit_parts_ok = false; emit_parts = 0; emit_rows = 0; break; }     // not the plain case: one pass over everything below
             if (!sA) {
                 // rows for the whole file, estimated from the first part (+ 1/8); when the estimate turns out short the decode is simply made again below

@@ -250,6 +250,16 @@ RGX_HD void expand_run(u32x4 &v0, u32x4 &v1, u32x4 &v2, u32x4 &v3, uint32_t d /*
     v0 = u32x4{(uint32_t)xl, (uint32_t)(xl >> 32), (uint32_t)xh, (uint32_t)(xh >> 32)};
 }
 
+// the two chunks cut by a member's ends, byte by byte (twice per member): a CALL -- inlined, this loop stood at every one of the eighteen places of the
+// symbol loop that can complete a chunk, and its bookkeeping took scalar registers the loop needed (61 of them spilled to lanes of a vector register)
+static RGX_COLD void store_chunk_edge(uint8_t *out, uint32_t cap, int32_t cb, uint64_t l, uint64_t h) {
+#pragma nounroll
+    for (int i = 0; i < 16; ++i) {
+        const int32_t m = cb + i;
+        if (m >= 0 && (uint32_t)m < cap) out[m] = (uint8_t)((i < 8 ? l >> (8 * i) : h >> (8 * (i - 8))) & 0xff);
+    }
+}
+
 struct OutStage {
     uint8_t *out; uint32_t cap, a;
     uint64_t lo, hi;
@@ -264,13 +274,7 @@ struct OutStage {
             u32x4 v = {(uint32_t)l, (uint32_t)(l >> 32), (uint32_t)h, (uint32_t)(h >> 32)};
             *(u32x4 *)(out + cb) = v;                                      // 16-byte aligned by construction
         } else {
-            // (only the two chunks cut by the member's ends get here: kept a LOOP -- unrolled, sixteen predicated byte stores were inlined at every site
-            //  that can complete a chunk)
-#pragma nounroll
-            for (int i = 0; i < 16; ++i) {
-                const int32_t m = cb + i;
-                if (m >= 0 && (uint32_t)m < cap) out[m] = (uint8_t)((i < 8 ? l >> (8 * i) : h >> (8 * (i - 8))) & 0xff);
-            }
+            store_chunk_edge(out, cap, cb, l, h);                          // (only the two chunks cut by the member's ends get here)
         }
     }
     // make memory agree with the stage up to o (a copy is about to read bytes that are still in registers)

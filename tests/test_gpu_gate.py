@@ -76,3 +76,62 @@ def test_gated_launch_equals_the_oracle(gpu_ctx, tmp_path, chunks):
             assert (one["rc"] == 0) == (rc == 0), (j["bam"], one["rc"], rc)
             if rc == 0:
                 assert one["bed"].encode("latin1") == exp, (j["bam"], j["args"])
+
+
+def test_early_tail_with_records_longer_than_its_margin(gpu_ctx, tmp_path):
+    """The early tail frames and decodes the front of the arena while the members behind it still inflate; its margin is one member (64 KiB).
+    A record that STARTS in the prefix and ends more than a member behind it (a CIGAR of tens of thousands of operations) must not be decoded
+    from bytes that are not there yet: the call has to notice (the verified chain's exit from the prefix) and take the one-pass order.  A
+    short-read file with one ~190 KB record laid across every boundary an early part can end on (multiples of 1,024 members: every member of
+    the file inflates to 0xff00 bytes, so those boundaries are known arena offsets)."""
+    import struct
+    import bamio
+    from regtools_amd import synth
+    src = str(tmp_path / "short.bam")
+    synth.write(src, 1_200_000, shape="short", seed=9)
+    inflated = bamio.inflate_all(src)
+    contigs, _ = bamio.split_records(inflated[: 1 << 16] + b"")       # (header only: the record list of the cut-off copy is not used)
+    hdr_len = len(bamio.header_bytes(contigs))
+    # upstream's header text may differ from bamio's: measure the header the file has
+    l_text = struct.unpack_from("<i", inflated, 4)[0]
+    q = 12 + l_text
+    for _ in range(struct.unpack_from("<i", inflated, 8 + l_text)[0]):
+        q += 8 + struct.unpack_from("<i", inflated, q)[0]
+    hdr_len = q
+    n_ops = 10000
+    cigar = [(8, 0), (75, 3)] * n_ops + [(8, 0)]
+    block, targets = 0xff00, []
+    n_hdr_members = (hdr_len + block - 1) // block
+    out, off, k = [], hdr_len, 1
+    # bamio.write_bam cuts the header into its own members and the record stream every 0xff00 bytes: member 1024 k starts at this stream offset
+    boundary = lambda kk: (1024 * kk - n_hdr_members) * block
+    pos, n_long, prev = hdr_len, 0, None
+    while pos + 4 <= len(inflated):
+        bs = struct.unpack_from("<i", inflated, pos)[0]
+        rec = inflated[pos: pos + 4 + bs]
+        stream_off = off - hdr_len
+        if prev is not None and stream_off >= boundary(k) - 150_000:
+            tid, p0 = struct.unpack_from("<ii", prev, 4)
+            long_rec = bamio.record(tid, p0, cigar, flag=99, qname="long%04d" % k, aux=bamio.tagA("XS", "+"))
+            assert len(long_rec) > 150_000 + 65536
+            out.append(long_rec); off += len(long_rec); n_long += 1; k += 1
+        out.append(rec); off += len(rec); prev = rec
+        pos += 4 + bs
+    assert n_long >= 3, n_long
+    p = str(tmp_path / "longtail.bam")
+    bamio.write_bam(p, contigs, out, level=1)
+    synth.index(p)
+    jobs = [dict(bam=p, kw=dict(strandness=0), args=["-s", "XS"]), dict(bam=src, kw=dict(strandness=0), args=["-s", "XS"])]
+    jf, of = str(tmp_path / "jobs.json"), str(tmp_path / "out.json")
+    json.dump(jobs, open(jf, "w"))
+    env = dict(os.environ, REGTOOLS_AMD_OVERLAP_MIN="0", REGTOOLS_AMD_INFLATE="coop", REGTOOLS_AMD_GATE_CHUNKS="16", REGTOOLS_AMD_TRACE="1", REGTOOLS_AMD_EARLY_TAIL_MIN="1", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", CHILD, jf, of], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert b"early tail: part" in r.stderr, r.stderr.decode()[-2000:]
+    assert b"behind the inflated part" in r.stderr, "no long record lay across an early part's end: the test's file misses its purpose\n" + r.stderr.decode()[-3000:]
+    got = json.load(open(of))
+    for j, res in zip(jobs, got):
+        rc, exp, _ = run_oracle(j["args"] + [j["bam"]])
+        assert rc == 0
+        for one in res:
+            assert one["rc"] == 0 and one["bed"].encode("latin1") == exp, j["bam"]
