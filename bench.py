@@ -44,14 +44,57 @@ def committed_traffic(key, kernel, alg_bytes):
         if pm.get("kernel") != kernel or abs(pm["algorithmic_bytes"] - alg_bytes) > 1e-3 * alg_bytes:
             return {"traffic": None}
         t = (pm["FETCH_SIZE_KiB"] + pm["WRITE_SIZE_KiB"]) * 1024.0
-        return {"traffic": t,
+        return {"traffic": (2 * pm["FETCH_SIZE_KiB"] + pm["WRITE_SIZE_KiB"]) * 1024.0, "traffic_uncorrected": t,
                 "traffic_source": "profiles/r04_pmc_traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel on this workload, tools/pmc_traffic_r4.sh; "
                                   "a committed measurement, not taken in this run)" % key,
-                "traffic_note": "(FETCH_SIZE + WRITE_SIZE) KiB, uncorrected = %.1f x the algorithmic bytes; with the guide's x2 on FETCH_SIZE = %.1f x (the x2 is calibrated for wide "
-                                "coalesced streams -- profiles/r03_pmc_tail_kernels.json -- not for this kernel's 16-byte requests of 64 lanes in 64 lines: the truth lies between)"
-                                % (t / alg_bytes, ((2 * pm["FETCH_SIZE_KiB"] + pm["WRITE_SIZE_KiB"]) * 1024.0) / alg_bytes)}
+                "traffic_note": "traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 = %.1f x the algorithmic bytes (the guide's gfx950 correction); uncorrected %.1f x (the x2 is "
+                                "calibrated for wide coalesced streams -- profiles/r03_pmc_tail_kernels.json -- not for this kernel's 16-byte requests of 64 lanes in 64 lines: the truth lies between)"
+                                % (((2 * pm["FETCH_SIZE_KiB"] + pm["WRITE_SIZE_KiB"]) * 1024.0) / alg_bytes, t / alg_bytes)}
     except Exception:
         return {"traffic": None}
+
+
+def live_traffic(bam, n_reads, kernel, alg_bytes, extra_args=()):
+    """HBM-side traffic of the DEFLATE launch measured IN THIS RUN: two separate `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE -- they do not fit
+    one pass, MI355X_MICROARCH.md PMC slots) over tools/inflate_bench.py, which launches the same kernel symbol on this very file through the stage entry
+    point (rgx_k_inflate_form 4) and checks a sample of members against zlib.  Units and correction as the guide's HBM section prescribes: the counters
+    are KiB, and on gfx950 FETCH_SIZE tallies 128-byte fabric requests at 64 bytes -- doubled before it is compared with a byte count.  None when
+    rocprofv3 is not on the PATH or a pass fails (the caller then quotes the committed measurement and says so)."""
+    import csv
+    import glob
+    import shutil
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    short = kernel.split("::")[-1].split("<")[0]
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            path = os.path.join(td, "w.bam")
+            with open(path, "wb") as f:
+                f.write(bam)
+            vals = {}
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(td, ctr)
+                cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
+                       os.path.join(ROOT, "tools", "inflate_bench.py"), "--reads", str(n_reads), "--forms", "4", "--reps", "2", "--bam", path] + list(extra_args)
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+                got = []
+                for fcsv in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                    for row in csv.DictReader(open(fcsv)):
+                        if short in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                            got.append(float(row["Counter_Value"]))
+                if r.returncode != 0 or not got:
+                    return None
+                vals[ctr] = sum(got) / len(got)
+        fetch, write = vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
+        return {"traffic": 2.0 * fetch + write, "traffic_uncorrected": fetch + write, "FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals["WRITE_SIZE"],
+                "traffic_source": "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over tools/inflate_bench.py launching %s on this file "
+                                  "(average of its launches)" % kernel,
+                "traffic_note": "traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 = %.1f x the algorithmic bytes -- gfx950's FETCH_SIZE counts 128-byte requests at 64 bytes "
+                                "(MI355X_MICROARCH.md, HBM); uncorrected %.1f x.  The doubling is calibrated on wide coalesced streams (profiles/r03_pmc_tail_kernels.json); this "
+                                "kernel's reads are 16-byte requests of 64 lanes in 64 lines, so the truth lies between the two" % ((2 * fetch + write) / alg_bytes, (fetch + write) / alg_bytes)}
+    except Exception:
+        return None
 
 
 def cpu_baseline(bam_path, n_reads, n_events):
@@ -232,6 +275,7 @@ def main():
                     help="N > 1: 'ranks' = one process per GPU, torch.distributed over RCCL (what torchrun launches; the default); 'cpp' = THIS process drives "
                          "all N devices through rgx_extract_multi (the C++ host of the CLI: a thread per device, one RCCL gather); without torchrun only")
     ap.add_argument("--dump-bed", default=None, help="(tests) rank 0 writes the last step's BED12 here")
+    ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes (the line then quotes the committed measurement)")
     args = ap.parse_args()
     if args.multi_host == "cpp" and args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         return main_cpp_host(args)
@@ -274,9 +318,11 @@ def main():
     pin = regtools_amd.PinnedBuffer(bam)
 
     merge_ms = []
+    launch_ms_in_step = []                 # the arrival-gated DEFLATE launch of every timed step (its own HIP events on the stream it runs on)
 
     def step():
         je.identify_junctions_from_BAM(bai_bytes=bai, host_ptr=pin.ptr, host_len=len(bam))
+        launch_ms_in_step.append(je.stats.get("ms_inflate_launch", 0.0))
         if world > 1:
             tm = time.time()
             m = rdist.gather_and_merge(je, min_anchor=8)
@@ -294,6 +340,7 @@ def main():
         step()
     fence()
     del merge_ms[:]
+    del launch_ms_in_step[:]
     t0 = time.time()
     last = None
     for _ in range(args.steps):
@@ -384,9 +431,13 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         # HBM-side traffic of the same kernel from rocprofv3 PMC passes (tools/pmc_traffic.sh; separate --pmc runs of this
         # very command).  Only quoted when the committed measurement was taken on this exact workload.
-        tr = committed_traffic("long10M" if args.shape == "long" else "realistic" if args.realistic else "default", inflate_kernel_for(s["compressed_bytes"], s["inflated_bytes"]), alg_bytes) \
-            if world == 1 else {"traffic": None}
+        tr = {"traffic": None}
+        if world == 1:
+            kname = inflate_kernel_for(s["compressed_bytes"], s["inflated_bytes"])
+            tr = (None if args.no_live_traffic else live_traffic(bam, n_reads, kname, alg_bytes, (["--realistic"] if args.realistic else []) + (["--shape", "long"] if args.shape == "long" else []))) \
+                or committed_traffic("long10M" if args.shape == "long" else "realistic" if args.realistic else "default", kname, alg_bytes)
         traffic, traffic_note, traffic_source = tr.get("traffic"), tr.get("traffic_note"), tr.get("traffic_source")
+        k_in_step = [x for x in launch_ms_in_step if x > 0]
         line = {
             "metric": "alignments/sec + junctions/sec, junctions extract, 1/2/4/8 MI355X",
             "value": aln_per_s, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -408,7 +459,12 @@ def main():
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "input_generation_s": round(t_gen, 2),
             "roofline": {"bound": "hbm", "kernel": inflate_kernel_for(s["compressed_bytes"], s["inflated_bytes"]), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source, "traffic_note": traffic_note, "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
+                         "traffic": traffic, "traffic_uncorrected": tr.get("traffic_uncorrected"), "traffic_source": traffic_source, "traffic_note": traffic_note,
+                         "kernel_ms": k_ms, "kernel_ms_is": "the whole-file launch of the device-resident pass (HIP events on the pipeline's stream): what achieved / frac are quoted on",
+                         "kernel_ms_in_step": (sum(k_in_step) / len(k_in_step)) if k_in_step else None,
+                         "kernel_ms_in_step_is": "the arrival-gated launch the TIMED step runs (same kernel under its PIECE symbol, HIP events on its own stream): it spans the upload -- "
+                                                 "its waves wait for the chunk their members lie in -- so its duration is not a rate of the kernel",
+                         "algorithmic_bytes": alg_bytes,
                          "note": "DEFLATE is a serial bit stream per member: one lane per member (long matches copied by the wave), bound by per-lane dependent ALU/LDS chains, the L1's rate of scattered per-lane accesses and one memory round trip per symbol trip, far below the HBM line (SURVEY 8d; DESIGN.md 5)",
                          "pipeline_frac": aln_per_s / world * (alg_bytes / n_reads) / (HBM_PEAK_GBS * 1e9)},
         }

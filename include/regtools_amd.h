@@ -96,6 +96,9 @@ typedef struct {
      * that does not inflate, an empty member, an unreadable record) instead of reaching the shard's upper cut.  The merges ignore the
      * shards behind such a one: a later shard is a seek past the damage, a sequential reader never gets there. */
     uint64_t   stream_ended;
+    double     ms_inflate_launch;   /* statistics: the whole-range DEFLATE launch alone, HIP events on the stream it ran on (0 = the range went up as several
+                                     * launches).  Host input: the arrival-gated launch -- it spans the upload, its waves wait for their chunk; ms_inflate
+                                     * is the pipeline stream's stage time, which with the early tail no longer covers that launch */
 } rgx_junction_table;
 
 int  rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errlen);

@@ -32,7 +32,8 @@ class JunctionTable(C.Structure):
                 ("ms_scan", C.c_double), ("ms_reduce", C.c_double),
                 ("first_seen", C.POINTER(C.c_uint64)), ("last_seen", C.POINTER(C.c_uint64)), ("framing_sweeps", C.c_uint64),
                 ("bc_row_begin", C.POINTER(C.c_uint64)), ("bc_count", C.POINTER(C.c_uint32)), ("bc_str_begin", C.POINTER(C.c_uint64)),
-                ("bc_text", C.POINTER(C.c_char)), ("bc_insert_rank", C.POINTER(C.c_uint32)), ("ms_barcodes", C.c_double), ("stream_ended", C.c_uint64)]
+                ("bc_text", C.POINTER(C.c_char)), ("bc_insert_rank", C.POINTER(C.c_uint32)), ("ms_barcodes", C.c_double), ("stream_ended", C.c_uint64),
+                ("ms_inflate_launch", C.c_double)]
 
 
 class Member(C.Structure):

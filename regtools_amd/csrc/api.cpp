@@ -98,7 +98,25 @@ struct DevBuf {
 
 }  // namespace
 
-constexpr int kSideStreams = 6;
+constexpr int kSideStreams = 2;
+// REGTOOLS_AMD_OVERLAP="min_bytes[,chunks[,early_min_members]]" (tests): the thresholds of the overlapped upload, so that files of test size take the path
+// the 533 MB bench file takes -- from how many bytes a host buffer goes up in chunks behind ONE arrival-gated inflate launch (default 8 MiB), in how many
+// chunks (16), and from how many members an early-tail part is worth cutting (4096; giving it also lifts the part's minimum of 1,024 segments).
+struct OverlapKnobs { size_t min_bytes = (size_t)8 << 20; unsigned chunks = 16; uint32_t early_min = 4096; bool early_small = false; };
+static const OverlapKnobs &overlap_knobs() {
+    static const OverlapKnobs k = [] {
+        OverlapKnobs v;
+        if (const char *e = getenv("REGTOOLS_AMD_OVERLAP")) {
+            long long a = -1, b = -1, c2 = -1;
+            const int n = sscanf(e, "%lld,%lld,%lld", &a, &b, &c2);
+            if (n >= 1 && a >= 0) v.min_bytes = (size_t)a;
+            if (n >= 2 && b >= 2) v.chunks = (unsigned)std::min<long long>(b, 64);
+            if (n >= 3 && c2 >= 1) { v.early_min = (uint32_t)c2; v.early_small = true; }
+        }
+        return v;
+    }();
+    return k;
+}
 struct rgx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -113,6 +131,7 @@ struct rgx_ctx {
     uint32_t gate_epoch = 0;                           // arrival gate of the overlapped upload (kernels.h InflateGate): this context's call counter
     hipEvent_t ev_ready = nullptr, ev_side[kSideStreams] = {}, ev_packed = nullptr;
     hipEvent_t ev[8] = {};
+    hipEvent_t ev_launch[2] = {}; bool launch_timed = false;   // around the call's whole-range DEFLATE launch, on the stream it runs on (host input: the arrival-gated launch, which spans the upload)
     std::map<std::string, DevBuf> bufs;
     void *pinned = nullptr; size_t pinned_cap = 0;     // small pinned staging for scalar readbacks
     std::vector<Member> hm_scratch;
@@ -189,6 +208,7 @@ extern "C" int rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errle
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     { const char *e = getenv("REGTOOLS_AMD_ONE_SHOT"); c->one_shot = e && strcmp(e, "0") != 0; }
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto &e : c->ev_launch) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
     c->pinned_cap = 4096;
     *out = c;
@@ -205,17 +225,11 @@ static hipError_t ensure_upload_streams(rgx_ctx *c) {
     if (c->one_shot) return hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
     hipError_t e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     if (e != hipSuccess) return e;
-    // the runtime maps the streams of one priority onto four hardware queues; streams of another priority come from another pool of queues
-    int pr_least = 0, pr_greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
-    const int prio[kSideStreams] = {0, 0, pr_greatest, pr_greatest, pr_least, pr_least};
-    // (three pieces: two side streams + the pipeline's own; REGTOOLS_AMD_PIECES may ask for more.  REGTOOLS_AMD_EARLY_TAIL_PRIO=1: a third one, of the
-    //  greatest priority, for the early tail's second inflate launch -- the members that arrive last are what the call waits for)
-    static const bool early_prio = [] { const char *e = getenv("REGTOOLS_AMD_EARLY_TAIL_PRIO"); return e && atoi(e) != 0; }();      // (measured: 26.8-26.9 ms per step with it, 26.0-26.1 without: off)
-    const unsigned want = early_prio ? 3 : 2;
+    // (the runtime maps the streams of one priority onto four hardware queues)
+    // two side streams + the pipeline's own (measured and not kept, round 4: a third one of the greatest priority for the early tail's launch, +0.8 ms;
+    // four to seven pieces on streams of other priorities, no gain: DESIGN.md 4.4)
     for (int k = 0; k < kSideStreams; ++k) {
-        if ((unsigned)k >= want && !getenv("REGTOOLS_AMD_PIECES")) break;
-        if ((e = hipStreamCreateWithPriority(&c->side[k], hipStreamNonBlocking, prio[k])) != hipSuccess) return e;
+        if ((e = hipStreamCreateWithPriority(&c->side[k], hipStreamNonBlocking, 0)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&c->ev_side[k], hipEventDisableTiming)) != hipSuccess) return e;
     }
     return hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
@@ -227,6 +241,7 @@ extern "C" void rgx_ctx_destroy(rgx_ctx *c) {
     (void)hipSetDevice(c->device);
     for (auto &kv : c->bufs) kv.second.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_launch) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->chunk_ev) if (e) (void)hipEventDestroy(e);
     ktime_collect(c);
     for (auto &e : c->kfree) (void)hipEventDestroy(e);
@@ -471,10 +486,8 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         HIP_TRY(b.ensure(bam_len + 64));
         d_bam = b.as<uint8_t>();
         mark("file buffer in HBM");
-        static const bool no_overlap = getenv("REGTOOLS_AMD_NO_OVERLAP") != nullptr;
-        // (REGTOOLS_AMD_OVERLAP_MIN: tests send small files through the overlapped path)
-        static const size_t overlap_min = [] { const char *e = getenv("REGTOOLS_AMD_OVERLAP_MIN"); return e ? (size_t)atoll(e) : (size_t)8 << 20; }();
-        if (allow_overlap && !d_true_sizes && !no_overlap && bam_len >= overlap_min) {
+        const size_t overlap_min = overlap_knobs().min_bytes;
+        if (allow_overlap && !d_true_sizes && bam_len >= overlap_min) {
             HIP_TRY(ensure_upload_streams(c));
             if (c->copy_stream) copy_q = c->copy_stream;
             mark("upload streams");
@@ -507,10 +520,9 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             // the file goes up in kGateChunks equal chunks, a 4-byte copy of this call's epoch into the chunk's flag word queued right behind each.
             // The members of the early chunks start ~0.6 ms into the upload; only those of the last chunk pay the lane-serial floor behind it
             // (round 3: three launches, each ~10 ms for a third of the members, the last one started when the last third had arrived).
-            // REGTOOLS_AMD_GATE=0, REGTOOLS_AMD_PIECES or a one-shot context: round 3's pieces.
-            static const bool gate_off = [] { const char *e = getenv("REGTOOLS_AMD_GATE"); return e && !strcmp(e, "0"); }();
-            static const unsigned gate_chunks = [] { const char *e = getenv("REGTOOLS_AMD_GATE_CHUNKS"); const int v = e ? atoi(e) : 16; return (unsigned)std::min(std::max(v, 2), 64); }();
-            gated = !gate_off && !c->gate_distrust && !c->one_shot && !getenv("REGTOOLS_AMD_PIECES") && up_hi - up_lo >= std::min(overlap_min, (size_t)8 << 20) && up_hi - up_lo >= 2 * 4096 * (size_t)gate_chunks;
+            // A one-shot context, or one whose gate once gave an unclean verdict: round 3's pieces.
+            const unsigned gate_chunks = overlap_knobs().chunks;
+            gated = !c->gate_distrust && !c->one_shot && up_hi - up_lo >= std::min(overlap_min, (size_t)8 << 20) && up_hi - up_lo >= 2 * 4096 * (size_t)gate_chunks;
             if (gated) {
                 // ... for payloads whose inflate is of the upload's order (measured: bench payload 27.5 -> 26.5 ms, random bases + qualities 98.2 ->
                 // 93.7); run-length payloads (long reads: 1 GB of file, 65 GB inflated, five rounds of waves) lose 5-6 ms of 158 to it and keep
@@ -529,14 +541,8 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             // small -- one lane per member).  Equal thirds measured best: 31.6 ms per step against 32.4-33.3 ms for pieces that shrink towards
             // the end, and 30.9-31.5 ms for four to six equal pieces on side streams of other priorities (= other queue pools), 32.6 for seven
             // (tools/lab/pieces.sh): the concurrent launches share the chip, finer pieces do not end sooner.
-            // REGTOOLS_AMD_PIECES="33,67" = the cuts in %, or "N" = N equal pieces, for experiments.
             std::vector<unsigned> cuts = {33, 67};
             if (c->one_shot) cuts.clear();                            // (one stream: pieces would only take turns on it)
-            if (const char *e = getenv("REGTOOLS_AMD_PIECES")) {
-                unsigned a = 0, b = 0;
-                if (sscanf(e, "%u,%u", &a, &b) == 2) { if (a > 0 && a < b && b < 100) cuts = {a, b}; }
-                else if (sscanf(e, "%u", &a) == 1 && a >= 1 && a <= (unsigned)kSideStreams + 1) { cuts.clear(); for (unsigned k = 1; k < a; ++k) cuts.push_back(100 * k / a); }
-            }
             if (gated) {
                 gate_chunk = (((up_hi - up_lo) + gate_chunks - 1) / gate_chunks + 4095) & ~(size_t)4095;
                 for (size_t e = up_lo + gate_chunk; e < up_hi; e += gate_chunk) up.end.push_back(e);
@@ -555,8 +561,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             up.copy_stream = copy_q;
             uint32_t *gate_flags = gated ? c->buf("gate_flags").as<uint32_t>() : nullptr;
             const uint32_t gate_epoch = c->gate_epoch;
-            static const int env_gate_side = [] { const char *e = getenv("REGTOOLS_AMD_GATE_SIDE"); return e ? atoi(e) : 1; }();
-            hipStream_t gate_q = env_gate_side && c->side[0] ? c->side[0] : copy_q;
+            hipStream_t gate_q = c->side[0] ? c->side[0] : copy_q;
             up.th = std::thread([c, dst, h_bam, hdr_hi, up_lo, copy_q, gate_q, gate_flags, gate_epoch, &up] {
                 if (hipSetDevice(c->device) != hipSuccess) { up.err = 1; up.recorded = (uint32_t)up.end.size(); return; }
                 if (hdr_hi && hipMemcpyAsync(dst, h_bam, hdr_hi, hipMemcpyHostToDevice, copy_q) != hipSuccess) up.err = 1;
@@ -876,7 +881,14 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // (every way out of this function while the side stream's launch may still run -- an error in the prefix's framing, say: the next call on this
     //  context must not meet it)
     struct SideGuard { bool &pending; hipEvent_t &ev; ~SideGuard() { if (pending && ev) (void)hipEventSynchronize(ev); } } side_guard{split_B, split_ev};
-    if (!overlap) launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below, 0, false, 0, d_bad, pairs);
+    c->launch_timed = false;
+    auto timed_launch = [&](hipStream_t q, bool piece, InflateGate gate) {      // the call's whole-range launch, with its own pair of events on its own stream
+        (void)hipEventRecord(c->ev_launch[0], q);
+        launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, q, ignore_below, 0, piece, 0, d_bad, pairs, false, gate);
+        (void)hipEventRecord(c->ev_launch[1], q);
+        c->launch_timed = true;
+    };
+    if (!overlap) timed_launch(st, false, InflateGate());
     else {
         // one launch per upload chunk, on the side streams: the members whose bytes (plus the decoder's 16-byte look-ahead) have arrived with
         // chunk j start as soon as its event fires, next to the launches of the chunks before it
@@ -890,7 +902,6 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             if (inflate_takes_coop(n_range)) {
                 InflateGate gate;
                 gate.flags = c->buf("gate_flags").as<uint32_t>(); gate.epoch = c->gate_epoch; gate.n_chunks = (uint32_t)up.end.size(); gate.lo = up.lo; gate.chunk_bytes = gate_chunk;
-                { static const int env_prio = [] { const char *e = getenv("REGTOOLS_AMD_GATE_PRIO"); return e ? atoi(e) : 0; }(); gate.prio = (uint32_t)env_prio; }
                 // Round 4, second half ("early tail"): the launch goes to a side stream and counts its finished waves per PART of the member list
                 // (parts cut where upload chunks end, at multiples of the lane-sorting group); the pipeline's stream waits for part after part
                 // (launch_wait_done) and frames, verifies and decodes the part of the arena behind it while the waves of the later parts still
@@ -903,7 +914,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
                     for (unsigned x : {a, b2, c2}) if ((int)v.size() < n && x > 0 && x < 16 && (v.empty() || x > v.back())) v.push_back(x);
                     return v;
                 }();
-                static const uint32_t early_min = [] { const char *e = getenv("REGTOOLS_AMD_EARLY_TAIL_MIN"); return e ? (uint32_t)atoi(e) : 4096u; }();     // (tests: small files)
+                const uint32_t early_min = overlap_knobs().early_min;
                 if (!env_cuts.empty() && !c->early_distrust && c->side[1] && up.end.size() >= 8 && !d_bad && !d_true_sizes) {
                     const uint32_t align = kInflateSortGroup;          // (a wave's members all come from one group of that many)
                     for (unsigned cut : env_cuts) {
@@ -924,16 +935,15 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
                     HIP_TRY(hipMemsetAsync(d_done, 0, 32, q));
                     gate.done = d_done;
                     for (size_t j = 0; j < early_parts.size(); ++j) gate.part_start[j] = early_parts[j].waves;
-                    launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, q, ignore_below, 0, /*piece=*/true, 0, d_bad, pairs, false, gate);
+                    timed_launch(q, /*piece=*/true, gate);
                     HIP_TRY(hipEventRecord(c->ev_side[1], q));
                     split_ev = c->ev_side[1];
                     split_B = true;
-                } else
-                launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below, 0, /*piece=*/true, 0, d_bad, pairs, false, gate);
+                } else timed_launch(st, /*piece=*/true, gate);
             } else {
                 while (up.recorded.load(std::memory_order_acquire) < up.end.size()) std::this_thread::yield();
                 HIP_TRY(hipStreamWaitEvent(st, c->chunk_ev[up.end.size() - 1], 0));
-                launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, st, ignore_below, 0, false, 0, d_bad, pairs);
+                timed_launch(st, false, InflateGate());
             }
             g_lo = m_hi;
         }
@@ -1140,7 +1150,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // chunk c = virtual offsets [u, v): a seek to u (bgzf_seek: the member at u >> 16, the offset inside it clipped to its length; no such
     // member = the read fails and the iteration is over), then records while the position in front of the next one is below v.
     SegGeom geom; memset(&geom, 0, sizeof geom);
-    static const int env_seg = [] { const char *e = getenv("REGTOOLS_AMD_SEG_BYTES"); return e ? atoi(e) : 0; }();      // (tests / lab) 16384 or 131072
+    const int env_seg = decode_knobs().seg_bytes;                   // (tests) 16384 or 131072
     const uint32_t seg_bytes = env_seg == (int)kSegBytes || env_seg == (int)kSegBytesLong ? (uint32_t)env_seg : (mean_rec >= kLongRecordBytes ? kSegBytesLong : kSegBytes);
     geom.seg_bytes = seg_bytes;
     std::vector<SegChunk> seg_chunks;
@@ -1195,7 +1205,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     uint64_t span = lim - pos0;
     uint32_t n_seg = (uint32_t)((span + seg_bytes - 1) / seg_bytes);
     geom.pos0 = pos0; geom.lim = lim; geom.data_end = lim; geom.seg_bytes = seg_bytes;
-    static const int env_lite = [] { const char *e = getenv("REGTOOLS_AMD_LITE_WALK"); return e ? atoi(e) : 1; }();
+    const int env_lite = 1;
     const bool lite_walk = env_lite && !c->walk_strict;
     geom.lite_walk = lite_walk ? 1u : 0u;
     if (geom.chunks) {
@@ -1304,8 +1314,8 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         seg_iter_e = (uint32_t *)q; q += per * 4; seg_long_e = (uint32_t *)q; q += per * 4; seg_long_base_e = (uint32_t *)q;
         HIP_TRY(b_tmp.ensure(scan_tmp_words(n_seg) * 4 + 64));
         bool early = split_B && spec && !geom.chunks && seg_bytes == kSegBytes && cut_hi == UINT64_MAX && !empty_stream && lim == total;
-        static const bool env_early_emit = [] { const char *e = getenv("REGTOOLS_AMD_EARLY_EMIT"); return !e || atoi(e) != 0; }();
-        static const bool small_ok = getenv("REGTOOLS_AMD_EARLY_TAIL_MIN") != nullptr;
+        const bool env_early_emit = true;
+        const bool small_ok = overlap_knobs().early_small;
         uint32_t waves_done = 0;
         for (size_t j = 0; early && j < early_parts.size(); ++j) {
             const EarlyPart &ep = early_parts[j];
@@ -1527,8 +1537,7 @@ static int reduce_events(rgx_ctx *c, EventSoA ev, uint32_t n_events, uint32_t gr
     if (n_events) {
         // Round 4: equal keys are grouped per tile of consecutive events first (k_preagg); what is sorted and reduced are the tiles' partial
         // rows.  Callers that need every event's row (the -b pass: row_map) keep the event form.
-        static const int env_preagg = [] { const char *e = getenv("REGTOOLS_AMD_PREAGG"); return e ? atoi(e) : 1; }();
-        const bool preagg = !row_map && (env_preagg > 1 || (env_preagg && allow_preagg));     // (REGTOOLS_AMD_PREAGG=2: also where it does not pay, tests)
+        const bool preagg = !row_map && allow_preagg;
         PartialSoA pr; memset(&pr, 0, sizeof pr);
         uint32_t *ev_flag = nullptr;           // preagg: one word per EVENT (first-seen flags, then their scan)
         EventSoA sev = ev;                     // what is sorted: the events, or the partial rows
@@ -1841,6 +1850,8 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     float ms = 0;
     HIP_TRY(hipEventSynchronize(c->ev[6]));
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); t->ms_inflate = ms;
+    t->ms_inflate_launch = 0;
+    if (c->launch_timed && hipEventSynchronize(c->ev_launch[1]) == hipSuccess && hipEventElapsedTime(&ms, c->ev_launch[0], c->ev_launch[1]) == hipSuccess) t->ms_inflate_launch = ms;
     (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[4]); t->ms_records = ms;
     (void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); t->ms_scan = ms;
     (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); t->ms_reduce = ms;

@@ -131,7 +131,7 @@ std::string GtfModel::load(const std::string &path) {
     // ---- pass 1 (threads): every line -> at most one exon record, filed under the part's own transcript list (first appearance order) ------
     struct LocalTx { View id, attrs, chrom; uint64_t hash; uint8_t strand; uint32_t n; uint32_t global; uint32_t fill; int32_t fill_chrom; };
     struct Part { BigVec<LocalTx> tx; std::vector<View> chroms; BigVec<uint32_t> r_tx, r_s, r_e; size_t err_pos = SIZE_MAX; const char *err = nullptr; };
-    static const unsigned thread_cap = [] { const char *e = getenv("REGTOOLS_AMD_GTF_THREADS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 256 ? (unsigned)v : 32u; }();   // (lab)
+    const unsigned thread_cap = 32u;
     const unsigned hw = usable_threads(thread_cap);
     // (four parts per thread, handed out as threads come free: on a host whose CPU quota is shared with the rest of the call, equal parts do not take equal time)
     size_t n_parts = text_len < (1u << 22) ? 1 : std::min<size_t>((size_t)hw * 4, text_len >> 20);

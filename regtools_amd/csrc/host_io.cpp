@@ -66,7 +66,7 @@ bool scan_members_parallel(const uint8_t *bam, size_t len, int threads, std::vec
     int T = threads < 1 ? 1 : threads;
     // The walk is a chain of dependent cache misses (BSIZE of one member names the next): every thread walks several chains in turn, so that a
     // core keeps as many misses in flight as a dozen threads would -- the ranks of a multi-GPU job share the host's cores.
-    static const int kChains = [] { const char *e = getenv("REGTOOLS_AMD_SCAN_CHAINS"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 64 ? v : 8; }();     // (lab)
+    constexpr int kChains = 8;
     size_t n_seg = (size_t)T * kChains;
     if (n_seg > len / (1u << 19) + 1) n_seg = len / (1u << 19) + 1;           // not worth a chain per few members
     if ((size_t)T > n_seg) T = (int)n_seg;

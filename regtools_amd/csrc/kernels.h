@@ -30,7 +30,6 @@ struct InflateGate {
     // Early tail (round 4): the launch's waves are counted as they finish, by part of the member list -- part j = the waves from part_start[j - 1]
     // (workgroup index; part 0 starts at 0) up to part_start[j] -- so that the pipeline's stream can frame and decode the front parts of the arena
     // (launch_wait_done) while the waves of the later parts still run.  done = null: nobody counts.
-    uint32_t prio = 0;                 // 1: a wave's issue priority (s_setprio 0..3) grows with the upload chunk it waits for
     uint32_t *done = nullptr;          // device memory, kGateParts words, zeroed by the caller in front of the launch
     uint32_t part_start[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
 };
@@ -108,6 +107,10 @@ void launch_member_stop(const Member *members, uint32_t max_members, const uint3
 // chunk's seg_base), its first segment starts exactly at a, its chain is followed up to b, and dlim is where the bytes a reader that
 // started at a can get end (the next empty or unreadable member).  The chunk table lives in HBM; null = the one chain.
 struct SegChunk { uint64_t a, b, dlim; uint32_t seg_base, pad; };
+// REGTOOLS_AMD_DECODE="lane|wave[,seg_bytes]" (tests): long-record files through the workgroup-per-segment decode the lane form replaced, and either
+// segment size (16384 / 131072) forced onto any file -- the extraction tests run the long-record path on short-read files with it.
+struct DecodeKnobs { bool wave_form = false; int seg_bytes = 0; };
+const DecodeKnobs &decode_knobs();
 struct SegGeom {
     uint64_t pos0, lim;
     uint64_t data_end;             // end of the inflated bytes (k_decode_seg's staging window may reach past a chunk's end)

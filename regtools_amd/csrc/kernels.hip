@@ -388,7 +388,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         // (the members of the last chunks are what the call waits for -- their own chain behind the last arrival: their waves issue ahead of the
         //  waves of earlier chunks that share their SIMD)
-        if (gate.prio) { const uint32_t q = need * 4u / gate.n_chunks; if (q >= 3) __builtin_amdgcn_s_setprio(3); else if (q == 2) __builtin_amdgcn_s_setprio(2); else if (q == 1) __builtin_amdgcn_s_setprio(1); }
         if (!arrived) {
             if (have) {
                 const uint32_t mi = m + index_bias;
@@ -548,9 +547,7 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
     // match behind a literal pair in the same trip, bit 2 = runs (distance <= 16) written from registers, 64 bytes a trip (round 4).
     // Same box, interleaved, ms (tools/lab/runs_ab.sh, profiles/r04_inflate_modes.txt): bench payload mode 1 15.2-15.3 / 3 14.2-15.1 / 7 14.1-15.0;
     // random bases + qualities 1: 48.2-48.4 / 3: 45.4-47.4; long reads 0: 121.2 / 1: 123.9-124.7 / 4: 79.8-79.9 / 5: 80.4-80.6 / 7: 80.5-80.9.
-    // REGTOOLS_AMD_INFLATE_PAIRS=<mode> overrides (lab / tests).
-    static const int env_pairs = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE_PAIRS"); return e ? atoi(e) : -1; }();
-    const uint32_t two = env_pairs >= 0 ? (uint32_t)env_pairs : (plan & 1) ? 7u : 4u;
+    const uint32_t two = (plan & 1) ? 7u : 4u;
     if (!form) form = inflate_form_env();
     if (!form) form = n_members <= kWaveFormMaxMembers ? 2 : (plan & 2) ? 1 : kDefaultLaneForm;
     const uint32_t blocks = (n_members + 63) / 64;
@@ -564,9 +561,8 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
     case 4: {
         // plan bit 0 set (payloads that compress up to 32 x): literal pairs and lanes sorted by compressed length; the windowed bit reader always
         // (round 4: its loads are no longer waited for on the spot -- long reads 117.5 ms with it against 120.7 without, kernels.h)
-        static const int env_tune = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE_TUNE"); return e ? atoi(e) : -1; }();      // (lab) bit 0 sort, bit 1 16-byte window
-        const bool sort = env_tune >= 0 ? (env_tune & 1) != 0 : (plan & 1) != 0;
-        const int win = env_tune >= 0 ? ((env_tune & 2) ? 1 : 0) : kDefaultWindow;
+        const bool sort = (plan & 1) != 0;
+        const int win = kDefaultWindow;
         uint32_t *perm = sort ? len_scratch + inflate_scratch_words(n_members) : nullptr;
         if (perm) hipLaunchKernelGGL(k_member_sort, dim3((n_members + kSortGroup - 1) / kSortGroup), dim3(256), 0, stream, members, n_members, perm);
         // (the veto word: behind the lane assignment in the scratch; only the stage entry point asks for the check)
@@ -583,8 +579,7 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
     }
     default: {
         // plan bit 1 = a payload of mostly literals (< 8 x): up to four of them per trip
-        static const int env_lits = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE_LITS"); return e ? atoi(e) : -1; }();      // (lab / tests) 1 or 4
-        const bool lits4 = form == 5 || (env_lits >= 0 ? env_lits > 1 : (plan & 2) != 0);          // (form 5: the stage entry point's way to ask for it)
+        const bool lits4 = form == 5 || (plan & 2) != 0;          // (form 5: the stage entry point's way to ask for it)
 #define RGX_LANE(PIECE_, LITS_) hipLaunchKernelGGL((k_inflate<false, PIECE_, LITS_>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad)
         if (piece) { if (lits4) RGX_LANE(true, 4); else RGX_LANE(true, 1); }
         else { if (lits4) RGX_LANE(false, 4); else RGX_LANE(false, 1); }
@@ -1023,6 +1018,17 @@ __global__ __launch_bounds__(64) void k_long_fill(uint32_t n_seg, const uint32_t
     }
 }
 
+const DecodeKnobs &decode_knobs() {
+    static const DecodeKnobs k = [] {
+        DecodeKnobs v;
+        if (const char *e = getenv("REGTOOLS_AMD_DECODE")) {
+            v.wave_form = !strncmp(e, "wave", 4);
+            if (const char *c = strchr(e, ',')) v.seg_bytes = atoi(c + 1);
+        }
+        return v;
+    }();
+    return k;
+}
 void launch_decode_seg(const uint8_t *arena, SegGeom g, uint32_t n_seg, const uint64_t *seg_start, const uint32_t *seg_base,
                        const uint32_t *seg_cnt, ExtractCfg cfg, ReadSoA soa, uint32_t *seg_iter, uint32_t *seg_long, const uint16_t *seg_cp, bool staged, hipStream_t stream,
                        uint32_t s_begin) {
@@ -1030,7 +1036,7 @@ void launch_decode_seg(const uint8_t *arena, SegGeom g, uint32_t n_seg, const ui
     const uint32_t n = n_seg - s_begin;
     if (staged && g.seg_bytes == kSegBytes) hipLaunchKernelGGL(k_decode_seg<true>, dim3(n), dim3(64), kSegBytes + kSegTail + 48, stream, arena, g, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp, s_begin);
     else {
-        static const bool wave_form = [] { const char *e = getenv("REGTOOLS_AMD_DECODE_SPARSE"); return e && !strcmp(e, "wave"); }();     // (tests / lab: the workgroup-per-segment form it replaced)
+        static const bool wave_form = decode_knobs().wave_form;     // (tests: the workgroup-per-segment form it replaced)
         if (wave_form && g.seg_bytes == kSegBytes) hipLaunchKernelGGL(k_decode_seg<false>, dim3(n), dim3(64), 0, stream, arena, g, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp, s_begin);
         else hipLaunchKernelGGL(k_decode_sparse, dim3((n + 63) / 64), dim3(64), 0, stream, arena, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, s_begin);
     }
@@ -1293,8 +1299,7 @@ void launch_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *to
 // 512-key tiles four times as many workgroups walk a quarter of the rows each
 constexpr uint32_t kRadixRowsLarge = 32, kRadixRowsSmall = 8, kRadixSmallMax = 2u << 20;
 static inline uint32_t radix_rows(uint32_t n) {
-    static const uint32_t small = [] { const char *e = getenv("REGTOOLS_AMD_RADIX_ROWS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? (uint32_t)v : kRadixRowsSmall; }();     // (lab)
-    return n <= kRadixSmallMax ? small : kRadixRowsLarge;
+    return n <= kRadixSmallMax ? kRadixRowsSmall : kRadixRowsLarge;
 }
 
 __device__ __forceinline__ uint32_t radix_digit(const uint32_t *__restrict__ word, const uint32_t *__restrict__ perm_in, uint32_t i,
@@ -1814,9 +1819,8 @@ void launch_rows_table(UniqueSoA u, const uint32_t *order, uint32_t n, uint32_t 
 }
 void launch_preagg(EventSoA ev, uint32_t n, PartialSoA p, uint32_t *p_total, hipStream_t stream) {
     if (!n) return;
-    static const int tile = [] { const char *e = getenv("REGTOOLS_AMD_AGG_TILE"); return e ? atoi(e) : 1024; }();      // (lab: 2048 events per tile = 80 KB of LDS, two workgroups per CU: reduce 1.52 ms on the bench file against 1.40-1.42 with 1024)
-    if (tile == 1024) hipLaunchKernelGGL(k_preagg<1024>, dim3((n + 1023) / 1024), dim3(256), 0, stream, ev, n, p, p_total);
-    else hipLaunchKernelGGL(k_preagg<2048>, dim3((n + 2047) / 2048), dim3(256), 0, stream, ev, n, p, p_total);
+    // (measured, round 4: 2048 events per tile = 80 KB of LDS, two workgroups per CU: reduce 1.52 ms on the bench file against 1.40-1.42 with 1024)
+    hipLaunchKernelGGL(k_preagg<1024>, dim3((n + 1023) / 1024), dim3(256), 0, stream, ev, n, p, p_total);
 }
 void launch_reduce_partials(PartialSoA p, const uint32_t *perm, const uint32_t *head, const uint32_t *seg_excl, uint32_t n, UniqueSoA u, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(k_reduce_partials, dim3((n + 255) / 256), dim3(256), 0, stream, p, perm, head, seg_excl, n, u);

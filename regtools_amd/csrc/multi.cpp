@@ -227,9 +227,10 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
         for (auto &t : pool) t.join();
     } else for (int g = 0; g < n; ++g) extract(g);
     for (int g = 0; g < n; ++g) if (S[(size_t)g].rc != RGX_OK) return failm(err, errlen, S[(size_t)g].rc, "%s", S[(size_t)g].err);
-    // (REGTOOLS_AMD_RCCL_SELFTEST: a one-device list goes through pack, ncclCommInitAll / ncclAllGather of one rank and the device merge
-    // as well -- the collective's call sequence on the real library where only one GPU is visible)
-    const bool selftest = getenv("REGTOOLS_AMD_RCCL_SELFTEST") != nullptr;
+    // (REGTOOLS_AMD_RCCL=selftest: a one-device list goes through pack, ncclCommInitAll / ncclAllGather of one rank and the device merge
+    // as well -- the collective's call sequence on the real library where only one GPU is visible; REGTOOLS_AMD_RCCL=off: the peer-copy fall-back on purpose)
+    const char *rccl_env = getenv("REGTOOLS_AMD_RCCL");
+    const bool selftest = rccl_env && !strcmp(rccl_env, "selftest");
     if (n == 1 && !selftest) { snprintf(g_exchange_kind, sizeof g_exchange_kind, "none (one shard)"); *out = S[0].table; S[0].table = nullptr; return RGX_OK; }
     if (n == 1) {
         // one rank through ncclCommInitAll / ncclAllGather on the real library (no peer to send to)
@@ -291,9 +292,10 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
     auto bytes_of = [&](int g) { return (size_t)part_rows[(size_t)g] * RGX_PACKED_ROW_BYTES; };
     bool by_rccl = false;
     std::string rccl_note = distinct ? X->rccl_error : std::string();
-    // (REGTOOLS_AMD_NO_RCCL: the fall-back on purpose -- how a multi-GPU box tests it)
-    if (distinct && getenv("REGTOOLS_AMD_NO_RCCL")) rccl_note = "REGTOOLS_AMD_NO_RCCL is set";
-    if (distinct && !X->comms.empty() && !getenv("REGTOOLS_AMD_NO_RCCL")) {
+    // (REGTOOLS_AMD_RCCL=off: the fall-back on purpose -- how a multi-GPU box tests it)
+    const bool rccl_off = getenv("REGTOOLS_AMD_RCCL") && !strcmp(getenv("REGTOOLS_AMD_RCCL"), "off");
+    if (distinct && rccl_off) rccl_note = "REGTOOLS_AMD_RCCL=off is set";
+    if (distinct && !X->comms.empty() && !rccl_off) {
         // a gather: rank g sends its rows, rank 0 receives n - 1 blocks, all in one group (its own rows are a device copy on its stream)
         int r = g_rccl.GroupStart();
         for (int g = 1; g < n && r == 0; ++g) {

@@ -179,7 +179,7 @@ class JunctionsExtractor(object):
         self.stats = dict(n_records=t.n_records, n_events=t.n_events, n_junctions=t.n, inflated_bytes=t.inflated_bytes,
                           compressed_bytes=t.compressed_bytes, n_members=t.n_members, ms_total=t.ms_total, ms_inflate=t.ms_inflate,
                           ms_records=t.ms_records, ms_scan=t.ms_scan, ms_reduce=t.ms_reduce, framing_sweeps=t.framing_sweeps,
-                          ms_barcodes=t.ms_barcodes, stream_ended=bool(t.stream_ended))
+                          ms_barcodes=t.ms_barcodes, stream_ended=bool(t.stream_ended), ms_inflate_launch=t.ms_inflate_launch)
         return 0
 
     def _free(self):

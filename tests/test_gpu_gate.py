@@ -1,6 +1,6 @@
 """The arrival-gated inflate launch of the overlapped upload (rgx_extract_mem on page-locked host bytes, round 4): ONE k_inflate_coop launch whose waves wait
 for the upload chunk their members lie in.  Files of the sizes the rest of the suite uses would not take that path (it starts at 8 MB and 2048
-members), so a child process lowers the thresholds (REGTOOLS_AMD_OVERLAP_MIN, REGTOOLS_AMD_INFLATE=coop) and runs synthetic files of every shape,
+members), so a child process lowers the thresholds (REGTOOLS_AMD_OVERLAP="min_bytes,chunks[,early_min_members]", REGTOOLS_AMD_INFLATE=coop) and runs synthetic files of every shape,
 a truncated file and the reference's golden BAM through it; the parent compares with the oracle."""
 import json
 import os
@@ -59,11 +59,9 @@ def test_gated_launch_equals_the_oracle(gpu_ctx, tmp_path, chunks):
     jf, of = str(tmp_path / "jobs.json"), str(tmp_path / "out.json")
     json.dump(jobs, open(jf, "w"))
     # "16-early-tail": the members of the last upload chunks as a second launch, the front part of the arena framed and decoded under it (round 4;
-    # REGTOOLS_AMD_EARLY_TAIL_MIN lets files of a few hundred members take that path)
-    env = dict(os.environ, REGTOOLS_AMD_OVERLAP_MIN="0", REGTOOLS_AMD_INFLATE="coop", REGTOOLS_AMD_GATE_CHUNKS=chunks.split("-")[0], REGTOOLS_AMD_TRACE="1", PYTHONPATH=ROOT)
-    if early:
-        env["REGTOOLS_AMD_EARLY_TAIL_MIN"] = "1"
-    else:
+    # the third number of REGTOOLS_AMD_OVERLAP lets files of a few hundred members take that path)
+    env = dict(os.environ, REGTOOLS_AMD_OVERLAP="0," + chunks.split("-")[0] + (",1" if early else ""), REGTOOLS_AMD_INFLATE="coop", REGTOOLS_AMD_TRACE="1", PYTHONPATH=ROOT)
+    if not early:
         env["REGTOOLS_AMD_EARLY_TAIL"] = "0"
     r = subprocess.run([sys.executable, "-c", CHILD, jf, of], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
@@ -113,7 +111,7 @@ def test_early_tail_with_records_longer_than_its_margin(gpu_ctx, tmp_path):
         if prev is not None and stream_off >= boundary(k) - 150_000:
             tid, p0 = struct.unpack_from("<ii", prev, 4)
             long_rec = bamio.record(tid, p0, cigar, flag=99, qname="long%04d" % k, aux=bamio.tagA("XS", "+"))
-            assert len(long_rec) > 150_000 + 65536
+            assert len(long_rec) > 150_000 + 16384          # starts in the prefix (a member and a segment in front of the boundary), ends behind the boundary
             out.append(long_rec); off += len(long_rec); n_long += 1; k += 1
         out.append(rec); off += len(rec); prev = rec
         pos += 4 + bs
@@ -124,7 +122,7 @@ def test_early_tail_with_records_longer_than_its_margin(gpu_ctx, tmp_path):
     jobs = [dict(bam=p, kw=dict(strandness=0), args=["-s", "XS"]), dict(bam=src, kw=dict(strandness=0), args=["-s", "XS"])]
     jf, of = str(tmp_path / "jobs.json"), str(tmp_path / "out.json")
     json.dump(jobs, open(jf, "w"))
-    env = dict(os.environ, REGTOOLS_AMD_OVERLAP_MIN="0", REGTOOLS_AMD_INFLATE="coop", REGTOOLS_AMD_GATE_CHUNKS="16", REGTOOLS_AMD_TRACE="1", REGTOOLS_AMD_EARLY_TAIL_MIN="1", PYTHONPATH=ROOT)
+    env = dict(os.environ, REGTOOLS_AMD_OVERLAP="0,16,1", REGTOOLS_AMD_INFLATE="coop", REGTOOLS_AMD_TRACE="1", PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-c", CHILD, jf, of], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     assert b"early tail: part" in r.stderr, r.stderr.decode()[-2000:]

@@ -28,7 +28,7 @@ def make_part(g, lo, n, rng):
     last = first + 1 + (k % 5)
     rows[:, 6] = first & 0xffffffff
     rows[:, 8] = last & 0xffffffff
-    rows[:, 10] = np.where((k + g) % 3 == 0, ord("-"), ord("+"))
+    rows[:, 10] = np.where(k % 3 == 0, ord("-"), ord("+"))                     # (the strand class is part of the key: a function of the key alone)
     rank = np.empty(n, dtype=np.int64)
     rank[np.argsort(first, kind="stable")] = np.arange(1, n + 1)
     rows[:, 11] = rank                                                  # name_index: first-seen rank inside the shard

@@ -506,20 +506,20 @@ def test_multi_device_host_equals_single_gpu(gpu_ctx, synth_dir):
         assert kind().startswith(want), (devs, kind())
     if n_gpu >= 2:
         # the fall-back a node without a working RCCL takes: the same rows as peer copies, and the call says so
-        os.environ["REGTOOLS_AMD_NO_RCCL"] = "1"
+        os.environ["REGTOOLS_AMD_RCCL"] = "off"
         try:
             assert regtools_amd.extract_multi(list(range(n_gpu)), bam=p, strandness=0).bed12() == single
-            assert kind().startswith("hipMemcpyPeerAsync") and "REGTOOLS_AMD_NO_RCCL" in kind(), kind()
+            assert kind().startswith("hipMemcpyPeerAsync") and "REGTOOLS_AMD_RCCL=off" in kind(), kind()
         finally:
-            del os.environ["REGTOOLS_AMD_NO_RCCL"]
+            del os.environ["REGTOOLS_AMD_RCCL"]
     for args, kw in ((["-s", "RF", "-a", "20"], dict(strandness=1, min_anchor_length=20)), (["-s", "XS", "-r", "chr3"], dict(strandness=0, region="chr3"))):
         exp = gpu_extract(gpu_ctx, p, args)[1]
         assert regtools_amd.extract_multi(lists[-1], bam=p, **kw).bed12() == exp, args
-    os.environ["REGTOOLS_AMD_RCCL_SELFTEST"] = "1"           # one rank through ncclCommInitAll / ncclAllGather (librccl.so.1 loaded at run time) + device merge
+    os.environ["REGTOOLS_AMD_RCCL"] = "selftest"           # one rank through ncclCommInitAll / ncclAllGather (librccl.so.1 loaded at run time) + device merge
     try:
         assert regtools_amd.extract_multi([0], bam=p, strandness=0).bed12() == single
     finally:
-        del os.environ["REGTOOLS_AMD_RCCL_SELFTEST"]
+        del os.environ["REGTOOLS_AMD_RCCL"]
     raw, bai = open(p, "rb").read(), open(p + ".bai", "rb").read()
     assert regtools_amd.extract_multi([0, 0, 0], bam_bytes=raw, bai_bytes=bai, strandness=0).bed12() == single
     # the CLI: REGTOOLS_AMD_DEVICES shards the file, the output file is the same
@@ -610,7 +610,7 @@ def test_bench_multi_rank_path_on_one_gpu(gpu_ctx, tmp_path):
 
 def test_long_record_decode_lane_form_equals_the_wave_form(gpu_ctx, synth_dir):
     """k_decode_sparse (long records: one lane follows a segment's two or three records) against k_decode_seg<false> (a workgroup per segment,
-    REGTOOLS_AMD_DECODE_SPARSE=wave), through the CLI: whole file, a region query (the end rule's stop / last-in reduction), intron limits; and
+    REGTOOLS_AMD_DECODE=wave), through the CLI: whole file, a region query (the end rule's stop / last-in reduction), intron limits; and
     against the oracle."""
     from regtools_amd import synth
     p = os.path.join(str(synth_dir), "sparse_long.bam")
@@ -620,7 +620,7 @@ def test_long_record_decode_lane_form_equals_the_wave_form(gpu_ctx, synth_dir):
         outs = []
         for form, seg in (("lane", "16384"), ("wave", "16384"), ("lane", "131072")):      # (the last: the segment size files of long records get, api.cpp seg_bytes)
             o = p + "." + form + seg + ".bed"
-            r = subprocess.run([exe, "junctions", "extract"] + args + ["-o", o, p], env=dict(os.environ, REGTOOLS_AMD_DECODE_SPARSE=form, REGTOOLS_AMD_SEG_BYTES=seg),
+            r = subprocess.run([exe, "junctions", "extract"] + args + ["-o", o, p], env=dict(os.environ, REGTOOLS_AMD_DECODE=form + "," + seg),
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             assert r.returncode == 0, r.stderr
             outs.append(open(o, "rb").read())

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 4 script, kept as the record of how profiles/r04_pmc_traffic.json was made: REGTOOLS_AMD_INFLATE_TUNE / _PAIRS left the product in round 5 -- bench.py measures the traffic in its own run now)
 # tools/pmc_traffic_r4.sh OUTDIR: FETCH_SIZE / WRITE_SIZE of the DEFLATE launch alone (tools/lab/bin/coop_lab_cur = the product's kernels + the lab's
 # timing main, tools/lab/build_cur.sh cur) on the three bench payloads, in the options the pipeline picks for each (kernels.h inflate_plan_for);
 # separate --pmc passes, as the guide prescribes.  Writes OUTDIR/r04_pmc_traffic.json (copied to profiles/ by hand).
