@@ -441,32 +441,27 @@ struct Prep {
 
 static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_bam, size_t bam_len, const uint8_t *bai, size_t bai_len,
                           const rgx_extract_params *p, bool want_read_span, Prep &P, char *err, size_t errlen, const uint32_t *d_true_sizes = nullptr,
-                          bool allow_overlap = true, bool region_to_file_end = false, const SharedMembers *shared = nullptr) {
-    if (!p || p->strandness < 0 || p->strandness > 3) return fail(err, errlen, RGX_ERR_ARG, "Please supply strandness mode with '-s' option!\n\n");
-    if (p->strandness == 3 && !p->fasta_path) return fail(err, errlen, RGX_ERR_ARG, "Strandness mode 'intron-motif' requires a fasta file!\n\n");
-    HIP_ENTER(c->device);
-    hipStream_t st = c->stream;
-    hipStream_t copy_q = c->copy_stream ? c->copy_stream : c->stream;     // where the file's upload goes (a one-shot context: its only stream)
-    const double t_begin = now_ms();
-    const bool trace = getenv("REGTOOLS_AMD_TRACE") != nullptr;
-    double t_last = t_begin;
-    auto mark = [&](const char *what) { if (trace) { double t = now_ms(); fprintf(stderr, "[rgx trace] %-28s +%8.3f ms  (at %8.3f)\n", what, t - t_last, t - t_begin); t_last = t; } };
+                          bool allow_overlap = true, bool region_to_file_end = false, const SharedMembers *shared = nullptr);
 
-    if (bam_len < 28) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
-    // -- index: ~1 ms of host parsing for a 5 MB .bai, done on a second host thread while this one feeds the device the member scan --
-    BaiInfo bi;
-    bool bai_ok = false;
+constexpr int kGoOn = -1;                                  // a stage of EventsRun: nothing to report, the next one
+
+// One call of the front half of the pipeline: file bytes -> junction events in file order.  The stages run in the order of
+// run(); each returns kGoOn, or the call's result (an error, or the result of the call starting over on another path: a file whose footers
+// lie, a record the lite walk must not accept, a shard whose range was not uploaded).  What one stage leaves for the next are the members below.
+struct EventsRun {
+    // -- the call's arguments (prepare_events) --
+    rgx_ctx *c; const uint8_t *d_bam_in; const uint8_t *h_bam; size_t bam_len; const uint8_t *bai; size_t bai_len;
+    const rgx_extract_params *p; bool want_read_span; Prep &P; char *err; size_t errlen; const uint32_t *d_true_sizes;
+    bool allow_overlap, region_to_file_end; const SharedMembers *shared;
+    // -- what the stages leave for one another --
+    hipStream_t st = nullptr, copy_q = nullptr;               // the pipeline's stream; where the file's upload goes
+    double t_begin = 0, t_last = 0; bool trace = false;
+    void mark(const char *what) { if (trace) { double t = now_ms(); fprintf(stderr, "[rgx trace] %-28s +%8.3f ms  (at %8.3f)\n", what, t - t_last, t - t_begin); t_last = t; } }
+    // stage_upload: the index (parsed on a second host thread), the file on its way to HBM, the host's member scan
+    BaiInfo bi; bool bai_ok = false;
     std::vector<uint8_t> index_image;                        // a .csi (or a compressed index) rewritten as a plain BAI image
-    std::thread bai_thread([&] {
-        bai_ok = bai && normalize_index(bai, bai_len, index_image, bai, bai_len) && parse_bai(bai, bai_len, bi, /*collect_anchors=*/false);
-    });
-    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } bai_joiner{bai_thread};
-    // -- upload ----------------------------------------------------------------------------------------------------------
-    // Host input: the file goes up in chunks on the copy stream from a helper thread (a pageable source makes hipMemcpyAsync block), while
-    // this thread finds the members on the host (scan_members_parallel) -- the inflate of chunk k's members then runs while chunk k+1 is
-    // still on the bus (SURVEY 8d times the path from file bytes in host memory).  A file the host scan does not vouch for waits for the
-    // whole upload and takes the device's member discovery, as does device input.
-    const uint8_t *d_bam = d_bam_in;
+    std::thread bai_thread;
+    const uint8_t *d_bam = nullptr;
     struct Upload {
         std::thread th; std::atomic<uint32_t> recorded{0}; std::atomic<int> err{0};
         std::vector<size_t> end;                            // end[j] = bytes [lo, end[j]) resident once chunk event j has fired
@@ -478,9 +473,195 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     } up;
     bool overlap = false, gated = false;
     size_t gate_chunk = 0;
+    uint64_t hm_total = 0;
+    uint32_t *d_sc = nullptr, *h_sc = nullptr;               // the call's scalars in HBM and their pinned host mirror
+    // before anything looks at the file through the device (the fallbacks of damaged files): the bytes a shard did not send
+    hipError_t complete_upload() {
+        if (!h_bam || !(up.lo || (up.hi && up.hi < bam_len))) return hipSuccess;
+        if (up.th.joinable()) up.th.join();
+        hipError_t e = hipStreamSynchronize(copy_q);
+        uint8_t *dst = c->buf("bam").as<uint8_t>();
+        if (e == hipSuccess && up.lo > up.hdr_hi) e = hipMemcpy(dst + up.hdr_hi, h_bam + up.hdr_hi, up.lo - up.hdr_hi, hipMemcpyHostToDevice);
+        if (e == hipSuccess && up.hi < bam_len) e = hipMemcpy(dst + up.hi, h_bam + up.hi, bam_len - up.hi, hipMemcpyHostToDevice);
+        up.lo = 0; up.hi = bam_len; up.hdr_hi = 0;
+        return e;
+    }
+    // stage_members: the member list (device discovery, or the host scan's), the record stream's start, cuts and chunks
+    uint32_t n_cand = 0;
+    uint64_t *cand = nullptr;
+    uint32_t *nx[2] = {nullptr, nullptr}, *c_isize = nullptr, *c_reach = nullptr, *c_rank = nullptr, *c_isz2 = nullptr, *c_tmp = nullptr;
+    Member *d_members = nullptr; hipMemcpyKind from_members = hipMemcpyDeviceToHost;
+    // the members = the candidates that chain up from offset 0 (and, second try below, from the offset a seek lands on)
+    void chain(uint64_t root2) {
+        launch_member_link(d_bam, bam_len, cand, n_cand, nx[0], c_isize, c_reach, root2, st);
+        int cur = 0;
+        for (uint32_t span = 1; span < n_cand; span <<= 1) { launch_member_jump(n_cand, nx[cur], nx[cur ^ 1], c_reach, st); cur ^= 1; }
+        launch_member_jump(n_cand, nx[cur], nx[cur ^ 1], c_reach, st);
+        launch_scan_u32(c_reach, c_rank, n_cand, d_sc + 17, c_tmp, st);
+        launch_member_compact(d_bam, bam_len, cand, c_isize, c_reach, c_rank, n_cand, d_members, c_isz2, st);
+        if (d_true_sizes) launch_member_fix(d_members, c_isz2, n_cand, d_sc + 17, d_true_sizes, st);     // second run: lengths from the probe, not the footers
+        launch_member_upos(d_members, c_isz2, d_sc + 17, (uint64_t *)(d_sc + 20), st);
+    }
+    bool whole = false, seek = false, chunked = false, geom_chunked_hint = false, empty_stream = false;
+    uint64_t seek_voff = 0, cut_lo = 0, cut_hi = UINT64_MAX, total_all = 0, q_upos[3] = {0, 0, 0};
+    std::vector<VChunk> chunks;
+    uint32_t n_members_all = 0, first_member = 0, stop = 0;
+    // stage_range_and_inflate: this call's member range, its arena, the launch (or launches) that fill it
+    uint32_t m_lo = 0, m_hi = 0, n_range = 0;
+    uint64_t upos_lo = 0, total = 0;
+    uint8_t *d_bad = nullptr;
+    hipError_t upos_of(uint32_t k, uint64_t &out_v) {
+        if (k >= n_members_all) { out_v = total_all; return hipSuccess; }
+        Member m;
+        hipError_t e = hipMemcpy(&m, d_members + k, sizeof m, from_members);
+        out_v = m.upos;
+        return e;
+    }
+    struct EarlyPart { uint32_t members, waves; uint64_t upos; };       // a part ends in front of member `members` of the range = workgroup `waves` = arena offset `upos`
+    std::vector<EarlyPart> early_parts;
+    bool split_B = false; hipEvent_t split_ev = nullptr;     // early tail: the gated launch still runs on a side stream; whoever reads its part of the arena waits for it
+    hipError_t join_B() {
+        if (!split_B) return hipSuccess;
+        split_B = false;
+        return hipStreamWaitEvent(st, split_ev, 0);
+    }
+    // stage_footers_and_header / stage_bounds_and_chains
+    bool spec = false; uint32_t mean_rec = 0;
+    BamHeader hdr; int32_t n_ref = 0;
+    uint64_t lim = 0, pos0 = 0; bool chain_ended = false;
+    ExtractCfg cfg; SegGeom geom; uint32_t seg_bytes = 0;
+    std::vector<SegChunk> seg_chunks;
+    // stage_framing (+ early tail) / stage_decode / stage_emit
+    const uint8_t *arena = nullptr; uint64_t span = 0; uint32_t n_seg = 0, n_rec = 0; bool lite_walk = false;
+    uint64_t *seg_start[2] = {nullptr, nullptr}, *seg_exit[2] = {nullptr, nullptr};
+    uint32_t *seg_cnt[2] = {nullptr, nullptr}, *seg_base = nullptr;
+    uint32_t *seg_iter_e = nullptr, *seg_long_e = nullptr, *seg_long_base_e = nullptr;      // early tail: per-segment outputs of the decode that the second framing must not overwrite
+    uint16_t *seg_cp = nullptr;
+    int cur = 0;
+    // One framing: the walk of segments [walk_from, n_s), then verification sweeps over [0, n_s) until the chain agrees.  Returns -1 to go on,
+    // anything else is the call's result (a restart on another path has run, or an error).  `ended` = the chain ends inside [0, n_s).
+    int frame(uint32_t n_s, uint32_t walk_from, bool &ended) {
+        DevBuf &b_tmp = c->buf("tmp");
+        launch_seg_walk(arena, geom, n_s, n_ref, seg_start[cur], seg_exit[cur], seg_cnt[cur], seg_cp, st, walk_from);
+        // d_sc[10]: leftmost disagreeing segment, d_sc[11]: leftmost chain end, d_sc[3]: record total
+        for (int iter = 0;; ++iter) {
+            HIP_TRY(hipMemsetAsync(d_sc + 10, 0xff, 8, st));
+            launch_seg_verify(arena, geom, n_s, seg_start[cur], seg_exit[cur], seg_cnt[cur], seg_start[cur ^ 1], seg_exit[cur ^ 1],
+                              seg_cnt[cur ^ 1], d_sc + 10, seg_cp, st);
+            cur ^= 1;
+            launch_scan_u32(seg_cnt[cur], seg_base, n_s, d_sc + 3, b_tmp.as<uint32_t>(), st);
+            HIP_TRY(hipMemcpyAsync(h_sc + 3, d_sc + 3, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_sc + 10, d_sc + 10, 8, hipMemcpyDeviceToHost, st));
+            if (spec && iter == 0) {
+                HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 8, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(h_sc + kStatusEarly, d_sc + kStatusEarly, 8, hipMemcpyDeviceToHost, st));
+            }
+            HIP_TRY(hipStreamSynchronize(st));
+            if (spec && iter == 0 && (h_sc[0] != 0xffffffffu || h_sc[kStatusEarly] != 0xffffffffu)) {
+                // some member did not inflate to its footer's length: nothing enqueued since is worth anything
+                mark("inflate verdict: not clean, starting over device-resident");
+                if (gated) { c->gate_distrust = true; if (trace) fprintf(stderr, "[rgx trace] arrival gate: verdict not clean, this context no longer uses it\n"); }
+                HIP_TRY(join_B());
+                HIP_TRY(complete_upload());
+                HIP_TRY(hipStreamSynchronize(copy_q));
+                HIP_TRY(hipStreamSynchronize(st));
+                const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, nullptr, false, region_to_file_end);
+                P.t_begin = t_begin;
+                return rc2;
+            }
+            ++P.framing_sweeps;
+            if (h_sc[11] != 0xffffffffu) ended = true;           // some segment's chain ends: an unreadable / cut-off record (sam.c:421-423)
+            // the chain ends inside the exact prefix (or everything is exact): nothing starts after that segment -- with one chain the
+            // end already spread to the right by itself; the chains of later chunks would not know
+            if (h_sc[11] != 0xffffffffu && (h_sc[11] < h_sc[10] || (h_sc[10] == 0xffffffffu && geom.chunks))) {
+                launch_seg_truncate(geom, n_s, h_sc[11], seg_start[cur], seg_exit[cur], seg_cnt[cur], st);
+                launch_scan_u32(seg_cnt[cur], seg_base, n_s, d_sc + 3, b_tmp.as<uint32_t>(), st);
+                HIP_TRY(hipMemcpyAsync(h_sc + 3, d_sc + 3, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                break;
+            }
+            if (h_sc[10] == 0xffffffffu) break;
+            if (iter > 1 << 20) return fail(err, errlen, RGX_ERR_FORMAT, "regtools_amd: record framing did not converge\n");
+        }
+        return -1;
+    }
+    uint32_t sA = 0;                                          // early tail: segments [0, sA) are framed, verified and decoded
+    bool emit_parts_ok = false; uint32_t emit_parts = 0, emit_rows = 0; size_t ev_lay = 0;      // early tail: rows [0, emit_rows) have their events out, in emit_parts parts
+    EventSoA ev_e;
+    EventSoA ev_layout(uint8_t *q, size_t E) {
+        EventSoA v; memset(&v, 0, sizeof v);
+        v.tid = (uint32_t *)q; q += E * 4; v.start = (uint32_t *)q; q += E * 4; v.ilen_cls = (uint32_t *)q; q += E * 4;
+        v.ts = (uint32_t *)q; q += E * 4; v.te = (uint32_t *)q; q += E * 4;
+        if (want_read_span) { v.rpos = (uint32_t *)q; q += E * 4; v.rend = (uint32_t *)q; q += E * 4; }
+        if (p->barcodes) { v.read = (uint32_t *)q; q += E * 4; }
+        v.strand = q;
+        return v;
+    }
+    size_t soa_cap = 0;                                       // rows the SoA columns are laid out for (early tail: an estimate made from the prefix)
+    ReadSoA soa;
+    uint32_t *ev_base = nullptr, *long_list = nullptr;
+    hipError_t soa_layout(size_t R) {
+        DevBuf &b_soa = c->buf("soa");
+        hipError_t e_ = b_soa.ensure(R * (4 + 4 + 4 + 8 + 1 + 4 + 4 + 4 + (p->barcodes ? 8 : 0)) + 256);
+        if (e_ != hipSuccess) return e_;
+        uint8_t *q = b_soa.as<uint8_t>();
+        soa.cig_off = (uint64_t *)q; q += R * 8;
+        if (p->barcodes) { soa.rec_off = (uint64_t *)q; q += R * 8; }
+        soa.tid = (int32_t *)q; q += R * 4; soa.pos = (int32_t *)q; q += R * 4; soa.flag_nc = (uint32_t *)q; q += R * 4;
+        soa.n_ev = (uint32_t *)q; q += R * 4; ev_base = (uint32_t *)q; q += R * 4; long_list = (uint32_t *)q; q += R * 4;
+        soa.strand = q;
+        soa_cap = R;
+        return hipSuccess;
+    }
+    uint32_t n_events = 0, n_long = 0; uint64_t n_iterated = 0;
+    // every way out while the side stream's launch may still run (an error in the prefix's framing, say: the next call on this context must not meet
+    // it) and while the index thread runs; `up` joins its helper and waits for the DMA out of the caller's buffer itself
+    ~EventsRun() { if (split_B && split_ev) (void)hipEventSynchronize(split_ev); if (bai_thread.joinable()) bai_thread.join(); }
+    int run();
+    int stage_upload();
+    int stage_members();
+    int stage_range_and_inflate();
+    int stage_footers_and_header();
+    int stage_bounds_and_chains();
+    int stage_framing();
+    int stage_decode();
+    int stage_emit();
+};
+
+int EventsRun::run() {
+    if (!p || p->strandness < 0 || p->strandness > 3) return fail(err, errlen, RGX_ERR_ARG, "Please supply strandness mode with '-s' option!\n\n");
+    if (p->strandness == 3 && !p->fasta_path) return fail(err, errlen, RGX_ERR_ARG, "Strandness mode 'intron-motif' requires a fasta file!\n\n");
+    HIP_ENTER(c->device);
+    st = c->stream;
+    copy_q = c->copy_stream ? c->copy_stream : c->stream;     // where the file's upload goes (a one-shot context: its only stream)
+    t_begin = now_ms();
+    trace = getenv("REGTOOLS_AMD_TRACE") != nullptr;
+    t_last = t_begin;
+
+    if (bam_len < 28) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
+    { const int rc = stage_upload(); if (rc != kGoOn) return rc; }
+    { const int rc = stage_members(); if (rc != kGoOn) return rc; }
+    { const int rc = stage_range_and_inflate(); if (rc != kGoOn) return rc; }
+    { const int rc = stage_footers_and_header(); if (rc != kGoOn) return rc; }
+    { const int rc = stage_bounds_and_chains(); if (rc != kGoOn) return rc; }
+    { const int rc = stage_framing(); if (rc != kGoOn) return rc; }
+    { const int rc = stage_decode(); if (rc != kGoOn) return rc; }
+    return stage_emit();
+}
+
+int EventsRun::stage_upload() {
+    // -- index: ~1 ms of host parsing for a 5 MB .bai, done on a second host thread while this one feeds the device the member scan --
+    bai_thread = std::thread([this] {
+        bai_ok = bai && normalize_index(bai, bai_len, index_image, bai, bai_len) && parse_bai(bai, bai_len, bi, /*collect_anchors=*/false);
+    });
+    // -- upload ----------------------------------------------------------------------------------------------------------
+    // Host input: the file goes up in chunks on the copy stream from a helper thread (a pageable source makes hipMemcpyAsync block), while
+    // this thread finds the members on the host (scan_members_parallel) -- the inflate of chunk k's members then runs while chunk k+1 is
+    // still on the bus (SURVEY 8d times the path from file bytes in host memory).  A file the host scan does not vouch for waits for the
+    // whole upload and takes the device's member discovery, as does device input.
+    d_bam = d_bam_in;
     std::vector<Member> &hm = c->hm_scratch;                 // the host scan's member list (overlap only; the context keeps its pages: a fresh 4 MB is a thousand page faults per call)
     hm.clear();
-    uint64_t hm_total = 0;
     if (!d_bam) {
         DevBuf &b = c->buf("bam");
         HIP_TRY(b.ensure(bam_len + 64));
@@ -562,7 +743,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             uint32_t *gate_flags = gated ? c->buf("gate_flags").as<uint32_t>() : nullptr;
             const uint32_t gate_epoch = c->gate_epoch;
             hipStream_t gate_q = c->side[0] ? c->side[0] : copy_q;
-            up.th = std::thread([c, dst, h_bam, hdr_hi, up_lo, copy_q, gate_q, gate_flags, gate_epoch, &up] {
+            up.th = std::thread([this, dst, hdr_hi, up_lo, gate_q, gate_flags, gate_epoch] {
                 if (hipSetDevice(c->device) != hipSuccess) { up.err = 1; up.recorded = (uint32_t)up.end.size(); return; }
                 if (hdr_hi && hipMemcpyAsync(dst, h_bam, hdr_hi, hipMemcpyHostToDevice, copy_q) != hipSuccess) up.err = 1;
                 size_t o = up_lo;
@@ -597,34 +778,26 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             }
         } else HIP_TRY(hipMemcpyAsync(b.p, h_bam, bam_len, hipMemcpyHostToDevice, st));
     }
-    // before anything looks at the file through the device (the fallbacks of damaged files): the bytes a shard did not send
-    auto complete_upload = [&]() -> hipError_t {
-        if (!h_bam || !(up.lo || (up.hi && up.hi < bam_len))) return hipSuccess;
-        if (up.th.joinable()) up.th.join();
-        hipError_t e = hipStreamSynchronize(copy_q);
-        uint8_t *dst = c->buf("bam").as<uint8_t>();
-        if (e == hipSuccess && up.lo > up.hdr_hi) e = hipMemcpy(dst + up.hdr_hi, h_bam + up.hdr_hi, up.lo - up.hdr_hi, hipMemcpyHostToDevice);
-        if (e == hipSuccess && up.hi < bam_len) e = hipMemcpy(dst + up.hi, h_bam + up.hi, bam_len - up.hi, hipMemcpyHostToDevice);
-        up.lo = 0; up.hi = bam_len; up.hdr_hi = 0;
-        return e;
-    };
-    DevBuf &b_arena = c->buf("arena"), &b_members = c->buf("members"), &b_scalars = c->buf("scalars"), &b_hdr = c->buf("hdr_arena"), &b_disc = c->buf("discover");
+    DevBuf &b_scalars = c->buf("scalars");
     HIP_TRY(b_scalars.ensure(512));
     // u32 scalars: [0]=first bad member [1]=its status [2]=changed [3]=n_rec [4]=n_events [5]=n_long [6]=n_unique [8..9]=n_iterated(u64)
     //              [12..13]=header inflate status [16]=n_cand [17]=n_members [18]=stop [20..21]=total inflated (u64)
     //              [24..26]=q_index [32..37]=q_upos (u64 x3) [40..45]=q_coff (u64 x3)
-    uint32_t *d_sc = b_scalars.as<uint32_t>();
-    uint32_t *h_sc = (uint32_t *)c->pinned;
+    d_sc = b_scalars.as<uint32_t>();
+    h_sc = (uint32_t *)c->pinned;
     HIP_TRY(hipMemsetAsync(d_sc, 0, 512, st));
     HIP_TRY(hipMemsetAsync(d_sc, 0xff, 4, st));
     HIP_TRY(hipMemsetAsync(d_sc + 12, 0xff, 4, st));
     HIP_TRY(hipMemsetAsync(d_sc + 18, 0xff, 4, st));
     HIP_TRY(hipMemsetAsync(d_sc + kStatusEarly, 0xff, 4, st));
 
+    return kGoOn;
+}
+
+int EventsRun::stage_members() {
     // -- BGZF member discovery on the device (replaces the serial BSIZE walk, bgzf.c:421-546) -------------------------------
-    uint32_t n_cand = 0;
-    uint64_t *cand = nullptr;
-    uint32_t *nx[2] = {nullptr, nullptr}, *c_isize = nullptr, *c_reach = nullptr, *c_rank = nullptr, *c_isz2 = nullptr, *c_tmp = nullptr;
+    std::vector<Member> &hm = c->hm_scratch;
+    DevBuf &b_members = c->buf("members"), &b_disc = c->buf("discover");
     if (overlap) {
         // the member list came from the host scan: what the discovery kernels would have left in HBM
         // (in page-locked host memory, read in place by the kernels -- 24 bytes per member, once: an upload would queue behind the file's
@@ -662,19 +835,8 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     c_isize = nx[1] + n_cand; c_reach = c_isize + n_cand; c_rank = c_reach + n_cand; c_isz2 = c_rank + n_cand; c_tmp = c_isz2 + n_cand;
     launch_magic_fill(d_bam, bam_len, n_tiles, tile_cnt, cand, st);
     }
-    Member *d_members = overlap ? (Member *)c->pinned_members : b_members.as<Member>();
-    const hipMemcpyKind from_members = overlap ? hipMemcpyHostToHost : hipMemcpyDeviceToHost;
-    // the members = the candidates that chain up from offset 0 (and, second try below, from the offset a seek lands on)
-    auto chain = [&](uint64_t root2) {
-        launch_member_link(d_bam, bam_len, cand, n_cand, nx[0], c_isize, c_reach, root2, st);
-        int cur = 0;
-        for (uint32_t span = 1; span < n_cand; span <<= 1) { launch_member_jump(n_cand, nx[cur], nx[cur ^ 1], c_reach, st); cur ^= 1; }
-        launch_member_jump(n_cand, nx[cur], nx[cur ^ 1], c_reach, st);
-        launch_scan_u32(c_reach, c_rank, n_cand, d_sc + 17, c_tmp, st);
-        launch_member_compact(d_bam, bam_len, cand, c_isize, c_reach, c_rank, n_cand, d_members, c_isz2, st);
-        if (d_true_sizes) launch_member_fix(d_members, c_isz2, n_cand, d_sc + 17, d_true_sizes, st);     // second run: lengths from the probe, not the footers
-        launch_member_upos(d_members, c_isz2, d_sc + 17, (uint64_t *)(d_sc + 20), st);
-    };
+    d_members = overlap ? (Member *)c->pinned_members : b_members.as<Member>();
+    from_members = overlap ? hipMemcpyHostToHost : hipMemcpyDeviceToHost;
     if (!overlap) chain(UINT64_MAX);
     if (bai_thread.joinable()) bai_thread.join();
     if (!bai_ok) return (void)hipStreamSynchronize(st), fail(err, errlen, RGX_ERR_INDEX, "%s", kMsgIndex);
@@ -682,9 +844,9 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // "." = every record from the first one on; "*" = every record behind the last reference's reads (hts_itr_querys, hts.c:1901-1904:
     // HTS_IDX_START / HTS_IDX_NOCOOR; both read to the end of the file without a predicate)
     const bool rest = p->region && !strcmp(p->region, "*");
-    const bool whole = rest || !strcmp(p->region ? p->region : ".", ".");
+    whole = rest || !strcmp(p->region ? p->region : ".", ".");
     // where the record stream starts (hts.c:1721-1741)
-    bool seek = false; uint64_t seek_voff = 0;
+    seek = false; seek_voff = 0;
     if (rest) {
         if (bi.have_nocoor) { seek_voff = bi.nocoor_voff; seek = seek_voff != 0; }
         else if (!bi.n_no_coor) return (void)hipStreamSynchronize(st), fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion);
@@ -694,7 +856,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     }
     // shard cut points: virtual offsets the BAI lists (every chunk begin / linear-index entry is a record start), so
     // no shard ever guesses its first record.  A record belongs to the shard in which its first byte lies.
-    uint64_t cut_lo = seek ? seek_voff : 0, cut_hi = UINT64_MAX;          // 0 = "right after the header"
+    cut_lo = seek ? seek_voff : 0; cut_hi = UINT64_MAX;          // 0 = "right after the header"
     if (p->n_shards > 1) {
         if (p->shard < 0 || p->shard >= p->n_shards) return (void)hipStreamSynchronize(st), fail(err, errlen, RGX_ERR_ARG, "regtools_amd: shard %d of %d\n", p->shard, p->n_shards);
         uint64_t tgt[2], got[2];
@@ -715,9 +877,8 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // every chunk becomes its own record chain (SegGeom) and k_decode_seg applies the end rule.  Needs the contig names before the
     // launch: the header is inflated on the host from the head of the file.  A header that cannot be read that way leaves the range
     // alone: the whole file is read and filtered by overlap (such a header is not readable upstream either).
-    std::vector<VChunk> chunks;
-    bool chunked = false;
-    const bool geom_chunked_hint = !whole;                    // (region queries keep the checked path: their chunk table wants the members' verdicts)
+    chunked = false;
+    geom_chunked_hint = !whole;                    // (region queries keep the checked path: their chunk table wants the members' verdicts)
     if (!whole && p->region) {
         const size_t head_len = std::min<size_t>(bam_len, (size_t)8 << 20);
         std::vector<uint8_t> head_copy;
@@ -751,7 +912,7 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         mark("region chunks");
     }
 
-    bool empty_stream = false;
+    empty_stream = false;
     auto query = [&]() -> hipError_t {
         uint64_t q[3] = {seek ? (seek_voff >> 16) : 0, cut_lo >> 16, cut_hi == UINT64_MAX ? UINT64_MAX - 64 : (cut_hi >> 16)};
         if (overlap) {
@@ -807,18 +968,24 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             HIP_TRY(query());
         }
     }
-    const uint32_t n_members_all = h_sc[17];
+    n_members_all = h_sc[17];
     if (n_members_all == 0) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);     // offset 0 is not a BGZF member
-    uint64_t total_all; memcpy(&total_all, h_sc + 20, 8);
-    const uint32_t first_member = seek ? h_sc[24] : 0;                                    // == n_members_all when the seek target is no member
-    const uint32_t stop = std::min(h_sc[18], n_members_all);
-    uint64_t q_upos[3]; memcpy(q_upos, h_sc + 32, sizeof q_upos);
+    memcpy(&total_all, h_sc + 20, 8);
+    first_member = seek ? h_sc[24] : 0;                                    // == n_members_all when the seek target is no member
+    stop = std::min(h_sc[18], n_members_all);
+    memcpy(q_upos, h_sc + 32, sizeof q_upos);
     mark("member discovery (2 syncs)");
 
+    return kGoOn;
+}
+
+int EventsRun::stage_range_and_inflate() {
     // -- member range of this call ---------------------------------------------------------------------------------------------
-    uint32_t m_lo = cut_lo ? h_sc[25] : 0;
+    std::vector<Member> &hm = c->hm_scratch;
+    DevBuf &b_arena = c->buf("arena");
+    m_lo = cut_lo ? h_sc[25] : 0;
     if (m_lo <= 4) m_lo = 0;        // keep the file head (BAM header) in the same launch: a lone lane needs milliseconds per member
-    uint32_t m_hi = stop;                                                  // exclusive
+    m_hi = stop;                                                  // exclusive
     if (cut_hi != UINT64_MAX) {
         const uint32_t mh = h_sc[26];
         const uint32_t hi_m = (mh < n_members_all && (cut_hi & 0xffff)) ? mh + 1 : mh;
@@ -842,25 +1009,19 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         }
     }
     // arena offsets of the range ends
-    auto upos_of = [&](uint32_t k, uint64_t &out_v) -> hipError_t {
-        if (k >= n_members_all) { out_v = total_all; return hipSuccess; }
-        Member m;
-        hipError_t e = hipMemcpy(&m, d_members + k, sizeof m, from_members);
-        out_v = m.upos;
-        return e;
-    };
-    uint64_t upos_lo = 0, upos_hi = 0;
+    uint64_t upos_hi = 0;
+    upos_lo = 0;
     HIP_TRY(upos_of(m_lo, upos_lo));
     HIP_TRY(upos_of(m_hi, upos_hi));
-    const uint64_t total = upos_hi - upos_lo;
-    const uint32_t n_range = m_hi - m_lo;
+    total = upos_hi - upos_lo;
+    n_range = m_hi - m_lo;
     HIP_TRY(b_arena.ensure(total + 256));
     HIP_TRY(hipEventRecord(c->ev[0], st));
     DevBuf &b_lens = c->buf("inflate_scratch");
     HIP_TRY(b_lens.ensure(inflate_scratch_bytes(std::max<uint32_t>(n_range, 64))));
     // with a seek, the members in front of its target are only inflated for the header's sake (same launch): their failures end nothing
     const uint32_t ignore_below = (seek && first_member < n_members_all && first_member > m_lo) ? first_member - m_lo : 0;
-    uint8_t *d_bad = nullptr;                                 // region queries: which members of the range did not inflate (every chunk has its own end of stream)
+    d_bad = nullptr;                                 // region queries: which members of the range did not inflate (every chunk has its own end of stream)
     if (chunked && !chunks.empty() && n_range) {
         DevBuf &b_bad = c->buf("bad_members");
         HIP_TRY(b_bad.ensure((size_t)n_range + 64));
@@ -870,17 +1031,6 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     const int pairs = inflate_plan_for(bam_len, total_all);      // (the whole file's ratio: a range of it is the same kind of payload)
     // (early tail: the second of two gated launches is still running on a side stream; whoever reads its part of the arena, or the launch's
     //  verdict, first makes the pipeline's stream wait for it)
-    struct EarlyPart { uint32_t members, waves; uint64_t upos; };       // a part ends in front of member `members` of the range = workgroup `waves` = arena offset `upos`
-    std::vector<EarlyPart> early_parts;
-    bool split_B = false; hipEvent_t split_ev = nullptr;
-    auto join_B = [&]() -> hipError_t {
-        if (!split_B) return hipSuccess;
-        split_B = false;
-        return hipStreamWaitEvent(st, split_ev, 0);
-    };
-    // (every way out of this function while the side stream's launch may still run -- an error in the prefix's framing, say: the next call on this
-    //  context must not meet it)
-    struct SideGuard { bool &pending; hipEvent_t &ev; ~SideGuard() { if (pending && ev) (void)hipEventSynchronize(ev); } } side_guard{split_B, split_ev};
     c->launch_timed = false;
     auto timed_launch = [&](hipStream_t q, bool piece, InflateGate gate) {      // the call's whole-range launch, with its own pair of events on its own stream
         (void)hipEventRecord(c->ev_launch[0], q);
@@ -976,6 +1126,10 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     HIP_TRY(hipEventRecord(c->ev[1], st));
     mark(gated && overlap && inflate_takes_coop(n_range) ? "launch inflate (gated)" : "launch inflate");
 
+    return kGoOn;
+}
+
+int EventsRun::stage_footers_and_header() {
     // -- files whose ISIZE footers lie ------------------------------------------------------------------------------------------
     // The arena was laid out from the footers; the reference never reads them (inflate_block, bgzf.c:292-316: a block is as long as
     // zlib says, at most 64 KiB).  When a member inflates to another length than its footer claims, or the member that ends the
@@ -984,9 +1138,10 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // Host input whose members the host scan vouched for: no round trip here.  The header comes from the host's own inflate of the file's head,
     // the stages behind the inflate are enqueued on the assumption that every member inflates to its footer's length (what a well-formed file
     // does), and the launch's verdict is read with the framing's counts: anything else starts over on the device-resident path below.
+    DevBuf &b_arena = c->buf("arena"), &b_hdr = c->buf("hdr_arena"), &b_lens = c->buf("inflate_scratch");
     BamHeader hdr_host;
-    uint32_t mean_rec = 0;                                    // mean size of the file's first records (0 = unknown: 16 KiB segments)
-    const bool spec = overlap && !d_true_sizes && !geom_chunked_hint && host_bam_header(h_bam, std::min<size_t>(bam_len, (size_t)8 << 20), hdr_host, nullptr, &mean_rec);
+    mean_rec = 0;                                    // mean size of the file's first records (0 = unknown: 16 KiB segments)
+    spec = overlap && !d_true_sizes && !geom_chunked_hint && host_bam_header(h_bam, std::min<size_t>(bam_len, (size_t)8 << 20), hdr_host, nullptr, &mean_rec);
     if (spec) { h_sc[0] = h_sc[1] = 0xffffffffu; h_sc[kStatusEarly] = h_sc[kStatusEarly + 1] = 0xffffffffu; }
     else {
         HIP_TRY(join_B());
@@ -1024,7 +1179,6 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
 
     // -- header (sam.c:114-223): it sits at the start of the arena when the range starts at member 0; otherwise the head of
     //    the file is inflated into its own small arena -----------------------------------------------------------------------
-    BamHeader hdr;
     if (spec) hdr = hdr_host;
     else {
         const uint32_t h_early = h_sc[kStatusEarly];            // read back right after the launch finished (below the footer check)
@@ -1071,11 +1225,15 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
             n_h = std::min(n_members_all, n_h * 4);
         }
     }
-    const int32_t n_ref = (int32_t)hdr.names.size();
+    n_ref = (int32_t)hdr.names.size();
     mark("header (sync: inflate done)");
 
+    return kGoOn;
+}
+
+int EventsRun::stage_bounds_and_chains() {
     // -- stream bounds inside the arena -------------------------------------------------------------------------------------
-    uint64_t lim = total;
+    lim = total;
     if (h_sc[0] != 0xffffffffu) {       // a member of the range failed to inflate: the stream ends where it starts
         uint64_t u = 0;
         HIP_TRY(upos_of(m_lo + h_sc[0], u));
@@ -1085,12 +1243,11 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         if (idx >= n_members_all || idx < m_lo || idx >= m_hi) return total;
         return std::min<uint64_t>(total, upos - upos_lo + (voff & 0xffff));
     };
-    uint64_t pos0;
     if (cut_lo) pos0 = arena_of(cut_lo, h_sc[25], q_upos[1]);
     else pos0 = hdr.end;                 // no seek: records start right after the header (range starts at member 0)
     // Did the stream stop for a reason that ends iteration upstream, rather than at this shard's upper cut?  (A later shard is a seek past
     // that point; the merge drops the shards behind one that ended, so that a damaged file gives the same table whatever the shard count.)
-    bool chain_ended = false;
+    chain_ended = false;
     P.stream_ended = empty_stream;
     if (cut_hi != UINT64_MAX) {
         const uint64_t cut_lim = arena_of(cut_hi, h_sc[26], q_upos[2]);
@@ -1105,7 +1262,6 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     if (pos0 > lim) pos0 = lim;
     if (empty_stream) lim = pos0;            // the seek target does not exist: no record is read
 
-    ExtractCfg cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.n_ref = n_ref; cfg.strandness = p->strandness; cfg.tag0 = (uint8_t)p->strand_tag[0]; cfg.tag1 = (uint8_t)p->strand_tag[1];
     cfg.min_anchor = p->min_anchor; cfg.min_intron = p->min_intron; cfg.max_intron = p->max_intron;
@@ -1149,11 +1305,10 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     // -- region queries: one record chain per chunk of the iterator -----------------------------------------------------------------
     // chunk c = virtual offsets [u, v): a seek to u (bgzf_seek: the member at u >> 16, the offset inside it clipped to its length; no such
     // member = the read fails and the iteration is over), then records while the position in front of the next one is below v.
-    SegGeom geom; memset(&geom, 0, sizeof geom);
+    memset(&geom, 0, sizeof geom);
     const int env_seg = decode_knobs().seg_bytes;                   // (tests) 16384 or 131072
-    const uint32_t seg_bytes = env_seg == (int)kSegBytes || env_seg == (int)kSegBytesLong ? (uint32_t)env_seg : (mean_rec >= kLongRecordBytes ? kSegBytesLong : kSegBytes);
+    seg_bytes = env_seg == (int)kSegBytes || env_seg == (int)kSegBytesLong ? (uint32_t)env_seg : (mean_rec >= kLongRecordBytes ? kSegBytesLong : kSegBytes);
     geom.seg_bytes = seg_bytes;
-    std::vector<SegChunk> seg_chunks;
     if (chunked && chunks.empty()) lim = pos0;                // an iterator without chunks returns nothing
     if (chunked && !chunks.empty() && !empty_stream) {
         std::vector<Member> rm(n_range);
@@ -1200,13 +1355,17 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         mark("chunk table");
     }
 
+    return kGoOn;
+}
+
+int EventsRun::stage_framing() {
     // -- record framing ------------------------------------------------------------------------------------------------
-    const uint8_t *arena = b_arena.as<uint8_t>();
-    uint64_t span = lim - pos0;
-    uint32_t n_seg = (uint32_t)((span + seg_bytes - 1) / seg_bytes);
+    arena = c->buf("arena").as<uint8_t>();
+    span = lim - pos0;
+    n_seg = (uint32_t)((span + seg_bytes - 1) / seg_bytes);
     geom.pos0 = pos0; geom.lim = lim; geom.data_end = lim; geom.seg_bytes = seg_bytes;
     const int env_lite = 1;
-    const bool lite_walk = env_lite && !c->walk_strict;
+    lite_walk = env_lite && !c->walk_strict;
     geom.lite_walk = lite_walk ? 1u : 0u;
     if (geom.chunks) {
         span = 0;
@@ -1215,93 +1374,20 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
         n_seg = lastc.seg_base + (uint32_t)((lastc.b - lastc.a + seg_bytes - 1) / seg_bytes);
         geom.data_end = total;
     }
-    uint32_t n_rec = 0;
+    n_rec = 0;
     DevBuf &b_seg = c->buf("seg"), &b_tmp = c->buf("tmp");
     HIP_TRY(hipEventRecord(c->ev[2], st));
-    uint64_t *seg_start[2] = {nullptr, nullptr}, *seg_exit[2] = {nullptr, nullptr};
-    uint32_t *seg_cnt[2] = {nullptr, nullptr}, *seg_base = nullptr;
-    uint32_t *seg_iter_e = nullptr, *seg_long_e = nullptr, *seg_long_base_e = nullptr;      // early tail: per-segment outputs of the decode that the second framing must not overwrite
-    uint16_t *seg_cp = nullptr;
-    int cur = 0;
-    // One framing: the walk of segments [walk_from, n_s), then verification sweeps over [0, n_s) until the chain agrees.  Returns -1 to go on,
-    // anything else is the call's result (a restart on another path has run, or an error).  `ended` = the chain ends inside [0, n_s).
-    auto frame = [&](uint32_t n_s, uint32_t walk_from, bool &ended) -> int {
-        launch_seg_walk(arena, geom, n_s, n_ref, seg_start[cur], seg_exit[cur], seg_cnt[cur], seg_cp, st, walk_from);
-        // d_sc[10]: leftmost disagreeing segment, d_sc[11]: leftmost chain end, d_sc[3]: record total
-        for (int iter = 0;; ++iter) {
-            HIP_TRY(hipMemsetAsync(d_sc + 10, 0xff, 8, st));
-            launch_seg_verify(arena, geom, n_s, seg_start[cur], seg_exit[cur], seg_cnt[cur], seg_start[cur ^ 1], seg_exit[cur ^ 1],
-                              seg_cnt[cur ^ 1], d_sc + 10, seg_cp, st);
-            cur ^= 1;
-            launch_scan_u32(seg_cnt[cur], seg_base, n_s, d_sc + 3, b_tmp.as<uint32_t>(), st);
-            HIP_TRY(hipMemcpyAsync(h_sc + 3, d_sc + 3, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(h_sc + 10, d_sc + 10, 8, hipMemcpyDeviceToHost, st));
-            if (spec && iter == 0) {
-                HIP_TRY(hipMemcpyAsync(h_sc, d_sc, 8, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipMemcpyAsync(h_sc + kStatusEarly, d_sc + kStatusEarly, 8, hipMemcpyDeviceToHost, st));
-            }
-            HIP_TRY(hipStreamSynchronize(st));
-            if (spec && iter == 0 && (h_sc[0] != 0xffffffffu || h_sc[kStatusEarly] != 0xffffffffu)) {
-                // some member did not inflate to its footer's length: nothing enqueued since is worth anything
-                mark("inflate verdict: not clean, starting over device-resident");
-                if (gated) { c->gate_distrust = true; if (trace) fprintf(stderr, "[rgx trace] arrival gate: verdict not clean, this context no longer uses it\n"); }
-                HIP_TRY(join_B());
-                HIP_TRY(complete_upload());
-                HIP_TRY(hipStreamSynchronize(copy_q));
-                HIP_TRY(hipStreamSynchronize(st));
-                const int rc2 = prepare_events(c, d_bam, nullptr, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, nullptr, false, region_to_file_end);
-                P.t_begin = t_begin;
-                return rc2;
-            }
-            ++P.framing_sweeps;
-            if (h_sc[11] != 0xffffffffu) ended = true;           // some segment's chain ends: an unreadable / cut-off record (sam.c:421-423)
-            // the chain ends inside the exact prefix (or everything is exact): nothing starts after that segment -- with one chain the
-            // end already spread to the right by itself; the chains of later chunks would not know
-            if (h_sc[11] != 0xffffffffu && (h_sc[11] < h_sc[10] || (h_sc[10] == 0xffffffffu && geom.chunks))) {
-                launch_seg_truncate(geom, n_s, h_sc[11], seg_start[cur], seg_exit[cur], seg_cnt[cur], st);
-                launch_scan_u32(seg_cnt[cur], seg_base, n_s, d_sc + 3, b_tmp.as<uint32_t>(), st);
-                HIP_TRY(hipMemcpyAsync(h_sc + 3, d_sc + 3, 4, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                break;
-            }
-            if (h_sc[10] == 0xffffffffu) break;
-            if (iter > 1 << 20) return fail(err, errlen, RGX_ERR_FORMAT, "regtools_amd: record framing did not converge\n");
-        }
-        return -1;
-    };
     // Early tail (round 4): while the side stream's launch still inflates the members of the last upload chunks, the segments that lie wholly
     // in front of their part of the arena (one member's margin: a walk only ever reads the 36 bytes behind its segment, a guess that
     // reads further is only a guess) are framed, verified and decoded -- exact for the same reason the whole chain is: segment 0 starts at
     // an exact offset.  Plain whole-file calls on 16 KiB segments only; anything unusual in the prefix (the chain ends there, sweeps beyond
     // the usual one) drops back to the one-pass order.
-    uint32_t sA = 0;                                          // early tail: segments [0, sA) are framed, verified and decoded
-    bool emit_parts_ok = false; uint32_t emit_parts = 0, emit_rows = 0; size_t ev_lay = 0;      // early tail: rows [0, emit_rows) have their events out, in emit_parts parts
-    EventSoA ev_e; memset(&ev_e, 0, sizeof ev_e);
-    auto ev_layout = [&](uint8_t *q, size_t E) {
-        EventSoA v; memset(&v, 0, sizeof v);
-        v.tid = (uint32_t *)q; q += E * 4; v.start = (uint32_t *)q; q += E * 4; v.ilen_cls = (uint32_t *)q; q += E * 4;
-        v.ts = (uint32_t *)q; q += E * 4; v.te = (uint32_t *)q; q += E * 4;
-        if (want_read_span) { v.rpos = (uint32_t *)q; q += E * 4; v.rend = (uint32_t *)q; q += E * 4; }
-        if (p->barcodes) { v.read = (uint32_t *)q; q += E * 4; }
-        v.strand = q;
-        return v;
-    };
-    size_t soa_cap = 0;                                       // rows the SoA columns are laid out for (early tail: an estimate made from the prefix)
-    DevBuf &b_soa = c->buf("soa");
-    ReadSoA soa; memset(&soa, 0, sizeof soa);
-    uint32_t *ev_base = nullptr, *long_list = nullptr;
-    auto soa_layout = [&](size_t R) -> hipError_t {
-        hipError_t e_ = b_soa.ensure(R * (4 + 4 + 4 + 8 + 1 + 4 + 4 + 4 + (p->barcodes ? 8 : 0)) + 256);
-        if (e_ != hipSuccess) return e_;
-        uint8_t *q = b_soa.as<uint8_t>();
-        soa.cig_off = (uint64_t *)q; q += R * 8;
-        if (p->barcodes) { soa.rec_off = (uint64_t *)q; q += R * 8; }
-        soa.tid = (int32_t *)q; q += R * 4; soa.pos = (int32_t *)q; q += R * 4; soa.flag_nc = (uint32_t *)q; q += R * 4;
-        soa.n_ev = (uint32_t *)q; q += R * 4; ev_base = (uint32_t *)q; q += R * 4; long_list = (uint32_t *)q; q += R * 4;
-        soa.strand = q;
-        soa_cap = R;
-        return hipSuccess;
-    };
+    sA = 0;
+    emit_parts_ok = false; emit_parts = 0; emit_rows = 0; ev_lay = 0;
+    memset(&ev_e, 0, sizeof ev_e);
+    soa_cap = 0;
+    memset(&soa, 0, sizeof soa);
+    ev_base = nullptr; long_list = nullptr;
     if (n_seg) {
         const size_t per = (size_t)n_seg;
         HIP_TRY(b_seg.ensure(per * (8 + 8 + 4) * 2 + per * 4 + per * 12 + 64));
@@ -1404,9 +1490,14 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     HIP_TRY(hipEventRecord(c->ev[3], st));
     mark("framing (sync)");
 
+    return kGoOn;
+}
+
+int EventsRun::stage_decode() {
     // -- decode + count -----------------------------------------------------------------------------------------------------
-    uint32_t n_events = 0, n_long = 0;
-    uint64_t n_iterated = 0;
+    DevBuf &b_tmp = c->buf("tmp");
+    n_events = 0; n_long = 0;
+    n_iterated = 0;
     if (n_rec) {
         const size_t R = n_rec;
         // (early tail: the prefix is decoded already, into columns laid out for an estimate of the row count; when that was short, or the chain
@@ -1478,6 +1569,10 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     HIP_TRY(hipEventRecord(c->ev[4], st));
     mark("decode+count (sync)");
 
+    return kGoOn;
+}
+
+int EventsRun::stage_emit() {
     // -- emit -----------------------------------------------------------------------------------------------------------------
     DevBuf &b_ev = c->buf("events");
     EventSoA ev; memset(&ev, 0, sizeof ev);
@@ -1501,6 +1596,13 @@ static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_
     P.hdr = hdr; P.arena = arena; P.soa = soa; P.ev = ev; P.n_rec = n_rec; P.n_events = n_events; P.n_range = n_range;
     P.n_iterated = n_iterated; P.total = total; P.t_begin = t_begin;
     return RGX_OK;
+}
+
+static int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_bam, size_t bam_len, const uint8_t *bai, size_t bai_len,
+                          const rgx_extract_params *p, bool want_read_span, Prep &P, char *err, size_t errlen, const uint32_t *d_true_sizes,
+                          bool allow_overlap, bool region_to_file_end, const SharedMembers *shared) {
+    EventsRun r{c, d_bam_in, h_bam, bam_len, bai, bai_len, p, want_read_span, P, err, errlen, d_true_sizes, allow_overlap, region_to_file_end, shared};
+    return r.run();
 }
 
 // Group-by of junction events + output order, generic over the leading key word `ev.tid` (the contig for
