@@ -389,6 +389,15 @@ std::string GtfModel::load(const std::string &path) {
         }
     }
     lap("bins");
+    // What is left is teardown: the parts' record lists and transcript lists, the merge's arrays, the mapping of the text -- page-table work the caller
+    // (identify's GTF thread, on the call's critical path once the extraction is done) need not wait for.  The process's background thread takes it
+    // (worker_pool.h Reaper: rgx_ctx_destroy and the process's exit wait for it).
+    {
+        auto later = [](auto &obj) { auto *h = new typename std::remove_reference<decltype(obj)>::type(std::move(obj)); Reaper::get().later([h] { delete h; }); };
+        later(parts); later(refs); later(rank); later(tmp); later(goff); later(gs); later(ge); later(order);
+        file.release_later();
+    }
+    lap("teardown handed over");
     return "";
 }
 

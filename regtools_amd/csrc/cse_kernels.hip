@@ -188,34 +188,65 @@ __global__ void k_window_ranges(EventSoA ev, uint32_t n_events, uint32_t n_win, 
     w_hi[w] = ev_lower_bound(ev, n_events, (uint32_t)t, (uint32_t)end);
 }
 
+// Round 5: two kernels.  Most windows have a handful of candidates (config 4: 19 k windows, 2.6 M pairs, a median window a few dozen events), a few -- over
+// a highly expressed gene -- hundreds of thousands.  A WAVE takes a small window whole (its four slices in turn: one launch of n_win / 4 workgroups, no
+// barrier; the four-workgroups-per-window form was 77 k workgroups of one step each -- the launch WAS its workgroups: 0.016 of the HBM line), the
+// windows above kBigWindow candidates keep the workgroup-per-slice form, a fixed grid striding over the windows and skipping the small ones.
+constexpr uint32_t kBigWindow = 4096;
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_window_pairs_small(EventSoA ev, uint32_t n_win, const int32_t *__restrict__ w_beg, const uint32_t *__restrict__ w_lo,
+                                                            const uint32_t *__restrict__ w_hi, uint32_t *count, const uint32_t *__restrict__ base, uint32_t *pair_ev,
+                                                            uint32_t *pair_win) {
+    const uint32_t lane = threadIdx.x & 63u, w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_win) return;
+    const uint32_t lo = w_lo[w], hi = w_hi[w];
+    const uint64_t len = hi - lo;
+    if (len > kBigWindow) return;                                             // (k_window_pairs' window)
+    const int32_t beg = w_beg[w];
+    for (uint32_t sl = 0; sl < kWinSlices; ++sl) {
+        const uint32_t a = lo + (uint32_t)(len * sl / kWinSlices), b = lo + (uint32_t)(len * (sl + 1) / kWinSlices);
+        uint32_t out = FILL ? base[(size_t)w * kWinSlices + sl] : 0u, total = 0;
+        for (uint32_t e0 = a; e0 < b; e0 += 64) {                             // (wave-uniform trip count)
+            const uint32_t e = e0 + lane;
+            const bool keep = e < b && (int32_t)ev.rend[e] > beg;             // pos < end holds for the whole range
+            const uint64_t m = __ballot(keep);
+            if (FILL && keep) { const uint32_t k = out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); pair_ev[k] = e; pair_win[k] = w; }
+            out += (uint32_t)__popcll(m); total += (uint32_t)__popcll(m);
+        }
+        if (!FILL && lane == 0) count[(size_t)w * kWinSlices + sl] = total;
+    }
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_window_pairs(EventSoA ev, uint32_t n_win, const int32_t *__restrict__ w_beg, const uint32_t *__restrict__ w_lo,
                                                       const uint32_t *__restrict__ w_hi, uint32_t *count, const uint32_t *__restrict__ base, uint32_t *pair_ev,
                                                       uint32_t *pair_win) {
     __shared__ uint32_t wave_cnt[4];
-    const uint32_t w = blockIdx.x, sl = blockIdx.y, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    if (w >= n_win) return;
-    const int32_t beg = w_beg[w];
-    const uint32_t lo = w_lo[w], hi = w_hi[w];
-    const uint64_t len = hi - lo;
-    const uint32_t a = lo + (uint32_t)(len * sl / kWinSlices), b = lo + (uint32_t)(len * (sl + 1) / kWinSlices);
-    uint32_t out = FILL ? base[(size_t)w * kWinSlices + sl] : 0u, total = 0;
-    for (uint32_t e0 = a; e0 < b; e0 += 256) {                                // (block-uniform trip count)
-        const uint32_t e = e0 + threadIdx.x;
-        const bool keep = e < b && (int32_t)ev.rend[e] > beg;               // pos < end holds for the whole range
-        const uint64_t m = __ballot(keep);
-        if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(m);
-        __syncthreads();
-        const uint32_t c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
-        if (FILL && keep) {
-            const uint32_t before = wv == 0 ? 0u : wv == 1 ? c0 : wv == 2 ? c0 + c1 : c0 + c1 + c2;
-            const uint32_t k = out + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            pair_ev[k] = e; pair_win[k] = w;
+    const uint32_t sl = blockIdx.y, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (uint32_t w = blockIdx.x; w < n_win; w += gridDim.x) {                // (everything below is uniform over the workgroup)
+        const uint32_t lo = w_lo[w], hi = w_hi[w];
+        const uint64_t len = hi - lo;
+        if (len <= kBigWindow) continue;                                      // (k_window_pairs_small's window)
+        const int32_t beg = w_beg[w];
+        const uint32_t a = lo + (uint32_t)(len * sl / kWinSlices), b = lo + (uint32_t)(len * (sl + 1) / kWinSlices);
+        uint32_t out = FILL ? base[(size_t)w * kWinSlices + sl] : 0u, total = 0;
+        for (uint32_t e0 = a; e0 < b; e0 += 256) {                            // (block-uniform trip count)
+            const uint32_t e = e0 + threadIdx.x;
+            const bool keep = e < b && (int32_t)ev.rend[e] > beg;             // pos < end holds for the whole range
+            const uint64_t m = __ballot(keep);
+            if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(m);
+            __syncthreads();
+            const uint32_t c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
+            if (FILL && keep) {
+                const uint32_t before = wv == 0 ? 0u : wv == 1 ? c0 : wv == 2 ? c0 + c1 : c0 + c1 + c2;
+                const uint32_t k = out + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                pair_ev[k] = e; pair_win[k] = w;
+            }
+            out += c0 + c1 + c2 + c3; total += c0 + c1 + c2 + c3;
+            __syncthreads();
         }
-        out += c0 + c1 + c2 + c3; total += c0 + c1 + c2 + c3;
-        __syncthreads();
+        if (!FILL && threadIdx.x == 0) count[(size_t)w * kWinSlices + sl] = total;
     }
-    if (!FILL && threadIdx.x == 0) count[(size_t)w * kWinSlices + sl] = total;
 }
 
 // `cis-splice-effects associate` (cis_splice_effects_associator.cc:261-272): window w keeps every junction of its contig whose start
@@ -281,10 +312,14 @@ void launch_window_pairs(bool fill, EventSoA ev, uint32_t n_events, uint32_t n_w
                          const uint32_t *max_span, uint32_t *w_lo, uint32_t *w_hi, uint32_t *count, const uint32_t *base, uint32_t *pair_ev, uint32_t *pair_win,
                          hipStream_t stream) {
     if (!n_win) return;
-    if (fill) hipLaunchKernelGGL(k_window_pairs<true>, dim3(n_win, kWinSlices), dim3(256), 0, stream, ev, n_win, w_beg, w_lo, w_hi, count, base, pair_ev, pair_win);
-    else {
+    const dim3 g_small((n_win + 3) / 4), g_big(std::min<uint32_t>(n_win, 1024), kWinSlices);
+    if (fill) {
+        hipLaunchKernelGGL(k_window_pairs_small<true>, g_small, dim3(256), 0, stream, ev, n_win, w_beg, w_lo, w_hi, count, base, pair_ev, pair_win);
+        hipLaunchKernelGGL(k_window_pairs<true>, g_big, dim3(256), 0, stream, ev, n_win, w_beg, w_lo, w_hi, count, base, pair_ev, pair_win);
+    } else {
         hipLaunchKernelGGL(k_window_ranges, dim3((n_win + 63) / 64), dim3(64), 0, stream, ev, n_events, n_win, w_tid, w_beg, w_end, max_span, w_lo, w_hi);
-        hipLaunchKernelGGL(k_window_pairs<false>, dim3(n_win, kWinSlices), dim3(256), 0, stream, ev, n_win, w_beg, w_lo, w_hi, count, base, pair_ev, pair_win);
+        hipLaunchKernelGGL(k_window_pairs_small<false>, g_small, dim3(256), 0, stream, ev, n_win, w_beg, w_lo, w_hi, count, base, pair_ev, pair_win);
+        hipLaunchKernelGGL(k_window_pairs<false>, g_big, dim3(256), 0, stream, ev, n_win, w_beg, w_lo, w_hi, count, base, pair_ev, pair_win);
     }
 }
 void launch_assoc_pairs(bool fill, uint32_t n_win, const int32_t *w_chrom, const uint32_t *w_ces, const uint32_t *w_cee, const uint32_t *chrom_off,

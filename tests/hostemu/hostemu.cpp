@@ -242,3 +242,14 @@ extern "C" int emu_pool_selftest(uint32_t seed, uint32_t n, uint32_t threads) {
     for (auto &s : names) if (!s.empty()) return 5;                 // strings ARE constructed (only trivial types are left untouched)
     return 0;
 }
+
+// (lab) wall time of GtfModel::load alone, in ms: what the call costs its caller including the teardown of its temporaries
+#include <chrono>
+extern "C" double emu_gtf_load_ms(const char *gtf_path) {
+    const auto t0 = std::chrono::steady_clock::now();
+    rgx::GtfModel *m = new rgx::GtfModel();
+    const std::string e = m->load(gtf_path);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    delete m;
+    return e.empty() ? ms : -1.0;
+}
