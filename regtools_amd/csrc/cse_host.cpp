@@ -116,7 +116,8 @@ static long field_atol(const char *s, size_t n) {
 }
 
 std::string GtfModel::load(const std::string &path) {
-    FileBytes file;
+    std::shared_ptr<FileBytes> file_h = std::make_shared<FileBytes>();
+    FileBytes &file = *file_h;
     if (!file.open(path)) return "\nUnable to open GTF file.";      // (the scan threads fault the mapping in, each its own range)
     const char *text = (const char *)file.data();
     const size_t text_len = file.size();
@@ -390,14 +391,13 @@ std::string GtfModel::load(const std::string &path) {
     }
     lap("bins");
     // What is left is teardown: the parts' record lists and transcript lists, the merge's arrays, the mapping of the text -- page-table work the caller
-    // (identify's GTF thread, on the call's critical path once the extraction is done) need not wait for.  The process's background thread takes it
-    // (worker_pool.h Reaper: rgx_ctx_destroy and the process's exit wait for it).
+    // (identify's GTF thread, on the call's critical path once the extraction is done) need not wait for: kept with the model (cse_host.h load_scratch).
     {
-        auto later = [](auto &obj) { auto *h = new typename std::remove_reference<decltype(obj)>::type(std::move(obj)); Reaper::get().later([h] { delete h; }); };
-        later(parts); later(refs); later(rank); later(tmp); later(goff); later(gs); later(ge); later(order);
-        file.release_later();
+        auto keep = [this](auto &obj) { typedef typename std::remove_reference<decltype(obj)>::type T; load_scratch.push_back(std::shared_ptr<void>(new T(std::move(obj)), [](void *q) { delete (T *)q; })); };
+        keep(parts); keep(refs); keep(rank); keep(tmp); keep(goff); keep(gs); keep(ge); keep(order);
+        load_scratch.push_back(file_h);
     }
-    lap("teardown handed over");
+    lap("teardown kept for later");
     return "";
 }
 

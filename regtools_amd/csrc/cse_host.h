@@ -6,6 +6,7 @@
 #include <stdio.h>
 
 #include <functional>
+#include <memory>
 #include <string>
 #include "bigvec.h"
 #include "vcf_model.h"
@@ -29,6 +30,11 @@ struct GtfModel {
     BigVec<uint32_t> bin_tx;
     BigVec<uint32_t> bin_start;                            // contigs x bin_stride + 1 entries: where (contig, bin)'s entries begin (empty: too many to index)
     uint32_t bin_stride = 0;
+    // What load() built the tables from -- the parts' record lists, the merge's arrays, the mapping of the text: taking them down is page-table work
+    // (13 ms for a GENCODE-scale file) that load()'s caller need not wait for.  They go with the model, or when release_load_scratch() says so
+    // (rgx_gtf_load: a model that lives long); `identify` hands the whole model to the process's background thread once its outputs are written.
+    std::vector<std::shared_ptr<void>> load_scratch;
+    void release_load_scratch() { load_scratch.clear(); }
     // returns "" on success, else the message the reference would die with
     std::string load(const std::string &path);
     int32_t chrom_of(const std::string &name) const { auto it = chrom_index.find(name); return it == chrom_index.end() ? -1 : it->second; }

@@ -217,11 +217,14 @@ __global__ __launch_bounds__(256) void k_window_pairs_small(EventSoA ev, uint32_
     }
 }
 
+// (sixteen waves per workgroup: a window over the file's most expressed gene holds hundreds of thousands of candidates -- config 4: 600 k -- and the
+//  launch is as long as that window's four slices: 117 us with four waves each, a quarter of that with sixteen)
+constexpr uint32_t kBigBlock = 1024;
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_window_pairs(EventSoA ev, uint32_t n_win, const int32_t *__restrict__ w_beg, const uint32_t *__restrict__ w_lo,
-                                                      const uint32_t *__restrict__ w_hi, uint32_t *count, const uint32_t *__restrict__ base, uint32_t *pair_ev,
-                                                      uint32_t *pair_win) {
-    __shared__ uint32_t wave_cnt[4];
+__global__ __launch_bounds__(kBigBlock) void k_window_pairs(EventSoA ev, uint32_t n_win, const int32_t *__restrict__ w_beg, const uint32_t *__restrict__ w_lo,
+                                                            const uint32_t *__restrict__ w_hi, uint32_t *count, const uint32_t *__restrict__ base, uint32_t *pair_ev,
+                                                            uint32_t *pair_win) {
+    __shared__ uint32_t wave_cnt[kBigBlock / 64];
     const uint32_t sl = blockIdx.y, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     for (uint32_t w = blockIdx.x; w < n_win; w += gridDim.x) {                // (everything below is uniform over the workgroup)
         const uint32_t lo = w_lo[w], hi = w_hi[w];
@@ -230,19 +233,20 @@ __global__ __launch_bounds__(256) void k_window_pairs(EventSoA ev, uint32_t n_wi
         const int32_t beg = w_beg[w];
         const uint32_t a = lo + (uint32_t)(len * sl / kWinSlices), b = lo + (uint32_t)(len * (sl + 1) / kWinSlices);
         uint32_t out = FILL ? base[(size_t)w * kWinSlices + sl] : 0u, total = 0;
-        for (uint32_t e0 = a; e0 < b; e0 += 256) {                            // (block-uniform trip count)
+        for (uint32_t e0 = a; e0 < b; e0 += kBigBlock) {                      // (block-uniform trip count)
             const uint32_t e = e0 + threadIdx.x;
             const bool keep = e < b && (int32_t)ev.rend[e] > beg;             // pos < end holds for the whole range
             const uint64_t m = __ballot(keep);
             if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(m);
             __syncthreads();
-            const uint32_t c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
+            uint32_t before = 0, all = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < kBigBlock / 64; ++k) { const uint32_t ck = wave_cnt[k]; before += k < wv ? ck : 0u; all += ck; }
             if (FILL && keep) {
-                const uint32_t before = wv == 0 ? 0u : wv == 1 ? c0 : wv == 2 ? c0 + c1 : c0 + c1 + c2;
                 const uint32_t k = out + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                 pair_ev[k] = e; pair_win[k] = w;
             }
-            out += c0 + c1 + c2 + c3; total += c0 + c1 + c2 + c3;
+            out += all; total += all;
             __syncthreads();
         }
         if (!FILL && threadIdx.x == 0) count[(size_t)w * kWinSlices + sl] = total;
@@ -312,14 +316,14 @@ void launch_window_pairs(bool fill, EventSoA ev, uint32_t n_events, uint32_t n_w
                          const uint32_t *max_span, uint32_t *w_lo, uint32_t *w_hi, uint32_t *count, const uint32_t *base, uint32_t *pair_ev, uint32_t *pair_win,
                          hipStream_t stream) {
     if (!n_win) return;
-    const dim3 g_small((n_win + 3) / 4), g_big(std::min<uint32_t>(n_win, 1024), kWinSlices);
+    const dim3 g_small((n_win + 3) / 4), g_big(std::min<uint32_t>(n_win, 256), kWinSlices);
     if (fill) {
         hipLaunchKernelGGL(k_window_pairs_small<true>, g_small, dim3(256), 0, stream, ev, n_win, w_beg, w_lo, w_hi, count, base, pair_ev, pair_win);
-        hipLaunchKernelGGL(k_window_pairs<true>, g_big, dim3(256), 0, stream, ev, n_win, w_beg, w_lo, w_hi, count, base, pair_ev, pair_win);
+        hipLaunchKernelGGL(k_window_pairs<true>, g_big, dim3(kBigBlock), 0, stream, ev, n_win, w_beg, w_lo, w_hi, count, base, pair_ev, pair_win);
     } else {
         hipLaunchKernelGGL(k_window_ranges, dim3((n_win + 63) / 64), dim3(64), 0, stream, ev, n_events, n_win, w_tid, w_beg, w_end, max_span, w_lo, w_hi);
         hipLaunchKernelGGL(k_window_pairs_small<false>, g_small, dim3(256), 0, stream, ev, n_win, w_beg, w_lo, w_hi, count, base, pair_ev, pair_win);
-        hipLaunchKernelGGL(k_window_pairs<false>, g_big, dim3(256), 0, stream, ev, n_win, w_beg, w_lo, w_hi, count, base, pair_ev, pair_win);
+        hipLaunchKernelGGL(k_window_pairs<false>, g_big, dim3(kBigBlock), 0, stream, ev, n_win, w_beg, w_lo, w_hi, count, base, pair_ev, pair_win);
     }
 }
 void launch_assoc_pairs(bool fill, uint32_t n_win, const int32_t *w_chrom, const uint32_t *w_ces, const uint32_t *w_cee, const uint32_t *chrom_off,

@@ -3,7 +3,7 @@
 # memory copies of the LAST step, relative to that step's first event (who overlaps whom)
 OUT=$1; shift
 R=$PWD; export TMPDIR=/tmp; mkdir -p $R/$OUT; cd /tmp
-timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $R/$OUT -o tl -- python $R/bench.py --no-cpu-baseline --host-only "$@" > $R/$OUT/bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $R/$OUT -o tl -- python $R/bench.py --no-cpu-baseline --no-live-traffic --host-only "$@" > $R/$OUT/bench.log 2>&1
 cd $R
 python3 - <<PY
 import csv,glob
