@@ -247,7 +247,7 @@ def extra_identify(regtools_amd, synth, ctx, reads, genes, variants, sample, see
                "counts": {k: S[k] for k in ("n_variants", "n_relevant", "n_windows", "n_pairs", "n_junctions", "n_records", "n_events", "exon_visits_variants", "exon_visits_junctions")},
                "roofline": {"k_variant_scan": roof(b_var, S["ms_k_variant_scan"]), "k_junction_scan": roof(b_jun, S["ms_k_junction_scan"]),
                             "k_window_pairs": roof(b_win, S["ms_k_window_pairs"]),
-                            "note": "random gathers over the flat GTF arrays: one lane per variant (k_variant_scan), one wave per junction (k_junction_scan_wave), a workgroup per window slice (k_window_pairs: 19 k windows, most with a handful of candidate events -- the launch is its 77 k tiny workgroups, not its bytes): far below the HBM line by construction (SURVEY 8d)"}}
+                            "note": "random gathers over the flat GTF arrays: one lane per variant (k_variant_scan), one wave per junction (k_junction_scan_wave), a wave per small window and sixteen waves per slice of a hot one (k_window_ranges + k_window_pairs_small + k_window_pairs, count and fill: 19 k windows, most with a few dozen candidate events, a few with 600 k -- two binary searches of ~23 dependent loads per window and the hottest window's slices are the launches' time, not the bytes): far below the HBM line by construction (SURVEY 8d)"}}
         spre, sst, sann = quartet(td, "s4", *sample)
         run(spre, sann, ".gpu")
         rc, dt = run_reference(["cis-splice-effects", "identify", "-s", "XS", "-o", spre + ".ref.tsv", "-v", spre + ".ref.vcf", "-j", spre + ".ref.bed",
