@@ -109,8 +109,9 @@ void parallel_sort(WorkerPool &pool, It b, It e, Less less) {
 
 // Things whose teardown is page-table or allocator work the caller need not wait for (unmapping a 500 MB file costs 8 ms, handing back the
 // tables of a 250 k-transcript annotation 4 ms): handed to ONE background thread of the process, in order.  drain() = wait until everything
-// handed over so far is gone (a context being destroyed; the process ending -- registered with atexit when the thread starts, which runs
-// before the HIP runtime's own exit handlers because it was registered after them).
+// handed over so far is gone (a context being destroyed; the process ending -- registered with atexit when the thread starts).  Round 5: what is
+// handed over is HOST teardown only (munmap, vectors, strings): a hipFree on this thread synchronised the device in the middle of the caller's next call,
+// and its order against the HIP runtime's own exit handlers was an assumption.
 class Reaper {
   public:
     static Reaper &get() { static Reaper *r = new Reaper(); return *r; }      // (never destroyed: no static-destruction order to get wrong)
