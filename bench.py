@@ -292,6 +292,8 @@ def main():
         raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
     # (BENCH_DEVICE / BENCH_BACKEND: test knobs -- several ranks on ONE GPU with the gloo backend exercise this script's N > 1 path where no
     # multi-GPU node is at hand; the driver's runs use neither)
+    if os.environ.get("BENCH_DEVICE") is not None:
+        os.environ.setdefault("REGTOOLS_AMD_ARENA_TRIALS", "0")      # (several ranks on ONE GPU: every process would hold a second arena for its placement trial at the same time)
     device_index = int(os.environ.get("BENCH_DEVICE", local_rank))
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(device_index)
@@ -464,6 +466,9 @@ def main():
                          "kernel_ms_in_step": (sum(k_in_step) / len(k_in_step)) if k_in_step else None,
                          "kernel_ms_in_step_is": "the arrival-gated launch the TIMED step runs (same kernel under its PIECE symbol, HIP events on its own stream): it spans the upload -- "
                                                  "its waves wait for the chunk their members lie in -- so its duration is not a rate of the kernel",
+                         "arena_placement_trials_ms": ctx.arena_trials(),
+                         "arena_placement_is": "the launch's time depends on where the arena's pages lie (stable per allocation; DESIGN.md 5.5): on its first large call the context "
+                                               "times the same launch into its arena ([0]) and into five fresh allocations and keeps the fastest; the timed steps and kernel_ms run on the kept one",
                          "algorithmic_bytes": alg_bytes,
                          "note": "DEFLATE is a serial bit stream per member: one lane per member (long matches copied by the wave), bound by per-lane dependent ALU/LDS chains, the L1's rate of scattered per-lane accesses and one memory round trip per symbol trip, far below the HBM line (SURVEY 8d; DESIGN.md 5)",
                          "pipeline_frac": aln_per_s / world * (alg_bytes / n_reads) / (HBM_PEAK_GBS * 1e9)},

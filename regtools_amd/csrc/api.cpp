@@ -131,6 +131,12 @@ struct rgx_ctx {
     uint32_t gate_epoch = 0;                           // arrival gate of the overlapped upload (kernels.h InflateGate): this context's call counter
     hipEvent_t ev_ready = nullptr, ev_side[kSideStreams] = {}, ev_packed = nullptr;
     hipEvent_t ev[8] = {};
+    // Arena placement (round 5): the DEFLATE launch's time depends on where the arena's pages lie -- 12.8 / 13.9 / 15.0 ms for the same launch into
+    // ten arenas of one process, stable per arena -- so a context that is not one-shot tries a few on its first large call and keeps the fastest.
+    uint64_t arena_calibrated_bytes = 0;                 // the size the kept arena was chosen at (0 = not yet)
+    DevBuf *arena_retired = nullptr;                     // the arena a call's data lies in after it lost to a challenger: released by the next call
+    hipEvent_t ev_trial[2] = {};
+    float arena_trial_ms[8] = {}; int arena_trials = 0;  // (statistics: the candidates' times of the last calibration, [0] = the arena the call ran on)
     hipEvent_t ev_launch[2] = {}; bool launch_timed = false;   // around the call's whole-range DEFLATE launch, on the stream it runs on (host input: the arrival-gated launch, which spans the upload)
     std::map<std::string, DevBuf> bufs;
     void *pinned = nullptr; size_t pinned_cap = 0;     // small pinned staging for scalar readbacks
@@ -209,6 +215,7 @@ extern "C" int rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errle
     { const char *e = getenv("REGTOOLS_AMD_ONE_SHOT"); c->one_shot = e && strcmp(e, "0") != 0; }
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto &e : c->ev_launch) HIP_TRY(hipEventCreate(&e));
+    for (auto &e : c->ev_trial) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
     c->pinned_cap = 4096;
     *out = c;
@@ -235,13 +242,25 @@ static hipError_t ensure_upload_streams(rgx_ctx *c) {
     return hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
 }
 
+// (multi.cpp: a context made for a device that a device list names a second time -- shards taking turns on one GPU, a test configuration -- does without the trials:
+//  several contexts of one device would each hold a second arena at the same time)
+void rgx_ctx_no_arena_trials(rgx_ctx *c) { if (c) c->arena_calibrated_bytes = UINT64_MAX; }
+
+extern "C" int rgx_ctx_arena_trials(const rgx_ctx *c, float *ms, int cap) {
+    if (!c) return 0;
+    for (int k = 0; k < c->arena_trials && k < cap; ++k) ms[k] = c->arena_trial_ms[k];
+    return c->arena_trials;
+}
+
 extern "C" void rgx_ctx_destroy(rgx_ctx *c) {
     if (!c) return;
     Reaper::get().drain();                                  // (deferred teardown of finished calls may still hold memory of this device)
     (void)hipSetDevice(c->device);
     for (auto &kv : c->bufs) kv.second.release();
+    if (c->arena_retired) { c->arena_retired->release(); delete c->arena_retired; }
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_launch) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_trial) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->chunk_ev) if (e) (void)hipEventDestroy(e);
     ktime_collect(c);
     for (auto &e : c->kfree) (void)hipEventDestroy(e);
@@ -618,6 +637,7 @@ struct EventsRun {
     // it) and while the index thread runs; `up` joins its helper and waits for the DMA out of the caller's buffer itself
     ~EventsRun() { if (split_B && split_ev) (void)hipEventSynchronize(split_ev); if (bai_thread.joinable()) bai_thread.join(); }
     int run();
+    int calibrate_arena();
     int stage_upload();
     int stage_members();
     int stage_range_and_inflate();
@@ -639,6 +659,7 @@ int EventsRun::run() {
     t_last = t_begin;
 
     if (bam_len < 28) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
+    if (c->arena_retired) { c->arena_retired->release(); delete c->arena_retired; c->arena_retired = nullptr; }      // (the arena the last call's data lay in, after it lost its place)
     { const int rc = stage_upload(); if (rc != kGoOn) return rc; }
     { const int rc = stage_members(); if (rc != kGoOn) return rc; }
     { const int rc = stage_range_and_inflate(); if (rc != kGoOn) return rc; }
@@ -646,7 +667,72 @@ int EventsRun::run() {
     { const int rc = stage_bounds_and_chains(); if (rc != kGoOn) return rc; }
     { const int rc = stage_framing(); if (rc != kGoOn) return rc; }
     { const int rc = stage_decode(); if (rc != kGoOn) return rc; }
-    return stage_emit();
+    const int rc_emit = stage_emit();
+    if (rc_emit == RGX_OK) { const int rc = calibrate_arena(); if (rc != RGX_OK) return rc; }
+    return rc_emit;
+}
+
+// Arena placement trials (rgx_ctx above).  On a context's first call with an arena of 2 GiB and more (and again when a later one is a quarter larger), once
+// the call's own work is enqueued: the same whole-range launch, plain, into the call's arena and into a few fresh allocations (two launches
+// each, the second one timed with HIP events; REGTOOLS_AMD_ARENA_TRIALS, default 5); the fastest becomes the context's arena (rgx_ctx_arena_trials reports the times).  The call's data stays where it is -- when a challenger wins, the old arena
+// is retired and released by the next call.  ~30 ms per candidate, once per context; a one-shot context (the CLI) never pays it.
+static int arena_challengers() {                          // REGTOOLS_AMD_ARENA_TRIALS=n (0 = off; tests, A/B runs): how many fresh allocations a calibration tries
+    static const int n = [] { const char *e = getenv("REGTOOLS_AMD_ARENA_TRIALS"); const int v = e ? atoi(e) : 5; return v < 0 ? 0 : v > 7 ? 7 : v; }();
+    return n;
+}
+int EventsRun::calibrate_arena() {
+    if (!arena_challengers() || c->one_shot || d_true_sizes || chunked || split_B || P.stream_ended || !n_range || n_range <= 2048 || total < ((uint64_t)2 << 30)) return RGX_OK;
+    if (c->arena_calibrated_bytes == UINT64_MAX || (c->arena_calibrated_bytes && total + 256 <= c->arena_calibrated_bytes + c->arena_calibrated_bytes / 4)) return RGX_OK;
+    static std::mutex trial_mu;                                // (one calibration at a time per process: the shards of a multi-device call run on threads of one)
+    std::lock_guard<std::mutex> trial_lock(trial_mu);
+    if (!inflate_takes_coop(n_range) || h_sc[0] != 0xffffffffu) return RGX_OK;
+    DevBuf &b_arena = c->buf("arena"), &b_lens = c->buf("inflate_scratch");
+    if (!b_arena.p || b_arena.cap < total + 256) return RGX_OK;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * b_arena.cap + ((size_t)16 << 30)) { c->arena_calibrated_bytes = b_arena.cap; return RGX_OK; }      // (room for a challenger AND for what the call still has to allocate)
+    const int plan = inflate_plan_for(bam_len, total_all);
+    uint32_t *d_dummy = d_sc + 100;                            // (the trial launches' verdicts: not looked at -- the call's own launch gave the verdict)
+    auto time_into = [&](uint8_t *arena_p, float &ms) -> hipError_t {
+        ms = 0;
+        for (int k = 0; k < 2; ++k) {                          // (the first launch into a fresh allocation also pays for its pages)
+            hipError_t e = hipMemsetAsync(d_dummy, 0xff, 8, st);
+            if (e != hipSuccess) return e;
+            if ((e = hipEventRecord(c->ev_trial[0], st)) != hipSuccess) return e;
+            launch_inflate(d_bam, d_members + m_lo, n_range, arena_p, upos_lo, b_lens.as<uint32_t>(), d_dummy, st, 0, 0, false, 0, nullptr, plan);
+            if ((e = hipEventRecord(c->ev_trial[1], st)) != hipSuccess) return e;
+        }
+        hipError_t e = hipEventSynchronize(c->ev_trial[1]);
+        if (e != hipSuccess) return e;
+        return hipEventElapsedTime(&ms, c->ev_trial[0], c->ev_trial[1]);
+    };
+    c->arena_trials = 0;
+    float best_ms = 0;
+    HIP_TRY(time_into(b_arena.as<uint8_t>(), best_ms));        // (the call's own arena: the same bytes written once more, in stream order behind everything that read them)
+    c->arena_trial_ms[c->arena_trials++] = best_ms;
+    DevBuf best;                                               // the fastest challenger so far (empty: the incumbent leads)
+    for (int k = 0; k < arena_challengers(); ++k) {
+        DevBuf cand;
+        if (cand.ensure(b_arena.cap) != hipSuccess) { (void)hipGetLastError(); break; }
+        float ms = 0;
+        const hipError_t e = time_into(cand.as<uint8_t>(), ms);
+        if (e != hipSuccess) { cand.release(); best.release(); return fail(err, errlen, RGX_ERR_DEVICE, "HIP error %s in the arena placement trial\n", hipGetErrorString(e)); }
+        if (c->arena_trials < 8) c->arena_trial_ms[c->arena_trials++] = ms;
+        if (ms < best_ms * 0.985f) { best.release(); best = cand; best_ms = ms; } else cand.release();
+    }
+    if (best.p) {
+        // the call's data lies in the old arena and the caller may still read it (P.arena): it is retired, not released
+        if (c->arena_retired) { c->arena_retired->release(); delete c->arena_retired; }
+        c->arena_retired = new DevBuf(b_arena);
+        b_arena = best;
+    }
+    c->arena_calibrated_bytes = b_arena.cap;
+    if (trace) {
+        fprintf(stderr, "[rgx trace] arena placement: call's arena %.3f ms", c->arena_trial_ms[0]);
+        for (int k = 1; k < c->arena_trials; ++k) fprintf(stderr, ", %.3f", c->arena_trial_ms[k]);
+        fprintf(stderr, " -> %s\n", best.p ? "a challenger kept" : "kept");
+    }
+    mark("arena placement trial");
+    return RGX_OK;
 }
 
 int EventsRun::stage_upload() {
@@ -1958,6 +2044,8 @@ static int run_pipeline(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_ba
     (void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); t->ms_scan = ms;
     (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); t->ms_reduce = ms;
     t->ms_total = now_ms() - P.t_begin;
+    // (nothing reads the call's arena any more: one that lost its place to a challenger goes now)
+    if (c->arena_retired) { c->arena_retired->release(); delete c->arena_retired; c->arena_retired = nullptr; }
     if (getenv("REGTOOLS_AMD_TRACE")) {
         fprintf(stderr, "[rgx trace] total %.3f ms; device buffers grown so far: %llu allocations, %.1f MB, %.3f ms\n", t->ms_total, (unsigned long long)g_alloc_stats.calls,
                 (double)g_alloc_stats.bytes / 1e6, g_alloc_stats.ms);

@@ -43,6 +43,8 @@ int rgx_extract_mem_scanned(rgx_ctx *ctx, const void *bam, size_t bam_len, const
 
 using namespace rgx;
 
+void rgx_ctx_no_arena_trials(rgx_ctx *c);            // api.cpp: no arena placement trials for this context
+
 namespace {
 
 int failm(char *err, size_t errlen, int code, const char *fmt, ...) {
@@ -107,7 +109,7 @@ rgx_ctx *context_for(int device, int nth, char *err, size_t errlen, int &rc) {
     if (it != g_ctx.end()) { rc = RGX_OK; return it->second; }
     rgx_ctx *c = nullptr;
     rc = rgx_ctx_create(device, &c, err, errlen);
-    if (rc == RGX_OK) g_ctx[{device, nth}] = c;
+    if (rc == RGX_OK) { g_ctx[{device, nth}] = c; if (nth > 0) rgx_ctx_no_arena_trials(c); }
     return c;
 }
 

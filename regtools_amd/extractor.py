@@ -50,6 +50,13 @@ class Context(object):
         if rc != 0:
             raise RegtoolsError(rc, err.value.decode())
 
+    def arena_trials(self):
+        """rgx_ctx_arena_trials: the DEFLATE launch's time into the call's own arena ([0]) and into the challengers the context's last placement
+        calibration tried (ms); [] when none has run."""
+        buf = (C.c_float * 8)()
+        n = self._lib.rgx_ctx_arena_trials(self._h, buf, 8)
+        return [round(float(buf[k]), 3) for k in range(min(n, 8))]
+
     def close(self):
         if self._h:
             self._lib.rgx_ctx_destroy(self._h)

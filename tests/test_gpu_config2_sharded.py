@@ -102,13 +102,8 @@ def test_config2_at_full_size_400M_reads_in_eight_shards(gpu_ctx, tmp_path):
     n_events = je.stats["n_events"]
     del je
     big_ctx.close()
-    # (a) the C++ host: eight shards of that file on the device list [0]*8 (rgx_extract_multi_mem: a thread and a context per listed device)
-    m = regtools_amd.extract_multi([0] * n, bai_bytes=bai, host_ptr=pin.ptr, host_len=n_bytes, strandness=0)
-    assert m.table.contents.n_records == n * reads and m.table.contents.n_events == n_events
-    assert m.bed12() == single
-    del m
-    pin.close()
-    # (b) bench.py's N = 8 path: eight ranks (gloo, all on this GPU), each with its own slice; the line checks itself (records conserved, the
+    # (b) bench.py's N = 8 path (first: the eight contexts rgx_extract_multi makes stay with this process, and eight rank processes of 15 GB each want the room)
+    # bench.py's N = 8 path: eight ranks (gloo, all on this GPU), each with its own slice; the line checks itself (records conserved, the
     # collective's table == an independent host merge of the ranks' tables, counts conserved) and the table it dumps must be `single`
     bed8 = str(tmp_path / "ranks8.bed")
     env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -121,3 +116,9 @@ def test_config2_at_full_size_400M_reads_in_eight_shards(gpu_ctx, tmp_path):
     ck = line["multi_gpu"]["checks"]
     assert ck["records_conserved"] and ck["bed12_equals_independent_merge"] and ck["counts_conserved"] and ck["supporting_reads"] == n_events
     assert open(bed8, "rb").read() == single
+    # (a) the C++ host: eight shards of that file on the device list [0]*8 (rgx_extract_multi_mem: a thread and a context per listed device)
+    m = regtools_amd.extract_multi([0] * n, bai_bytes=bai, host_ptr=pin.ptr, host_len=n_bytes, strandness=0)
+    assert m.table.contents.n_records == n * reads and m.table.contents.n_events == n_events
+    assert m.bed12() == single
+    del m
+    pin.close()
