@@ -293,7 +293,7 @@ def main():
     # (BENCH_DEVICE / BENCH_BACKEND: test knobs -- several ranks on ONE GPU with the gloo backend exercise this script's N > 1 path where no
     # multi-GPU node is at hand; the driver's runs use neither)
     if os.environ.get("BENCH_DEVICE") is not None:
-        os.environ.setdefault("REGTOOLS_AMD_ARENA_TRIALS", "0")      # (several ranks on ONE GPU: every process would hold a second arena for its placement trial at the same time)
+        os.environ.setdefault("REGTOOLS_AMD_ARENA", "0")      # (several ranks on ONE GPU: every process would hold a second arena for its placement trial at the same time)
     device_index = int(os.environ.get("BENCH_DEVICE", local_rank))
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(device_index)

@@ -104,7 +104,7 @@ typedef struct {
 int  rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errlen);
 void rgx_ctx_destroy(rgx_ctx *ctx);
 /* Statistics: the DEFLATE launch's time depends on where the arena's pages lie (12.8 / 13.9 / 15.0 ms for the same launch into ten arenas of one
- * process), so a context tries a few allocations on its first large call and keeps the fastest (REGTOOLS_AMD_ARENA_TRIALS=n, 0 = off; never in a one-shot
+ * process), so a context tries a few allocations on its first large call and keeps the fastest (REGTOOLS_AMD_ARENA=n, 0 = off; never in a one-shot
  * context).  ms[0] = the call's own arena, ms[1..] = the challengers; returns how many were timed by the last calibration (0 = none yet). */
 int  rgx_ctx_arena_trials(const rgx_ctx *ctx, float *ms, int cap);
 

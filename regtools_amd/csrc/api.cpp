@@ -71,9 +71,58 @@ uint32_t bitlen(uint32_t v) { uint32_t b = 0; while (v) { ++b; v >>= 1; } return
 // (inflate_ring.h, kArenaFrontPad), and for the first member of an arena that is in front of the buffer.
 struct AllocStats { double ms = 0; uint64_t calls = 0, bytes = 0; };
 static AllocStats g_alloc_stats;                                   // (REGTOOLS_AMD_TRACE: what growing the device buffers cost a call)
+// REGTOOLS_AMD_ARENA="trials[,piece_MiB]" (tests, A/B runs): how many fresh arenas a context's first large call times its DEFLATE launch into (default 5, 0 = none; calibrate_arena),
+// and the size of the pieces the arena's device memory is created in (default 512, 0 = one hipMalloc block; DevBuf::map_pieces).
+struct ArenaKnobs { int trials = 5; size_t piece = (size_t)512 << 20; };
+static const ArenaKnobs &arena_knobs() {
+    static const ArenaKnobs k = [] {
+        ArenaKnobs v;
+        if (const char *e = getenv("REGTOOLS_AMD_ARENA")) {
+            long long a = -1, b = -1;
+            const int n = sscanf(e, "%lld,%lld", &a, &b);
+            if (n >= 1 && a >= 0) v.trials = (int)std::min<long long>(a, 7);
+            if (n >= 2 && b >= 0) v.piece = b == 0 ? 0 : (size_t)std::min<long long>(std::max<long long>(b, 2), 16384) << 20;
+        }
+        return v;
+    }();
+    return k;
+}
 struct DevBuf {
     static constexpr size_t kFront = 256;
     void *p = nullptr; size_t cap = 0;
+    size_t piece = 0;               // asked for by the owner (the arena): memory created in pieces of this size and mapped side by side, see map_pieces (0: one hipMalloc block)
+    size_t mapped = 0;              // bytes of the reserved address range the pieces are mapped into (0: a hipMalloc block)
+    // The arena's form (round 5).  The DEFLATE launch writes 169,000 streams 64 KB apart at once, and what it costs depends on the memory under them: 13.9-15.9 ms
+    // into one hipMalloc block of 11 GB, 12.3-12.6 ms into the same bytes created as pieces of 1 GiB (hipMemCreate) and mapped side by side into one reserved address range --
+    // whatever the order of the pieces (profiles/r05_inflate_arena_pieces.txt: forty pieces, 110 subsets, 12.30-12.37 ms).  Pieces of 2 MiB: 16.0 ms; 32 MiB: 12.8-13.7;
+    // 256 MiB: 12.4-13.7.  A runtime that refuses any of the calls leaves the buffer to hipMalloc.
+    hipError_t map_pieces(size_t bytes, void **out) {
+        constexpr size_t kRound = (size_t)2 << 20;
+        const size_t total = (bytes + kRound - 1) / kRound * kRound;
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        hipMemAllocationProp prop = {}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+        void *base = nullptr;
+        if ((e = hipMemAddressReserve(&base, total, 0, nullptr, 0)) != hipSuccess) return e;
+        size_t done = 0;
+        while (done < total) {
+            const size_t n = std::min(piece, total - done);
+            hipMemGenericAllocationHandle_t h;
+            if ((e = hipMemCreate(&h, n, &prop, 0)) != hipSuccess) break;
+            e = hipMemMap((uint8_t *)base + done, n, 0, h, 0);
+            (void)hipMemRelease(h);                                 // (the mapping keeps the memory; an unmapped, released piece is gone)
+            if (e != hipSuccess) break;
+            done += n;
+        }
+        if (e == hipSuccess) {
+            hipMemAccessDesc ad = {}; ad.location.type = hipMemLocationTypeDevice; ad.location.id = dev; ad.flags = hipMemAccessFlagsProtReadWrite;
+            e = hipMemSetAccess(base, total, &ad, 1);
+        }
+        if (e != hipSuccess) { if (done) (void)hipMemUnmap(base, done); (void)hipMemAddressFree(base, total); return e; }
+        *out = base; mapped = total;
+        return hipSuccess;
+    }
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         static const bool trace = getenv("REGTOOLS_AMD_TRACE") != nullptr;
@@ -84,7 +133,9 @@ struct DevBuf {
         static const bool no_slack = [] { const char *e = getenv("REGTOOLS_AMD_ONE_SHOT"); return e && strcmp(e, "0") != 0; }();      // (first use: after main() said so)
         size_t want = bytes + (no_slack ? 0 : bytes / 8) + 256;
         void *raw = nullptr;
-        hipError_t e = hipMalloc(&raw, want + kFront);
+        hipError_t e = hipErrorNotSupported;
+        if (piece && want + kFront >= piece) { e = map_pieces(want + kFront, &raw); if (e != hipSuccess) { (void)hipGetLastError(); raw = nullptr; mapped = 0; } }
+        if (e != hipSuccess) e = hipMalloc(&raw, want + kFront);
         if (e == hipSuccess) { p = (uint8_t *)raw + kFront; cap = want; }
         if (trace) {                                                 // (shards of a multi-device call grow their buffers on their own threads)
             static std::mutex mu; std::lock_guard<std::mutex> lock(mu);
@@ -92,7 +143,12 @@ struct DevBuf {
         }
         return e;
     }
-    void release() { if (p) (void)hipFree((uint8_t *)p - kFront); p = nullptr; cap = 0; }
+    void release() {
+        if (p && mapped) { void *base = (uint8_t *)p - kFront; (void)hipDeviceSynchronize();    /* (what hipFree does by itself: nothing in flight may still touch the range) */
+                           (void)hipMemUnmap(base, mapped); (void)hipMemAddressFree(base, mapped); }
+        else if (p) (void)hipFree((uint8_t *)p - kFront);
+        p = nullptr; cap = 0; mapped = 0;
+    }
     template <class T> T *as() const { return (T *)p; }
 };
 
@@ -213,6 +269,7 @@ extern "C" int rgx_ctx_create(int device, rgx_ctx **out, char *err, size_t errle
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     { const char *e = getenv("REGTOOLS_AMD_ONE_SHOT"); c->one_shot = e && strcmp(e, "0") != 0; }
+    c->buf("arena").piece = arena_knobs().piece;                     // (DevBuf::map_pieces: what the DEFLATE launch writes into)
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto &e : c->ev_launch) HIP_TRY(hipEventCreate(&e));
     for (auto &e : c->ev_trial) HIP_TRY(hipEventCreate(&e));
@@ -674,12 +731,9 @@ int EventsRun::run() {
 
 // Arena placement trials (rgx_ctx above).  On a context's first call with an arena of 2 GiB and more (and again when a later one is a quarter larger), once
 // the call's own work is enqueued: the same whole-range launch, plain, into the call's arena and into a few fresh allocations (two launches
-// each, the second one timed with HIP events; REGTOOLS_AMD_ARENA_TRIALS, default 5); the fastest becomes the context's arena (rgx_ctx_arena_trials reports the times).  The call's data stays where it is -- when a challenger wins, the old arena
+// each, the second one timed with HIP events; REGTOOLS_AMD_ARENA, default 5); the fastest becomes the context's arena (rgx_ctx_arena_trials reports the times).  The call's data stays where it is -- when a challenger wins, the old arena
 // is retired and released by the next call.  ~30 ms per candidate, once per context; a one-shot context (the CLI) never pays it.
-static int arena_challengers() {                          // REGTOOLS_AMD_ARENA_TRIALS=n (0 = off; tests, A/B runs): how many fresh allocations a calibration tries
-    static const int n = [] { const char *e = getenv("REGTOOLS_AMD_ARENA_TRIALS"); const int v = e ? atoi(e) : 5; return v < 0 ? 0 : v > 7 ? 7 : v; }();
-    return n;
-}
+static int arena_challengers() { return arena_knobs().trials; }
 int EventsRun::calibrate_arena() {
     if (!arena_challengers() || c->one_shot || d_true_sizes || chunked || split_B || P.stream_ended || !n_range || n_range <= 2048 || total < ((uint64_t)2 << 30)) return RGX_OK;
     if (c->arena_calibrated_bytes == UINT64_MAX || (c->arena_calibrated_bytes && total + 256 <= c->arena_calibrated_bytes + c->arena_calibrated_bytes / 4)) return RGX_OK;
@@ -711,7 +765,9 @@ int EventsRun::calibrate_arena() {
     c->arena_trial_ms[c->arena_trials++] = best_ms;
     DevBuf best;                                               // the fastest challenger so far (empty: the incumbent leads)
     for (int k = 0; k < arena_challengers(); ++k) {
-        DevBuf cand;
+        // (what makes one placement faster than another is not known -- DESIGN 5.5 -- so the challengers are not of one kind)
+        static const size_t kLadder[] = {(size_t)1 << 30, (size_t)256 << 20, (size_t)512 << 20, (size_t)128 << 20, 0, (size_t)2 << 30, (size_t)512 << 20};
+        DevBuf cand; cand.piece = b_arena.piece ? kLadder[k % 7] : 0;
         if (cand.ensure(b_arena.cap) != hipSuccess) { (void)hipGetLastError(); break; }
         float ms = 0;
         const hipError_t e = time_into(cand.as<uint8_t>(), ms);

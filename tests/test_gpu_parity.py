@@ -657,6 +657,28 @@ def test_arena_placement_trials_leave_the_results_alone(gpu_ctx):
             "je.identify_junctions_from_BAM(bam_bytes=bam, bai_bytes=bai)\n"
             "assert ctx.arena_trials() == [], ctx.arena_trials()\n"
             "sys.stdout.buffer.write(je.bed12())\n")
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REGTOOLS_AMD_ARENA_TRIALS="0", PYTHONPATH=ROOT), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REGTOOLS_AMD_ARENA="0,0", PYTHONPATH=ROOT), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert r.stdout == beds[0]
+
+
+def test_arena_made_of_pieces_grows_and_shrinks_like_a_block(gpu_ctx):
+    """The arena's device memory is created in pieces and mapped side by side into one reserved address range (DevBuf::map_pieces, DESIGN 5.5; 512 MiB pieces
+    by default, so only files of millions of reads take that form).  With 2 MiB pieces every file beyond a few thousand reads does: one context sees files of
+    growing and shrinking size (the range is unmapped, released and reserved anew as the arena grows) and must print what a context with a hipMalloc arena prints."""
+    import sys
+    code = ("import sys, hashlib, regtools_amd; from regtools_amd import synth\n"
+            "ctx = regtools_amd.Context(0)\n"
+            "for n, seed in ((2_000, 3), (300_000, 4), (1_500_000, 5), (300_000, 4), (2_500_000, 6)):\n"
+            "    bam, bai, st = synth.generate(n, shape='short', seed=seed)\n"
+            "    je = regtools_amd.JunctionsExtractor(strandness=0, ctx=ctx)\n"
+            "    je.identify_junctions_from_BAM(bam_bytes=bam, bai_bytes=bai)\n"
+            "    assert je.stats['n_records'] == st['n_reads']\n"
+            "    print(n, len(je.bed12()), hashlib.sha256(je.bed12()).hexdigest())\n"
+            "ctx.close()\n")
+    outs = []
+    for knob in ("0,2", "0,64", "0,0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REGTOOLS_AMD_ARENA=knob, PYTHONPATH=ROOT), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, (knob, r.stderr.decode()[-2000:])
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] == outs[2] and outs[0].count(b"\n") == 5, outs
