@@ -766,7 +766,7 @@ int EventsRun::calibrate_arena() {
     DevBuf best;                                               // the fastest challenger so far (empty: the incumbent leads)
     for (int k = 0; k < arena_challengers(); ++k) {
         // (what makes one placement faster than another is not known -- DESIGN 5.5 -- so the challengers are not of one kind)
-        static const size_t kLadder[] = {(size_t)1 << 30, (size_t)256 << 20, (size_t)512 << 20, (size_t)128 << 20, 0, (size_t)2 << 30, (size_t)512 << 20};
+        static const size_t kLadder[] = {(size_t)1 << 30, (size_t)256 << 20, (size_t)512 << 20, (size_t)128 << 20, (size_t)1 << 30, (size_t)64 << 20, (size_t)512 << 20};     // (a hipMalloc block never won one: 15.6-16.3 ms beside 12.7-13.6)
         DevBuf cand; cand.piece = b_arena.piece ? kLadder[k % 7] : 0;
         if (cand.ensure(b_arena.cap) != hipSuccess) { (void)hipGetLastError(); break; }
         float ms = 0;
