@@ -764,6 +764,12 @@ int EventsRun::calibrate_arena() {
     HIP_TRY(time_into(b_arena.as<uint8_t>(), best_ms));        // (the call's own arena: the same bytes written once more, in stream order behind everything that read them)
     c->arena_trial_ms[c->arena_trials++] = best_ms;
     DevBuf best;                                               // the fastest challenger so far (empty: the incumbent leads)
+    // A challenger that lost is kept until the trials are over when there is room for all of them: released at once, its memory is what the next one is
+    // handed (five challengers timed 13.53-13.60 ms beside an incumbent of 13.16: one placement drawn five times; profiles/r05_inflate_arena_pieces.txt).
+    std::vector<DevBuf> losers;
+    const bool hold_losers = free_b >= (size_t)(arena_challengers() + 1) * (b_arena.cap + b_arena.cap / 8 + ((size_t)1 << 30)) + ((size_t)16 << 30);
+    auto drop = [&](DevBuf &d) { if (hold_losers && d.p) losers.push_back(d); else d.release(); d = DevBuf(); };
+    struct DropLosers { std::vector<DevBuf> &v; ~DropLosers() { for (DevBuf &d : v) d.release(); } } drop_losers{losers};
     for (int k = 0; k < arena_challengers(); ++k) {
         // (what makes one placement faster than another is not known -- DESIGN 5.5 -- so the challengers are not of one kind)
         static const size_t kLadder[] = {(size_t)1 << 30, (size_t)256 << 20, (size_t)512 << 20, (size_t)128 << 20, (size_t)1 << 30, (size_t)64 << 20, (size_t)512 << 20};     // (a hipMalloc block never won one: 15.6-16.3 ms beside 12.7-13.6)
@@ -773,7 +779,7 @@ int EventsRun::calibrate_arena() {
         const hipError_t e = time_into(cand.as<uint8_t>(), ms);
         if (e != hipSuccess) { cand.release(); best.release(); return fail(err, errlen, RGX_ERR_DEVICE, "HIP error %s in the arena placement trial\n", hipGetErrorString(e)); }
         if (c->arena_trials < 8) c->arena_trial_ms[c->arena_trials++] = ms;
-        if (ms < best_ms * 0.985f) { best.release(); best = cand; best_ms = ms; } else cand.release();
+        if (ms < best_ms * 0.985f) { drop(best); best = cand; best_ms = ms; } else drop(cand);
     }
     if (best.p) {
         // the call's data lies in the old arena and the caller may still read it (P.arena): it is retired, not released
