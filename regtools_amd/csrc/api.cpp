@@ -1205,11 +1205,13 @@ int EventsRun::stage_range_and_inflate() {
                 // (launch_wait_done) and frames, verifies and decodes the part of the arena behind it while the waves of the later parts still
                 // run -- what is left behind the launch's end is the last part's framing and decode, not the whole file's.  (A member's own
                 // chain puts the end of the launch 6-9 ms behind the last chunk's arrival, whatever the chip does meanwhile.)
-                // REGTOOLS_AMD_EARLY_TAIL="8,12,14" = the cuts in sixteenths of the upload (up to three), "0" = off.
+                // REGTOOLS_AMD_EARLY_TAIL="6,9,12,14" = the cuts in sixteenths of the upload (up to seven; the default since round 5: 23.5 ms per step where "8,12,14" gives 24.5 -- the tail
+                // under the launch is the critical path from the first part on, so it starts earlier and in smaller parts; profiles/r05_step_early_tail_four_cuts_ab.txt), "0" = off.
                 static const std::vector<unsigned> env_cuts = [] {
                     std::vector<unsigned> v; const char *e = getenv("REGTOOLS_AMD_EARLY_TAIL");
-                    unsigned a = 0, b2 = 0, c2 = 0; const int n = sscanf(e ? e : "8,12,14", "%u,%u,%u", &a, &b2, &c2);
-                    for (unsigned x : {a, b2, c2}) if ((int)v.size() < n && x > 0 && x < 16 && (v.empty() || x > v.back())) v.push_back(x);
+                    unsigned x7[7] = {0, 0, 0, 0, 0, 0, 0};
+                    const int n = sscanf(e ? e : "6,9,12,14", "%u,%u,%u,%u,%u,%u,%u", &x7[0], &x7[1], &x7[2], &x7[3], &x7[4], &x7[5], &x7[6]);
+                    for (unsigned x : x7) if ((int)v.size() < n && x > 0 && x < 16 && (v.empty() || x > v.back())) v.push_back(x);
                     return v;
                 }();
                 const uint32_t early_min = overlap_knobs().early_min;
@@ -1600,7 +1602,7 @@ int EventsRun::stage_framing() {
                 emit_parts_ok = env_early_emit && ev_lay >= 4096;
                 if (emit_parts_ok) { HIP_TRY(b_tmp.ensure(scan_tmp_words((uint32_t)std::min<size_t>(soa_cap, 0xffffffffu)) * 4 + 64)); ev_e = ev_layout(b_ev0.as<uint8_t>(), ev_lay); }
             }
-            if (emit_parts_ok && emit_parts < 4) {
+            if (emit_parts_ok && emit_parts < kGateParts - 1) {
                 launch_scan_u32(soa.n_ev + emit_rows, ev_base + emit_rows, n_rec_J - emit_rows, d_sc + 84 + emit_parts, b_tmp.as<uint32_t>(), st);
                 launch_emit_short(arena, n_rec_J, cfg, soa, ev_base, ev_e, st, emit_rows, d_sc + 84, emit_parts, (uint32_t)std::min<size_t>(ev_lay, 0xffffffffu));
                 emit_rows = n_rec_J; ++emit_parts;
@@ -1675,7 +1677,7 @@ int EventsRun::stage_decode() {
                 // the last part's events, emitted like the others'; the event total = the parts' totals
                 launch_scan_u32(soa.n_ev + emit_rows, ev_base + emit_rows, n_rec - emit_rows, d_sc + 84 + emit_parts, b_tmp.as<uint32_t>(), st);
                 launch_emit_short(arena, n_rec, cfg, soa, ev_base, ev_e, st, emit_rows, d_sc + 84, emit_parts, (uint32_t)std::min<size_t>(ev_lay, 0xffffffffu));
-                HIP_TRY(hipMemcpyAsync(h_sc + 84, d_sc + 84, 20, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(h_sc + 84, d_sc + 84, 4 * kGateParts, hipMemcpyDeviceToHost, st));
             } else launch_scan_u32(soa.n_ev, ev_base, n_rec, d_sc + 4, b_tmp.as<uint32_t>(), st);
             launch_scan_u32(seg_iter, seg_iter, n_seg, d_sc + 8, b_tmp.as<uint32_t>(), st);
             launch_scan_u32(seg_long, seg_long_base, n_seg, d_sc + 5, b_tmp.as<uint32_t>(), st);
@@ -1700,7 +1702,7 @@ int EventsRun::stage_decode() {
         n_events = h_sc[4]; n_long = h_sc[5];
         if (emit_parts_ok && s_from) {
             uint64_t tot = 0;
-            for (uint32_t k = 0; k <= emit_parts && k < 5; ++k) tot += h_sc[84 + k];
+            for (uint32_t k = 0; k <= emit_parts && k < kGateParts; ++k) tot += h_sc[84 + k];
             if (tot > ev_lay || tot > 0xffffffffull || n_long) {
                 // the recycled block was too small after all (or wave-per-read rows want their global slots): everything once more, the plain way
                 emit_parts_ok = false;

@@ -31,9 +31,9 @@ struct InflateGate {
     // (workgroup index; part 0 starts at 0) up to part_start[j] -- so that the pipeline's stream can frame and decode the front parts of the arena
     // (launch_wait_done) while the waves of the later parts still run.  done = null: nobody counts.
     uint32_t *done = nullptr;          // device memory, kGateParts words, zeroed by the caller in front of the launch
-    uint32_t part_start[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+    uint32_t part_start[7] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
 };
-constexpr uint32_t kGateParts = 4;
+constexpr uint32_t kGateParts = 8;
 constexpr uint32_t kInflateSortGroup = 1024;   // k_inflate_coop: the lanes of a wave take their members from one group of that many consecutive ones (k_member_sort)
 // one lane on `stream` waits until done[0] reaches `expected` (a wave count); gives up after ~2 s and sets *timed_out
 void launch_wait_done(const uint32_t *done, uint32_t expected, uint32_t *timed_out, hipStream_t stream);

@@ -336,7 +336,9 @@ __device__ __forceinline__ void gate_wave_done(const InflateGate &gate, uint32_t
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane == 0) {
         const uint32_t b = blockIdx.x;
-        const uint32_t part = (b >= gate.part_start[0] ? 1u : 0u) + (b >= gate.part_start[1] ? 1u : 0u) + (b >= gate.part_start[2] ? 1u : 0u);
+        uint32_t part = 0;
+#pragma unroll
+        for (uint32_t k = 0; k + 1 < kGateParts; ++k) part += b >= gate.part_start[k] ? 1u : 0u;
         __hip_atomic_fetch_add(gate.done + part, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

@@ -38,13 +38,14 @@ json.dump(out, open(sys.argv[2], "w"))
 """
 
 
-@pytest.mark.parametrize("chunks", ["2", "7", "16", "16-early-tail"])
+@pytest.mark.parametrize("chunks", ["2", "7", "16", "16-early-tail", "16-early-tail-7cuts"])
 def test_gated_launch_equals_the_oracle(gpu_ctx, tmp_path, chunks):
     from regtools_amd import synth
     jobs = []
-    early = chunks.endswith("early-tail")
+    early = "early-tail" in chunks
+    seven = chunks.endswith("7cuts")           # (round 5: up to seven cuts; the parts are multiples of 1,024 members, so the file has eleven thousand)
     # (the early tail cuts the member list at multiples of 1024 members: its variant needs a file of a few thousand)
-    for shape, n, seed in (("short", 1200000 if early else 120000, 3), ("fuzz", 20000, 4), ("long", 2000, 5)):
+    for shape, n, seed in (("short", 3200000 if seven else 1200000 if early else 120000, 3), ("fuzz", 20000, 4), ("long", 2000, 5)):
         p = str(tmp_path / ("%s.bam" % shape))
         synth.write(p, n, shape=shape, seed=seed)
         jobs.append(dict(bam=p, kw=dict(strandness=0), args=["-s", "XS"]))
@@ -63,9 +64,13 @@ def test_gated_launch_equals_the_oracle(gpu_ctx, tmp_path, chunks):
     env = dict(os.environ, REGTOOLS_AMD_OVERLAP="0," + chunks.split("-")[0] + (",1" if early else ""), REGTOOLS_AMD_INFLATE="coop", REGTOOLS_AMD_TRACE="1", PYTHONPATH=ROOT)
     if not early:
         env["REGTOOLS_AMD_EARLY_TAIL"] = "0"
+    if seven:
+        env["REGTOOLS_AMD_EARLY_TAIL"] = "2,4,6,8,10,12,14"
     r = subprocess.run([sys.executable, "-c", CHILD, jf, of], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     assert b"gated" in r.stderr, "the calls did not take the gated launch:\n" + r.stderr.decode()[-2000:]
+    if seven:
+        assert b"early tail: part 5" in r.stderr, "fewer parts than the test means to run:\n" + r.stderr.decode()[-2000:]
     assert (b"early tail" in r.stderr) == early, "early tail taken / not taken against the test's intent:\n" + r.stderr.decode()[-2000:]
     got = json.load(open(of))
     for j, res in zip(jobs, got):
