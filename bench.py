@@ -262,8 +262,8 @@ def extra_identify(regtools_amd, synth, ctx, reads, genes, variants, sample, see
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)     # (three: the context settles -- arena placement, page-locked table block, recycled event block -- over its first calls: 23.6-23.8 ms per step behind three, 23.8-24.3 behind one)
     ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU (config 2: 50M)")
     ap.add_argument("--shape", default="short", choices=["short", "long"])
     ap.add_argument("--seed", type=int, default=1)
