@@ -259,6 +259,30 @@ def extra_identify(regtools_amd, synth, ctx, reads, genes, variants, sample, see
     return out
 
 
+def bind_to_gpu_numa(device_index):
+    """N > 1 (one process per GPU): this rank's threads -- and with them the first touch of its page-locked file buffer -- go to the CPUs of the NUMA node its
+    GPU hangs on (sysfs: the PCI device's numa_node, the node's cpulist), so that eight uploads of 53 GB/s do not cross the sockets.  Returns what it did (for
+    the JSON line); anything missing or odd (no sysfs, node -1, a cpuset that shares no CPU with the node) leaves the process as it is."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return "none (the device reports no NUMA node)"
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        mine = os.sched_getaffinity(0) & cpus
+        if not mine:
+            return "none (node %d shares no CPU with this process's set)" % node
+        os.sched_setaffinity(0, mine)
+        return "node %d of %s, %d CPUs" % (node, bdf, len(mine))
+    except Exception as e:           # (never in the way of the run)
+        return "none (%s)" % type(e).__name__
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,6 +321,9 @@ def main():
     device_index = int(os.environ.get("BENCH_DEVICE", local_rank))
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(device_index)
+    host_binding = "none (one process)"
+    if (world > 1 and os.environ.get("BENCH_DEVICE") is None) or os.environ.get("BENCH_NUMA_BIND"):
+        host_binding = bind_to_gpu_numa(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -447,7 +474,7 @@ def main():
             "dtype": "u8/u32 integer", "data": "synthetic",
             "config": {"workload": ("configs[1]: synthetic %d-read 101 bp BAM per GPU, ~15%% reads with one N-op, junctions extract -s XS%s" % (n_reads, " (realistic payload)" if args.realistic else "")) if args.shape == "short" else
                                    "configs[4]-shape: synthetic %d long reads per GPU (l_qseq 1000-10000, n_cigar <= 64, 5-20 N ops), junctions extract -s XS" % n_reads,
-                       "reads_per_gpu": n_reads, "shape": args.shape, "seed": args.seed, "sharding": "coordinate slice per GPU, all-gather of packed junction rows" if world > 1 else "single GPU",
+                       "reads_per_gpu": n_reads, "shape": args.shape, "seed": args.seed, "sharding": "coordinate slice per GPU, all-gather of packed junction rows" if world > 1 else "single GPU", "host_binding_rank0": host_binding,
                        "bgzf_members": s["n_members"], "compressed_bytes_per_gpu": s["compressed_bytes"], "inflated_bytes_per_gpu": s["inflated_bytes"],
                        "bytes_per_alignment": {"compressed": s["compressed_bytes"] / n_reads, "inflated": s["inflated_bytes"] / n_reads}},
             "junction_events_per_s": total_events * args.steps / dt,
