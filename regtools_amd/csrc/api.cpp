@@ -732,7 +732,7 @@ int EventsRun::run() {
 // Arena placement trials (rgx_ctx above).  On a context's first call with an arena of 2 GiB and more (and again when a later one is a quarter larger), once
 // the call's own work is enqueued: the same whole-range launch, plain, into the call's arena and into a few fresh allocations (two launches
 // each, the second one timed with HIP events; REGTOOLS_AMD_ARENA, default 5); the fastest becomes the context's arena (rgx_ctx_arena_trials reports the times).  The call's data stays where it is -- when a challenger wins, the old arena
-// is retired and released by the next call.  ~30 ms per candidate, once per context; a one-shot context (the CLI) never pays it.
+// is retired and released by the next call.  ~55 ms per candidate, 0.3 s once per context (what a context that lives for a few hundred files gets back; REGTOOLS_AMD_ARENA=0 for one that does not); a one-shot context (the CLI) never pays it.
 static int arena_challengers() { return arena_knobs().trials; }
 int EventsRun::calibrate_arena() {
     if (!arena_challengers() || c->one_shot || d_true_sizes || chunked || split_B || P.stream_ended || !n_range || n_range <= 2048 || total < ((uint64_t)2 << 30)) return RGX_OK;
