@@ -316,6 +316,8 @@ def main():
         raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
     # (BENCH_DEVICE / BENCH_BACKEND: test knobs -- several ranks on ONE GPU with the gloo backend exercise this script's N > 1 path where no
     # multi-GPU node is at hand; the driver's runs use neither)
+    if args.warmup == 0:
+        os.environ.setdefault("REGTOOLS_AMD_ARENA", "0")      # (no warm-up step: the context's first call is timed, and the placement trials -- 0.3 s, once -- have no untimed call to run in)
     if os.environ.get("BENCH_DEVICE") is not None:
         os.environ.setdefault("REGTOOLS_AMD_ARENA", "0")      # (several ranks on ONE GPU: every process would hold a second arena for its placement trial at the same time)
     device_index = int(os.environ.get("BENCH_DEVICE", local_rank))
