@@ -34,6 +34,12 @@ typedef u32x4 u32x4_unaligned __attribute__((aligned(1), may_alias));
 RGX_HD u32x4 ld128(const uint8_t *p) { return *(const u32x4_unaligned *)p; }
 RGX_HD void st128(uint8_t *p, u32x4 v) { *(u32x4_unaligned *)p = v; }
 
+// smallest of three unsigned words (one v_min3_u32 on gfx950)
+RGX_HD uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t m = a < b ? a : b;
+    return m < c ? m : c;
+}
+
 constexpr uint32_t kBgzfMaxBlock = 0x10000;  // htslib/bgzf.h:42 BGZF_MAX_BLOCK_SIZE
 
 // one BGZF member as the device sees it

@@ -50,9 +50,14 @@ struct Code { uint32_t c[16]; };
 // returns the index into the sorted symbol list; len = 0 when v starts no code
 RGX_HD uint32_t code_lookup(const Code &C, uint32_t v15, uint32_t &len) {
     const uint32_t key = v15 << 13 | 0x1fffu;
-    uint32_t m = C.c[0];
+    // The words ascend (bounds never fall, lengths rise), so "the last word <= key" is the LARGEST word <= key, and that is key minus the
+    // smallest of the sixteen unsigned differences key - c[k]: a word above key wraps to a difference larger than any real one (c[0] <= 0x1fff
+    // <= key always gives a real one).  Sixteen independent subtractions and eight three-way minima -- no compare, hence no condition
+    // register between a compare and its select (gfx950 pads every such pair with two wait states: round 6).
+    uint32_t d = key - C.c[0];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) m = (C.c[k] <= key) ? C.c[k] : m;
+    for (int k = 1; k < 16; k += 2) d = min3u(d, key - C.c[k], k + 1 < 16 ? key - C.c[k + 1] : 0xffffffffu);
+    const uint32_t m = key - d;
     len = (m >> 9) & 15u;
     return (m & 0x1ffu) + ((v15 - (m >> 13)) >> (15u - len));
 }
