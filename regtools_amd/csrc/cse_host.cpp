@@ -416,14 +416,14 @@ std::string VcfText::load(const std::string &path) {
         if (text.size() < 9 || memcmp(text.data(), "BCF\2\2", 5)) return "Unable to read header.\n\n";       // "only BCFv2.2 is supported"
         uint32_t l_text; memcpy(&l_text, text.data() + 5, 4);
         if (text.size() - 9 < l_text) return "Unable to read header.\n\n";
-        hdr.parse(std::string(text.data() + 9, strnlen(text.data() + 9, l_text)));
-        if (!hdr.error.empty()) return hdr.error + "\n";
+        hdr.ingest(std::string(text.data() + 9, strnlen(text.data() + 9, l_text)));
+        if (!hdr.failure().empty()) return hdr.failure() + "\n";
         size_t o = 9 + (size_t)l_text;
         while (text.size() - o >= 32) {
             uint32_t x[4]; memcpy(x, text.data() + o, 16);
             if (x[0] < 24 || text.size() - o - 8 < (size_t)x[0] + x[1]) break;                     // a record cut short: the read fails, the loop ends
             const int32_t rid = (int32_t)x[2];
-            recs.push_back({o, rid >= 0 && (size_t)rid < hdr.contig_name.size() ? hdr.contig_name[(size_t)rid] : std::string(), x[3]});
+            recs.push_back({o, hdr.contig_name(rid), x[3]});
             o += 8 + (size_t)x[0] + x[1];
         }
         return "";
@@ -451,8 +451,8 @@ std::string VcfText::load(const std::string &path) {
             if (n < 2 || l[1] != '#') { closed = true; first_rec_line = i + 1; break; }
         }
         if (!closed) return "Unable to read header.\n\n";
-        hdr.parse(htxt);
-        if (!hdr.error.empty()) return hdr.error + "\n";
+        hdr.ingest(htxt);
+        if (!hdr.failure().empty()) return hdr.failure() + "\n";
         // a tabix index next to the file: the sequence names it lists that the header does not declare join the header as ##contig lines
         // (vcf_hdr_read, vcf.c:1289-1309) -- they are written out with it, and a record on such a contig draws no warning.  An index that
         // cannot be read is no index (tbx_index_load returns NULL).
@@ -488,7 +488,7 @@ std::string VcfText::load(const std::string &path) {
                     for (int32_t k = 0; k < n_ref && q < e; ++k) {
                         const size_t ln = strnlen(q, (size_t)(e - q));
                         const std::string name(q, ln);
-                        if (hdr.contigs.find(name) == hdr.contigs.end()) hdr.append("##contig=<ID=" + name + ">");
+                        if (!hdr.knows_contig(name)) hdr.declare("##contig=<ID=" + name + ">");
                         q += ln + 1;
                     }
                 }
@@ -497,7 +497,7 @@ std::string VcfText::load(const std::string &path) {
     }
     // CHROM and POS of every record line, by several threads over ranges of lines (file order kept: the ranges are concatenated in order).
     // vcf_parse refuses a record whose sample columns do not match the header (vcf.c:1551-1556, 1760-1766): the read loop ends there.
-    const size_t n_samples = hdr.samples.size();
+    const size_t n_samples = hdr.n_samples();
     const size_t T = n_lines_ < (1u << 16) ? 1 : usable_threads(16);
     std::vector<std::vector<Rec>> part(T);
     std::vector<size_t> part_stop(T, SIZE_MAX), part_first_id(T, SIZE_MAX);       // (first record of the range that has an ID column)
@@ -549,38 +549,40 @@ std::string VcfText::load(const std::string &path) {
     return "";
 }
 
-bool VcfText::typed(size_t i, VcfHdr &h, VcfRec &r) const {
-    if (bcf) return bcf_parse_record((const uint8_t *)text.data() + recs[i].line, text.size() - recs[i].line, r) != 0;
+ReadResult VcfText::typed(size_t i, VcfDictionary &h, VcfRecord &r) const {
+    if (bcf) return read_bcf_record((const uint8_t *)text.data() + recs[i].line, text.size() - recs[i].line, r) ? ReadResult::kOk : ReadResult::kRefused;
     const char *l; size_t n; line(recs[i].line, l, n);
-    return vcf_parse_line(h, l, n, r) == 0;
+    return read_text_record(h, l, n, r);
 }
 
 std::string write_annotated_vcf_records(FILE *fv, const VcfText &vcf, const std::vector<size_t> &todo, const std::function<VcfAnnot(size_t)> &annot) {
-    VcfHdr hdr = vcf.hdr;
-    hdr.append("##INFO=<ID=genes,Number=1,Type=String,Description=\"The Variant falls in the splice region of these genes\">");
-    hdr.append("##INFO=<ID=transcripts,Number=1,Type=String,Description=\"The Variant falls in the splice region of these transcripts\">");
-    hdr.append("##INFO=<ID=distances,Number=1,Type=String,Description=\"Vector of Min(Distance from start/end of exon in the transcript.)\">");
-    hdr.append("##INFO=<ID=annotations,Number=1,Type=String,Description=\"Does the variant fall in exonic/intronic splicing related space in the transcript.\">");
-    { std::string h; hdr.format(h); fwrite(h.data(), 1, h.size(), fv); }
+    VcfDictionary hdr = vcf.hdr;
+    hdr.declare("##INFO=<ID=genes,Number=1,Type=String,Description=\"The Variant falls in the splice region of these genes\">");
+    hdr.declare("##INFO=<ID=transcripts,Number=1,Type=String,Description=\"The Variant falls in the splice region of these transcripts\">");
+    hdr.declare("##INFO=<ID=distances,Number=1,Type=String,Description=\"Vector of Min(Distance from start/end of exon in the transcript.)\">");
+    hdr.declare("##INFO=<ID=annotations,Number=1,Type=String,Description=\"Does the variant fall in exonic/intronic splicing related space in the transcript.\">");
+    { std::string h; hdr.render(h); fwrite(h.data(), 1, h.size(), fv); }
     // records are independent: ranges of them are re-serialised by several threads, each with its own copy of the dictionary (a name the
     // header does not declare joins the copy; what is printed is the name), and written in order
     const size_t T = todo.size() < 4096 ? 1 : usable_threads(16);
     std::vector<std::string> outs(T), fatal(T);
     auto work = [&](size_t t) {
-        VcfHdr h = hdr;
-        VcfRec rec;
+        VcfDictionary h = hdr;
+        VcfRecord rec;
         std::string &o = outs[t];
         static const std::string kNA = "NA";
         for (size_t k = todo.size() * t / T; k < todo.size() * (t + 1) / T; ++k) {
             const size_t ri = todo[k];
-            if (!vcf.typed(ri, h, rec)) { if (!h.error.empty()) { fatal[t] = h.error; return; } continue; }
-            rec.id_buffer_used = vcf.first_with_id < ri;
+            const ReadResult got = vcf.typed(ri, h, rec);
+            if (got == ReadResult::kFatal) { fatal[t] = h.failure(); return; }
+            if (got != ReadResult::kOk) continue;
+            rec.id_seen_before = vcf.first_with_id < ri;
             const VcfAnnot a = annot(ri);
-            vcf_update_info_string(h, rec, "genes", a.genes ? *a.genes : kNA);
-            vcf_update_info_string(h, rec, "transcripts", a.transcripts ? *a.transcripts : kNA);
-            vcf_update_info_string(h, rec, "distances", a.distances ? *a.distances : kNA);
-            vcf_update_info_string(h, rec, "annotations", a.annotations ? *a.annotations : kNA);
-            vcf_format_line(h, rec, o);
+            set_info_text(h, rec, "genes", a.genes ? *a.genes : kNA);
+            set_info_text(h, rec, "transcripts", a.transcripts ? *a.transcripts : kNA);
+            set_info_text(h, rec, "distances", a.distances ? *a.distances : kNA);
+            set_info_text(h, rec, "annotations", a.annotations ? *a.annotations : kNA);
+            write_text_record(h, rec, o);
         }
     };
     {

@@ -9,7 +9,7 @@
 #include <memory>
 #include <string>
 #include "bigvec.h"
-#include "vcf_model.h"
+#include "vcf_rewrite.h"
 #include <unordered_map>
 #include <vector>
 
@@ -49,12 +49,12 @@ struct VcfText {
     bool bcf = false;
     size_t first_with_id = (size_t)-1; // first record that carries an ID column: bcf_unpack gives the reader's record its ID buffer there, and a
                                        // later record WITHOUT the column prints that buffer, emptied, where an earlier one prints "." (vcf.c:2012-2018, :2075)
-    VcfHdr hdr;                        // the header dictionary as bcf_hdr_read leaves it
+    VcfDictionary hdr;                 // the header as the reference's reader holds it (vcf_rewrite.h)
     std::string load(const std::string &path);
     size_t n_lines() const { return line_off.empty() ? 0 : line_off.size() - 1; }
     void line(size_t i, const char *&p, size_t &len) const;
-    // record i in BCF's typed form (h = a private copy of hdr: names the header does not declare join it).  false = unreadable.
-    bool typed(size_t i, VcfHdr &h, VcfRec &r) const;
+    // record i as typed values (h = a private copy of hdr: names the header does not declare join it)
+    ReadResult typed(size_t i, VcfDictionary &h, VcfRecord &r) const;
 };
 
 // The annotated VCF: header with the four INFO lines appended, then records `todo` (indices into vcf.recs, ascending), each with the four

@@ -147,7 +147,7 @@ extern "C" long emu_scan_members(const uint8_t *bam, size_t n, int threads, uint
     return (long)m.size();
 }
 
-// the annotated-VCF writer (cse_host.cpp write_annotated_vcf_records over vcf_model.cpp) with "NA" for every record: what
+// the annotated-VCF writer (cse_host.cpp write_annotated_vcf_records over vcf_rewrite.cpp) with "NA" for every record: what
 // `variants annotate` writes when no transcript is near any variant.  Returns 0, 1 = load error (message in err), 2 = writer error.
 #include "../../regtools_amd/csrc/cse_host.h"
 extern "C" int emu_vcf_rewrite(const char *in_path, const char *out_path, char *err, size_t errlen) {

@@ -120,7 +120,7 @@ def test_malformed_gtf_exit_codes(gpu_ctx, work):
             assert ac.read(out) == ac.read(os.path.join(ac.REF, "expected-annotate.out")), path
 
 
-# -- the annotated VCF through htslib's typed round trip (regtools_amd/csrc/vcf_model.cpp): "%g" floats, FORMAT fill-in, header
+# -- the annotated VCF through htslib's typed round trip (regtools_amd/csrc/vcf_rewrite.cpp): "%g" floats, FORMAT fill-in, header
 #    de-duplication, undeclared tags, gzip and BCF input -- against the real reference's output for the same input and GTF
 import json  # noqa: E402
 

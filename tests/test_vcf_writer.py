@@ -1,4 +1,4 @@
-"""The annotated-VCF writer (`identify -v`, `variants annotate -o`) on the CPU: regtools_amd/csrc/vcf_model.cpp + cse_host.cpp compiled
+"""The annotated-VCF writer (`identify -v`, `variants annotate -o`) on the CPU: regtools_amd/csrc/vcf_rewrite.cpp + cse_host.cpp compiled
 into tests/hostemu, every record given "NA" tags, against what the REAL reference writes for the same input with a GTF that is nowhere near
 a variant (tests/golden/vcf_writer/*.far.vcf, made by tests/golden/make_golden_vcf.py).  Covers htslib's typed round trip: "%g" floats,
 integer re-formatting, FORMAT fill-in, header de-duplication, undeclared tags, gzip and BCF input.  The same inputs with real annotations

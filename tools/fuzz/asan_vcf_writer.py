@@ -1,4 +1,4 @@
-"""ASan/UBSan run of the annotated-VCF writer (vcf_model.cpp + cse_host.cpp in tests/hostemu, built with -fsanitize=address,undefined)
+"""ASan/UBSan run of the annotated-VCF writer (vcf_rewrite.cpp + cse_host.cpp in tests/hostemu, built with -fsanitize=address,undefined)
 on mutated VCF / gzip / BCF inputs: byte flips, deleted and duplicated spans, truncation.  No reference involved: the run looks for
 memory errors only.  Build line and usage: tools/fuzz/README.md.  Run as
     LD_PRELOAD=$(gcc -print-file-name=libasan.so) python tools/fuzz/asan_vcf_writer.py /tmp/libhostemu_asan.so 3000"""
