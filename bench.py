@@ -299,6 +299,7 @@ def main():
                     help="N > 1: 'ranks' = one process per GPU, torch.distributed over RCCL (what torchrun launches; the default); 'cpp' = THIS process drives "
                          "all N devices through rgx_extract_multi (the C++ host of the CLI: a thread per device, one RCCL gather); without torchrun only")
     ap.add_argument("--dump-bed", default=None, help="(tests) rank 0 writes the last step's BED12 here")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the pass with two files in flight (value_sustained)")
     ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes (the line then quotes the committed measurement)")
     args = ap.parse_args()
     if args.multi_host == "cpp" and args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
@@ -316,10 +317,6 @@ def main():
         raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
     # (BENCH_DEVICE / BENCH_BACKEND: test knobs -- several ranks on ONE GPU with the gloo backend exercise this script's N > 1 path where no
     # multi-GPU node is at hand; the driver's runs use neither)
-    if args.warmup == 0:
-        os.environ.setdefault("REGTOOLS_AMD_ARENA", "0")      # (no warm-up step: the context's first call is timed, and the placement trials -- 0.3 s, once -- have no untimed call to run in)
-    if os.environ.get("BENCH_DEVICE") is not None:
-        os.environ.setdefault("REGTOOLS_AMD_ARENA", "0")      # (several ranks on ONE GPU: every process would hold a second arena for its placement trial at the same time)
     device_index = int(os.environ.get("BENCH_DEVICE", local_rank))
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(device_index)
@@ -441,6 +438,39 @@ def main():
             stage_ms[k] += s["ms_" + k] / (1 if args.host_only else args.steps)
     fence()
     dt_res = (time.time() - t1) * (args.steps if args.host_only else 1)
+    # Sustained: files back to back with TWO in flight (rgx_pipeline, csrc/pipeline.cpp: file k+1's upload and arrival-gated inflate run under file k's
+    # tail; N > 1: under file k's collective and merge as well).  The per-file headline above stays what SURVEY 8d defines; this is what a cohort run sees.
+    sustained = None
+    if not args.host_only and not args.no_sustained:
+        n_files = max(8, args.steps)
+        pl = regtools_amd.Pipeline(device_index, 2)
+
+        def run_files(nf):
+            tickets, out = [pl.submit(bai_bytes=bai, host_ptr=pin.ptr, host_len=len(bam), strandness=0)], None
+            for k in range(nf):
+                if k + 1 < nf:
+                    tickets.append(pl.submit(bai_bytes=bai, host_ptr=pin.ptr, host_len=len(bam), strandness=0))
+                jk = pl.wait(tickets[k])
+                out = rdist.gather_and_merge(jk, min_anchor=8) if world > 1 else jk
+            return out
+
+        run_files(2)                                   # (both contexts' first call: their workspaces)
+        fence()
+        t2 = time.time()
+        last_p = run_files(n_files)
+        fence()
+        dt_sus = time.time() - t2
+        same = bool(last_p.bed12() == (je.bed12() if world == 1 else last.bed12()))
+        del last_p
+        pl.close()
+        if world > 1:
+            t3 = torch.tensor([dt_sus, 0.0 if same else 1.0], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+            dt_sus, same = float(t3[0].item()), t3[1].item() == 0.0
+        sustained = {"files": n_files, "in_flight": 2, "ms_per_file": 1e3 * dt_sus / n_files, "table_identical_to_the_timed_step": same,
+                     "is": "files back to back through rgx_extract_submit / rgx_extract_wait, two contexts on the device taking turns: file k+1's upload and gated "
+                           "inflate run under file k's tail" + (" and under file k's all-gather + merge" if world > 1 else "")}
+        assert same, "sustained pass: the table differs from the timed step's"
     if world > 1:
         tt = torch.tensor([dt, dt_res], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -482,6 +512,7 @@ def main():
             "junction_events_per_s": total_events * args.steps / dt,
             "timed_region": "file bytes in page-locked host memory -> sorted junction table in host memory (SURVEY.md 8d): chunked H2D upload inside every step, overlapped with the inflate",
             "value_device_resident": total_reads * args.steps / dt_res, "ms_per_step_device_resident": 1e3 * dt_res / args.steps,
+            "value_sustained": (total_reads * 1e3 / sustained["ms_per_file"]) if sustained else None, "sustained": sustained,
             "junction_rows": s["n_junctions"] if world == 1 else int(last.n),
             "multi_gpu": None if world == 1 else {"host": "one process per GPU (torchrun), torch.distributed backend %s" % backend, "rccl_ranks": world if backend == "nccl" else 0,
                                                   "exchange": "all_gather_into_tensor of the ranks' packed 48-byte rows into HBM + rgx_table_merge_device on every rank" if backend == "nccl"
@@ -496,8 +527,8 @@ def main():
                          "kernel_ms_in_step_is": "the arrival-gated launch the TIMED step runs (same kernel under its PIECE symbol, HIP events on its own stream): it spans the upload -- "
                                                  "its waves wait for the chunk their members lie in -- so its duration is not a rate of the kernel",
                          "arena_placement_trials_ms": ctx.arena_trials(),
-                         "arena_placement_is": "the launch's time depends on where the arena's pages lie (stable per allocation; DESIGN.md 5.5): on its first large call the context "
-                                               "times the same launch into its arena ([0]) and into five fresh allocations and keeps the fastest; the timed steps and kernel_ms run on the kept one",
+                         "arena_placement_is": "opt-in since round 6 (REGTOOLS_AMD_ARENA=5; [] = the default, no trials): the launch's time depends on where the arena's pages lie (stable per "
+                                               "allocation; DESIGN.md 5.5) and a context can time the same launch into fresh allocations, one at a time, and keep a faster one",
                          "algorithmic_bytes": alg_bytes,
                          "note": "DEFLATE is a serial bit stream per member: one lane per member (long matches copied by the wave), bound by per-lane dependent ALU/LDS chains, the L1's rate of scattered per-lane accesses and one memory round trip per symbol trip, far below the HBM line (SURVEY 8d; DESIGN.md 5)",
                          "pipeline_frac": aln_per_s / world * (alg_bytes / n_reads) / (HBM_PEAK_GBS * 1e9)},

@@ -123,6 +123,23 @@ void  rgx_host_free(void *p);
 int  rgx_extract_mem(rgx_ctx *ctx, const void *bam, size_t bam_len, const void *bai, size_t bai_len,
                      const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen);
 
+/* Several files in flight on one device (round 6).  Replaces the loop a cohort run makes around `regtools junctions extract` -- one process per BAM, one
+ * after the other (junctions_main.cc:45-59).  A pipeline owns `depth` contexts on `device`; rgx_extract_submit hands file k to context k mod depth and
+ * returns at once with a ticket, rgx_extract_wait returns that file's table (or its error) -- each file is one ordinary rgx_extract_mem call, so the
+ * tables are those of sequential calls, while file k+1's upload and inflate run under file k's tail.  `bam` / `bai` must stay readable until the
+ * file's rgx_extract_wait returns (page-locked memory: rgx_host_alloc); the parameter struct and its strings are copied by submit.  Tickets may be
+ * waited for in any order, each once.  rgx_pipeline_destroy runs what is still queued to its end and frees tables nobody waited for. */
+typedef struct rgx_pipeline rgx_pipeline;
+int  rgx_pipeline_create(int device, int depth /* 1..8, 2 = one file's tail under the next one's upload */, rgx_pipeline **out, char *err, size_t errlen);
+int  rgx_pipeline_depth(const rgx_pipeline *pl);
+/* The context file `ticket` runs on.  After rgx_extract_wait its rows are still in that context's HBM (rgx_last_table_pack_device) until the file `depth`
+ * tickets later is submitted: a rank of a multi-GPU job merges file k with the other ranks' there while file k+1 is already going up. */
+rgx_ctx *rgx_pipeline_ctx(const rgx_pipeline *pl, uint64_t ticket);
+int  rgx_extract_submit(rgx_pipeline *pl, const void *bam, size_t bam_len, const void *bai, size_t bai_len, const rgx_extract_params *p,
+                        uint64_t *ticket, char *err, size_t errlen);
+int  rgx_extract_wait(rgx_pipeline *pl, uint64_t ticket, rgx_junction_table **out, char *err, size_t errlen);
+void rgx_pipeline_destroy(rgx_pipeline *pl);
+
 /* Same, with the .bam bytes ALREADY RESIDENT IN HBM at d_bam (the measured configuration: bench.py, or a
  * pipeline that DMA'd the file straight to the device).  No host copy of the BAM is needed: even the BGZF
  * member chain (BSIZE at +16 of every member, bgzf.c:525) is discovered on the device.  Only the (small) .bai is

@@ -4,7 +4,7 @@ Layout: csrc/ (HIP kernels, C ABI, host CLI, synthetic-input tooling), _ffi.py (
 extractor.py (host mirror of the reference's JunctionsExtractor interface), cse.py (mirrors of CisSpliceEffectsIdentifier /
 CisSpliceEffectsAssociator / VariantsAnnotator / JunctionsAnnotator), synth.py (synthetic inputs), distributed.py (shard merge).
 """
-from .extractor import Context, Junction, JunctionsExtractor, PinnedBuffer, RegtoolsError, extract_multi, junctions_extract  # noqa: F401
+from .extractor import Context, Junction, JunctionsExtractor, PinnedBuffer, Pipeline, RegtoolsError, extract_multi, junctions_extract  # noqa: F401
 from .cse import (CisSpliceEffectsAssociator, CisSpliceEffectsIdentifier, JunctionsAnnotator, VariantsAnnotator,  # noqa: F401
                   cis_splice_effects_identify)
 

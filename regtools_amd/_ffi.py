@@ -48,7 +48,8 @@ EXPORTS = ["rgx_extract_params_default", "rgx_ctx_create", "rgx_ctx_destroy", "r
            "rgx_gtf_transcript_id", "rgx_variant_windows", "rgx_variant_hits_free", "rgx_annotate_junctions", "rgx_junction_annot_free",
            "rgx_associate", "rgx_variants_annotate", "rgx_junctions_annotate", "rgx_junctions_annotate_opts", "rgx_table_merge_device", "rgx_window_join", "rgx_window_rows_free", "rgx_last_table_pack_device",
            "rgx_host_alloc", "rgx_host_free", "rgx_extract_multi", "rgx_extract_multi_mem", "rgx_multi_exchange_kind", "rgx_k_inflate_form", "rgx_table_merge_barcodes",
-           "rgx_table_pack_barcodes", "rgx_table_unpack_barcodes", "rgx_identify_multi", "rgx_ctx_arena_trials"]
+           "rgx_table_pack_barcodes", "rgx_table_unpack_barcodes", "rgx_identify_multi", "rgx_ctx_arena_trials",
+           "rgx_pipeline_create", "rgx_pipeline_depth", "rgx_pipeline_ctx", "rgx_extract_submit", "rgx_extract_wait", "rgx_pipeline_destroy"]
 
 
 class IdentifyParams(C.Structure):
@@ -120,6 +121,13 @@ def lib():
         L.rgx_extract_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                          P(ExtractParams), P(P(JunctionTable)), C.c_char_p, C.c_size_t]
         L.rgx_table_free.argtypes = [P(JunctionTable)]
+        L.rgx_pipeline_create.argtypes = [C.c_int, C.c_int, P(C.c_void_p), C.c_char_p, C.c_size_t]
+        L.rgx_pipeline_depth.argtypes = [C.c_void_p]
+        L.rgx_pipeline_ctx.argtypes = [C.c_void_p, C.c_uint64]
+        L.rgx_pipeline_ctx.restype = C.c_void_p
+        L.rgx_extract_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, P(ExtractParams), P(C.c_uint64), C.c_char_p, C.c_size_t]
+        L.rgx_extract_wait.argtypes = [C.c_void_p, C.c_uint64, P(P(JunctionTable)), C.c_char_p, C.c_size_t]
+        L.rgx_pipeline_destroy.argtypes = [C.c_void_p]
         L.rgx_extract_multi.argtypes = [P(C.c_int), C.c_int, C.c_char_p, P(ExtractParams), P(P(JunctionTable)), C.c_char_p, C.c_size_t]
         L.rgx_multi_exchange_kind.restype = C.c_char_p
         L.rgx_multi_exchange_kind.argtypes = []

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <charconv>
 #include <chrono>
 #include <map>
@@ -71,9 +72,10 @@ uint32_t bitlen(uint32_t v) { uint32_t b = 0; while (v) { ++b; v >>= 1; } return
 // (inflate_ring.h, kArenaFrontPad), and for the first member of an arena that is in front of the buffer.
 struct AllocStats { double ms = 0; uint64_t calls = 0, bytes = 0; };
 static AllocStats g_alloc_stats;                                   // (REGTOOLS_AMD_TRACE: what growing the device buffers cost a call)
-// REGTOOLS_AMD_ARENA="trials[,piece_MiB]" (tests, A/B runs): how many fresh arenas a context's first large call times its DEFLATE launch into (default 5, 0 = none; calibrate_arena),
+// REGTOOLS_AMD_ARENA="trials[,piece_MiB]": how many fresh arenas a context's first large call times its DEFLATE launch into (default 0 = none: the trials are
+// OPT-IN since round 6 -- on the driver's box five of them bought 14.5 -> 14.0 ms for 0.3 s and an arena's worth of transient memory; calibrate_arena),
 // and the size of the pieces the arena's device memory is created in (default 512, 0 = one hipMalloc block; DevBuf::map_pieces).
-struct ArenaKnobs { int trials = 5; size_t piece = (size_t)512 << 20; };
+struct ArenaKnobs { int trials = 0; size_t piece = (size_t)512 << 20; };
 static const ArenaKnobs &arena_knobs() {
     static const ArenaKnobs k = [] {
         ArenaKnobs v;
@@ -92,35 +94,51 @@ struct DevBuf {
     void *p = nullptr; size_t cap = 0;
     size_t piece = 0;               // asked for by the owner (the arena): memory created in pieces of this size and mapped side by side, see map_pieces (0: one hipMalloc block)
     size_t mapped = 0;              // bytes of the reserved address range the pieces are mapped into (0: a hipMalloc block)
+    std::vector<size_t> piece_len;  // the mappings inside that range, in address order (each is unmapped on its own)
     // The arena's form (round 5).  The DEFLATE launch writes 169,000 streams 64 KB apart at once, and what it costs depends on the memory under them: 13.9-15.9 ms
     // into one hipMalloc block of 11 GB, 12.3-12.6 ms into the same bytes created as pieces of 1 GiB (hipMemCreate) and mapped side by side into one reserved address range --
     // whatever the order of the pieces (profiles/r05_inflate_arena_pieces.txt: forty pieces, 110 subsets, 12.30-12.37 ms).  Pieces of 2 MiB: 16.0 ms; 32 MiB: 12.8-13.7;
     // 256 MiB: 12.4-13.7.  A runtime that refuses any of the calls leaves the buffer to hipMalloc.
+    static void unmap_range(void *base, const std::vector<size_t> &lens, size_t reserved) {
+        static const bool trace = getenv("REGTOOLS_AMD_TRACE") != nullptr;
+        size_t at = 0;
+        for (size_t n : lens) {                                     // (one mapping at a time: the form HIP's own tests use; a refusal would leak the piece silently)
+            const hipError_t e = hipMemUnmap((uint8_t *)base + at, n);
+            if (e != hipSuccess && trace) fprintf(stderr, "[rgx trace] hipMemUnmap of %zu bytes at +%zu: %s\n", n, at, hipGetErrorString(e));
+            if (e != hipSuccess) (void)hipGetLastError();
+            at += n;
+        }
+        const hipError_t e = hipMemAddressFree(base, reserved);
+        if (e != hipSuccess) { if (trace) fprintf(stderr, "[rgx trace] hipMemAddressFree of %zu bytes: %s\n", reserved, hipGetErrorString(e)); (void)hipGetLastError(); }
+    }
     hipError_t map_pieces(size_t bytes, void **out) {
-        constexpr size_t kRound = (size_t)2 << 20;
-        const size_t total = (bytes + kRound - 1) / kRound * kRound;
         int dev = 0;
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
         hipMemAllocationProp prop = {}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+        size_t gran = 0;                                            // what this runtime wants sizes and addresses to be multiples of (2 MiB on ROCm 7.2)
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) { (void)hipGetLastError(); gran = (size_t)2 << 20; }
+        const size_t total = (bytes + gran - 1) / gran * gran, each = std::max(gran, piece / gran * gran);
         void *base = nullptr;
         if ((e = hipMemAddressReserve(&base, total, 0, nullptr, 0)) != hipSuccess) return e;
+        std::vector<size_t> lens;
         size_t done = 0;
         while (done < total) {
-            const size_t n = std::min(piece, total - done);
+            const size_t n = std::min(each, total - done);
             hipMemGenericAllocationHandle_t h;
             if ((e = hipMemCreate(&h, n, &prop, 0)) != hipSuccess) break;
             e = hipMemMap((uint8_t *)base + done, n, 0, h, 0);
             (void)hipMemRelease(h);                                 // (the mapping keeps the memory; an unmapped, released piece is gone)
             if (e != hipSuccess) break;
+            lens.push_back(n);
             done += n;
         }
         if (e == hipSuccess) {
             hipMemAccessDesc ad = {}; ad.location.type = hipMemLocationTypeDevice; ad.location.id = dev; ad.flags = hipMemAccessFlagsProtReadWrite;
             e = hipMemSetAccess(base, total, &ad, 1);
         }
-        if (e != hipSuccess) { if (done) (void)hipMemUnmap(base, done); (void)hipMemAddressFree(base, total); return e; }
-        *out = base; mapped = total;
+        if (e != hipSuccess) { unmap_range(base, lens, total); return e; }
+        *out = base; mapped = total; piece_len.swap(lens);
         return hipSuccess;
     }
     hipError_t ensure(size_t bytes) {
@@ -134,7 +152,7 @@ struct DevBuf {
         size_t want = bytes + (no_slack ? 0 : bytes / 8) + 256;
         void *raw = nullptr;
         hipError_t e = hipErrorNotSupported;
-        if (piece && want + kFront >= piece) { e = map_pieces(want + kFront, &raw); if (e != hipSuccess) { (void)hipGetLastError(); raw = nullptr; mapped = 0; } }
+        if (piece && want + kFront >= piece) { e = map_pieces(want + kFront, &raw); if (e != hipSuccess) { (void)hipGetLastError(); raw = nullptr; mapped = 0; piece_len.clear(); } }
         if (e != hipSuccess) e = hipMalloc(&raw, want + kFront);
         if (e == hipSuccess) { p = (uint8_t *)raw + kFront; cap = want; }
         if (trace) {                                                 // (shards of a multi-device call grow their buffers on their own threads)
@@ -144,10 +162,10 @@ struct DevBuf {
         return e;
     }
     void release() {
-        if (p && mapped) { void *base = (uint8_t *)p - kFront; (void)hipDeviceSynchronize();    /* (what hipFree does by itself: nothing in flight may still touch the range) */
-                           (void)hipMemUnmap(base, mapped); (void)hipMemAddressFree(base, mapped); }
+        if (p && mapped) { (void)hipDeviceSynchronize();    /* (what hipFree does by itself: nothing in flight may still touch the range) */
+                           unmap_range((uint8_t *)p - kFront, piece_len, mapped); }
         else if (p) (void)hipFree((uint8_t *)p - kFront);
-        p = nullptr; cap = 0; mapped = 0;
+        p = nullptr; cap = 0; mapped = 0; piece_len.clear();
     }
     template <class T> T *as() const { return (T *)p; }
 };
@@ -173,8 +191,33 @@ static const OverlapKnobs &overlap_knobs() {
     }();
     return k;
 }
+// Two things the contexts of one pipeline (pipeline.cpp) take in turns, first come first served:
+//   wire -- the host link: a call's upload starts when the call before it has ITS file on the device (two uploads at once halve the link between them);
+//   chip -- the DEFLATE launch: a call's launch is enqueued when the launch before it has finished.  One launch is 2,647 of the chip's 3,072 wave slots and all
+//           of its LDS; two at once leave the first file's framing / decode / sort kernels nowhere to run until the second file's waves drain (measured: both
+//           files of a pair end together, 43 ms for the two).  One after the other, a file's tail runs in the slots its successor's launch leaves free.
+struct Turn {
+    std::mutex mu; std::condition_variable cv; uint64_t next = 0, serving = 0;
+};
+struct LinkTurn { Turn wire, chip; };
+// one context's hold on a turn: taken by the call's host thread, given back from a host function on the stream when the copy / the launch is over
+// (or by the end of the call, whichever comes first).  Lives in the context: a stream may still owe the give when a failed call has returned.
+struct TurnHold {
+    Turn *t = nullptr; std::atomic<bool> held{false};
+    void take(Turn *x) {
+        if (!x || held.load()) return;
+        std::unique_lock<std::mutex> lk(x->mu);
+        const uint64_t mine = x->next++;
+        x->cv.wait(lk, [&] { return x->serving == mine; });
+        t = x; held.store(true);
+    }
+    void give() { if (held.exchange(false)) { { std::lock_guard<std::mutex> lk(t->mu); ++t->serving; } t->cv.notify_all(); } }
+};
+
 struct rgx_ctx {
     int device = 0;
+    LinkTurn *link = nullptr;                          // (not owned; nullptr = a context on its own)
+    TurnHold wire_hold, chip_hold;
     hipStream_t stream = nullptr;
     // host input (rgx_extract_mem / rgx_extract): the file goes up in chunks on its own stream while the members that have arrived are
     // being inflated on the side streams (prepare_events)
@@ -302,6 +345,10 @@ static hipError_t ensure_upload_streams(rgx_ctx *c) {
 // (multi.cpp: a context made for a device that a device list names a second time -- shards taking turns on one GPU, a test configuration -- does without the trials:
 //  several contexts of one device would each hold a second arena at the same time)
 void rgx_ctx_no_arena_trials(rgx_ctx *c) { if (c) c->arena_calibrated_bytes = UINT64_MAX; }
+// pipeline.cpp: the contexts of one pipeline take the host link in turns
+void *rgx_link_turn_create() { return new LinkTurn; }
+void rgx_link_turn_destroy(void *l) { delete (LinkTurn *)l; }
+void rgx_ctx_set_link(rgx_ctx *c, void *l) { if (c) c->link = (LinkTurn *)l; }
 
 extern "C" int rgx_ctx_arena_trials(const rgx_ctx *c, float *ms, int cap) {
     if (!c) return 0;
@@ -532,7 +579,7 @@ struct EventsRun {
     // -- what the stages leave for one another --
     hipStream_t st = nullptr, copy_q = nullptr;               // the pipeline's stream; where the file's upload goes
     double t_begin = 0, t_last = 0; bool trace = false;
-    void mark(const char *what) { if (trace) { double t = now_ms(); fprintf(stderr, "[rgx trace] %-28s +%8.3f ms  (at %8.3f)\n", what, t - t_last, t - t_begin); t_last = t; } }
+    void mark(const char *what) { if (trace) { double t = now_ms(); fprintf(stderr, "[rgx trace] %-28s +%8.3f ms  (at %8.3f)%s\n", what, t - t_last, t - t_begin, c->link ? (" clock " + std::to_string(fmod(t, 1e5))).c_str() : ""); t_last = t; } }
     // stage_upload: the index (parsed on a second host thread), the file on its way to HBM, the host's member scan
     BaiInfo bi; bool bai_ok = false;
     std::vector<uint8_t> index_image;                        // a .csi (or a compressed index) rewritten as a plain BAI image
@@ -692,7 +739,11 @@ struct EventsRun {
     uint32_t n_events = 0, n_long = 0; uint64_t n_iterated = 0;
     // every way out while the side stream's launch may still run (an error in the prefix's framing, say: the next call on this context must not meet
     // it) and while the index thread runs; `up` joins its helper and waits for the DMA out of the caller's buffer itself
-    ~EventsRun() { if (split_B && split_ev) (void)hipEventSynchronize(split_ev); if (bai_thread.joinable()) bai_thread.join(); }
+    ~EventsRun() {
+        if (split_B && split_ev) (void)hipEventSynchronize(split_ev);
+        if (bai_thread.joinable()) bai_thread.join();
+        if (c->link && !d_bam_in) { c->wire_hold.give(); c->chip_hold.give(); }      // (a call that ended early: the other contexts must not wait for it)
+    }
     int run();
     int calibrate_arena();
     int stage_upload();
@@ -729,63 +780,65 @@ int EventsRun::run() {
     return rc_emit;
 }
 
-// Arena placement trials (rgx_ctx above).  On a context's first call with an arena of 2 GiB and more (and again when a later one is a quarter larger), once
-// the call's own work is enqueued: the same whole-range launch, plain, into the call's arena and into a few fresh allocations (two launches
-// each, the second one timed with HIP events; REGTOOLS_AMD_ARENA, default 5); the fastest becomes the context's arena (rgx_ctx_arena_trials reports the times).  The call's data stays where it is -- when a challenger wins, the old arena
-// is retired and released by the next call.  ~55 ms per candidate, 0.3 s once per context (what a context that lives for a few hundred files gets back; REGTOOLS_AMD_ARENA=0 for one that does not); a one-shot context (the CLI) never pays it.
+// Arena placement trials (rgx_ctx above) -- OPT-IN (REGTOOLS_AMD_ARENA=5) since round 6.  On a context's first call with an arena of 2 GiB and more
+// (and again when a later one is a quarter larger), once the call's own work is enqueued: the same whole-range launch, plain, into the call's arena and into
+// fresh allocations ONE AT A TIME (a warm-up launch, then the median of three timed with HIP events); a challenger that beats the incumbent's median by 1.5 %
+// becomes the context's arena (rgx_ctx_arena_trials reports the times).  The call's data stays where it is -- when a challenger wins, the old arena is
+// retired and released by the next call.  At most ONE arena's worth of extra memory is ever held, free memory is asked for again before every candidate, and
+// anything that goes wrong inside a trial leaves the incumbent in place: the caller's result is complete before the first trial starts.
 static int arena_challengers() { return arena_knobs().trials; }
 int EventsRun::calibrate_arena() {
     if (!arena_challengers() || c->one_shot || d_true_sizes || chunked || split_B || P.stream_ended || !n_range || n_range <= 2048 || total < ((uint64_t)2 << 30)) return RGX_OK;
     if (c->arena_calibrated_bytes == UINT64_MAX || (c->arena_calibrated_bytes && total + 256 <= c->arena_calibrated_bytes + c->arena_calibrated_bytes / 4)) return RGX_OK;
-    static std::mutex trial_mu;                                // (one calibration at a time per process: the shards of a multi-device call run on threads of one)
-    std::lock_guard<std::mutex> trial_lock(trial_mu);
+    static std::mutex trial_mu[16];                            // (one calibration at a time per DEVICE: the arenas of different devices have nothing to do with one another)
+    std::lock_guard<std::mutex> trial_lock(trial_mu[(unsigned)c->device % 16u]);
     if (!inflate_takes_coop(n_range) || h_sc[0] != 0xffffffffu) return RGX_OK;
     DevBuf &b_arena = c->buf("arena"), &b_lens = c->buf("inflate_scratch");
     if (!b_arena.p || b_arena.cap < total + 256) return RGX_OK;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * b_arena.cap + ((size_t)16 << 30)) { c->arena_calibrated_bytes = b_arena.cap; return RGX_OK; }      // (room for a challenger AND for what the call still has to allocate)
+    auto room_for_one = [&] {                                  // (a challenger AND what the call -- or a co-tenant of the device -- may still allocate)
+        size_t free_b = 0, total_b = 0;
+        return hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= b_arena.cap + b_arena.cap / 8 + ((size_t)16 << 30);
+    };
     const int plan = inflate_plan_for(bam_len, total_all);
     uint32_t *d_dummy = d_sc + 100;                            // (the trial launches' verdicts: not looked at -- the call's own launch gave the verdict)
     auto time_into = [&](uint8_t *arena_p, float &ms) -> hipError_t {
-        ms = 0;
-        for (int k = 0; k < 2; ++k) {                          // (the first launch into a fresh allocation also pays for its pages)
+        float t[3] = {0, 0, 0};
+        for (int k = 0; k < 4; ++k) {                          // (the first launch into a fresh allocation also pays for its pages: not timed)
             hipError_t e = hipMemsetAsync(d_dummy, 0xff, 8, st);
             if (e != hipSuccess) return e;
             if ((e = hipEventRecord(c->ev_trial[0], st)) != hipSuccess) return e;
             launch_inflate(d_bam, d_members + m_lo, n_range, arena_p, upos_lo, b_lens.as<uint32_t>(), d_dummy, st, 0, 0, false, 0, nullptr, plan);
             if ((e = hipEventRecord(c->ev_trial[1], st)) != hipSuccess) return e;
+            if ((e = hipEventSynchronize(c->ev_trial[1])) != hipSuccess) return e;
+            if (k && (e = hipEventElapsedTime(&t[k - 1], c->ev_trial[0], c->ev_trial[1])) != hipSuccess) return e;
         }
-        hipError_t e = hipEventSynchronize(c->ev_trial[1]);
-        if (e != hipSuccess) return e;
-        return hipEventElapsedTime(&ms, c->ev_trial[0], c->ev_trial[1]);
+        std::sort(t, t + 3);
+        ms = t[1];
+        return hipSuccess;
     };
     c->arena_trials = 0;
     float best_ms = 0;
-    HIP_TRY(time_into(b_arena.as<uint8_t>(), best_ms));        // (the call's own arena: the same bytes written once more, in stream order behind everything that read them)
+    if (time_into(b_arena.as<uint8_t>(), best_ms) != hipSuccess) { (void)hipGetLastError(); return RGX_OK; }      // (the call's own arena: the same bytes written once more, behind everything that read them)
     c->arena_trial_ms[c->arena_trials++] = best_ms;
     DevBuf best;                                               // the fastest challenger so far (empty: the incumbent leads)
-    // A challenger that lost is kept until the trials are over when there is room for all of them: released at once, its memory is what the next one is
-    // handed (five challengers timed 13.53-13.60 ms beside an incumbent of 13.16: one placement drawn five times; profiles/r05_inflate_arena_pieces.txt).
-    std::vector<DevBuf> losers;
-    const bool hold_losers = free_b >= (size_t)(arena_challengers() + 1) * (b_arena.cap + b_arena.cap / 8 + ((size_t)1 << 30)) + ((size_t)16 << 30);
-    auto drop = [&](DevBuf &d) { if (hold_losers && d.p) losers.push_back(d); else d.release(); d = DevBuf(); };
-    struct DropLosers { std::vector<DevBuf> &v; ~DropLosers() { for (DevBuf &d : v) d.release(); } } drop_losers{losers};
     for (int k = 0; k < arena_challengers(); ++k) {
+        if (best.p) break;                                     // (a winner is kept at once: never two challengers' memory at a time)
+        if (!room_for_one()) break;
         // (what makes one placement faster than another is not known -- DESIGN 5.5 -- so the challengers are not of one kind)
         static const size_t kLadder[] = {(size_t)1 << 30, (size_t)256 << 20, (size_t)512 << 20, (size_t)128 << 20, (size_t)1 << 30, (size_t)64 << 20, (size_t)512 << 20};     // (a hipMalloc block never won one: 15.6-16.3 ms beside 12.7-13.6)
         DevBuf cand; cand.piece = b_arena.piece ? kLadder[k % 7] : 0;
         if (cand.ensure(b_arena.cap) != hipSuccess) { (void)hipGetLastError(); break; }
         float ms = 0;
-        const hipError_t e = time_into(cand.as<uint8_t>(), ms);
-        if (e != hipSuccess) { cand.release(); best.release(); return fail(err, errlen, RGX_ERR_DEVICE, "HIP error %s in the arena placement trial\n", hipGetErrorString(e)); }
+        if (time_into(cand.as<uint8_t>(), ms) != hipSuccess) { (void)hipGetLastError(); cand.release(); break; }
         if (c->arena_trials < 8) c->arena_trial_ms[c->arena_trials++] = ms;
-        if (ms < best_ms * 0.985f) { drop(best); best = cand; best_ms = ms; } else drop(cand);
+        if (ms < best_ms * 0.985f) { best = cand; best_ms = ms; } else cand.release();
     }
     if (best.p) {
         // the call's data lies in the old arena and the caller may still read it (P.arena): it is retired, not released
         if (c->arena_retired) { c->arena_retired->release(); delete c->arena_retired; }
         c->arena_retired = new DevBuf(b_arena);
         b_arena = best;
+        b_arena.piece = arena_knobs().piece;                   // (a later regrow is made of the configured pieces, not of the winner's ladder size)
     }
     c->arena_calibrated_bytes = b_arena.cap;
     if (trace) {
@@ -815,6 +868,7 @@ int EventsRun::stage_upload() {
         HIP_TRY(b.ensure(bam_len + 64));
         d_bam = b.as<uint8_t>();
         mark("file buffer in HBM");
+        if (c->link) { c->wire_hold.take(&c->link->wire); mark("the link is ours"); }
         const size_t overlap_min = overlap_knobs().min_bytes;
         if (allow_overlap && !d_true_sizes && bam_len >= overlap_min) {
             HIP_TRY(ensure_upload_streams(c));
@@ -910,6 +964,10 @@ int EventsRun::stage_upload() {
                     o = up.end[j];
                     up.recorded.store((uint32_t)j + 1, std::memory_order_release);
                 }
+                // the file is on the device: the next call's upload may start.  A host function behind the last copy, not a wait in this thread -- a thread
+                // blocked in hipEventSynchronize kept the call's own launches from being enqueued until the upload was over (round 6: the gated launch
+                // went out 8.8 ms late).
+                if (c->link && hipLaunchHostFunc(copy_q, [](void *h) { ((TurnHold *)h)->give(); }, &c->wire_hold) != hipSuccess) { (void)hipGetLastError(); c->wire_hold.give(); }
             });
             if (shared) { hm = *shared->members; hm_total = shared->total_inflated; overlap = !hm.empty(); }
             else overlap = scan_members_parallel(h_bam, bam_len, (int)usable_threads(24), hm, hm_total);
@@ -1181,9 +1239,11 @@ int EventsRun::stage_range_and_inflate() {
     //  verdict, first makes the pipeline's stream wait for it)
     c->launch_timed = false;
     auto timed_launch = [&](hipStream_t q, bool piece, InflateGate gate) {      // the call's whole-range launch, with its own pair of events on its own stream
+        if (c->link) { c->chip_hold.take(&c->link->chip); mark("the chip's DEFLATE turn is ours"); }
         (void)hipEventRecord(c->ev_launch[0], q);
         launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, q, ignore_below, 0, piece, 0, d_bad, pairs, false, gate);
         (void)hipEventRecord(c->ev_launch[1], q);
+        if (c->link && hipLaunchHostFunc(q, [](void *h) { ((TurnHold *)h)->give(); }, &c->chip_hold) != hipSuccess) { (void)hipGetLastError(); c->chip_hold.give(); }
         c->launch_timed = true;
     };
     if (!overlap) timed_launch(st, false, InflateGate());

@@ -270,6 +270,67 @@ class JunctionsExtractor(object):
         return self._table
 
 
+class _BorrowedContext(object):
+    """A context the pipeline owns, as far as the merge calls need one (they take ctx._h)."""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+
+
+class Pipeline(object):
+    """rgx_pipeline: several files in flight on one device (depth contexts, file k on context k mod depth).  submit() returns a ticket at once,
+    wait(ticket) a JunctionsExtractor holding that file's table -- the same table a sequential identify_junctions_from_BAM gives.  The caller
+    keeps the input buffers alive until wait() returns (bytes objects are pinned to the ticket here)."""
+
+    def __init__(self, device=0, depth=2):
+        self._lib = _ffi.lib()
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = self._lib.rgx_pipeline_create(device, depth, C.byref(self._h), err, len(err))
+        if rc != 0:
+            raise RegtoolsError(rc, err.value.decode())
+        self._open = {}
+
+    def submit(self, bam_bytes=None, bai_bytes=None, host_ptr=None, host_len=0, **kw):
+        je = JunctionsExtractor(**kw)
+        p = je._params()
+        ticket = C.c_uint64()
+        err = C.create_string_buffer(512)
+        if host_ptr is not None:
+            rc = self._lib.rgx_extract_submit(self._h, C.c_void_p(host_ptr), host_len, bai_bytes, len(bai_bytes), C.byref(p), C.byref(ticket), err, len(err))
+        else:
+            rc = self._lib.rgx_extract_submit(self._h, bam_bytes, len(bam_bytes), bai_bytes, len(bai_bytes), C.byref(p), C.byref(ticket), err, len(err))
+        if rc != 0:
+            raise RegtoolsError(rc, err.value.decode())
+        self._open[ticket.value] = (je, bam_bytes, bai_bytes)
+        return ticket.value
+
+    def wait(self, ticket):
+        je, _, _ = self._open.pop(ticket)
+        tab = C.POINTER(_ffi.JunctionTable)()
+        err = C.create_string_buffer(512)
+        rc = self._lib.rgx_extract_wait(self._h, ticket, C.byref(tab), err, len(err))
+        if rc != 0:
+            raise RegtoolsError(rc, err.value.decode())
+        je._table = tab
+        je._ctx = _BorrowedContext(self._lib.rgx_pipeline_ctx(self._h, ticket))      # (rgx_pipeline_ctx: where this file's rows still lie, for a device-side merge)
+        t = tab.contents
+        je.stats = dict(n_records=t.n_records, n_events=t.n_events, n_junctions=t.n, ms_total=t.ms_total, stream_ended=bool(t.stream_ended))
+        return je
+
+    def close(self):
+        if self._h:
+            self._lib.rgx_pipeline_destroy(self._h)
+            self._h = C.c_void_p()
+            self._open = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def extract_multi(devices, bam=None, bam_bytes=None, bai_bytes=None, host_ptr=None, host_len=0, **kw):
     """rgx_extract_multi: `junctions extract` sharded over `devices` (a host thread per device, one RCCL gather of the shards' rows to
     devices[0], merge there).  kw: the JunctionsExtractor constructor's arguments.  host_ptr / host_len: the file in (page-locked) host memory

@@ -2,6 +2,7 @@
 reference outputs stored by tests/golden/make_golden.py, and the CPU oracle on seeded inputs.  Bit-exact: every
 comparison is on BED12 bytes.  Run with `-m gpu` on an MI355X."""
 import ctypes as C
+import json
 import os
 import subprocess
 import zlib
@@ -630,36 +631,39 @@ def test_long_record_decode_lane_form_equals_the_wave_form(gpu_ctx, synth_dir):
 
 
 def test_arena_placement_trials_leave_the_results_alone(gpu_ctx):
-    """A context that is not one-shot times its first large DEFLATE launch into a few fresh arenas and keeps the fastest (rgx_ctx_arena_trials):
-    the call that calibrates, the calls behind it (on the kept arena, possibly another one than the first call's data lies in) and a context with the trials
-    switched off must print the same bytes; the calibration happens once."""
+    """Opt-in since round 6 (REGTOOLS_AMD_ARENA=5): a context that is not one-shot times its first large DEFLATE launch into fresh arenas, one at a time, and
+    keeps a faster one (rgx_ctx_arena_trials).  The call that calibrates, the calls behind it (on the kept arena, possibly another one than the
+    first call's data lies in) and a context with the default (no trials) must print the same bytes; the calibration happens once."""
     import subprocess
     import sys
-    import regtools_amd
-    from regtools_amd import synth
-    bam, bai, st = synth.generate(10_000_000, shape="short", seed=21)
-    ctx = regtools_amd.Context(0)
-    try:
-        beds, trials = [], []
-        for k in range(3):
-            je = regtools_amd.JunctionsExtractor(strandness=0, ctx=ctx)
-            je.identify_junctions_from_BAM(bam_bytes=bam, bai_bytes=bai)
-            assert je.stats["n_records"] == st["n_reads"]
-            beds.append(je.bed12()); trials.append(ctx.arena_trials())
-        assert beds[0] == beds[1] == beds[2] and len(beds[0]) > 1000
-        assert len(trials[0]) == 6 and all(t > 0 for t in trials[0]), trials          # the call's arena + five challengers
-        assert trials[0] == trials[1] == trials[2]                                    # once per context
-    finally:
-        ctx.close()
-    code = ("import sys, regtools_amd; from regtools_amd import synth\n"
+    code = ("import sys, json, regtools_amd; from regtools_amd import synth\n"
             "bam, bai, st = synth.generate(10_000_000, shape='short', seed=21)\n"
-            "ctx = regtools_amd.Context(0); je = regtools_amd.JunctionsExtractor(strandness=0, ctx=ctx)\n"
-            "je.identify_junctions_from_BAM(bam_bytes=bam, bai_bytes=bai)\n"
-            "assert ctx.arena_trials() == [], ctx.arena_trials()\n"
-            "sys.stdout.buffer.write(je.bed12())\n")
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REGTOOLS_AMD_ARENA="0,0", PYTHONPATH=ROOT), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-    assert r.returncode == 0, r.stderr.decode()[-2000:]
-    assert r.stdout == beds[0]
+            "ctx = regtools_amd.Context(0); beds, trials = [], []\n"
+            "for k in range(3):\n"
+            "    je = regtools_amd.JunctionsExtractor(strandness=0, ctx=ctx)\n"
+            "    je.identify_junctions_from_BAM(bam_bytes=bam, bai_bytes=bai)\n"
+            "    assert je.stats['n_records'] == st['n_reads']\n"
+            "    beds.append(je.bed12()); trials.append(ctx.arena_trials())\n"
+            "ctx.close()\n"
+            "assert beds[0] == beds[1] == beds[2] and len(beds[0]) > 1000\n"
+            "sys.stderr.write('TRIALS ' + json.dumps(trials) + '\\n')\n"
+            "sys.stdout.buffer.write(beds[0])\n")
+    outs = {}
+    for knob in ("5", None):
+        env = dict(os.environ, PYTHONPATH=ROOT)
+        env.pop("REGTOOLS_AMD_ARENA", None)
+        if knob: env["REGTOOLS_AMD_ARENA"] = knob
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        trials = json.loads([l for l in r.stderr.decode().splitlines() if l.startswith("TRIALS ")][-1][7:])
+        if knob:
+            # the call's arena + one to five challengers (the first that wins ends the trials: never two challengers' memory at once), once per context
+            assert 2 <= len(trials[0]) <= 6 and all(t > 0 for t in trials[0]), trials
+            assert trials[0] == trials[1] == trials[2]
+        else:
+            assert trials == [[], [], []], trials                                      # the default: no trials
+        outs[knob] = r.stdout
+    assert outs["5"] == outs[None] and len(outs[None]) > 1000
 
 
 def test_arena_made_of_pieces_grows_and_shrinks_like_a_block(gpu_ctx):
