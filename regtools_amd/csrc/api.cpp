@@ -633,10 +633,17 @@ struct EventsRun {
     uint32_t m_lo = 0, m_hi = 0, n_range = 0;
     uint64_t upos_lo = 0, total = 0;
     uint8_t *d_bad = nullptr;
+    // one member of the list (the host scan's list is host memory; the device's is read on the pipeline's stream -- never through the null stream, which
+    // would wait for whatever any other stream of the process has in flight)
+    hipError_t member_at(uint32_t k, Member &m) {
+        if (from_members == hipMemcpyHostToHost) { memcpy(&m, d_members + k, sizeof m); return hipSuccess; }
+        hipError_t e = hipMemcpyAsync(&m, d_members + k, sizeof m, from_members, st);
+        return e == hipSuccess ? hipStreamSynchronize(st) : e;
+    }
     hipError_t upos_of(uint32_t k, uint64_t &out_v) {
         if (k >= n_members_all) { out_v = total_all; return hipSuccess; }
         Member m;
-        hipError_t e = hipMemcpy(&m, d_members + k, sizeof m, from_members);
+        hipError_t e = member_at(k, m);
         out_v = m.upos;
         return e;
     }
@@ -1364,10 +1371,10 @@ int EventsRun::stage_footers_and_header() {
         bool lies = size_trouble(0) || size_trouble(kStatusEarly);
         if (!lies && stop < n_members_all) {
             Member ms; uint8_t two[2] = {0, 0};
-            HIP_TRY(hipMemcpy(&ms, d_members + stop, sizeof ms, from_members));
+            HIP_TRY(member_at(stop, ms));
             if (ms.isize == 0 && ms.clen >= 2) {
                 if (h_bam && ms.cpos + 2 <= bam_len) memcpy(two, h_bam + ms.cpos, 2);
-                else HIP_TRY(hipMemcpy(two, d_bam + ms.cpos, 2, hipMemcpyDeviceToHost));
+                else { HIP_TRY(hipMemcpyAsync(two, d_bam + ms.cpos, 2, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); }
             }
             // fine: an empty block (03 00, the EOF marker) or a member cut off by the end of the file
             lies = !(ms.isize == 0 && two[0] == 3 && two[1] == 0) && ms.isize != 0xffffffffu;
