@@ -412,18 +412,25 @@ int cse_main(int argc, char **argv) {
 
 }  // namespace
 
-// regtools.cc:36-74
+// regtools.cc:36-74: the banner and the top-level usage are the reference's bytes (pinned against the reference's own main() in tests/test_cli_contract.py);
+// the library's own version string is rgx_version() (REGTOOLS_AMD_TRACE prints it)
 int main(int argc, char **argv) {
     setenv("REGTOOLS_AMD_ONE_SHOT", "1", 0);                   // this process makes one library call: the context does without streams of its own (api.cpp ensure_upload_streams)
-    std::cerr << "\nProgram:\tregtools (MI355X build)\nVersion:\t" << rgx_version() << std::endl;
+    std::cerr << "\nProgram:\tregtools\nVersion:\t1.0.0" << std::endl;
+    if (getenv("REGTOOLS_AMD_TRACE")) std::cerr << "[rgx trace] " << rgx_version() << std::endl;
     if (argc > 1) {
         std::string sub = argv[1];
         if (sub == "junctions") return junctions_main(argc - 1, argv + 1);
         if (sub == "cis-splice-effects") return cse_main(argc - 1, argv + 1);
         if (sub == "variants") return variants_main(argc - 1, argv + 1);
+        if (sub == "cis-ase") {                                // listed by the usage text below, as upstream's; not part of this build (out of scope)
+            std::cerr << "regtools-amd: the cis-ase commands are not part of the MI355X build; use the reference binary for them\n";
+            return 1;
+        }
     }
     std::cerr << "Usage:\t\tregtools <command> [options]\n"
               << "Command:\tjunctions\t\tTools that operate on feature junctions (e.g. exon-exon junctions from RNA-seq).\n"
+              << "\t\tcis-ase\t\t\tTools related to allele specific expression in cis.\n"
               << "\t\tcis-splice-effects\tTools related to splicing effects of variants.\n"
               << "\t\tvariants\t\tTools that operate on variants.\n\n";
     return 0;
