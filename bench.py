@@ -383,13 +383,26 @@ def main():
     # N > 1: what every rank spent where, for a scaling line that checks itself (one small all-gather, outside the timed region)
     rank_report = None
     if world > 1:
+        # every rank's host link with ALL ranks copying at once (256 MiB out of page-locked memory, three times, the best): whether eight uploads share
+        # one socket's memory or cross the sockets shows here, next to the rank's binding
+        probe_src = torch.empty(256 << 20, dtype=torch.uint8, pin_memory=True)
+        probe_dst = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+        h2d = 0.0
+        for _ in range(3):
+            fence()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); probe_dst.copy_(probe_src, non_blocking=True); e1.record(); e1.synchronize()
+            h2d = max(h2d, (256 << 20) / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        del probe_src, probe_dst
+        bindings = [None] * world
+        dist.all_gather_object(bindings, host_binding)
         mine = torch.tensor([je.stats["ms_inflate"], je.stats["ms_records"], je.stats["ms_scan"], je.stats["ms_reduce"], je.stats["ms_total"],
-                             sum(merge_ms) / max(1, len(merge_ms)), float(n_reads), float(je.stats["n_junctions"]), float(je.stats["n_records"])], dtype=torch.float64, device=coll_dev)
+                             sum(merge_ms) / max(1, len(merge_ms)), float(n_reads), float(je.stats["n_junctions"]), float(je.stats["n_records"]), h2d], dtype=torch.float64, device=coll_dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         rank_report = [dict(rank=r, inflate_ms=round(v[0].item(), 3), records_ms=round(v[1].item(), 3), scan_ms=round(v[2].item(), 3), reduce_ms=round(v[3].item(), 3),
                             extract_total_ms=round(v[4].item(), 3), gather_and_merge_ms=round(v[5].item(), 3), reads=int(v[6].item()), rows=int(v[7].item()),
-                            n_records=int(v[8].item())) for r, v in enumerate(allr)]
+                            n_records=int(v[8].item()), upload_GBps_all_ranks_at_once=round(v[9].item(), 1), host_binding=bindings[r]) for r, v in enumerate(allr)]
         # The N > 1 line checks itself (outside the timed region; the driver runs this path on hardware nobody else has seen it on):
         #  (i) every rank decoded its whole slice: sum of n_records == N x reads;
         #  (ii) the table the collective + device merge produced == an INDEPENDENT merge of the same per-rank tables -- every rank's packed rows
@@ -517,7 +530,11 @@ def main():
             "multi_gpu": None if world == 1 else {"host": "one process per GPU (torchrun), torch.distributed backend %s" % backend, "rccl_ranks": world if backend == "nccl" else 0,
                                                   "exchange": "all_gather_into_tensor of the ranks' packed 48-byte rows into HBM + rgx_table_merge_device on every rank" if backend == "nccl"
                                                               else "all_gather of packed rows on the host + rgx_table_merge (test backend)",
-                                                  "merge_ms": round(max(r["gather_and_merge_ms"] for r in rank_report), 3), "checks": multi_checks, "per_rank": rank_report},
+                                                  "merge_ms": round(max(r["gather_and_merge_ms"] for r in rank_report), 3),
+                                                  "merge_is": "serial behind the extraction in the timed step; in the sustained pass it runs under the next file's upload",
+                                                  "upload_GBps_all_ranks_at_once": [r["upload_GBps_all_ranks_at_once"] for r in rank_report],
+                                                  "bound_hint": "host link" if min(r["upload_GBps_all_ranks_at_once"] for r in rank_report) < 35 else "device",
+                                                  "checks": multi_checks, "per_rank": rank_report},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "input_generation_s": round(t_gen, 2),
             "roofline": {"bound": "hbm", "kernel": inflate_kernel_for(s["compressed_bytes"], s["inflated_bytes"]), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -585,6 +585,10 @@ def test_bench_multi_rank_path_on_one_gpu(gpu_ctx, tmp_path):
     ck = line["multi_gpu"]["checks"]                 # the line's own assertions (bench.py): records, an independent host merge, supporting reads
     assert ck["records_conserved"] and ck["bed12_equals_independent_merge"] and ck["counts_conserved"] and ck["merged_rows"] == line["junction_rows"] == ck["independent_host_merge_rows"]
     assert sum(r["n_records"] for r in line["multi_gpu"]["per_rank"]) == 400000
+    # round 6: every rank reports its host link with all ranks copying at once and its NUMA binding; the sustained pass (two files in flight per rank,
+    # the collective and the merge under the next file's upload) ran and produced the timed step's table
+    assert all(r["upload_GBps_all_ranks_at_once"] > 0 and isinstance(r["host_binding"], str) for r in line["multi_gpu"]["per_rank"])
+    assert line["value_sustained"] > 0 and line["sustained"]["table_identical_to_the_timed_step"] and line["sustained"]["in_flight"] == 2
     # the same two slices, one rank each, merged here
     import regtools_amd
     from regtools_amd import distributed
