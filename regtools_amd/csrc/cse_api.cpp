@@ -1,5 +1,7 @@
-// cse_api.inc -- `cis-splice-effects identify` on the device (included at the end of api.cpp: shares rgx_ctx, DevBuf,
-// prepare_events / reduce_events).  Host code here parses text and assembles strings; every interval computation is a kernel.
+// cse_api.cpp -- `cis-splice-effects identify / associate`, `variants annotate`, `junctions annotate` behind the C ABI.
+#include "api_internal.h"
+
+// `cis-splice-effects identify` on the device (rgx_ctx, DevBuf, prepare_events / reduce_events: api_internal.h).  Host code here parses text and assembles strings; every interval computation is a kernel.
 #include <set>
 #include <tuple>
 
@@ -33,7 +35,8 @@ static int gtf_upload(rgx_ctx *c, rgx_gtf *g, char *err, size_t errlen, bool poo
     HIP_ENTER(c->device);
     uint8_t *d = nullptr;
     struct Piece { size_t off; const void *src; size_t bytes; };
-    const Piece pieces[8] = {{o_strand, m.tx_strand.data(), T}, {o_off, m.tx_exon_off.data(), T * 4}, {o_n, m.tx_n_exons.data(), T * 4}, {o_es, m.es.data(), E * 4},
+    const Piece pieces[8] = {{o_strand, m.tx_strand.data(), T}, {o_off, m.tx_exon_off.data(), T * 4}, {o_n, m.tx_n_exons.data(), T * 4}, {o_es, m.es.data(),
+        E * 4},
                              {o_ee, m.ee.data(), E * 4}, {o_bk, m.bin_key.data(), B * 8}, {o_bt, m.bin_tx.data(), B * 4}, {o_bs, m.bin_start.data(), S * 4}};
     if (pooled) {
         DevBuf &b = c->buf("gtf_tables");
@@ -50,7 +53,8 @@ static int gtf_upload(rgx_ctx *c, rgx_gtf *g, char *err, size_t errlen, bool poo
         // the pieces into the staging block, the large ones in slices on the stage's threads
         struct Slice { uint8_t *dst; const uint8_t *src; size_t n; };
         std::vector<Slice> sl;
-        for (const Piece &q : pieces) for (size_t o = 0; o < q.bytes; o += (size_t)1 << 20) sl.push_back({stage + q.off + o, (const uint8_t *)q.src + o, std::min<size_t>((size_t)1 << 20, q.bytes - o)});
+        for (const Piece &q : pieces) for (size_t o = 0; o < q.bytes; o += (size_t)1 << 20) sl.push_back({stage + q.off + o, (const uint8_t *)q.src + o,
+            std::min<size_t>((size_t)1 << 20, q.bytes - o)});
         if (tl_pool && sl.size() > 1) tl_pool->run(sl.size(), [&](size_t k) { memcpy(sl[k].dst, sl[k].src, sl[k].n); });
         else for (const Slice &x : sl) memcpy(x.dst, x.src, x.n);
         HIP_TRY(hipMemcpyAsync(d, stage, total - 256, hipMemcpyHostToDevice, c->stream));
@@ -174,8 +178,10 @@ extern "C" int rgx_variant_windows(rgx_ctx *ctx, const rgx_gtf *g, uint64_t n, c
     int rc = variant_windows(ctx, g, ci, ps, o, H, err, errlen);
     if (rc != RGX_OK) return rc;
     rgx_variant_hits *r = (rgx_variant_hits *)calloc(1, sizeof *r);
-    auto dup = [](const std::vector<uint32_t> &v) { uint32_t *p = (uint32_t *)malloc((v.size() + 1) * 4); if (!v.empty()) memcpy(p, v.data(), v.size() * 4); return p; };
-    r->n = n; r->cis_start = dup(H.ces); r->cis_end = dup(H.cee); r->hit_off = dup(H.off); r->hit_transcript = dup(H.tx); r->hit_annotation = dup(H.ann); r->hit_distance = dup(H.dist);
+    auto dup = [](const std::vector<uint32_t> &v) { uint32_t *p = (uint32_t *)malloc((v.size() + 1) * 4); if (!v.empty()) memcpy(p, v.data(), v.size() * 4);
+        return p; };
+    r->n = n; r->cis_start = dup(H.ces); r->cis_end = dup(H.cee); r->hit_off = dup(H.off); r->hit_transcript = dup(H.tx); r->hit_annotation = dup(H.ann);
+        r->hit_distance = dup(H.dist);
     *out = r;
     return RGX_OK;
 }
@@ -188,7 +194,8 @@ extern "C" void rgx_variant_hits_free(rgx_variant_hits *h) {
 struct JunctionAnnotHost { std::vector<uint32_t> flags, n_acc, n_exo, n_don, tx_off, tx; };
 
 static int annotate_junctions(rgx_ctx *c, const rgx_gtf *g, const std::vector<int32_t> &chrom, const std::vector<uint32_t> &js, const std::vector<uint32_t> &je,
-                              const std::vector<uint8_t> &strand, JunctionAnnotHost &A, char *err, size_t errlen, uint64_t *exon_visits = nullptr, bool keep_single = false) {
+                              const std::vector<uint8_t> &strand, JunctionAnnotHost &A, char *err, size_t errlen, uint64_t *exon_visits = nullptr,
+                                  bool keep_single = false) {
     const uint32_t n = (uint32_t)chrom.size();
     GtfView view = g->view; view.keep_single = keep_single ? 1u : 0u;          // (`junctions annotate -S` only)
     A = JunctionAnnotHost();
@@ -221,7 +228,8 @@ static int annotate_junctions(rgx_ctx *c, const rgx_gtf *g, const std::vector<in
     std::vector<uint32_t> off((size_t)n + 1), kind(total), ia(total), ib(total);
     A.flags.resize(N);
     HIP_TRY(hipMemcpy(A.flags.data(), d_flags, N * 4, hipMemcpyDeviceToHost));
-    if (exon_visits) {                                                 // SURVEY 8d's E_j: the lane form adds into one counter, the wave form writes one count per junction
+    // SURVEY 8d's E_j: the lane form adds into one counter, the wave form writes one count per junction
+    if (exon_visits) {
         HIP_TRY(hipMemcpy(off.data(), d_visit_each, N * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < N; ++i) h_visits += off[i];
         *exon_visits = h_visits;
@@ -278,7 +286,8 @@ extern "C" int rgx_annotate_junctions(rgx_ctx *ctx, const rgx_gtf *g, uint64_t n
     int rc = annotate_junctions(ctx, g, ci, js, je, sd, A, err, errlen);
     if (rc != RGX_OK) return rc;
     rgx_junction_annot *r = (rgx_junction_annot *)calloc(1, sizeof *r);
-    auto dup = [](const std::vector<uint32_t> &v) { uint32_t *p = (uint32_t *)malloc((v.size() + 1) * 4); if (!v.empty()) memcpy(p, v.data(), v.size() * 4); return p; };
+    auto dup = [](const std::vector<uint32_t> &v) { uint32_t *p = (uint32_t *)malloc((v.size() + 1) * 4); if (!v.empty()) memcpy(p, v.data(), v.size() * 4);
+        return p; };
     r->n = n; r->flags = dup(A.flags); r->n_acceptors_skipped = dup(A.n_acc); r->n_exons_skipped = dup(A.n_exo); r->n_donors_skipped = dup(A.n_don);
     r->tx_off = dup(A.tx_off); r->tx = dup(A.tx);
     *out = r;
@@ -320,14 +329,16 @@ static int window_join(rgx_ctx *c, const Prep &P, const std::vector<int32_t> &w_
         std::vector<uint32_t> h_slices(Sn);
         HIP_TRY(hipMemcpyAsync(h_slices.data(), d_cnt, Sn * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        for (size_t k = 0; k < Wn; ++k) { uint64_t c = 0; for (uint32_t q = 0; q < kWinSlices; ++q) c += h_slices[k * kWinSlices + q]; h_cnt[k] = c > 0xffffffffull ? 0xffffffffu : (uint32_t)c; }
+        for (size_t k = 0; k < Wn; ++k) { uint64_t c = 0; for (uint32_t q = 0; q < kWinSlices; ++q) c += h_slices[k * kWinSlices + q];
+            h_cnt[k] = c > 0xffffffffull ? 0xffffffffu : (uint32_t)c; }
     }
     static const uint64_t kPairBatch = getenv("REGTOOLS_AMD_PAIR_BATCH") ? strtoull(getenv("REGTOOLS_AMD_PAIR_BATCH"), nullptr, 10) : (1ull << 26);
     for (uint32_t w0 = 0; w0 < W;) {
         uint64_t total64 = h_cnt[w0];
         uint32_t w1 = w0 + 1;
         while (w1 < W && total64 + h_cnt[w1] <= kPairBatch) total64 += h_cnt[w1++];
-        if (total64 >= (1ull << 31)) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: one variant window holds %llu junction-supporting reads; more than the join handles\n", (unsigned long long)total64);
+        if (total64 >= (1ull << 31)) return fail(err, errlen, RGX_ERR_ARG,
+            "regtools_amd: one variant window holds %llu junction-supporting reads; more than the join handles\n", (unsigned long long)total64);
         const uint32_t nw = w1 - w0, total = (uint32_t)total64;
         n_pairs += total;
         if (total) {
@@ -340,13 +351,15 @@ static int window_join(rgx_ctx *c, const Prep &P, const std::vector<int32_t> &w_
             EventSoA pe; memset(&pe, 0, sizeof pe);
             pe.tid = q; q += Pn; pe.start = q; q += Pn; pe.ilen_cls = q; q += Pn; pe.ts = q; q += Pn; pe.te = q; q += Pn; pe.strand = (uint8_t *)q;
             ktime_begin(c, 2);
-            launch_window_pairs(true, P.ev, P.n_events, nw, d_tid + w0, d_beg + w0, d_end + w0, d_span, d_lo + w0, d_hi + w0, d_cnt + (size_t)w0 * kWinSlices, d_base + (size_t)w0 * kWinSlices, pair_ev, pair_win, st);
+            launch_window_pairs(true, P.ev, P.n_events, nw, d_tid + w0, d_beg + w0, d_end + w0, d_span, d_lo + w0, d_hi + w0,
+                d_cnt + (size_t)w0 * kWinSlices, d_base + (size_t)w0 * kWinSlices, pair_ev, pair_win, st);
             ktime_end(c);
             launch_pair_gather(P.ev, pair_ev, pair_win, total, pe, st);
             std::vector<uint32_t> ident(nw);
             for (uint32_t i = 0; i < nw; ++i) ident[i] = i;
             HostRows B;
-            int rc = reduce_events(c, pe, total, std::max<uint32_t>(1, bitlen(nw - 1)), ilen_bits, ident.data(), nw, B, err, errlen, false, nullptr, nullptr, /*allow_preagg=*/false);
+            int rc = reduce_events(c, pe, total, std::max<uint32_t>(1, bitlen(nw - 1)), ilen_bits, ident.data(), nw, B, err, errlen, false, nullptr, nullptr,
+                /*allow_preagg=*/false);
             if (rc != RGX_OK) return rc;
             // rows of the batch, window indices made absolute; name ranks stay batch-local (callers only use them inside a window)
             for (uint32_t &g : B.group) g += w0;
@@ -413,7 +426,8 @@ struct VStr { std::string genes, transcripts, distances, annotations; };
 struct VariantStage {
     VcfText vcf;
     VariantHitsHost H;
-    std::vector<VStr> vstr;            // comma strings in visitation order (variants_annotator.cc:479-506), one entry per splice relevant record (the others are written as "NA" x4)
+    // comma strings in visitation order (variants_annotator.cc:479-506), one entry per splice relevant record (the others are written as "NA" x4)
+    std::vector<VStr> vstr;
     std::vector<uint32_t> vstr_of;     // record -> its entry of vstr, UINT32_MAX when not splice relevant
     std::vector<size_t> relevant;      // indices into vcf.recs
 };
@@ -482,27 +496,34 @@ static int write_annotated_vcf(const char *path, const VariantStage &V, bool all
     return RGX_OK;
 }
 
-static const char *kJunctionHeader = "chrom\tstart\tend\tname\tscore\tstrand\tsplice_site\tacceptors_skipped\texons_skipped\tdonors_skipped\tanchor\tknown_donor\tknown_acceptor\tknown_junction\tgene_names\tgene_ids\ttranscripts";
+static const char *kJunctionHeader = "chrom\tstart\tend\tname\tscore\tstrand\tsplice_site\tacceptors_skipped\texons_skipped\tdonors_skipped\t"
+                                     "anchor\tknown_donor\tknown_acceptor\tknown_junction\tgene_names\tgene_ids\ttranscripts";
 
 // get_splice_site (junctions_annotator.cc:94-114); je = AnnotatedJunction.end
-static int splice_site(const Fasta &fa, const std::string &chrom, uint32_t js, uint32_t je, const std::string &strand, std::string &site, char *err, size_t errlen) {
+static int splice_site(const Fasta &fa, const std::string &chrom, uint32_t js, uint32_t je, const std::string &strand, std::string &site, char *err,
+    size_t errlen) {
     std::string s1, s2;
-    if (!fa.fetch(chrom, (int64_t)js + 1, (int64_t)js + 2, s1)) return fail(err, errlen, RGX_ERR_FASTA, "Unable to extract FASTA sequence for position %s:%u-%u\n\n", chrom.c_str(), js + 1, js + 2);
-    if (!fa.fetch(chrom, (int64_t)je - 2, (int64_t)je - 1, s2)) return fail(err, errlen, RGX_ERR_FASTA, "Unable to extract FASTA sequence for position %s:%u-%u\n\n", chrom.c_str(), je - 2, je - 1);
+    if (!fa.fetch(chrom, (int64_t)js + 1, (int64_t)js + 2, s1)) return fail(err, errlen, RGX_ERR_FASTA,
+        "Unable to extract FASTA sequence for position %s:%u-%u\n\n", chrom.c_str(), js + 1, js + 2);
+    if (!fa.fetch(chrom, (int64_t)je - 2, (int64_t)je - 1, s2)) return fail(err, errlen, RGX_ERR_FASTA,
+        "Unable to extract FASTA sequence for position %s:%u-%u\n\n", chrom.c_str(), je - 2, je - 1);
     site = strand == "-" ? rev_comp(s2) + "-" + rev_comp(s1) : s1 + "-" + s2;
     return RGX_OK;
 }
 
 // AnnotatedJunction::print (junctions_annotator.h:84-126) up to the transcripts column, row i of an annotate_junctions() result
-// (text is appended to strings with to_chars: 66 k rows through fprintf into memory streams were 8.5 ms on 16 threads, a std::set of string pairs per row among them)
+// (text is appended to strings with to_chars: 66 k rows through fprintf into memory streams were 8.5 ms on 16 threads, a std::set of string pairs per row
+// among them)
 static inline void put_u(std::string &o, uint64_t v) { char b[24]; auto r = std::to_chars(b, b + sizeof b, v); o.append(b, (size_t)(r.ptr - b)); }
 static inline void put_i(std::string &o, int64_t v) { char b[24]; auto r = std::to_chars(b, b + sizeof b, v); o.append(b, (size_t)(r.ptr - b)); }
-static void append_junction_row(std::string &o, const rgx_gtf *g, const JunctionAnnotHost &A, size_t i, const std::string &chrom, uint32_t js, uint32_t je, const std::string &name,
+static void append_junction_row(std::string &o, const rgx_gtf *g, const JunctionAnnotHost &A, size_t i, const std::string &chrom, uint32_t js, uint32_t je,
+    const std::string &name,
                                 const std::string &score, const std::string &strand, const std::string &site) {
     const uint32_t f = A.flags[i];
     const bool kd = f & 1, ka = f & 2, kj = f & 4;
     const char *anchor = kj ? "DA" : kd ? (ka ? "NDA" : "D") : ka ? "A" : "N";          // annotate_anchor :295-308
-    o += chrom; o += '\t'; put_u(o, js); o += '\t'; put_u(o, je); o += '\t'; o += name; o += '\t'; o += score; o += '\t'; o += strand; o += '\t'; o += site; o += '\t';
+    o += chrom; o += '\t'; put_u(o, js); o += '\t'; put_u(o, je); o += '\t'; o += name; o += '\t'; o += score; o += '\t'; o += strand; o += '\t'; o += site;
+        o += '\t';
     put_u(o, A.n_acc[i]); o += '\t'; put_u(o, A.n_exo[i]); o += '\t'; put_u(o, A.n_don[i]); o += '\t'; o += anchor;
     o += kd ? "\t1" : "\t0"; o += ka ? "\t1" : "\t0"; o += kj ? "\t1" : "\t0";
     if (A.tx_off[i + 1] > A.tx_off[i]) {
@@ -512,14 +533,16 @@ static void append_junction_row(std::string &o, const rgx_gtf *g, const Junction
         auto less = [](const std::pair<const std::string *, const std::string *> &x, const std::pair<const std::string *, const std::string *> &y) {
             const int c = x.first->compare(*y.first); return c < 0 || (c == 0 && *x.second < *y.second); };
         std::sort(genes.begin(), genes.end(), less);
-        genes.erase(std::unique(genes.begin(), genes.end(), [](const auto &x, const auto &y) { return *x.first == *y.first && *x.second == *y.second; }), genes.end());
+        genes.erase(std::unique(genes.begin(), genes.end(), [](const auto &x, const auto &y) { return *x.first == *y.first && *x.second == *y.second; }),
+            genes.end());
         o += '\t'; for (size_t k = 0; k < genes.size(); ++k) { if (k) o += ','; o += *genes[k].first; }
         o += '\t'; for (size_t k = 0; k < genes.size(); ++k) { if (k) o += ','; o += *genes[k].second; }
         o += '\t';
         for (uint32_t k = A.tx_off[i]; k < A.tx_off[i + 1]; ++k) { if (k != A.tx_off[i]) o += ','; o += g->m.tx_id[A.tx[k]]; }
     } else o += "\tNA\tNA\tNA";
 }
-static void print_junction_row(FILE *fo, const rgx_gtf *g, const JunctionAnnotHost &A, size_t i, const std::string &chrom, uint32_t js, uint32_t je, const std::string &name,
+static void print_junction_row(FILE *fo, const rgx_gtf *g, const JunctionAnnotHost &A, size_t i, const std::string &chrom, uint32_t js, uint32_t je,
+    const std::string &name,
                                const std::string &score, const std::string &strand, const std::string &site) {
     std::string o;
     append_junction_row(o, g, A, i, chrom, js, je, name, score, strand, site);
@@ -540,7 +563,8 @@ struct JTable {
     struct Row { uint32_t crank, js, jend; JEntry e; uint32_t v0, v1; };
     std::vector<Row> rows;
     std::vector<std::pair<uint32_t, uint32_t>> vars;         // (variant contig rank, pos0)
-    void add(uint32_t crank, uint32_t js, uint32_t jend, uint32_t vrank, uint32_t vpos, uint32_t src) { cand.push_back(Cand{crank, js, jend, (uint32_t)cand.size(), vrank, vpos, src}); }
+    void add(uint32_t crank, uint32_t js, uint32_t jend, uint32_t vrank, uint32_t vpos, uint32_t src) { cand.push_back(Cand{crank, js, jend,
+        (uint32_t)cand.size(), vrank, vpos, src}); }
     template <class F> void finish(F entry_of /* src -> JEntry, asked once per junction */) {
         std::vector<uint32_t> idx(cand.size());
         for (uint32_t i = 0; i < idx.size(); ++i) idx[i] = i;
@@ -558,7 +582,8 @@ struct JTable {
             const Cand &f = cand[idx[i]];                       // the first arrival of this key: its fields stay (map::insert)
             size_t j = i;
             const uint32_t v0 = (uint32_t)vars.size();
-            while (j < idx.size() && cand[idx[j]].crank == f.crank && cand[idx[j]].js == f.js && cand[idx[j]].jend == f.jend) { vars.push_back({cand[idx[j]].vrank, cand[idx[j]].vpos}); ++j; }
+            while (j < idx.size() && cand[idx[j]].crank == f.crank && cand[idx[j]].js == f.js &&
+                cand[idx[j]].jend == f.jend) { vars.push_back({cand[idx[j]].vrank, cand[idx[j]].vpos}); ++j; }
             std::sort(vars.begin() + v0, vars.end());
             vars.erase(std::unique(vars.begin() + v0, vars.end()), vars.end());
             rows.push_back(Row{f.crank, f.js, f.jend, entry_of(f.src), v0, (uint32_t)vars.size()});
@@ -582,10 +607,12 @@ static void string_ranks(const std::vector<std::string> &names, std::vector<uint
 }
 
 // a11 + outputs (annotate_junctions identifier.cc:222-246 / associator.cc:182-203)
-static int write_junction_outputs(rgx_ctx *c, const rgx_gtf *g, const char *fasta_path, const JMap &uj, const char *out_tsv, const char *out_bed, uint64_t *exon_visits,
+static int write_junction_outputs(rgx_ctx *c, const rgx_gtf *g, const char *fasta_path, const JMap &uj, const char *out_tsv, const char *out_bed,
+    uint64_t *exon_visits,
                                   double *ms_annotate, char *err, size_t errlen) {
     const double t0 = now_ms();
-    struct Teardown { double t = 0; const char *what; ~Teardown() { if (t > 0) fprintf(stderr, "[rgx trace] %s +%8.3f ms\n", what, now_ms() - t); } } teardown{0, "outputs: locals released"};
+    struct Teardown { double t = 0; const char *what; ~Teardown() { if (t > 0) fprintf(stderr, "[rgx trace] %s +%8.3f ms\n", what, now_ms() - t);
+        } } teardown{0, "outputs: locals released"};
     Fasta *fap = host_fasta(c, fasta_path);
     if (!fap) return fail(err, errlen, RGX_ERR_FASTA, "Unable to open FASTA file.\n\n");
     const Fasta &fa = *fap;
@@ -605,7 +632,8 @@ static int write_junction_outputs(rgx_ctx *c, const rgx_gtf *g, const char *fast
     if (ms_annotate) *ms_annotate += now_ms() - t0;
     const bool trace = getenv("REGTOOLS_AMD_TRACE") != nullptr;
     double t_last = now_ms();
-    auto lap = [&](const char *what) { if (trace) { const double t = now_ms(); fprintf(stderr, "[rgx trace] outputs: %-18s +%8.3f ms\n", what, t - t_last); t_last = t; } };
+    auto lap = [&](const char *what) { if (trace) { const double t = now_ms(); fprintf(stderr, "[rgx trace] outputs: %-18s +%8.3f ms\n", what, t - t_last);
+        t_last = t; } };
     // get_splice_site for every junction up front, on several host threads: two 2-base reads at random places of a multi-GB FASTA mapping are
     // two page faults per junction (0.13 s of config 4's 0.47 s when done row by row in the print loop).  The FIRST junction that fails, in
     // output order, ends the run with its message after the rows before it were written -- as the row-by-row loop did.
@@ -620,7 +648,8 @@ static int write_junction_outputs(rgx_ctx *c, const rgx_gtf *g, const char *fast
             for (size_t k = n * t / T; k < n * (t + 1) / T; ++k) {
                 const JTable::Row &r = rows[k];
                 char e2[512] = {0};
-                if (splice_site(fa, uj.chrom_name[r.crank], r.js, r.jend + 1, r.e.strand, sites[k], e2, sizeof e2) != RGX_OK) { bad[t] = k; msg[t] = e2; return; }
+                if (splice_site(fa, uj.chrom_name[r.crank], r.js, r.jend + 1, r.e.strand, sites[k], e2, sizeof e2) != RGX_OK) { bad[t] = k; msg[t] = e2;
+                    return; }
             }
         };
         run_tasks(T, work);
@@ -663,7 +692,8 @@ static int write_junction_outputs(rgx_ctx *c, const rgx_gtf *g, const char *fast
                 { char nb[32]; snprintf(nb, sizeof nb, "JUNC%08zu", i + 1); name = nb; }
                 if (want_bed) {
                     std::string &b = ck.bed;
-                    b += chrom; b += '\t'; put_u(b, e.ts); b += '\t'; put_u(b, e.te); b += '\t'; b += name; b += '\t'; put_u(b, e.count); b += '\t'; b += e.strand; b += '\t';
+                    b += chrom; b += '\t'; put_u(b, e.ts); b += '\t'; put_u(b, e.te); b += '\t'; b += name; b += '\t'; put_u(b, e.count); b += '\t';
+                        b += e.strand; b += '\t';
                     put_u(b, e.ts); b += '\t'; put_u(b, e.te); b += '\t'; b += e.color; b += '\t'; put_i(b, e.nblocks); b += '\t';
                     put_u(b, (uint32_t)(js - e.ts)); b += ','; put_u(b, (uint32_t)(e.te - jend)); b += "\t0,"; put_u(b, (uint32_t)(jend - e.ts)); b += '\n';
                 }
@@ -672,18 +702,21 @@ static int write_junction_outputs(rgx_ctx *c, const rgx_gtf *g, const char *fast
                 ck.tsv += '\t';
                 for (uint32_t k = r.v0; k < r.v1; ++k) {                                // variant_set_to_string
                     if (k != r.v0) ck.tsv += ',';
-                    ck.tsv += uj.vchrom_name[uj.vars[k].first]; ck.tsv += ':'; put_i(ck.tsv, (int)uj.vars[k].second); ck.tsv += '-'; put_i(ck.tsv, (int)(uj.vars[k].second + 1));
+                    ck.tsv += uj.vchrom_name[uj.vars[k].first]; ck.tsv += ':'; put_i(ck.tsv, (int)uj.vars[k].second); ck.tsv += '-'; put_i(ck.tsv,
+                        (int)(uj.vars[k].second + 1));
                 }
                 ck.tsv += '\n';
             }
         } catch (const std::bad_alloc &) { ck.ok = false; }
     };
     run_tasks(T, format);
-    if (trace) { double lo = 1e9, hi = 0, sum = 0; for (double v : task_ms) { lo = std::min(lo, v); hi = std::max(hi, v); sum += v; } fprintf(stderr, "[rgx trace] outputs: %zu format tasks: min %.3f avg %.3f max %.3f ms\n", T, lo, sum / (double)T, hi); }
+    if (trace) { double lo = 1e9, hi = 0, sum = 0; for (double v : task_ms) { lo = std::min(lo, v); hi = std::max(hi, v); sum += v; } fprintf(stderr,
+        "[rgx trace] outputs: %zu format tasks: min %.3f avg %.3f max %.3f ms\n", T, lo, sum / (double)T, hi); }
     lap("rows formatted");
     bool mem_ok = true;
     for (const Chunk &ck : chunks) if (!ck.ok) mem_ok = false;
-    if (mem_ok) for (Chunk &ck : chunks) { if (!ck.tsv.empty()) fwrite(ck.tsv.data(), 1, ck.tsv.size(), fo); if (fj && !ck.bed.empty()) fwrite(ck.bed.data(), 1, ck.bed.size(), fj); }
+    if (mem_ok) for (Chunk &ck : chunks) { if (!ck.tsv.empty()) fwrite(ck.tsv.data(), 1, ck.tsv.size(), fo); if (fj && !ck.bed.empty()) fwrite(ck.bed.data(),
+        1, ck.bed.size(), fj); }
     if (!mem_ok) { if (fo != stdout) fclose(fo); if (fj) fclose(fj); return fail(err, errlen, RGX_ERR_OPEN, "regtools_amd: no memory for the output rows\n"); }
     if (first_bad != SIZE_MAX) { if (fo != stdout) fclose(fo); if (fj) fclose(fj); return fail(err, errlen, RGX_ERR_FASTA, "%s", bad_msg); }
     if (fo != stdout) fclose(fo);
@@ -703,12 +736,14 @@ rgx_ctx *rgx_multi_context(int device, int nth, char *err, size_t errlen, int *r
 // where the windows are joined as on one device.  The gather is device-to-device copies (hipMemcpyPeerAsync: xGMI between two GPUs, a plain copy when
 // a device is listed twice) -- no reduction is involved, so no collective.  A shard whose record stream ended for a reason that ends iteration upstream
 // ends the event list (the shards behind it are dropped, as the table merge drops them).
-static int prepare_events_sharded(const std::vector<rgx_ctx *> &cs, const uint8_t *bam, size_t bam_len, const uint8_t *bai, size_t bai_len, const rgx_extract_params *ep,
+static int prepare_events_sharded(const std::vector<rgx_ctx *> &cs, const uint8_t *bam, size_t bam_len, const uint8_t *bai, size_t bai_len,
+    const rgx_extract_params *ep,
                                   Prep &P, char *err, size_t errlen) {
     const int n = (int)cs.size();
     std::vector<Member> members; uint64_t total_inflated = 0;
     if (bam_len < ((size_t)8 << 20) || !scan_members_parallel(bam, bam_len, (int)usable_threads(24), members, total_inflated))
-        return prepare_events(cs[0], nullptr, bam, bam_len, bai, bai_len, ep, true, P, err, errlen);      // a file the host scan does not vouch for: one device, its own member discovery
+        // a file the host scan does not vouch for: one device, its own member discovery
+        return prepare_events(cs[0], nullptr, bam, bam_len, bai, bai_len, ep, true, P, err, errlen);
     SharedMembers sm{&members, total_inflated};
     std::vector<Prep> parts((size_t)n);
     std::vector<int> rcs((size_t)n, RGX_OK);
@@ -716,7 +751,8 @@ static int prepare_events_sharded(const std::vector<rgx_ctx *> &cs, const uint8_
     auto run = [&](int g) {
         rgx_extract_params q = *ep;
         q.shard = g; q.n_shards = n;
-        rcs[(size_t)g] = prepare_events(cs[(size_t)g], nullptr, bam, bam_len, bai, bai_len, &q, true, parts[(size_t)g], &errs[(size_t)g][0], 512, nullptr, true, false, &sm);
+        rcs[(size_t)g] = prepare_events(cs[(size_t)g], nullptr, bam, bam_len, bai, bai_len, &q, true, parts[(size_t)g], &errs[(size_t)g][0], 512, nullptr,
+            true, false, &sm);
     };
     bool distinct = true;
     for (int a = 0; a < n; ++a) for (int b = a + 1; b < n; ++b) if (cs[(size_t)a]->device == cs[(size_t)b]->device) distinct = false;
@@ -754,7 +790,8 @@ static int prepare_events_sharded(const std::vector<rgx_ctx *> &cs, const uint8_
         (void)rgx_enable_peer(c0->device, dg);                       // (xGMI instead of a bounce through the host; a copy works either way)
         HIP_TRY(hipSetDevice(c0->device));
 #define RGX_GATHER(F, BYTES) HIP_TRY(hipMemcpyPeerAsync((uint8_t *)all.F + off * (BYTES), c0->device, pg.ev.F, dg, k * (BYTES), c0->stream))
-        RGX_GATHER(tid, 4); RGX_GATHER(start, 4); RGX_GATHER(ilen_cls, 4); RGX_GATHER(ts, 4); RGX_GATHER(te, 4); RGX_GATHER(rpos, 4); RGX_GATHER(rend, 4); RGX_GATHER(strand, 1);
+        RGX_GATHER(tid, 4); RGX_GATHER(start, 4); RGX_GATHER(ilen_cls, 4); RGX_GATHER(ts, 4); RGX_GATHER(te, 4); RGX_GATHER(rpos, 4); RGX_GATHER(rend, 4);
+            RGX_GATHER(strand, 1);
 #undef RGX_GATHER
         off += k;
     }
@@ -766,7 +803,8 @@ static int prepare_events_sharded(const std::vector<rgx_ctx *> &cs, const uint8_
 }
 
 static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const rgx_identify_params *p, rgx_identify_stats *stats, char *err, size_t errlen);
-extern "C" int rgx_identify(rgx_ctx *c, const rgx_identify_params *p, rgx_identify_stats *stats, char *err, size_t errlen) { return identify_run(c, nullptr, p, stats, err, errlen); }
+extern "C" int rgx_identify(rgx_ctx *c, const rgx_identify_params *p, rgx_identify_stats *stats, char *err, size_t errlen) { return identify_run(c, nullptr,
+    p, stats, err, errlen); }
 
 // `identify` with the extraction sharded over the listed devices (prepare_events_sharded); everything behind it on the first one.  A device may be
 // listed more than once (its shards take turns on it).  The outputs do not depend on the list.
@@ -788,7 +826,8 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
     if (!c || !p) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
     if (!p->vcf_path || !p->bam_path || !p->fasta_path || !p->gtf_path) return fail(err, errlen, RGX_ERR_ARG, "Error parsing inputs!(2)\n\n");
     if (p->strandness < 0 || p->strandness > 3) return fail(err, errlen, RGX_ERR_ARG, "Please supply strand specificity with '-s' option!\n\n");
-    struct Teardown { double t = 0; const char *what; ~Teardown() { if (t > 0) fprintf(stderr, "[rgx trace] %s +%8.3f ms\n", what, now_ms() - t); } } teardown{0, "identify: locals released"};
+    struct Teardown { double t = 0; const char *what; ~Teardown() { if (t > 0) fprintf(stderr, "[rgx trace] %s +%8.3f ms\n", what, now_ms() - t);
+        } } teardown{0, "identify: locals released"};
     rgx_identify_stats S; memset(&S, 0, sizeof S);
     ktime_collect(c); c->kms[0] = c->kms[1] = c->kms[2] = 0;
     const double t0 = now_ms();
@@ -806,8 +845,10 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
     VariantStage &V = *V_holder;
     std::string gtf_err, vcf_err;
     double gtf_thread_ms = 0, vcf_thread_ms = 0;
-    std::thread t_gtf([&] { const double t = now_ms(); try { gtf_err = g->m.load(p->gtf_path); } catch (const std::exception &e) { gtf_err = std::string("regtools_amd: ") + e.what() + "\n"; } gtf_thread_ms = now_ms() - t; });
-    std::thread t_vcf([&] { const double t = now_ms(); try { vcf_err = V.vcf.load(p->vcf_path); } catch (const std::exception &e) { vcf_err = std::string("regtools_amd: ") + e.what() + "\n"; } vcf_thread_ms = now_ms() - t; });
+    std::thread t_gtf([&] { const double t = now_ms(); try { gtf_err = g->m.load(p->gtf_path);
+        } catch (const std::exception &e) { gtf_err = std::string("regtools_amd: ") + e.what() + "\n"; } gtf_thread_ms = now_ms() - t; });
+    std::thread t_vcf([&] { const double t = now_ms(); try { vcf_err = V.vcf.load(p->vcf_path);
+        } catch (const std::exception &e) { vcf_err = std::string("regtools_amd: ") + e.what() + "\n"; } vcf_thread_ms = now_ms() - t; });
     struct Joiner { std::thread &a, &b; ~Joiner() { if (a.joinable()) a.join(); if (b.joinable()) b.join(); } } joiner{t_gtf, t_vcf};
 
     // ---- identify: the extraction, ONCE for all windows (the reference re-opens the BAM per variant: identifier.cc:288-290) ----
@@ -823,7 +864,8 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
         std::string idx;
         if (!bam.open(p->bam_path)) rc_bam = fail(err_bam, sizeof err_bam, RGX_ERR_OPEN, "%s", kMsgOpen);
         else if (find_index(p->bam_path, idx) != 0 || !read_index(idx, bai)) rc_bam = fail(err_bam, sizeof err_bam, RGX_ERR_INDEX, "%s", kMsgIndex);
-        else if (shards && shards->size() > 1) rc_bam = prepare_events_sharded(*shards, bam.data(), bam.size(), bai.data(), bai.size(), &ep, P, err_bam, sizeof err_bam);
+        else if (shards && shards->size() > 1) rc_bam = prepare_events_sharded(*shards, bam.data(), bam.size(), bai.data(), bai.size(), &ep, P, err_bam,
+            sizeof err_bam);
         else rc_bam = prepare_events(c, nullptr, bam.data(), bam.size(), bai.data(), bai.size(), &ep, true, P, err_bam, sizeof err_bam);
         lap(S.ms_extract);
     }
@@ -841,7 +883,8 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
     // a10: every variant against the annotation
     t_vcf.join();
     if (!vcf_err.empty()) return fail(err, errlen, RGX_ERR_OPEN, "%s", vcf_err.c_str());
-    if (getenv("REGTOOLS_AMD_TRACE")) fprintf(stderr, "[rgx trace] inputs: gtf thread %8.3f ms, vcf thread %8.3f ms, extraction %8.3f ms (side by side)\n", gtf_thread_ms, vcf_thread_ms, S.ms_extract);
+    if (getenv("REGTOOLS_AMD_TRACE")) fprintf(stderr, "[rgx trace] inputs: gtf thread %8.3f ms, vcf thread %8.3f ms, extraction %8.3f ms (side by side)\n",
+        gtf_thread_ms, vcf_thread_ms, S.ms_extract);
     VariantOpts vo{p->intronic_min, p->exonic_min, p->all_intronic, p->all_exonic, p->skip_single};
     rc = variant_scan_stage(c, g, vo, V, &S.exon_visits_variants, err, errlen);
     if (rc != RGX_OK) return rc;
@@ -854,7 +897,8 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
     char err_vcf[512]; err_vcf[0] = 0;
     double vcf_ms = 0;
     std::thread t_vcfout;
-    if (p->out_vcf) t_vcfout = std::thread([&] { const double t = now_ms(); rc_vcf = write_annotated_vcf(p->out_vcf, V, false, err_vcf, sizeof err_vcf); vcf_ms = now_ms() - t; });
+    if (p->out_vcf) t_vcfout = std::thread([&] { const double t = now_ms(); rc_vcf = write_annotated_vcf(p->out_vcf, V, false, err_vcf, sizeof err_vcf);
+        vcf_ms = now_ms() - t; });
     struct JoinOne { std::thread &t; ~JoinOne() { if (t.joinable()) t.join(); } } join_vcfout{t_vcfout};
 
     JMap uj;
@@ -865,18 +909,21 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
         // bucket by contig, file order kept inside a bucket
         std::unordered_map<std::string, int32_t> cidx; std::vector<std::string> cname;
         std::vector<int32_t> jch(B.n());
-        for (size_t i = 0; i < B.n(); ++i) { auto it = cidx.find(B.chrom[i]); if (it == cidx.end()) { it = cidx.emplace(B.chrom[i], (int32_t)cname.size()).first; cname.push_back(B.chrom[i]); } jch[i] = it->second; }
+        for (size_t i = 0; i < B.n(); ++i) { auto it = cidx.find(B.chrom[i]); if (it == cidx.end()) { it = cidx.emplace(B.chrom[i],
+            (int32_t)cname.size()).first; cname.push_back(B.chrom[i]); } jch[i] = it->second; }
         std::vector<uint32_t> chrom_off(cname.size() + 1, 0), order(B.n()), js(B.n()), je(B.n());
         for (size_t i = 0; i < B.n(); ++i) chrom_off[(size_t)jch[i] + 1]++;
         for (size_t k = 0; k < cname.size(); ++k) chrom_off[k + 1] += chrom_off[k];
         { std::vector<uint32_t> fill(chrom_off.begin(), chrom_off.end() - 1);
-          for (size_t i = 0; i < B.n(); ++i) { const uint32_t q = fill[(size_t)jch[i]]++; order[q] = (uint32_t)i; js[q] = B.start[i]; je[q] = B.end[i] - 1; } }     // Junction.end = line.end - 1 (:221)
+          // Junction.end = line.end - 1 (:221)
+          for (size_t i = 0; i < B.n(); ++i) { const uint32_t q = fill[(size_t)jch[i]]++; order[q] = (uint32_t)i; js[q] = B.start[i]; je[q] = B.end[i] - 1; } }
         const uint32_t W = (uint32_t)relevant.size(), J = (uint32_t)B.n();
         S.n_windows = W; S.n_events = J;
         std::vector<uint32_t> pj, pw;
         if (W && J) {
             std::vector<int32_t> wch(W); std::vector<uint32_t> wces(W), wcee(W);
-            for (uint32_t w = 0; w < W; ++w) { const size_t vi = relevant[w]; auto it = cidx.find(vcf.recs[vi].chrom); wch[w] = it == cidx.end() ? -1 : it->second; wces[w] = H.ces[vi]; wcee[w] = H.cee[vi]; }
+            for (uint32_t w = 0; w < W; ++w) { const size_t vi = relevant[w]; auto it = cidx.find(vcf.recs[vi].chrom); wch[w] = it == cidx.end() ? -1 :
+                it->second; wces[w] = H.ces[vi]; wcee[w] = H.cee[vi]; }
             hipStream_t st = c->stream;
             HIP_ENTER(c->device);
             DevBuf &b = c->buf("cse_assoc"), &sc = c->buf("scalars");
@@ -884,12 +931,16 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
             const size_t Wn = W, Jn = J, Cn = chrom_off.size();
             HIP_TRY(b.ensure((Wn * 5 + Jn * 2 + Cn + scan_tmp_words(W)) * 4 + 512));
             uint32_t *w = b.as<uint32_t>();
-            int32_t *d_wch = (int32_t *)w; w += Wn; uint32_t *d_ces = w; w += Wn; uint32_t *d_cee = w; w += Wn; uint32_t *d_cnt = w; w += Wn; uint32_t *d_base = w; w += Wn;
+            int32_t *d_wch = (int32_t *)w; w += Wn; uint32_t *d_ces = w; w += Wn; uint32_t *d_cee = w; w += Wn; uint32_t *d_cnt = w; w += Wn;
+                uint32_t *d_base = w; w += Wn;
             uint32_t *d_js = w; w += Jn; uint32_t *d_je = w; w += Jn; uint32_t *d_off = w; w += Cn; uint32_t *d_tmp = w;
             uint32_t *d_total = sc.as<uint32_t>() + 68;
-            HIP_TRY(hipMemcpyAsync(d_wch, wch.data(), Wn * 4, hipMemcpyHostToDevice, st)); HIP_TRY(hipMemcpyAsync(d_ces, wces.data(), Wn * 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(d_cee, wcee.data(), Wn * 4, hipMemcpyHostToDevice, st)); HIP_TRY(hipMemcpyAsync(d_js, js.data(), Jn * 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(d_je, je.data(), Jn * 4, hipMemcpyHostToDevice, st)); HIP_TRY(hipMemcpyAsync(d_off, chrom_off.data(), Cn * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d_wch, wch.data(), Wn * 4, hipMemcpyHostToDevice, st)); HIP_TRY(hipMemcpyAsync(d_ces, wces.data(), Wn * 4,
+                hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d_cee, wcee.data(), Wn * 4, hipMemcpyHostToDevice, st)); HIP_TRY(hipMemcpyAsync(d_js, js.data(), Jn * 4,
+                hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d_je, je.data(), Jn * 4, hipMemcpyHostToDevice, st)); HIP_TRY(hipMemcpyAsync(d_off, chrom_off.data(), Cn * 4,
+                hipMemcpyHostToDevice, st));
             launch_assoc_pairs(false, W, d_wch, d_ces, d_cee, d_off, d_js, d_je, d_cnt, nullptr, nullptr, nullptr, st);
             launch_scan_u32(d_cnt, d_base, W, d_total, d_tmp, st);
             uint32_t total = 0;
@@ -898,7 +949,8 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
             HIP_TRY(hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             { uint64_t t64 = 0; for (uint32_t x : h_cnt) t64 += x;                   // the device scan is 32 bits wide
-              if (t64 >= (1ull << 31)) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: %llu (variant, junction) pairs; more than the join handles\n", (unsigned long long)t64); }
+              if (t64 >= (1ull << 31)) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: %llu (variant, junction) pairs; more than the join handles\n",
+                  (unsigned long long)t64); }
             if (total) {
                 DevBuf &bp = c->buf("cse_pairs");
                 HIP_TRY(bp.ensure((size_t)total * 8 + 256));
@@ -916,7 +968,8 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
             std::vector<uint32_t> crank_of, vrank_of;
             string_ranks(cname, crank_of, uj.chrom_name);
             std::vector<std::string> vnames; std::unordered_map<std::string, uint32_t> vidx; std::vector<uint32_t> v_name(relevant.size());
-            for (size_t w = 0; w < relevant.size(); ++w) { const std::string &cn = vcf.recs[relevant[w]].chrom; auto it = vidx.find(cn); if (it == vidx.end()) { it = vidx.emplace(cn, (uint32_t)vnames.size()).first; vnames.push_back(cn); } v_name[w] = it->second; }
+            for (size_t w = 0; w < relevant.size(); ++w) { const std::string &cn = vcf.recs[relevant[w]].chrom; auto it = vidx.find(cn);
+                if (it == vidx.end()) { it = vidx.emplace(cn, (uint32_t)vnames.size()).first; vnames.push_back(cn); } v_name[w] = it->second; }
             string_ranks(vnames, vrank_of, uj.vchrom_name);
             uj.cand.reserve(pj.size());
             for (size_t r = 0; r < pj.size(); ++r) {
@@ -957,10 +1010,12 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
                     w_tid[w] = tid; w_beg[w] = beg; w_end[w] = en;
                 }
             });
-            for (size_t t = 0; t < nt; ++t) if (bad[t] != SIZE_MAX) return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion);   // aborts the run
+            // aborts the run
+            for (size_t t = 0; t < nt; ++t) if (bad[t] != SIZE_MAX) return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion);
         }
         S.n_windows = w_tid.size();
-        auto jlap = [&](const char *what) { if (jtrace) { const double t = now_ms(); fprintf(stderr, "[rgx trace] join: %-22s +%8.3f ms\n", what, t - jt); jt = t; } };
+        auto jlap = [&](const char *what) { if (jtrace) { const double t = now_ms(); fprintf(stderr, "[rgx trace] join: %-22s +%8.3f ms\n", what, t - jt);
+            jt = t; } };
         jlap("window regions");
         HostRows R;
         rc = window_join(c, P, w_tid, w_beg, w_end, std::min<uint32_t>(32, bitlen(p->max_intron) + 2), R, S.n_pairs, err, errlen);
@@ -976,7 +1031,8 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
                 const std::string *last = nullptr; uint32_t last_idx = 0;
                 for (size_t w = 0; w < relevant.size(); ++w) {
                     const std::string &cn = vcf.recs[relevant[w]].chrom;
-                    if (!last || *last != cn) { auto it = vidx.find(cn); if (it == vidx.end()) { it = vidx.emplace(cn, (uint32_t)vnames.size()).first; vnames.push_back(cn); } last = &cn; last_idx = it->second; }
+                    if (!last || *last != cn) { auto it = vidx.find(cn); if (it == vidx.end()) { it = vidx.emplace(cn, (uint32_t)vnames.size()).first;
+                        vnames.push_back(cn); } last = &cn; last_idx = it->second; }
                     v_name[w] = last_idx;
                 }
             }
@@ -1018,7 +1074,8 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
         const int dev = c->device;
         bam.release_later();
         (void)dev;
-        Reaper::get().later([vs, gg] { delete vs; rgx_gtf_free(gg); });      // (host memory only: the annotation's device tables are the context's, gtf_upload(pooled) -- no HIP call on that thread)
+        // (host memory only: the annotation's device tables are the context's, gtf_upload(pooled) -- no HIP call on that thread)
+        Reaper::get().later([vs, gg] { delete vs; rgx_gtf_free(gg); });
     }
     return RGX_OK;
 }
@@ -1044,7 +1101,8 @@ extern "C" int rgx_variants_annotate(rgx_ctx *c, const rgx_identify_params *p, r
     struct GtfGuard { rgx_gtf *g; ~GtfGuard() { rgx_gtf_free(g); } } guard{g};
     VariantStage V;
     std::string vcf_err;
-    std::thread t_vcf([&] { try { vcf_err = V.vcf.load(p->vcf_path); } catch (const std::exception &e) { vcf_err = std::string("regtools_amd: ") + e.what() + "\n"; } });
+    std::thread t_vcf([&] { try { vcf_err = V.vcf.load(p->vcf_path);
+        } catch (const std::exception &e) { vcf_err = std::string("regtools_amd: ") + e.what() + "\n"; } });
     struct JoinOne { std::thread &t; ~JoinOne() { if (t.joinable()) t.join(); } } join_vcf{t_vcf};
     {
         std::string e;
@@ -1075,7 +1133,8 @@ extern "C" int rgx_junctions_annotate(rgx_ctx *c, const char *bed_path, const ch
     return rgx_junctions_annotate_opts(c, bed_path, fasta_path, gtf_path, out_path, 0, n_rows, err, errlen);
 }
 // include_single_exon: -S (junctions_annotator.cc:392-393: skip_single_exon_genes_ = false)
-extern "C" int rgx_junctions_annotate_opts(rgx_ctx *c, const char *bed_path, const char *fasta_path, const char *gtf_path, const char *out_path, int include_single_exon,
+extern "C" int rgx_junctions_annotate_opts(rgx_ctx *c, const char *bed_path, const char *fasta_path, const char *gtf_path, const char *out_path,
+    int include_single_exon,
                                            uint64_t *n_rows, char *err, size_t errlen) {
     if (!c || !bed_path || !fasta_path || !gtf_path) return fail(err, errlen, RGX_ERR_ARG, "Error parsing inputs!(2)\n\n");
     rgx_gtf *g = nullptr;
@@ -1097,7 +1156,8 @@ extern "C" int rgx_junctions_annotate_opts(rgx_ctx *c, const char *bed_path, con
     size_t done = 0;
     for (size_t i = 0; i < n && rc == RGX_OK; ++i) {
         std::string site;
-        if (!have_fa) { rc = fail(err, errlen, RGX_ERR_FASTA, "Unable to extract FASTA sequence for position %s:%u-%u\n\n", B.chrom[i].c_str(), B.start[i] + 1, B.start[i] + 2); break; }
+        if (!have_fa) { rc = fail(err, errlen, RGX_ERR_FASTA, "Unable to extract FASTA sequence for position %s:%u-%u\n\n", B.chrom[i].c_str(),
+            B.start[i] + 1, B.start[i] + 2); break; }
         rc = splice_site(*fap, B.chrom[i], B.start[i], B.end[i], B.strand[i], site, err, errlen);
         if (rc != RGX_OK) break;
         print_junction_row(fo, g, A, i, B.chrom[i], B.start[i], B.end[i], B.name[i], B.score[i], B.strand[i], site);

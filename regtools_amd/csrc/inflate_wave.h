@@ -10,7 +10,7 @@
 //   * a match is copied by all lanes at once inside the 64 KiB output window in LDS (lane i moves byte i; an overlapping match is its own
 //     period, out[o + i] = out[o - dist + i % dist]); the window goes to HBM once, in 16-byte stores of consecutive lanes.
 // ~150-500 cycles per symbol instead of ~2,000 per lane trip: a member in 1-2 ms.  Two workgroups per CU (69 KB of LDS each), so it only
-// pays below a few thousand members; the host picks (api.cpp).
+// pays below a few thousand members; the host picks (api_front.cpp).
 // The algorithm is plain C++ over a `Wave` policy (lane loops, shared memory) so that tests/hostemu runs it on the host against zlib.
 #pragma once
 #include "inflate_core.h"

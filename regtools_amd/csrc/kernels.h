@@ -21,7 +21,7 @@ size_t inflate_scratch_bytes(uint32_t n_members);
 hipError_t pending_launch_error();
 // Arrival gate of the overlapped upload (round 4): ONE k_inflate_coop launch covers the whole range while the file is still on the bus; a wave
 // starts once the upload chunk holding the last byte its members need has landed -- flags[k] == epoch, written by a 4-byte copy queued on the
-// copy stream right behind chunk k (api.cpp prepare_events).  flags = nullptr: no gate.
+// copy stream right behind chunk k (api_front.cpp stage_upload).  flags = nullptr: no gate.
 struct InflateGate {
     const uint32_t *flags = nullptr;   // device memory, one word per upload chunk
     uint32_t epoch = 0;                // this call's value (the words keep earlier calls' values: smaller)
@@ -228,7 +228,7 @@ void launch_gather_u32(uint32_t n, const uint32_t *table, const uint32_t *idx, u
 void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t stream);
 // ten u32 columns of n rows each, in `order`: tid,start,end,ts,te,count,name_rank,first_seen,last_seen,strand
 void launch_rows_out(UniqueSoA u, const uint32_t *order, uint32_t n, uint32_t *out, hipStream_t stream);
-// The result table's host block, written on the device so that ONE copy fills every column (api.cpp table_alloc): m = padded row count;
+// The result table's host block, written on the device so that ONE copy fills every column (api_ctx.cpp table_alloc): m = padded row count;
 // u64 name_index[m], first_seen[m], last_seen[m]; u32 tid[m], start[m], end[m], thick_start[m], thick_end[m], read_count[m]; u8 strand[m], left_ok[m], right_ok[m]
 RGX_HD size_t table_block_rows(uint64_t n) { return ((size_t)n + 1 + 15) & ~(size_t)15; }
 RGX_HD size_t table_block_bytes(uint64_t n) { return table_block_rows(n) * (8 * 3 + 4 * 6 + 3); }

@@ -498,7 +498,7 @@ static int inflate_form_env() {
 // may get here together)
 // A configuration step that failed (hipFuncSetAttribute on this device's copy of a kernel) must not pass silently: the launch behind it
 // would fail or run with too little LDS, the arena would stay untouched and the stages behind it would read it.  The error is kept per host
-// thread until the caller's next checked HIP call (api.cpp HIP_TRY -> pending_launch_error) turns it into RGX_ERR_DEVICE.
+// thread until the caller's next checked HIP call (api_internal.h HIP_TRY -> pending_launch_error) turns it into RGX_ERR_DEVICE.
 static thread_local hipError_t tl_launch_error = hipSuccess;
 hipError_t pending_launch_error() {
     hipError_t e = tl_launch_error; tl_launch_error = hipSuccess;

@@ -3,14 +3,14 @@
 //
 // Replaces, for a multi-GPU node, the single call junctions_extract() makes into JunctionsExtractor::identify_junctions_from_BAM
 // (/root/reference/src/junctions/junctions_main.cc:45-59).  One host thread, one context and one stream per device:
-//   thread g:  shard g of n (contiguous BGZF member range cut at record starts the index lists, api.cpp prepare_events) ->
+//   thread g:  shard g of n (contiguous BGZF member range cut at record starts the index lists, api_front.cpp stage_members) ->
 //              the whole single-GPU pipeline on device g -> its unique rows packed in HBM (48 bytes per row)
 //   exchange:  ONE grouped gather of the padded row blocks to the first device over xGMI (ncclSend / ncclRecv in one group; RCCL is loaded
 //              at run time: librccl.so.1 is the only thing this library needs from it, and a process that also runs PyTorch must not end
 //              up with two RCCL copies bound at link time).  Communicators, exchange buffers and streams are made once per device list
 //              and kept for the life of the process, like the contexts.
 //   host:      the file's BGZF members are found ONCE (scan_members_parallel) and every shard uploads only the header's members and its
-//              own byte range (api.cpp prepare_events): N shards move the file over PCIe once, not N times.
+//              own byte range (api_front.cpp stage_upload): N shards move the file over PCIe once, not N times.
 //   merge:     on the first device, rgx_table_merge_device: radix sort by key, sum / min / max, first-seen naming by (shard, rank),
 //              strand of the last shard that saw the key, output order.  Shard order = file order, so the table is the single-GPU table.
 // The same device may be listed more than once (the shards then run one after the other on it and the exchange is a device copy): that
@@ -34,16 +34,16 @@
 
 #include "host_io.h"
 
-// api.cpp (not part of the C ABI): the rows of a context's last extraction packed on ITS stream, an event behind the kernel; peer access per pair
+// api_entry.cpp (not part of the C ABI): the rows of a context's last extraction packed on ITS stream, an event behind the kernel; peer access per pair
 int rgx_last_table_pack_async(rgx_ctx *c, const rgx_junction_table *t, void **d_packed, hipEvent_t *done, char *err, size_t errlen);
 bool rgx_enable_peer(int a, int b);
-// api.cpp: rgx_extract_mem with the member list the caller scanned (not part of the C ABI)
+// api_entry.cpp: rgx_extract_mem with the member list the caller scanned (not part of the C ABI)
 int rgx_extract_mem_scanned(rgx_ctx *ctx, const void *bam, size_t bam_len, const void *bai, size_t bai_len, const rgx_extract_params *p,
                             const std::vector<rgx::Member> *members, uint64_t total_inflated, rgx_junction_table **out, char *err, size_t errlen);
 
 using namespace rgx;
 
-void rgx_ctx_no_arena_trials(rgx_ctx *c);            // api.cpp: no arena placement trials for this context
+void rgx_ctx_no_arena_trials(rgx_ctx *c);            // api_ctx.cpp: no arena placement trials for this context
 
 namespace {
 
@@ -114,8 +114,9 @@ rgx_ctx *context_for(int device, int nth, char *err, size_t errlen, int &rc) {
 }
 
 }  // namespace
-// (for rgx_identify_multi, cse_api.inc: the same cache)
-rgx_ctx *rgx_multi_context(int device, int nth, char *err, size_t errlen, int *rc) { int r = RGX_OK; rgx_ctx *c = context_for(device, nth, err, errlen, r); if (rc) *rc = r; return c; }
+// (for rgx_identify_multi, cse_api.cpp: the same cache)
+rgx_ctx *rgx_multi_context(int device, int nth, char *err, size_t errlen, int *rc) { int r = RGX_OK; rgx_ctx *c = context_for(device, nth, err, errlen, r);
+    if (rc) *rc = r; return c; }
 namespace {
 
 // What the exchange needs besides the contexts, per device LIST: RCCL communicators (ncclCommInitAll on an 8-GPU node takes hundreds of
@@ -151,7 +152,8 @@ int exchange_for(const int *devices, int n, bool distinct, size_t block, const s
             else {
                 x.comms.assign((size_t)n, nullptr);
                 const int r = g_rccl.CommInitAll(x.comms.data(), n, devices);
-                if (r != 0) { x.comms.clear(); x.rccl_error = std::string("ncclCommInitAll failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); }
+                if (r != 0) { x.comms.clear(); x.rccl_error = std::string("ncclCommInitAll failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) :
+                    "?"); }
             }
             while (!x.rccl_error.empty() && (x.rccl_error.back() == '\n' || x.rccl_error.back() == ' ')) x.rccl_error.pop_back();
         }
@@ -161,7 +163,8 @@ int exchange_for(const int *devices, int n, bool distinct, size_t block, const s
         if (hipSetDevice(devices[g]) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: device %d\n", devices[g]);
         if (x.d_send[(size_t)g]) (void)hipFree(x.d_send[(size_t)g]);
         x.d_send[(size_t)g] = nullptr; x.send_cap[(size_t)g] = 0;
-        if (hipMalloc(&x.d_send[(size_t)g], block + block / 4 + 4096) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no memory for the row exchange on device %d\n", devices[g]);
+        if (hipMalloc(&x.d_send[(size_t)g], block + block / 4 + 4096) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE,
+            "regtools_amd: no memory for the row exchange on device %d\n", devices[g]);
         x.send_cap[(size_t)g] = block + block / 4 + 4096;
     }
     if (x.recv_cap < block * (size_t)n) {
@@ -169,7 +172,8 @@ int exchange_for(const int *devices, int n, bool distinct, size_t block, const s
         if (x.d_recv) (void)hipFree(x.d_recv);
         x.d_recv = nullptr; x.recv_cap = 0;
         const size_t want = (block + block / 4 + 4096) * (size_t)n;
-        if (hipMalloc(&x.d_recv, want) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no memory for the row exchange on device %d\n", devices[0]);
+        if (hipMalloc(&x.d_recv, want) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE,
+            "regtools_amd: no memory for the row exchange on device %d\n", devices[0]);
         x.recv_cap = want;
     }
     out = &x;
@@ -202,7 +206,8 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
     //    discovery on the whole file, as a single-GPU call would) -----------------------------------------------------------------------
     const double t_begin = now_ms();
     std::vector<Member> members; uint64_t total_inflated = 0;
-    if (n > 1 && bam_len >= ((size_t)8 << 20) && !scan_members_parallel((const uint8_t *)bam, bam_len, (int)usable_threads(24), members, total_inflated)) members.clear();
+    if (n > 1 && bam_len >= ((size_t)8 << 20) && !scan_members_parallel((const uint8_t *)bam, bam_len, (int)usable_threads(24), members,
+        total_inflated)) members.clear();
     const double t_scan = now_ms();
     // -- one extraction per shard: a thread per device (shards that share a device take turns on it) -------------------------------------
     auto extract = [&](int g) {
@@ -243,19 +248,23 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
         bool ok = r == 0 && hipSetDevice(devices[0]) == hipSuccess && hipMalloc(&d_a, blk) == hipSuccess && hipMalloc(&d_b, blk) == hipSuccess &&
                   hipStreamCreateWithFlags(&st1, hipStreamNonBlocking) == hipSuccess;
         if (ok && S[0].table->n) ok = rgx_last_table_pack_device(S[0].ctx, S[0].table, d_a, S[0].table->n, err, errlen) == RGX_OK;
-        if (ok) { r = g_rccl.GroupStart(); if (r == 0) r = g_rccl.AllGather(d_a, d_b, blk, kNcclUint8, comm, st1); const int r2 = g_rccl.GroupEnd(); ok = r == 0 && r2 == 0 && hipStreamSynchronize(st1) == hipSuccess; }
+        if (ok) { r = g_rccl.GroupStart(); if (r == 0) r = g_rccl.AllGather(d_a, d_b, blk, kNcclUint8, comm, st1); const int r2 = g_rccl.GroupEnd();
+            ok = r == 0 && r2 == 0 && hipStreamSynchronize(st1) == hipSuccess; }
         rgx_junction_table *m1 = nullptr;
         uint64_t rows1 = S[0].table->n;
-        int rc1 = ok ? rgx_table_merge_device(S[0].ctx, d_b, std::max<uint64_t>(1, rows1), &rows1, 1, p->min_anchor, S[0].table, &m1, err, errlen) : RGX_ERR_DEVICE;
+        int rc1 = ok ? rgx_table_merge_device(S[0].ctx, d_b, std::max<uint64_t>(1, rows1), &rows1, 1, p->min_anchor, S[0].table, &m1, err, errlen) :
+            RGX_ERR_DEVICE;
         if (comm) g_rccl.CommDestroy(comm);
         if (d_a) (void)hipFree(d_a);
         if (d_b) (void)hipFree(d_b);
         if (st1) (void)hipStreamDestroy(st1);
         if (rc1 != RGX_OK) return ok ? rc1 : failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: RCCL self test failed\n");
         const rgx_junction_table *t = S[0].table;
-        m1->n_records = t->n_records; m1->n_events = t->n_events; m1->inflated_bytes = t->inflated_bytes; m1->n_members = t->n_members; m1->compressed_bytes = bam_len;
+        m1->n_records = t->n_records; m1->n_events = t->n_events; m1->inflated_bytes = t->inflated_bytes; m1->n_members = t->n_members;
+            m1->compressed_bytes = bam_len;
         m1->stream_ended = t->stream_ended; m1->framing_sweeps = t->framing_sweeps;
-        if (p->barcodes) { const rgx_junction_table *parts1[1] = {t}; rc1 = rgx_table_merge_barcodes(parts1, 1, m1, err, errlen); if (rc1 != RGX_OK) { rgx_table_free(m1); return rc1; } }
+        if (p->barcodes) { const rgx_junction_table *parts1[1] = {t}; rc1 = rgx_table_merge_barcodes(parts1, 1, m1, err, errlen);
+            if (rc1 != RGX_OK) { rgx_table_free(m1); return rc1; } }
         *out = m1;
         return RGX_OK;
     }
@@ -280,12 +289,14 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
         if (hipSetDevice(s.device) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: device %d\n", s.device);
         if (s.d_packed) {
             // the exchange stream of this shard waits for the pack ON THE DEVICE
-            if (hipStreamWaitEvent(X->streams[(size_t)g], s.ev_packed, 0) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no wait on the rows of device %d\n", s.device);
+            if (hipStreamWaitEvent(X->streams[(size_t)g], s.ev_packed, 0) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE,
+                "regtools_amd: no wait on the rows of device %d\n", s.device);
             src[(size_t)g] = s.d_packed;
         } else {
             std::vector<uint8_t> h((size_t)s.table->n * RGX_PACKED_ROW_BYTES);
             rgx_table_pack(s.table, h.data(), h.size());
-            if (hipMemcpy(X->d_send[(size_t)g], h.data(), h.size(), hipMemcpyHostToDevice) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: row upload failed\n");
+            if (hipMemcpy(X->d_send[(size_t)g], h.data(), h.size(), hipMemcpyHostToDevice) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE,
+                "regtools_amd: row upload failed\n");
             src[(size_t)g] = X->d_send[(size_t)g];
         }
     }
@@ -306,14 +317,16 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
             r = g_rccl.Send(src[(size_t)g], bytes_of(g), kNcclUint8, 0, X->comms[(size_t)g], X->streams[(size_t)g]);
         }
         if (r == 0 && hipSetDevice(devices[0]) != hipSuccess) r = -1;
-        for (int g = 1; g < n && r == 0; ++g) if (bytes_of(g)) r = g_rccl.Recv((uint8_t *)X->d_recv + (size_t)g * block, bytes_of(g), kNcclUint8, g, X->comms[0], X->streams[0]);
+        for (int g = 1; g < n && r == 0; ++g) if (bytes_of(g)) r = g_rccl.Recv((uint8_t *)X->d_recv + (size_t)g * block, bytes_of(g), kNcclUint8, g,
+            X->comms[0], X->streams[0]);
         const int r2 = g_rccl.GroupEnd();
         by_rccl = r == 0 && r2 == 0;
         if (by_rccl) {
             for (int g = 0; g < n && by_rccl; ++g)
                 if (hipSetDevice(devices[g]) != hipSuccess || hipStreamSynchronize(X->streams[(size_t)g]) != hipSuccess) by_rccl = false;
             if (!by_rccl) rccl_note = "the grouped ncclSend / ncclRecv did not complete";
-        } else rccl_note = std::string("the grouped ncclSend / ncclRecv failed: ") + (r < 0 ? "device selection" : g_rccl.GetErrorString ? g_rccl.GetErrorString(r > 0 ? r : r2) : "?");
+        } else rccl_note = std::string("the grouped ncclSend / ncclRecv failed: ") + (r < 0 ? "device selection" : g_rccl.GetErrorString ?
+            g_rccl.GetErrorString(r > 0 ? r : r2) : "?");
         (void)hipGetLastError();
     }
     if (hipSetDevice(devices[0]) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: device %d\n", devices[0]);
@@ -322,9 +335,12 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
     for (int g = 0; g < n; ++g) {
         if (!bytes_of(g) || (by_rccl && g > 0)) continue;
         const Shard &s = S[(size_t)g];
-        if (s.d_packed && hipStreamWaitEvent(X->streams[0], s.ev_packed, 0) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: no wait on the rows of device %d\n", s.device);
-        const hipError_t e = s.device == devices[0] ? hipMemcpyAsync((uint8_t *)X->d_recv + (size_t)g * block, src[(size_t)g], bytes_of(g), hipMemcpyDeviceToDevice, X->streams[0])
-                                                    : hipMemcpyPeerAsync((uint8_t *)X->d_recv + (size_t)g * block, devices[0], src[(size_t)g], s.device, bytes_of(g), X->streams[0]);
+        if (s.d_packed && hipStreamWaitEvent(X->streams[0], s.ev_packed, 0) != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE,
+            "regtools_amd: no wait on the rows of device %d\n", s.device);
+        const hipError_t e = s.device == devices[0] ? hipMemcpyAsync((uint8_t *)X->d_recv + (size_t)g * block, src[(size_t)g], bytes_of(g),
+            hipMemcpyDeviceToDevice, X->streams[0])
+                                                    : hipMemcpyPeerAsync((uint8_t *)X->d_recv + (size_t)g * block, devices[0], src[(size_t)g], s.device,
+                                                        bytes_of(g), X->streams[0]);
         if (e != hipSuccess) return failm(err, errlen, RGX_ERR_DEVICE, "regtools_amd: row copy from device %d failed: %s\n", s.device, hipGetErrorString(e));
     }
     // (the merge runs on the context's own stream: the rows must be there before it is enqueued)
@@ -332,13 +348,15 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
     {
         bool all_peer = true; for (int g = 1; g < n; ++g) if (!X->peer[(size_t)g]) all_peer = false;
         if (!distinct) snprintf(g_exchange_kind, sizeof g_exchange_kind, "device copies (a device is listed more than once)");
-        else if (by_rccl) snprintf(g_exchange_kind, sizeof g_exchange_kind, "rccl grouped send/recv, %d ranks%s", n, all_peer ? ", peer access on" : ", peer access NOT available");
-        else snprintf(g_exchange_kind, sizeof g_exchange_kind, "hipMemcpyPeerAsync%s (RCCL not used: %.90s)", all_peer ? " over peer access" : " WITHOUT peer access", rccl_note.c_str());
+        else if (by_rccl) snprintf(g_exchange_kind, sizeof g_exchange_kind, "rccl grouped send/recv, %d ranks%s", n, all_peer ? ", peer access on" :
+            ", peer access NOT available");
+        else snprintf(g_exchange_kind, sizeof g_exchange_kind, "hipMemcpyPeerAsync%s (RCCL not used: %.90s)", all_peer ? " over peer access" :
+            " WITHOUT peer access", rccl_note.c_str());
     }
     const double t_exchange = now_ms();
 
     // -- merge on the first device.  A shard whose record stream ENDED (a member that does not inflate, an unreadable record) hides the
-    //    shards behind it: a sequential reader never gets there (api.cpp, rgx_table_merge) ---------------------------------------------------
+    //    shards behind it: a sequential reader never gets there (api_entry.cpp, rgx_table_merge) ---------------------------------------------------
     std::vector<uint64_t> merge_rows = part_rows;
     for (int g = 0; g < n; ++g) if (S[(size_t)g].table->stream_ended) { for (int k = g + 1; k < n; ++k) merge_rows[(size_t)k] = 0; break; }
     rgx_junction_table *m = nullptr;
@@ -360,7 +378,7 @@ extern "C" int rgx_extract_multi_mem(const int *devices, int n_devices, const vo
         if (t->stream_ended) { m->stream_ended = 1; break; }
     }
     m->compressed_bytes = bam_len;
-    if (p->barcodes) {          // -b: the shards' per-junction barcode lists, one after the other in file order (api.cpp rgx_table_merge_barcodes)
+    if (p->barcodes) {          // -b: the shards' per-junction barcode lists, one after the other in file order (api_entry.cpp rgx_table_merge_barcodes)
         std::vector<const rgx_junction_table *> parts((size_t)n);
         for (int g = 0; g < n; ++g) parts[(size_t)g] = S[(size_t)g].table;
         rc = rgx_table_merge_barcodes(parts.data(), n, m, err, errlen);
@@ -379,6 +397,7 @@ extern "C" int rgx_extract_multi(const int *devices, int n_devices, const char *
     FileBytes bam; std::vector<uint8_t> bai;
     if (!bam.open(bam_path)) return failm(err, errlen, RGX_ERR_OPEN, "Unable to open BAM/SAM file.\n\n");
     std::string idx;
-    if (find_index(bam_path, idx) != 0 || !read_index(idx, bai)) return failm(err, errlen, RGX_ERR_INDEX, "Unable to open BAM/SAM index. Make sure alignments are indexed\n\n");
+    if (find_index(bam_path, idx) != 0 || !read_index(idx, bai)) return failm(err, errlen, RGX_ERR_INDEX,
+        "Unable to open BAM/SAM index. Make sure alignments are indexed\n\n");
     return rgx_extract_multi_mem(devices, n_devices, bam.data(), bam.size(), bai.data(), bai.size(), p, out, err, errlen);
 }

@@ -20,7 +20,7 @@
 
 #include "../../include/regtools_amd.h"
 
-// api.cpp: the contexts of a pipeline take the host link in turns (a call's upload starts when the call before it has its file on the device)
+// api_ctx.cpp: the contexts of a pipeline take the host link in turns (a call's upload starts when the call before it has its file on the device)
 void *rgx_link_turn_create();
 void rgx_link_turn_destroy(void *l);
 void rgx_ctx_set_link(rgx_ctx *c, void *l);
@@ -70,7 +70,8 @@ static void lane_loop(rgx_pipeline *pl, size_t k) {
         const auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double t_in = now();
         const int rc = rgx_extract_mem(ln.ctx, j->bam, j->bam_len, j->bai, j->bai_len, &j->params, &j->table, err, sizeof err);
-        if (trace) fprintf(stderr, "[rgx trace] pipeline: ticket %llu on context %zu from %.3f to %.3f ms (%.3f)\n", (unsigned long long)j->ticket, k, fmod(t_in, 1e5), fmod(now(), 1e5), now() - t_in);
+        if (trace) fprintf(stderr, "[rgx trace] pipeline: ticket %llu on context %zu from %.3f to %.3f ms (%.3f)\n", (unsigned long long)j->ticket, k,
+            fmod(t_in, 1e5), fmod(now(), 1e5), now() - t_in);
         {
             std::lock_guard<std::mutex> lock(pl->mu);
             j->rc = rc; j->err = err; j->done = true;
@@ -80,14 +81,17 @@ static void lane_loop(rgx_pipeline *pl, size_t k) {
 }
 
 extern "C" int rgx_pipeline_create(int device, int depth, rgx_pipeline **out, char *err, size_t errlen) {
-    if (!out || depth < 1 || depth > 8) { if (err && errlen) snprintf(err, errlen, "regtools_amd: a pipeline holds 1 to 8 files in flight\n"); return RGX_ERR_ARG; }
+    if (!out || depth < 1 || depth > 8) { if (err && errlen) snprintf(err, errlen, "regtools_amd: a pipeline holds 1 to 8 files in flight\n");
+        return RGX_ERR_ARG; }
     // Every context has four streams, and the runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment says otherwise,
-    // read when HIP starts).  Two contexts share queues pairwise and work; with three and more, a file's arrival-gated waves and the one-lane kernels that release
+    // read when HIP starts).  Two contexts share queues pairwise and work; with three and more, a file's arrival-gated waves and the one-lane kernels that
+    // release
     // them end up behind one another in ONE hardware queue and every such wave waits out its 2 s time-out (measured: 130-240 ms per file instead of 21).
     if (depth > 2) {
         const char *q = getenv("GPU_MAX_HW_QUEUES");
         if (!q || atoi(q) < 8) {
-            if (err && errlen) snprintf(err, errlen, "regtools_amd: more than two files in flight need GPU_MAX_HW_QUEUES=8 or more in the environment before HIP starts\n");
+            if (err && errlen) snprintf(err, errlen,
+                "regtools_amd: more than two files in flight need GPU_MAX_HW_QUEUES=8 or more in the environment before HIP starts\n");
             return RGX_ERR_ARG;
         }
     }
@@ -113,7 +117,8 @@ extern "C" rgx_ctx *rgx_pipeline_ctx(const rgx_pipeline *pl, uint64_t ticket) {
 
 extern "C" int rgx_extract_submit(rgx_pipeline *pl, const void *bam, size_t bam_len, const void *bai, size_t bai_len, const rgx_extract_params *p,
                                   uint64_t *ticket, char *err, size_t errlen) {
-    if (!pl || !p || !ticket) { if (err && errlen) snprintf(err, errlen, "regtools_amd: rgx_extract_submit needs a pipeline, parameters and a ticket\n"); return RGX_ERR_ARG; }
+    if (!pl || !p || !ticket) { if (err && errlen) snprintf(err, errlen, "regtools_amd: rgx_extract_submit needs a pipeline, parameters and a ticket\n");
+        return RGX_ERR_ARG; }
     std::shared_ptr<Job> j(new Job);
     j->bam = bam; j->bam_len = bam_len; j->bai = bai; j->bai_len = bai_len; j->params = *p;
     if (p->region) { j->region = p->region; j->params.region = j->region.c_str(); }
@@ -122,7 +127,8 @@ extern "C" int rgx_extract_submit(rgx_pipeline *pl, const void *bam, size_t bam_
         std::lock_guard<std::mutex> lock(pl->mu);
         if (pl->stopping) return RGX_ERR_ARG;
         j->ticket = pl->next_ticket++;
-        pl->lanes[(size_t)((j->ticket - 1) % pl->lanes.size())].q.push_back(j);      // file k -> context k mod depth: which context a file meets does not depend on timing
+        // file k -> context k mod depth: which context a file meets does not depend on timing
+        pl->lanes[(size_t)((j->ticket - 1) % pl->lanes.size())].q.push_back(j);
         pl->open.push_back(j);
         *ticket = j->ticket;
     }
@@ -137,7 +143,8 @@ extern "C" int rgx_extract_wait(rgx_pipeline *pl, uint64_t ticket, rgx_junction_
     {
         std::unique_lock<std::mutex> lock(pl->mu);
         for (auto &o : pl->open) if (o->ticket == ticket && !o->claimed) { j = o; break; }
-        if (!j) { if (err && errlen) snprintf(err, errlen, "regtools_amd: no file in flight under ticket %llu\n", (unsigned long long)ticket); return RGX_ERR_ARG; }
+        if (!j) { if (err && errlen) snprintf(err, errlen, "regtools_amd: no file in flight under ticket %llu\n", (unsigned long long)ticket);
+            return RGX_ERR_ARG; }
         j->claimed = true;
         pl->finished.wait(lock, [&] { return j->done; });
         for (auto it = pl->open.begin(); it != pl->open.end(); ++it) if (it->get() == j.get()) { pl->open.erase(it); break; }
@@ -151,7 +158,8 @@ extern "C" void rgx_pipeline_destroy(rgx_pipeline *pl) {
     if (!pl) return;
     { std::lock_guard<std::mutex> lock(pl->mu); pl->stopping = true; }
     pl->work.notify_all();
-    for (Lane &ln : pl->lanes) if (ln.th.joinable()) ln.th.join();      // (files still queued are run to their end: their buffers were promised to the pipeline)
+    // (files still queued are run to their end: their buffers were promised to the pipeline)
+    for (Lane &ln : pl->lanes) if (ln.th.joinable()) ln.th.join();
     for (auto &j : pl->open) if (j->table) rgx_table_free(j->table);     // results nobody waited for
     for (Lane &ln : pl->lanes) rgx_ctx_destroy(ln.ctx);
     if (pl->link) rgx_link_turn_destroy(pl->link);

@@ -152,7 +152,7 @@ def test_annotated_vcf_equals_the_reference(gpu_ctx, vcf_inputs, name):
 
 
 def test_a_genome_rewritten_between_two_calls_is_read_again(gpu_ctx, work):
-    """The context keeps the last FASTA mapped from call to call (api.cpp host_fasta): a file that changed under the same name is a new file."""
+    """The context keeps the last FASTA mapped from call to call (api_ctx.cpp host_fasta): a file that changed under the same name is a new file."""
     import regtools_amd
     src = ac.read(os.path.join(ac.CSE_REF, "test_chr22.fa")).decode()
     fa = os.path.join(str(work), "again.fa")

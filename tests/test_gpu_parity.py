@@ -623,7 +623,7 @@ def test_long_record_decode_lane_form_equals_the_wave_form(gpu_ctx, synth_dir):
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "regtools-amd")
     for args in (["-s", "XS"], ["-s", "RF", "-m", "200", "-M", "20000"], ["-s", "XS", "-r", "chr2:1000000-90000000"], ["-s", "FR", "-r", "chr1"]):
         outs = []
-        for form, seg in (("lane", "16384"), ("wave", "16384"), ("lane", "131072")):      # (the last: the segment size files of long records get, api.cpp seg_bytes)
+        for form, seg in (("lane", "16384"), ("wave", "16384"), ("lane", "131072")):      # (the last: the segment size files of long records get, api_records.cpp seg_bytes)
             o = p + "." + form + seg + ".bed"
             r = subprocess.run([exe, "junctions", "extract"] + args + ["-o", o, p], env=dict(os.environ, REGTOOLS_AMD_DECODE=form + "," + seg),
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE)

@@ -31,7 +31,7 @@ def gpu_extract(ctx, bam, args):
 
 
 def gpu_extract_sharded(ctx, bam, args, n_shards):
-    """The same query with the iterator's chunk list dealt to n_shards shards (api.cpp: runs of the list, in order) and the shard tables merged:
+    """The same query with the iterator's chunk list dealt to n_shards shards (api_front.cpp: runs of the list, in order) and the shard tables merged:
     what several ranks / devices would do with a region query.  (0, bed12) or (1, b"")."""
     import regtools_amd
     from regtools_amd import distributed
