@@ -17,3 +17,18 @@ for argv, rc in t.CASES[t.TOP_LEVEL:]:
 os.makedirs(os.path.join(HERE, "cli"), exist_ok=True)
 json.dump(out, open(os.path.join(HERE, "cli", "cli_streams.json"), "w"), indent=1, sort_keys=True)
 print("%d argument lists recorded" % len(out))
+
+# round 6: a GTF with an empty line -- the reference dies of an uncaught std::out_of_range (SIGABRT, libstdc++'s terminate message on stderr)
+import subprocess, tempfile
+ab = {}
+with tempfile.TemporaryDirectory() as td:
+    g = open(t.GTF).read().splitlines()
+    bad = os.path.join(td, "empty_line.gtf")
+    open(bad, "w").write("\n".join(g[:20] + [""] + g[20:]) + "\n")
+    for argv in t.abort_cases(bad):
+        r = subprocess.run([t.REF] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        fix = lambda b: b.replace(t.ROOT.encode(), b"@ROOT@").replace(td.encode(), b"@TMP@")
+        ab[t.case_id(argv)] = {"rc": r.returncode, "stdout": fix(r.stdout).decode("latin-1"), "stderr": fix(r.stderr).decode("latin-1")}
+        assert r.returncode in (-6, 1), (argv, r.returncode)
+json.dump(ab, open(os.path.join(HERE, "cli", "cli_abort_streams.json"), "w"), indent=1, sort_keys=True)
+print("%d aborting argument lists recorded" % len(ab))

@@ -54,6 +54,12 @@ CASES = [
 TOP_LEVEL = 0                # (round 5: the first three lists ended in a stand-in's usage text and were compared by exit code only)
 
 
+def abort_cases(bad_gtf):
+    """argument lists that end in GtfParser::load meeting an empty line (gtf_parser.cc:230: line.at(0), uncaught -> SIGABRT)"""
+    return [["junctions", "annotate", BED, FA, bad_gtf], ["variants", "annotate", VCF, bad_gtf],
+            ["cis-splice-effects", "identify", "-s", "XS", VCF, BAM, FA, bad_gtf], ["cis-splice-effects", "associate", VCF, BED, FA, bad_gtf]]
+
+
 def case_id(argv):
     return " ".join(os.path.basename(a) for a in argv) or "(none)"
 
@@ -88,3 +94,22 @@ def test_stdout_and_stderr_bytes_match_the_reference(built, k, suite):
     assert rc == ref_rc
     assert out == want_out
     assert err == want_err
+
+
+@pytest.mark.gpu
+def test_empty_gtf_line_ends_the_process_as_upstream(built, tmp_path):
+    """An empty line in a GTF: upstream's loader calls line.at(0) outside any try block; `junctions annotate` and `variants annotate` die of SIGABRT behind
+    libstdc++'s terminate message (status 134 in a shell), the two `cis-splice-effects` commands catch std::exception and print its what() (status 1).
+    The tool does the same call when the library reports such a line: same status, same streams.
+    (The context is made before the annotation is read, hence the gpu marker.)"""
+    gold = json.load(open(os.path.join(GOLD, "cli", "cli_abort_streams.json")))
+    g = open(GTF).read().splitlines()
+    bad = os.path.join(str(tmp_path), "empty_line.gtf")
+    open(bad, "w").write("\n".join(g[:20] + [""] + g[20:]) + "\n")
+    for argv in abort_cases(bad):
+        want = gold[case_id(argv)]
+        r = subprocess.run([EXE] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        fix = lambda b: b.replace(ROOT.encode(), b"@ROOT@").replace(str(tmp_path).encode(), b"@TMP@")
+        assert r.returncode == want["rc"] and want["rc"] in (-6, 1), (argv, r.returncode, r.stderr[-300:])
+        assert fix(r.stdout) == want["stdout"].encode("latin-1"), argv
+        assert fix(r.stderr) == want["stderr"].encode("latin-1"), argv
