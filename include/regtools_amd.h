@@ -254,6 +254,9 @@ typedef struct {
     uint32_t    max_intron;    /* -M */
     int32_t     override_motif;/* -C */
     const char *bed_path;      /* rgx_associate only: junctions BED12 (second positional of `cis-splice-effects associate`) */
+    int32_t     echo;          /* 1: write to stderr what upstream writes while it works -- "exonic_min_distance_ is 3" (variants_annotator.h:151), and per
+                                * splice-relevant variant "Variant <chrom> <start> <end> <score>" + "Variant region is <region>" (identifier.cc:265-277,
+                                * associator.cc:243-257); the tool sets it, a library caller normally does not [0] */
 } rgx_identify_params;
 
 typedef struct {
@@ -289,11 +292,14 @@ int  rgx_variants_annotate(rgx_ctx *ctx, const rgx_identify_params *p, rgx_ident
  * a malformed line ends the run with the reference's message after the rows before it were written. */
 int  rgx_junctions_annotate(rgx_ctx *ctx, const char *bed_path, const char *fasta_path, const char *gtf_path, const char *out_path,
                             uint64_t *n_rows, char *err, size_t errlen);
-/* The same with -S (junctions_annotator.cc:392-393, consumed at :131 / :231): include_single_exon != 0 lets single-exon transcripts take part
- * in the scan (they can make a junction's donor or acceptor known, never skip anything).  The reference's one unchecked read on this path
- * (exons[i + 1] behind a transcript's last exon, with or without -S) is "no match" here, as in the default mode. */
+/* The same with options.  Bit 0 = -S (junctions_annotator.cc:392-393, consumed at :131 / :231): single-exon transcripts take part in the scan (they
+ * can make a junction's donor or acceptor known, never skip anything); the reference's one unchecked read on this path (exons[i + 1] behind a
+ * transcript's last exon, with or without -S) is "no match" here, as in the default mode.  Bit 1 = echo: "position = <region>" on stderr for each of
+ * a junction's two FASTA look-ups, as get_reference_sequence writes it (junctions_annotator.cc:366-370); the tool sets it. */
+#define RGX_ANNOTATE_SINGLE_EXON 1
+#define RGX_ANNOTATE_ECHO        2
 int  rgx_junctions_annotate_opts(rgx_ctx *ctx, const char *bed_path, const char *fasta_path, const char *gtf_path, const char *out_path,
-                                 int include_single_exon, uint64_t *n_rows, char *err, size_t errlen);
+                                 int options, uint64_t *n_rows, char *err, size_t errlen);
 
 /* Stage entry points over a loaded annotation (flat exon/transcript/bin arrays in HBM). */
 typedef struct rgx_gtf rgx_gtf;

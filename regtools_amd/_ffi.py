@@ -57,7 +57,7 @@ class IdentifyParams(C.Structure):
                 ("out_tsv", C.c_char_p), ("out_vcf", C.c_char_p), ("out_bed", C.c_char_p), ("window", C.c_uint32),
                 ("intronic_min", C.c_uint32), ("exonic_min", C.c_uint32), ("all_intronic", C.c_int32), ("all_exonic", C.c_int32),
                 ("skip_single", C.c_int32), ("strandness", C.c_int32), ("strand_tag", C.c_char * 2), ("min_anchor", C.c_uint32),
-                ("min_intron", C.c_uint32), ("max_intron", C.c_uint32), ("override_motif", C.c_int32), ("bed_path", C.c_char_p)]
+                ("min_intron", C.c_uint32), ("max_intron", C.c_uint32), ("override_motif", C.c_int32), ("bed_path", C.c_char_p), ("echo", C.c_int32)]
 
 
 class IdentifyStats(C.Structure):

@@ -205,7 +205,7 @@ int junctions_annotate(int argc, char **argv) {
         rgx_ctx *ctx = open_ctx();
         char err[512] = {0};
         uint64_t n = 0;
-        int rc = rgx_junctions_annotate_opts(ctx, bed.c_str(), ref.c_str(), gtf.c_str(), out == "NA" ? nullptr : out.c_str(), skip_single ? 0 : 1, &n, err, sizeof err);
+        int rc = rgx_junctions_annotate_opts(ctx, bed.c_str(), ref.c_str(), gtf.c_str(), out == "NA" ? nullptr : out.c_str(), (skip_single ? 0 : RGX_ANNOTATE_SINGLE_EXON) | RGX_ANNOTATE_ECHO, &n, err, sizeof err);
         rgx_ctx_destroy(ctx);
         if (rc != RGX_OK) { die_as_upstream_on_empty_gtf_line(err); throw std::runtime_error(err); }
         std::cerr << "\nAnnotated " << n << " lines.\n";
@@ -308,7 +308,14 @@ int cse_identify(int argc, char **argv, bool associate = false) {
         if (associate) p.strandness = 0;
         if (p.strandness == -1) { identify_usage(std::cerr); throw std::runtime_error("Please supply strand specificity with '-s' option!\n\n"); }
         if (!file_exists(vcf) || !file_exists(bam) || !file_exists(ref) || !file_exists(gtf)) throw std::runtime_error("Please make sure input files exist.\n\n");
-        std::cerr << "Variant file: " << vcf << (associate ? "\nJunctions BED file: " : "\nAlignment file: ") << bam << "\nReference fasta file: " << ref << "\nAnnotation file: " << gtf << "\n\n";
+        // the echo of parse_options (identifier.cc:203-218, associator.cc:156-171), then what identify() / associate() write while they work (p.echo)
+        std::cerr << "Variant file: " << vcf << (associate ? "\nJunctions BED file: " : "\nAlignment file: ") << bam << "\nReference fasta file: " << ref << "\nAnnotation file: " << gtf << "\n";
+        if (p.window != 0) std::cerr << "Window size: " << p.window << "\n";
+        if (out_tsv != "NA") std::cerr << "Output file: " << out_tsv << "\n";
+        if (out_bed != "NA") std::cerr << "Output junctions BED file: " << out_bed << "\n";
+        if (out_vcf != "NA") std::cerr << "Annotated variants file: " << out_vcf << "\n";
+        std::cerr << "\n";
+        p.echo = 1;
         if (associate) p.bed_path = bam.c_str();
         p.vcf_path = vcf.c_str(); p.bam_path = bam.c_str(); p.fasta_path = ref.c_str(); p.gtf_path = gtf.c_str();
         p.out_tsv = out_tsv == "NA" ? nullptr : out_tsv.c_str(); p.out_vcf = out_vcf == "NA" ? nullptr : out_vcf.c_str(); p.out_bed = out_bed == "NA" ? nullptr : out_bed.c_str();
@@ -387,10 +394,17 @@ int variants_annotate(int argc, char **argv) {
                 default: variants_usage(std::cout); throw std::runtime_error("Error parsing inputs!(1)\n\n");
             }
         }
-        if (argc - optind < 2) { variants_usage(std::cout); throw std::runtime_error("Error parsing inputs!(2)\n\n"); }
-        const std::string vcf = argv[optind], gtf = argv[optind + 1];
+        std::string vcf = "NA", gtf = "NA";
+        if (argc - optind >= 2) { vcf = argv[optind++]; gtf = argv[optind++]; }
+        if (optind < argc || vcf == "NA" || gtf == "NA") { variants_usage(std::cout); throw std::runtime_error("Error parsing inputs!(2)\n\n"); }
         p.vcf_path = vcf.c_str(); p.gtf_path = gtf.c_str(); p.out_vcf = out == "NA" ? nullptr : out.c_str();
-        std::cerr << "Variant file: " << vcf << "\nGTF file: " << gtf << "\n\n";
+        // variants_annotator.cc:93-108
+        std::cerr << "Variant file: " << vcf << "\nGTF file: " << gtf << "\nOutput vcf file: " << out << "\n";
+        if (!p.all_intronic) std::cerr << "Intronic min distance: " << p.intronic_min << "\n";
+        if (!p.all_exonic) std::cerr << "Exonic min distance: " << p.exonic_min << "\n";
+        if (!p.skip_single) std::cerr << "Not skipping single exon genes.\n";
+        if (out != "NA") std::cerr << "Output file: " << out << "\n";
+        std::cerr << "\n";
         rgx_ctx *ctx = open_ctx();
         char err[512] = {0};
         int rc = rgx_variants_annotate(ctx, &p, nullptr, err, sizeof err);

@@ -114,7 +114,7 @@ static void run_tasks(size_t T, const std::function<void(size_t)> &f) {
 }
 
 // ---- a10 ----------------------------------------------------------------------------------------------------------------
-struct VariantHitsHost { std::vector<uint32_t> ces, cee, off, tx, ann, dist; };
+struct VariantHitsHost { std::vector<uint32_t> ces, cee, off, tx, ann, dist, last; };      // last: upstream's variant.score behind the walk (0xffffffff = "-1")
 
 static int variant_windows(rgx_ctx *c, const rgx_gtf *g, const std::vector<int32_t> &chrom, const std::vector<uint32_t> &pos0, const VariantOpts &o,
                            VariantHitsHost &H, char *err, size_t errlen, uint64_t *exon_visits = nullptr) {
@@ -127,17 +127,17 @@ static int variant_windows(rgx_ctx *c, const rgx_gtf *g, const std::vector<int32
     DevBuf &b = c->buf("cse_variants"), &sc = c->buf("scalars");
     HIP_TRY(sc.ensure(512));
     const size_t N = n;
-    HIP_TRY(b.ensure(N * 4 * 6 + scan_tmp_words(n) * 4 + 256));
+    HIP_TRY(b.ensure(N * 4 * 7 + scan_tmp_words(n) * 4 + 256));
     uint32_t *w = b.as<uint32_t>();
     int32_t *d_chrom = (int32_t *)w; w += N; uint32_t *d_pos = w; w += N; uint32_t *d_cnt = w; w += N; uint32_t *d_base = w; w += N;
-    uint32_t *d_ces = w; w += N; uint32_t *d_cee = w; w += N; uint32_t *d_tmp = w;
+    uint32_t *d_ces = w; w += N; uint32_t *d_cee = w; w += N; uint32_t *d_last = w; w += N; uint32_t *d_tmp = w;
     uint32_t *d_total = sc.as<uint32_t>() + 60;
     HIP_TRY(hipMemcpyAsync(d_chrom, chrom.data(), N * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_pos, pos0.data(), N * 4, hipMemcpyHostToDevice, st));
     unsigned long long *d_visits = (unsigned long long *)(sc.as<uint32_t>() + 64), h_visits = 0;
     HIP_TRY(hipMemsetAsync(d_visits, 0, 8, st));
     ktime_begin(c, 0);
-    launch_variant_scan(false, g->view, n, d_chrom, d_pos, o, d_cnt, nullptr, d_ces, d_cee, nullptr, nullptr, d_visits, st);
+    launch_variant_scan(false, g->view, n, d_chrom, d_pos, o, d_cnt, nullptr, d_ces, d_cee, nullptr, nullptr, d_visits, st, d_last);
     ktime_end(c);
     launch_scan_u32(d_cnt, d_base, n, d_total, d_tmp, st);
     uint32_t total = 0;
@@ -145,7 +145,8 @@ static int variant_windows(rgx_ctx *c, const rgx_gtf *g, const std::vector<int32
     HIP_TRY(hipMemcpyAsync(&h_visits, d_visits, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (exon_visits) *exon_visits = h_visits;
-    H.ces.resize(N); H.cee.resize(N);
+    H.ces.resize(N); H.cee.resize(N); H.last.resize(N);
+    HIP_TRY(hipMemcpy(H.last.data(), d_last, N * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(H.ces.data(), d_ces, N * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(H.cee.data(), d_cee, N * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(H.off.data(), d_base, N * 4, hipMemcpyDeviceToHost));
@@ -511,6 +512,12 @@ static int splice_site(const Fasta &fa, const std::string &chrom, uint32_t js, u
     return RGX_OK;
 }
 
+// what get_reference_sequence writes to stderr for a junction's two look-ups (junctions_annotator.cc:366-370), the second only if the first one was read
+static void append_positions(std::string &o, const std::string &chrom, uint32_t js, uint32_t je, bool both = true) {
+    o += "position = "; o += chrom; o += ':'; o += std::to_string(js + 1); o += '-'; o += std::to_string(js + 2); o += '\n';
+    if (both) { o += "position = "; o += chrom; o += ':'; o += std::to_string(je - 2); o += '-'; o += std::to_string(je - 1); o += '\n'; }
+}
+
 // AnnotatedJunction::print (junctions_annotator.h:84-126) up to the transcripts column, row i of an annotate_junctions() result
 // (text is appended to strings with to_chars: 66 k rows through fprintf into memory streams were 8.5 ms on 16 threads, a std::set of string pairs per row
 // among them)
@@ -609,7 +616,7 @@ static void string_ranks(const std::vector<std::string> &names, std::vector<uint
 // a11 + outputs (annotate_junctions identifier.cc:222-246 / associator.cc:182-203)
 static int write_junction_outputs(rgx_ctx *c, const rgx_gtf *g, const char *fasta_path, const JMap &uj, const char *out_tsv, const char *out_bed,
     uint64_t *exon_visits,
-                                  double *ms_annotate, char *err, size_t errlen) {
+                                  double *ms_annotate, char *err, size_t errlen, bool echo = false) {
     const double t0 = now_ms();
     struct Teardown { double t = 0; const char *what; ~Teardown() { if (t > 0) fprintf(stderr, "[rgx trace] %s +%8.3f ms\n", what, now_ms() - t);
         } } teardown{0, "outputs: locals released"};
@@ -656,6 +663,18 @@ static int write_junction_outputs(rgx_ctx *c, const rgx_gtf *g, const char *fast
         for (size_t t = 0; t < T; ++t) if (bad[t] < first_bad) { first_bad = bad[t]; snprintf(bad_msg, sizeof bad_msg, "%s", msg[t].c_str()); }
     }
     lap("splice sites");
+    if (echo) {                                                    // (in output order; the junction whose look-up fails is the last one heard of)
+        std::string s;
+        const size_t upto = std::min(rows.size(), first_bad);
+        s.reserve(upto * 64);
+        for (size_t k = 0; k < upto; ++k) append_positions(s, uj.chrom_name[rows[k].crank], rows[k].js, rows[k].jend + 1);
+        if (first_bad != SIZE_MAX) {
+            const JTable::Row &r = rows[first_bad];
+            std::string tmp;
+            append_positions(s, uj.chrom_name[r.crank], r.js, r.jend + 1, fa.fetch(uj.chrom_name[r.crank], (int64_t)r.js + 1, (int64_t)r.js + 2, tmp));
+        }
+        fwrite(s.data(), 1, s.size(), stderr);
+    }
     FILE *fo = out_tsv ? fopen(out_tsv, "w") : stdout;
     if (!fo) return fail(err, errlen, RGX_ERR_OPEN, "Unable to open %s", out_tsv);
     FILE *fj = out_bed ? fopen(out_bed, "w") : nullptr;
@@ -892,6 +911,7 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
     struct PoolScope { WorkerPool *prev; PoolScope(WorkerPool *p) : prev(tl_pool) { tl_pool = p; } ~PoolScope() { tl_pool = prev; } } pool_scope{&stage_pool};
     t_gtf.join();
     if (!gtf_err.empty()) return fail(err, errlen, RGX_ERR_FORMAT, "%s", gtf_err.c_str());
+    if (p->echo) fputs("exonic_min_distance_ is 3\n", stderr);      // (the annotator's constructor prints the member before it assigns it: always the default, variants_annotator.h:141-152)
     int rc = gtf_upload(c, g, err, errlen, /*pooled=*/true);
     if (rc != RGX_OK) return rc;
     lap(S.ms_gtf);                                              // (what of the GTF was still to do when the extraction was done)
@@ -900,6 +920,7 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
     // a10: every variant against the annotation
     t_vcf.join();
     if (!vcf_err.empty()) return fail(err, errlen, RGX_ERR_OPEN, "%s", vcf_err.c_str());
+    if (p->echo) fputs("\n", stderr);                                // (identifier.cc:265, associator.cc:243)
     if (getenv("REGTOOLS_AMD_TRACE")) fprintf(stderr, "[rgx trace] inputs: gtf thread %8.3f ms, vcf thread %8.3f ms, extraction %8.3f ms (side by side)\n",
         gtf_thread_ms, vcf_thread_ms, S.ms_extract);
     VariantOpts vo{p->intronic_min, p->exonic_min, p->all_intronic, p->all_exonic, p->skip_single};
@@ -918,8 +939,26 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
         vcf_ms = now_ms() - t; });
     struct JoinOne { std::thread &t; ~JoinOne() { if (t.joinable()) t.join(); } } join_vcfout{t_vcfout};
 
+    // p->echo: what upstream writes to stderr for every splice-relevant variant, in file order, before it looks at the alignments of its window
+    // (identifier.cc:275-277, associator.cc:255-257): "Variant " + BED's operator<< (chrom, start, end, score, strand, each followed by a tab;
+    // bedFile.h:183-194; the score is what the annotation walk left there: H.last) and the window as the region string
+    auto echo_variants = [&](size_t upto) {
+        if (!p->echo) return;
+        std::string s;
+        s.reserve(std::min(upto, relevant.size()) * 72);
+        for (size_t w = 0; w < upto && w < relevant.size(); ++w) {
+            const size_t i = relevant[w];
+            const uint32_t start = vcf.recs[i].pos0, end = start + 1;
+            const uint32_t rs = p->window ? (uint32_t)(start - p->window) : H.ces[i], re = p->window ? (uint32_t)(end + p->window) : H.cee[i];
+            s += "Variant "; s += vcf.recs[i].chrom; s += '\t'; put_u(s, start); s += '\t'; put_u(s, end); s += '\t';
+            if (H.last[i] == 0xffffffffu) s += "-1"; else put_u(s, H.last[i]);
+            s += "\t\t\nVariant region is "; s += vcf.recs[i].chrom; s += ':'; put_u(s, rs); s += '-'; put_u(s, re); s += "\n\n";
+        }
+        fwrite(s.data(), 1, s.size(), stderr);
+    };
     JMap uj;
     if (p->bed_path) {
+        echo_variants(relevant.size());
         // ---- associate: junctions from a BED12 (associator.cc:206-276) ----
         BedJunctions B;
         { std::string e = B.load(p->bed_path); if (!e.empty()) return fail(err, errlen, RGX_ERR_FORMAT, "%s", e.c_str()); }
@@ -998,7 +1037,7 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
         S.n_junctions = uj.size();
         lap(S.ms_join);
     } else {
-        if (!relevant.empty() && rc_bam != RGX_OK) return fail(err, errlen, rc_bam, "%s", err_bam);
+        if (!relevant.empty() && rc_bam != RGX_OK) { echo_variants(1); return fail(err, errlen, rc_bam, "%s", err_bam); }      // (upstream opens the BAM for the first such variant)
         if (relevant.empty()) P = Prep();                       // (no variant asks for the BAM: upstream never opens it)
         S.n_records = P.n_iterated; S.n_events = P.n_events;
 
@@ -1028,8 +1067,9 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
                 }
             });
             // aborts the run
-            for (size_t t = 0; t < nt; ++t) if (bad[t] != SIZE_MAX) return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion);
+            for (size_t t = 0; t < nt; ++t) if (bad[t] != SIZE_MAX) { echo_variants(bad[t] + 1); return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion); }
         }
+        echo_variants(relevant.size());
         S.n_windows = w_tid.size();
         auto jlap = [&](const char *what) { if (jtrace) { const double t = now_ms(); fprintf(stderr, "[rgx trace] join: %-22s +%8.3f ms\n", what, t - jt);
             jt = t; } };
@@ -1075,7 +1115,7 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
     if (rc_vcf != RGX_OK) return fail(err, errlen, rc_vcf, "%s", err_vcf);
     if (getenv("REGTOOLS_AMD_TRACE")) fprintf(stderr, "[rgx trace] outputs: annotated VCF (side thread) %8.3f ms\n", vcf_ms);
     lap(S.ms_output);                                           // (what of the VCF was still being written when the join was done)
-    rc = write_junction_outputs(c, g, p->fasta_path, uj, p->out_tsv, p->out_bed, &S.exon_visits_junctions, &S.ms_annotate, err, errlen);
+    rc = write_junction_outputs(c, g, p->fasta_path, uj, p->out_tsv, p->out_bed, &S.exon_visits_junctions, &S.ms_annotate, err, errlen, p->echo != 0);
     if (rc != RGX_OK) return rc;
     { const double t = now_ms(); S.ms_output += t - tl - S.ms_annotate; tl = t; }
     ktime_collect(c); S.ms_k_variant_scan = c->kms[0]; S.ms_k_junction_scan = c->kms[1]; S.ms_k_window_pairs = c->kms[2];
@@ -1151,8 +1191,10 @@ extern "C" int rgx_junctions_annotate(rgx_ctx *c, const char *bed_path, const ch
 }
 // include_single_exon: -S (junctions_annotator.cc:392-393: skip_single_exon_genes_ = false)
 extern "C" int rgx_junctions_annotate_opts(rgx_ctx *c, const char *bed_path, const char *fasta_path, const char *gtf_path, const char *out_path,
-    int include_single_exon,
+    int options,
                                            uint64_t *n_rows, char *err, size_t errlen) {
+    const int include_single_exon = options & RGX_ANNOTATE_SINGLE_EXON;
+    const bool echo = (options & RGX_ANNOTATE_ECHO) != 0;
     if (!c || !bed_path || !fasta_path || !gtf_path) return fail(err, errlen, RGX_ERR_ARG, "Error parsing inputs!(2)\n\n");
     rgx_gtf *g = nullptr;
     int rc = rgx_gtf_load(c, gtf_path, &g, err, errlen);
@@ -1173,9 +1215,15 @@ extern "C" int rgx_junctions_annotate_opts(rgx_ctx *c, const char *bed_path, con
     size_t done = 0;
     for (size_t i = 0; i < n && rc == RGX_OK; ++i) {
         std::string site;
+        std::string said;
         if (!have_fa) { rc = fail(err, errlen, RGX_ERR_FASTA, "Unable to extract FASTA sequence for position %s:%u-%u\n\n", B.chrom[i].c_str(),
-            B.start[i] + 1, B.start[i] + 2); break; }
+            B.start[i] + 1, B.start[i] + 2); if (echo) { append_positions(said, B.chrom[i], B.start[i], B.end[i], false); fputs(said.c_str(), stderr); } break; }
         rc = splice_site(*fap, B.chrom[i], B.start[i], B.end[i], B.strand[i], site, err, errlen);
+        if (echo) {
+            std::string tmp;
+            append_positions(said, B.chrom[i], B.start[i], B.end[i], rc == RGX_OK || fap->fetch(B.chrom[i], (int64_t)B.start[i] + 1, (int64_t)B.start[i] + 2, tmp));
+            fputs(said.c_str(), stderr);
+        }
         if (rc != RGX_OK) break;
         print_junction_row(fo, g, A, i, B.chrom[i], B.start[i], B.end[i], B.name[i], B.score[i], B.strand[i], site);
         fputc('\n', fo);

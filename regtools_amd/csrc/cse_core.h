@@ -109,9 +109,14 @@ RGX_HD uint32_t variant_vs_transcript(char strand, const uint32_t *s, const uint
 
 // One variant against every candidate transcript, in the reference's visitation order (level fine->coarse, bin ascending,
 // transcript id ascending) -- variants_annotator.cc:455-518.  `hit(t, ann, dist)` is called per hit, in order.
+// last (optional): what upstream's `variant.score` holds when the walk is over -- the distance of the LAST transcript looked at if that one was a hit,
+// "-1" (0xffffffff here) if it was not (get_variant_overlaps_spliceregion_* reset the field on entry, :265 / :349); identify / associate print it
+// with every splice-relevant variant (cis_splice_effects_identifier.cc:275).
 template <class Hit>
-RGX_HD void variant_scan(const GtfView &g, int32_t chrom, uint32_t pos0, const VariantOpts &o, uint32_t &ces, uint32_t &cee, uint32_t &exon_visits, Hit &&hit) {
+RGX_HD void variant_scan(const GtfView &g, int32_t chrom, uint32_t pos0, const VariantOpts &o, uint32_t &ces, uint32_t &cee, uint32_t &exon_visits, Hit &&hit,
+                         uint32_t *last = nullptr) {
     ces = 0xffffffffu; cee = 0; exon_visits = 0;
+    if (last) *last = 0xffffffffu;
     if (chrom < 0) return;
     uint32_t sb = (uint32_t)(pos0 - o.intronic_min) >> 14, eb = (uint32_t)(pos0 + o.intronic_min) >> 14;
     for (int lvl = 0; lvl < 7; ++lvl) {
@@ -126,6 +131,7 @@ RGX_HD void variant_scan(const GtfView &g, int32_t chrom, uint32_t pos0, const V
                 uint32_t dist = 0;
                 const uint32_t ann = variant_vs_transcript((char)g.tx_strand[t], g.es + g.tx_exon_off[t], g.ee + g.tx_exon_off[t], n, pos0 + 1, o, dist, ces, cee);
                 if (ann != ANN_NONE) hit(t, ann, dist);
+                if (last) *last = ann != ANN_NONE ? dist : 0xffffffffu;
             }
         }
         sb >>= 3; eb >>= 3;

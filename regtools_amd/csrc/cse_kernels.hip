@@ -25,16 +25,16 @@ __device__ __forceinline__ void wave_add_visits(uint32_t v, unsigned long long *
 template <bool FILL>
 __global__ void k_variant_scan(GtfView g, uint32_t n, const int32_t *__restrict__ chrom, const uint32_t *__restrict__ pos0, VariantOpts o,
                                uint32_t *count, const uint32_t *__restrict__ base, uint32_t *ces, uint32_t *cee, uint32_t *hit_tx, uint32_t *hit_ad,
-                               unsigned long long *visits) {
+                               unsigned long long *visits, uint32_t *last_score) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t a, b, k = 0, ev = 0;
+    uint32_t a, b, k = 0, ev = 0, last = 0xffffffffu;
     if (i < n) {
         const uint32_t off = FILL ? base[i] : 0u;
         variant_scan(g, chrom[i], pos0[i], o, a, b, ev, [&](uint32_t t, uint32_t ann, uint32_t dist) {
             if (FILL) { hit_tx[off + k] = t; hit_ad[2 * (size_t)(off + k)] = ann; hit_ad[2 * (size_t)(off + k) + 1] = dist; }
             ++k;
-        });
-        if (!FILL) { count[i] = k; ces[i] = a; cee[i] = b; }
+        }, &last);
+        if (!FILL) { count[i] = k; ces[i] = a; cee[i] = b; if (last_score) last_score[i] = last; }
     }
     if (!FILL) wave_add_visits(ev, visits);
 }
@@ -288,10 +288,10 @@ __global__ void k_pair_gather(EventSoA ev, const uint32_t *__restrict__ pair_ev,
 }
 
 void launch_variant_scan(bool fill, GtfView g, uint32_t n, const int32_t *chrom, const uint32_t *pos0, VariantOpts o, uint32_t *count, const uint32_t *base,
-                         uint32_t *ces, uint32_t *cee, uint32_t *hit_tx, uint32_t *hit_ad, unsigned long long *visits, hipStream_t stream) {
+                         uint32_t *ces, uint32_t *cee, uint32_t *hit_tx, uint32_t *hit_ad, unsigned long long *visits, hipStream_t stream, uint32_t *last_score) {
     if (!n) return;
-    if (fill) hipLaunchKernelGGL(k_variant_scan<true>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, pos0, o, count, base, ces, cee, hit_tx, hit_ad, visits);
-    else hipLaunchKernelGGL(k_variant_scan<false>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, pos0, o, count, base, ces, cee, hit_tx, hit_ad, visits);
+    if (fill) hipLaunchKernelGGL(k_variant_scan<true>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, pos0, o, count, base, ces, cee, hit_tx, hit_ad, visits, last_score);
+    else hipLaunchKernelGGL(k_variant_scan<false>, dim3((n + 127) / 128), dim3(128), 0, stream, g, n, chrom, pos0, o, count, base, ces, cee, hit_tx, hit_ad, visits, last_score);
 }
 void launch_junction_scan(bool fill, GtfView g, uint32_t n, const int32_t *chrom, const uint32_t *js, const uint32_t *je, const uint8_t *strand, uint32_t *count,
                           const uint32_t *base, uint32_t *flags, uint32_t *item_kind, uint32_t *item_a, uint32_t *item_b, unsigned long long *visits, uint32_t *visit_each,

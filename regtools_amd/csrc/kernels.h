@@ -263,7 +263,7 @@ namespace rgx {
 // count pass (fill = false): count[i], ces[i], cee[i]; fill pass: hit_tx[base[i]+k], hit_ad[2*(base[i]+k)] = annotation, +1 = distance
 void launch_variant_scan(bool fill, GtfView g, uint32_t n, const int32_t *chrom, const uint32_t *pos0, VariantOpts o, uint32_t *count, const uint32_t *base,
                          uint32_t *ces, uint32_t *cee, uint32_t *hit_tx, uint32_t *hit_ad, unsigned long long *visits /* count pass: += exon records visited */,
-                         hipStream_t stream);
+                         hipStream_t stream, uint32_t *last_score = nullptr /* count pass: upstream's variant.score behind the walk (cse_core.h) */);
 // count pass: count[i], flags[i] = known_donor | known_acceptor<<1 | known_junction<<2; fill pass: items (kind,a,b) in visitation order
 void launch_junction_scan(bool fill, GtfView g, uint32_t n, const int32_t *chrom, const uint32_t *js, const uint32_t *je, const uint8_t *strand, uint32_t *count,
                           const uint32_t *base, uint32_t *flags, uint32_t *item_kind, uint32_t *item_a, uint32_t *item_b, unsigned long long *visits,

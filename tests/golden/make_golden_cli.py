@@ -32,3 +32,14 @@ with tempfile.TemporaryDirectory() as td:
         assert r.returncode in (-6, 1), (argv, r.returncode)
 json.dump(ab, open(os.path.join(HERE, "cli", "cli_abort_streams.json"), "w"), indent=1, sort_keys=True)
 print("%d aborting argument lists recorded" % len(ab))
+
+# round 6: runs that go all the way -- the whole of stderr
+va = {}
+with tempfile.TemporaryDirectory() as td:
+    for argv in t.valid_cases(td):
+        r = subprocess.run([t.REF] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        fix = lambda b: b.replace(t.ROOT.encode(), b"@ROOT@").replace(td.encode(), b"@TMP@")
+        assert r.returncode == 0, (argv, r.returncode, r.stderr[-300:])
+        va[t.case_id(argv)] = {"rc": 0, "stdout": fix(r.stdout).decode("latin-1"), "stderr": fix(r.stderr).decode("latin-1")}
+json.dump(va, open(os.path.join(HERE, "cli", "cli_valid_streams.json"), "w"), indent=1, sort_keys=True)
+print("%d complete runs recorded" % len(va))

@@ -60,6 +60,22 @@ def abort_cases(bad_gtf):
             ["cis-splice-effects", "identify", "-s", "XS", VCF, BAM, FA, bad_gtf], ["cis-splice-effects", "associate", VCF, BED, FA, bad_gtf]]
 
 
+def valid_cases(td):
+    """runs that go all the way: every byte the reference writes to stderr on the way (option echo, "exonic_min_distance_ is 3", a block per
+    splice-relevant variant, "Annotated n lines.") and the exit status; outputs go to files under td"""
+    o = lambda n: os.path.join(td, n)
+    return [["junctions", "extract", "-s", "XS", "-o", o("je.bed"), BAM],
+            ["junctions", "extract", "-s", "RF", "-a", "6", "-m", "50", "-M", "100000", "-r", "22:1-1000000", "-o", o("je2.bed"), BAM],
+            ["junctions", "annotate", "-o", o("ja.tsv"), BED, FA, GTF], ["junctions", "annotate", "-S", "-o", o("ja2.tsv"), BED, FA, GTF],
+            ["variants", "annotate", "-o", o("va.vcf"), VCF, GTF], ["variants", "annotate", "-E", "-I", "-S", "-o", o("va2.vcf"), VCF, GTF],
+            ["variants", "annotate", "-e", "5", "-i", "4", "-o", o("va3.vcf"), VCF, GTF],
+            ["cis-splice-effects", "identify", "-s", "XS", "-o", o("ci.tsv"), "-v", o("ci.vcf"), "-j", o("ci.bed"), VCF, BAM, FA, GTF],
+            ["cis-splice-effects", "identify", "-s", "RF", "-w", "100", "-o", o("ci2.tsv"), VCF, BAM, FA, GTF],
+            ["cis-splice-effects", "identify", "-s", "XS", "-E", "-I", "-o", o("ci3.tsv"), VCF, BAM, FA, GTF],
+            ["cis-splice-effects", "associate", "-o", o("ca.tsv"), "-v", o("ca.vcf"), "-j", o("ca.bed"), VCF, BED, FA, GTF],
+            ["cis-splice-effects", "associate", "-w", "500", "-o", o("ca2.tsv"), VCF, BED, FA, GTF]]
+
+
 def case_id(argv):
     return " ".join(os.path.basename(a) for a in argv) or "(none)"
 
@@ -113,3 +129,19 @@ def test_empty_gtf_line_ends_the_process_as_upstream(built, tmp_path):
         assert r.returncode == want["rc"] and want["rc"] in (-6, 1), (argv, r.returncode, r.stderr[-300:])
         assert fix(r.stdout) == want["stdout"].encode("latin-1"), argv
         assert fix(r.stderr) == want["stderr"].encode("latin-1"), argv
+
+
+@pytest.mark.gpu
+def test_stderr_of_runs_that_go_all_the_way(built, tmp_path):
+    """The reference talks on stderr while it works: the option echo, "exonic_min_distance_ is 3" from the annotator's constructor, for every
+    splice-relevant variant "Variant <BED fields>" and "Variant region is <region>", "Annotated n lines." -- byte for byte (round 6:
+    rgx_identify_params.echo, the tool's echo blocks)."""
+    gold = json.load(open(os.path.join(GOLD, "cli", "cli_valid_streams.json")))
+    td = str(tmp_path)
+    for argv in valid_cases(td):
+        want = gold[case_id(argv)]
+        r = subprocess.run([EXE] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        fix = lambda b: b.replace(ROOT.encode(), b"@ROOT@").replace(td.encode(), b"@TMP@")
+        assert r.returncode == want["rc"] == 0, (argv, r.returncode, r.stderr[-300:])
+        assert fix(r.stdout) == want["stdout"].encode("latin-1"), argv
+        assert fix(r.stderr) == want["stderr"].encode("latin-1"), (argv, fix(r.stderr)[-400:])
