@@ -1128,9 +1128,12 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
     {
         VariantStage *vs = V_holder.release();
         rgx_gtf *gg = guard.g; guard.g = nullptr;
-        const int dev = c->device;
+        // (the junction table and the index image go the same way, and FIRST: freed by this thread, their blocks' munmap waited for the address-space
+        //  lock behind the background thread's unmapping of the 533 MB BAM -- 5-7 ms of the caller's time between "total" and the return, round 6)
+        JMap *ujh = new JMap(std::move(uj));
+        std::vector<uint8_t> *baih = new std::vector<uint8_t>(std::move(bai));
+        Reaper::get().later([ujh, baih] { delete ujh; delete baih; });
         bam.release_later();
-        (void)dev;
         // (host memory only: the annotation's device tables are the context's, gtf_upload(pooled) -- no HIP call on that thread)
         Reaper::get().later([vs, gg] { delete vs; rgx_gtf_free(gg); });
     }
