@@ -29,6 +29,8 @@ extern "C" {
 #define RGX_ERR_FORMAT     6  /* malformed BGZF/BAM beyond what the reference tolerates silently */
 #define RGX_ERR_ARG        7
 #define RGX_ERR_FASTA      8  /* "Unable to extract FASTA sequence for position ...\n\n" junctions_extractor.cc:553 */
+#define RGX_ERR_ABORT      9  /* the reference abort()s on this input (`junctions extract -s XS`: an aux field of unknown type in front of the strand tag of a
+                               * spliced read, sam.c:1233-1252 skip_aux); the tool then calls abort() itself, a library caller gets this code */
 
 typedef struct rgx_ctx rgx_ctx;   /* one per process+device: HIP stream(s) and a reusable HBM workspace */
 

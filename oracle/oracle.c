@@ -485,7 +485,9 @@ char orc_strand_from_flag(uint32_t flag, int strandness) {
 }
 
 /* junctions_extractor.cc:283-294 + sam.c:1254-1266 bam_aux_get, :1233-1252 skip_aux, :1301-1307 bam_aux2A */
-static char strand_from_tag(const uint8_t *aux, const uint8_t *end, const char tag[2]) {
+/* *unknown is set when a field of a type skip_aux does not know stands in front of the tag: the reference abort()s there (sam.c:1248) -- when it gets
+ * that far, i.e. when a junction of the read asks for the strand (junction_emit) */
+static char strand_from_tag(const uint8_t *aux, const uint8_t *end, const char tag[2], int *unknown) {
     const uint8_t *s = aux;
     while (s + 3 <= end) {                 /* two tag bytes + one type byte must be present */
         int hit = (s[0] == (uint8_t)tag[0] && s[1] == (uint8_t)tag[1]);
@@ -509,7 +511,7 @@ static char strand_from_tag(const uint8_t *aux, const uint8_t *end, const char t
                 s += (size_t)sz * n;
                 break;
             }
-            default: return '?'; /* the reference abort()s here; treated as "tag not found" */
+            default: *unknown = 1; return '?'; /* the reference abort()s here */
         }
     }
     return '?';
@@ -766,6 +768,7 @@ typedef struct {
     char xs_or_flag_strand;       /* strand from the tag / flag rule for this read */
     const fasta *fa; const char *chrom; char carried; /* motif mode: strand carried over within the read */
     int fa_error;
+    int tag_unknown, aborts;         /* -s XS: the read's tag lies behind a field of unknown type / a junction asked for it: the reference abort()ed */
     const char *bc; size_t bc_len;   /* -b: this read's barcode */
 } emit_ctx;
 
@@ -788,6 +791,7 @@ static void junction_emit(void *vc, uint32_t start, uint32_t end, uint32_t ts, u
         if (strand == '?') strand = c->xs_or_flag_strand;
         c->carried = strand;
     } else strand = c->xs_or_flag_strand;
+    if (p->strandness == 0 && c->tag_unknown) { c->aborts = 1; return; }      /* set_junction_strand_XS -> bam_aux_get -> skip_aux -> abort() */
 
     /* junction_qc :160-170 (unsigned) */
     uint32_t ilen = end - start;
@@ -955,7 +959,8 @@ int orc_extract(const orc_params *p, orc_table **out, char *err, size_t errlen) 
         if (n_cigar <= 1) continue;             /* junctions_extractor.cc:378-380 */
         if (tid < 0 || tid >= t->n_ref) continue; /* UB upstream; skipped */
         ec.tid = tid; ec.chrom = t->ref_name[tid]; ec.carried = 0;
-        if (p->strandness == 0) ec.xs_or_flag_strand = strand_from_tag(data + aux_off, data + l_data, p->strand_tag);
+        ec.tag_unknown = 0;
+        if (p->strandness == 0) ec.xs_or_flag_strand = strand_from_tag(data + aux_off, data + l_data, p->strand_tag, &ec.tag_unknown);
         else ec.xs_or_flag_strand = orc_strand_from_flag(flag, p->strandness);
         if (p->barcodes) {
             const uint8_t *v = NULL; size_t vl = 0;
@@ -964,6 +969,7 @@ int orc_extract(const orc_params *p, orc_table **out, char *err, size_t errlen) 
             if (r) { ec.bc = (const char *)v; ec.bc_len = vl; } else { ec.bc = "?"; ec.bc_len = 1; }
         }
         cigar_walk(pos, cig, (int)n_cigar, junction_emit, &ec);
+        if (ec.aborts) { rc = fail(err, errlen, "abort()\n"); break; }
         if (ec.fa_error) { rc = fail(err, errlen, "Unable to extract FASTA sequence for position\n\n"); break; }
     }
     t->inflated_bytes = rd.inflated;

@@ -121,7 +121,7 @@ int main(int argc, char **argv) {
 
     char err[256]; orc_table *t = NULL;
     double t0 = now();
-    if (orc_extract(&p, &t, err, sizeof err)) { fputs(err, stderr); return 1; }
+    if (orc_extract(&p, &t, err, sizeof err)) { if (!strcmp(err, "abort()\n")) abort(); fputs(err, stderr); return 1; }
     double t1 = now();
     if (timing) {
         printf("{\"records\": %llu, \"events\": %llu, \"junctions\": %zu, \"inflated_bytes\": %llu, \"seconds\": %.6f}\n",

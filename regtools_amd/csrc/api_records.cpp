@@ -139,6 +139,8 @@ int EventsRun::stage_bounds_and_chains() {
 
     memset(&cfg, 0, sizeof cfg);
     cfg.n_ref = n_ref; cfg.strandness = p->strandness; cfg.tag0 = (uint8_t)p->strand_tag[0]; cfg.tag1 = (uint8_t)p->strand_tag[1];
+    // (`junctions extract` only: identify's per-window extractions upstream meet such a read only inside a window -- DESIGN 8)
+    if (p->strandness == 0 && !want_read_span) { cfg.abort_out = d_sc + 96; HIP_TRY(hipMemsetAsync(d_sc + 96, 0xff, 4, st)); }
     cfg.min_anchor = p->min_anchor; cfg.min_intron = p->min_intron; cfg.max_intron = p->max_intron;
     cfg.region_tid = -2; cfg.long_threshold = 16;
     if (!whole) {
@@ -422,6 +424,7 @@ int EventsRun::stage_decode() {
             HIP_TRY(hipMemcpyAsync(h_sc + 4, d_sc + 4, 24, hipMemcpyDeviceToHost, st));
             if (cfg.stop_out) HIP_TRY(hipMemcpyAsync(h_sc + 80, d_sc + 80, 8, hipMemcpyDeviceToHost, st));
             if (cfg.insane_out) HIP_TRY(hipMemcpyAsync(h_sc + 82, d_sc + 82, 4, hipMemcpyDeviceToHost, st));
+            if (cfg.abort_out) HIP_TRY(hipMemcpyAsync(h_sc + 96, d_sc + 96, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (cfg.insane_out && h_sc[82]) {
                 // a record the reference's reader would not have accepted (sam.c:421-423) lies on the chain the block_size walk followed:
@@ -438,6 +441,9 @@ int EventsRun::stage_decode() {
             if (pass || !cfg.stop_out || h_sc[80] == 0xffffffffu || h_sc[81] <= h_sc[80] + 1) break;
             cfg.stop_index = h_sc[80];
         }
+        // an iterated read (in front of the record that ends the iteration) whose strand tag upstream cannot get at
+        if (cfg.abort_out && h_sc[96] != 0xffffffffu && h_sc[96] < (cfg.stop_out ? cfg.stop_index : 0xffffffffu))
+            return fail(err, errlen, RGX_ERR_ABORT, "regtools_amd: record %u has an auxiliary field of unknown type in front of its strand tag: the reference abort()s here\n", h_sc[96]);
         n_events = h_sc[4]; n_long = h_sc[5];
         if (emit_parts_ok && s_from) {
             uint64_t tot = 0;

@@ -58,7 +58,8 @@ RGX_HD char strand_from_flag(uint32_t flag, int strandness) {
 
 // junctions_extractor.cc:283-294 + sam.c:1254-1266 bam_aux_get / :1233-1252 skip_aux / :1301-1307 bam_aux2A.
 // First tag equal to `tag`: type 'A' with a non-NUL value gives that char, anything else '?'.
-RGX_HD char strand_from_tag(const uint8_t *aux, const uint8_t *end, uint8_t t0, uint8_t t1) {
+// *unknown (optional) is set when a tag of a type skip_aux does not know stands in front of the one looked for: upstream abort()s there (sam.c:1248).
+RGX_HD char strand_from_tag(const uint8_t *aux, const uint8_t *end, uint8_t t0, uint8_t t1, bool *unknown = nullptr) {
     const uint8_t *s = aux;
     while (s + 3 <= end) {
         bool hit = s[0] == t0 && s[1] == t1;
@@ -79,7 +80,7 @@ RGX_HD char strand_from_tag(const uint8_t *aux, const uint8_t *end, uint8_t t0, 
                 if ((uint64_t)es * n > (uint64_t)(end - s)) return '?';
                 sz = es * n; break;
             }
-            default: return '?';   // upstream abort()s on an unknown type; treated as "not found"
+            default: if (unknown) *unknown = true; return '?';   // upstream abort()s on an unknown type (the caller is told; the strand reads "not found")
         }
         s += sz;
     }

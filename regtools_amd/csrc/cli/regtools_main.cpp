@@ -123,6 +123,8 @@ int junctions_extract(int argc, char **argv) {
         rgx_junction_table *t = nullptr;
         int rc = devices.size() > 1 ? rgx_extract_multi(devices.data(), (int)devices.size(), o.bam.c_str(), &p, &t, err, sizeof err)
                                     : rgx_extract(ctx, o.bam.c_str(), &p, &t, err, sizeof err);
+        // (an aux field of unknown type in front of a spliced read's strand tag: upstream's bam_aux_get abort()s, sam.c:1248 -- nothing printed, SIGABRT)
+        if (rc == RGX_ERR_ABORT) { std::cerr.flush(); fflush(nullptr); abort(); }
         if (rc != RGX_OK) { if (ctx) rgx_ctx_destroy(ctx); throw std::runtime_error(err); }
         const double t_extract = wall_ms();
         // one formatting pass: a row is a contig name + at most 160 bytes of numbers (Junction::print, junctions_extractor.h:90-98)

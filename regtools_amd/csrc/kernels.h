@@ -163,6 +163,9 @@ struct ExtractCfg {
     uint32_t *stop_out;
     uint32_t stop_index;
     uint32_t *insane_out;          // null = the framing made bam_read1's acceptance test itself; else [0] is set when a decoded record fails it (SegGeom::lite_walk)
+    // -s XS: the smallest index of an iterated read with an N operation whose strand tag lies behind an aux field of unknown type (preset ~0; null =
+    // off): the reference's bam_aux_get abort()s on it (sam.c:1233-1252) when the read's first junction asks for its strand (junctions_extractor.cc:283-286)
+    uint32_t *abort_out;
 };
 
 // one wave per framing segment, segment bytes staged through LDS (replaces launch_seg_fill + launch_decode on the hot path)

@@ -895,18 +895,22 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
         uint32_t nev = 0;
         char strand = '?';
         if (in_region && h.n_cigar > 1 && h.tid >= 0 && h.tid < cfg.n_ref) {
+            bool has_n = false;
             for (uint32_t q = 0; q < h.n_cigar; ++q) {
                 const uint32_t c = cigar_at(q);
-                if (cig_is_N(c)) { const uint32_t len = c >> 4; nev += !(len < cfg.min_intron || len > cfg.max_intron); }
+                if (cig_is_N(c)) { const uint32_t len = c >> 4; nev += !(len < cfg.min_intron || len > cfg.max_intron); has_n = true; }
             }
-            if (nev) {
+            // (the tag is asked for by every junction the walk reaches, also one junction_qc then drops: any N operation, cc:415 / :447 / :467 / :490)
+            if (nev || (has_n && cfg.abort_out && cfg.strandness == 0)) {
                 if (cfg.strandness == 0) {
                     const int64_t l_data = (int64_t)h.block_len - 32;
+                    bool unknown = false;
                     // two call sites on purpose: the LDS one compiles to ds_read_u8, the other to global loads (no flat/generic pointer)
-                    if (in_win) { const uint8_t *body = s_buf + ro + 36; strand = strand_from_tag(body + h.aux_off, body + l_data, cfg.tag0, cfg.tag1); }
-                    else strand = strand_from_tag(g_data + h.aux_off, g_data + l_data, cfg.tag0, cfg.tag1);
+                    if (in_win) { const uint8_t *body = s_buf + ro + 36; strand = strand_from_tag(body + h.aux_off, body + l_data, cfg.tag0, cfg.tag1, &unknown); }
+                    else strand = strand_from_tag(g_data + h.aux_off, g_data + l_data, cfg.tag0, cfg.tag1, &unknown);
+                    if (unknown && cfg.abort_out) atomicMin(cfg.abort_out, i);
                 } else strand = strand_from_flag(h.flag, cfg.strandness);
-                n_long += h.n_cigar > cfg.long_threshold ? 1u : 0u;
+                if (nev) n_long += h.n_cigar > cfg.long_threshold ? 1u : 0u;
             }
         }
         soa.strand[i] = (uint8_t)strand;
@@ -974,16 +978,19 @@ __global__ __launch_bounds__(64) void k_decode_sparse(const uint8_t *__restrict_
                 uint32_t nev = 0;
                 char strand = '?';
                 if (in_region && h.n_cigar > 1 && h.tid >= 0 && h.tid < cfg.n_ref) {
+                    bool has_n = false;
                     for (uint32_t q = 0; q < h.n_cigar; ++q) {
                         const uint32_t c = cigar_at(q);
-                        if (cig_is_N(c)) { const uint32_t len = c >> 4; nev += !(len < cfg.min_intron || len > cfg.max_intron); }
+                        if (cig_is_N(c)) { const uint32_t len = c >> 4; nev += !(len < cfg.min_intron || len > cfg.max_intron); has_n = true; }
                     }
-                    if (nev) {
+                    if (nev || (has_n && cfg.abort_out && cfg.strandness == 0)) {
                         if (cfg.strandness == 0) {
                             const int64_t l_data = (int64_t)h.block_len - 32;
-                            strand = strand_from_tag(g_data + h.aux_off, g_data + l_data, cfg.tag0, cfg.tag1);
+                            bool unknown = false;
+                            strand = strand_from_tag(g_data + h.aux_off, g_data + l_data, cfg.tag0, cfg.tag1, &unknown);
+                            if (unknown && cfg.abort_out) atomicMin(cfg.abort_out, i);
                         } else strand = strand_from_flag(h.flag, cfg.strandness);
-                        n_long += h.n_cigar > cfg.long_threshold ? 1u : 0u;
+                        if (nev) n_long += h.n_cigar > cfg.long_threshold ? 1u : 0u;
                     }
                 }
                 soa.strand[i] = (uint8_t)strand;

@@ -1,0 +1,72 @@
+"""An aux field whose type byte skip_aux does not know (sam.c:1233-1252): when `junctions extract -s XS` asks for the strand tag of a read (it does for
+every junction the CIGAR walk reaches, junctions_extractor.cc:283-286) and such a field stands in FRONT of the tag, the reference abort()s -- SIGABRT,
+nothing printed.  A field behind the tag, a read without an N operation, a read outside the region, `-s RF`: nothing happens.  CPU: the oracle against
+the real reference; GPU: the tool dies the same way (RGX_ERR_ABORT from the library, abort() in the tool), the harmless cases print the oracle's bytes."""
+import os
+import subprocess
+
+import pytest
+
+import bamio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE = os.path.join(ROOT, "oracle", "oracle_cli")
+REF = os.path.join(ROOT, "oracle", "_ref", "regtools_ref")
+EXE = os.path.join(ROOT, "bin", "regtools-amd")
+ODD = b"ZZq\x01\x02\x03"          # tag ZZ, type 'q': no such type
+XS = bamio.tagA("XS", "+")
+
+
+def build(path, kind):
+    good = [bamio.record(0, 1000 + 50 * k, "30M200N30M", qname="g%d" % k, aux=XS) for k in range(20)]
+    spliced_before = bamio.record(0, 1500, "30M300N30M", qname="bad", aux=ODD + XS)
+    spliced_behind = bamio.record(0, 1500, "30M300N30M", qname="bad", aux=XS + ODD)
+    unspliced = bamio.record(0, 1500, "60M", qname="bad", aux=ODD + XS)
+    short_intron = bamio.record(0, 1500, "30M20N30M", qname="bad", aux=ODD + XS)       # the junction fails junction_qc, the tag is asked for before that
+    far = bamio.record(0, 900000, "30M300N30M", qname="bad", aux=ODD + XS)
+    recs = {"before": good[:10] + [spliced_before] + good[10:], "behind": good[:10] + [spliced_behind] + good[10:],
+            "unspliced": good[:10] + [unspliced] + good[10:], "short_intron": good[:10] + [short_intron] + good[10:], "far": good + [far]}[kind]
+    bamio.write_bam(path, [("chrT", 1000000)], recs)
+    from regtools_amd import synth
+    synth.index(path)
+    return path
+
+
+# (kind, extra options, dies?)
+CASES = [("before", ["-s", "XS"], True), ("short_intron", ["-s", "XS"], True), ("behind", ["-s", "XS"], False), ("unspliced", ["-s", "XS"], False),
+         ("before", ["-s", "RF"], False), ("far", ["-s", "XS", "-r", "chrT:1-5000"], False), ("far", ["-s", "XS"], True)]
+
+
+def run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
+    return r.returncode, r.stdout
+
+
+@pytest.mark.parametrize("kind,opts,dies", CASES, ids=["%s %s" % (c[0], " ".join(c[1])) for c in CASES])
+def test_oracle_follows_the_reference(built, tmp_path, kind, opts, dies):
+    p = build(os.path.join(str(tmp_path), kind + ".bam"), kind)
+    got = run([ORACLE, "extract"] + opts + [p])
+    assert (got[0] == -6) == dies, got[0]
+    if os.path.exists(REF):
+        want = run([REF, "junctions", "extract"] + opts + [p])
+        assert want[0] == (-6 if dies else 0), "the recorded behaviour of the reference is stale"
+        assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,opts,dies", CASES, ids=["%s %s" % (c[0], " ".join(c[1])) for c in CASES])
+def test_product_follows_the_reference(gpu_ctx, tmp_path, kind, opts, dies):
+    import regtools_amd
+    p = build(os.path.join(str(tmp_path), kind + ".bam"), kind)
+    want = run([ORACLE, "extract"] + opts + [p])
+    got = run([EXE, "junctions", "extract"] + opts + [p])
+    assert got == want
+    je = regtools_amd.JunctionsExtractor(ctx=gpu_ctx)
+    je.parse_options(opts + [p])
+    if dies:
+        with pytest.raises(regtools_amd.RegtoolsError) as e:
+            je.identify_junctions_from_BAM()
+        assert e.value.code == 9                                   # RGX_ERR_ABORT
+    else:
+        je.identify_junctions_from_BAM()
+        assert je.bed12() == want[1]
