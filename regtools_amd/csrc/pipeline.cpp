@@ -85,13 +85,14 @@ extern "C" int rgx_pipeline_create(int device, int depth, rgx_pipeline **out, ch
         return RGX_ERR_ARG; }
     // Every context has four streams, and the runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment says otherwise,
     // read when HIP starts).  Two contexts share queues pairwise and work; with three and more, a file's arrival-gated waves and the one-lane kernels that
-    // release
-    // them end up behind one another in ONE hardware queue and every such wave waits out its 2 s time-out (measured: 130-240 ms per file instead of 21).
+    // release them end up behind one another in ONE hardware queue and every such wave waits out its 2 s time-out (measured: 130-240 ms per file instead
+    // of 21).  A hardware queue per stream is what was seen to be safe: four files in flight on eight queues still timed out on a payload whose launches
+    // are long (profiles/r06_sustained_pipeline_ab.txt).
     if (depth > 2) {
         const char *q = getenv("GPU_MAX_HW_QUEUES");
-        if (!q || atoi(q) < 8) {
+        if (!q || atoi(q) < 4 * depth) {
             if (err && errlen) snprintf(err, errlen,
-                "regtools_amd: more than two files in flight need GPU_MAX_HW_QUEUES=8 or more in the environment before HIP starts\n");
+                "regtools_amd: %d files in flight need GPU_MAX_HW_QUEUES=%d or more in the environment before HIP starts\n", depth, 4 * depth);
             return RGX_ERR_ARG;
         }
     }
