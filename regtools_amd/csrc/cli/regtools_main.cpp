@@ -34,6 +34,14 @@ void die_as_upstream_on_empty_gtf_line(const char *err, bool caught = false) {
     try { (void)std::string().at(0); } catch (const std::out_of_range &e) { throw std::runtime_error(e.what()); }
 }
 
+// htslib ends the process itself on two kinds of VCF record (vcf.c:1610-1614 exit(1); :1638-1639 abort()), past every handler of the tool: the
+// library reports them (RGX_ERR_EXIT / RGX_ERR_ABORT with what htslib printed) and the tool goes the same way.
+void die_where_upstreams_library_does(int rc, const char *err) {
+    if (rc != RGX_ERR_EXIT && rc != RGX_ERR_ABORT) return;
+    std::cerr.flush(); fputs(err, stderr); fflush(nullptr);
+    if (rc == RGX_ERR_ABORT) abort();
+    exit(1);
+}
 
 struct HelpRequested { std::string text; };
 
@@ -337,6 +345,7 @@ int cse_identify(int argc, char **argv, bool associate = false) {
         int rc = associate ? rgx_associate(ctx, &p, &st, err, sizeof err)
                            : multi ? rgx_identify_multi(devices.data(), (int)devices.size(), &p, &st, err, sizeof err) : rgx_identify(ctx, &p, &st, err, sizeof err);
         if (ctx) rgx_ctx_destroy(ctx);
+        die_where_upstreams_library_does(rc, err);
         if (rc != RGX_OK) { die_as_upstream_on_empty_gtf_line(err, /*caught=*/true); throw std::runtime_error(err); }
         if (barcodes != "NA") {
             // identify's extractor is built without a barcode file (identifier.cc:288 -> junctions_extractor.h:197-205), so every junction's map
@@ -411,6 +420,7 @@ int variants_annotate(int argc, char **argv) {
         char err[512] = {0};
         int rc = rgx_variants_annotate(ctx, &p, nullptr, err, sizeof err);
         rgx_ctx_destroy(ctx);
+        die_where_upstreams_library_does(rc, err);
         if (rc != RGX_OK) { die_as_upstream_on_empty_gtf_line(err); throw std::runtime_error(err); }
     } catch (const HelpRequested &h) {
         std::cerr << h.text << std::endl;

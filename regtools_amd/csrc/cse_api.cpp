@@ -479,7 +479,7 @@ static int variant_scan_stage(rgx_ctx *c, const rgx_gtf *g, const VariantOpts &v
 // -v / `variants annotate -o`: what htslib writes for bcf_hdr_append x4 + bcf_hdr_write, then per record bcf_update_info_string x4 +
 // bcf_write (variants_annotator.cc:130-154, 521-533) -- every record goes through BCF's typed form and back (vcf_rewrite.h).
 // all_records = false writes only the splice relevant ones (identifier.cc:278-280), true every one (annotator.cc:545-548).
-static int write_annotated_vcf(const char *path, const VariantStage &V, bool all_records, char *err, size_t errlen) {
+static int write_annotated_vcf(const char *path, const VariantStage &V, bool all_records, char *err, size_t errlen, bool print_notes = true) {
     FILE *fv = path ? fopen(path, "w") : stdout;
     if (!fv) return fail(err, errlen, RGX_ERR_OPEN, "Unable to open output VCF file.\n\n");
     if (fv != stdout) setvbuf(fv, nullptr, _IOFBF, 1 << 22);
@@ -491,9 +491,10 @@ static int write_annotated_vcf(const char *path, const VariantStage &V, bool all
         if (V.H.off[ri + 1] == V.H.off[ri]) return VcfAnnot{nullptr, nullptr, nullptr, nullptr};
         const VStr &s = V.vstr[V.vstr_of[ri]];
         return VcfAnnot{&s.genes, &s.transcripts, &s.distances, &s.annotations};
-    });
+    }, print_notes);
     if (fv != stdout) fclose(fv);
-    if (!e.empty()) return fail(err, errlen, RGX_ERR_OPEN, "%s\n", e.c_str());
+    // (the record the reference's process ends in -- exit(1), or abort() -- is the one behind the last one written)
+    if (!e.empty()) return fail(err, errlen, e != vcf.fatal ? RGX_ERR_OPEN : vcf.fatal_aborts ? RGX_ERR_ABORT : RGX_ERR_EXIT, "%s\n", e.c_str());
     return RGX_OK;
 }
 
@@ -883,7 +884,7 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
     double gtf_thread_ms = 0, vcf_thread_ms = 0;
     std::thread t_gtf([&] { const double t = now_ms(); try { gtf_err = g->m.load(p->gtf_path);
         } catch (const std::exception &e) { gtf_err = std::string("regtools_amd: ") + e.what() + "\n"; } gtf_thread_ms = now_ms() - t; });
-    std::thread t_vcf([&] { const double t = now_ms(); try { vcf_err = V.vcf.load(p->vcf_path);
+    std::thread t_vcf([&] { const double t = now_ms(); try { vcf_err = V.vcf.load(p->vcf_path, /*annotating=*/p->out_vcf != nullptr);
         } catch (const std::exception &e) { vcf_err = std::string("regtools_amd: ") + e.what() + "\n"; } vcf_thread_ms = now_ms() - t; });
     struct Joiner { std::thread &a, &b; ~Joiner() { if (a.joinable()) a.join(); if (b.joinable()) b.join(); } } joiner{t_gtf, t_vcf};
 
@@ -919,7 +920,7 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
 
     // a10: every variant against the annotation
     t_vcf.join();
-    if (!vcf_err.empty()) return fail(err, errlen, RGX_ERR_OPEN, "%s", vcf_err.c_str());
+    if (!vcf_err.empty()) return fail(err, errlen, V.vcf.death == 2 ? RGX_ERR_ABORT : V.vcf.death == 1 ? RGX_ERR_EXIT : RGX_ERR_OPEN, "%s", vcf_err.c_str());
     if (p->echo) fputs("\n", stderr);                                // (identifier.cc:265, associator.cc:243)
     if (getenv("REGTOOLS_AMD_TRACE")) fprintf(stderr, "[rgx trace] inputs: gtf thread %8.3f ms, vcf thread %8.3f ms, extraction %8.3f ms (side by side)\n",
         gtf_thread_ms, vcf_thread_ms, S.ms_extract);
@@ -935,19 +936,26 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
     char err_vcf[512]; err_vcf[0] = 0;
     double vcf_ms = 0;
     std::thread t_vcfout;
-    if (p->out_vcf) t_vcfout = std::thread([&] { const double t = now_ms(); rc_vcf = write_annotated_vcf(p->out_vcf, V, false, err_vcf, sizeof err_vcf);
-        vcf_ms = now_ms() - t; });
+    if (p->out_vcf) t_vcfout = std::thread([&] { const double t = now_ms(); rc_vcf = write_annotated_vcf(p->out_vcf, V, false, err_vcf, sizeof err_vcf,
+        /*print_notes=*/false); vcf_ms = now_ms() - t; });
     struct JoinOne { std::thread &t; ~JoinOne() { if (t.joinable()) t.join(); } } join_vcfout{t_vcfout};
 
     // p->echo: what upstream writes to stderr for every splice-relevant variant, in file order, before it looks at the alignments of its window
     // (identifier.cc:275-277, associator.cc:255-257): "Variant " + BED's operator<< (chrom, start, end, score, strand, each followed by a tab;
     // bedFile.h:183-194; the score is what the annotation walk left there: H.last) and the window as the region string
+    // What reading the records says (vcf.notes: a name the header does not declare, ...) comes out here as well, a record's lines in front of its
+    // "Variant" lines: upstream reads, annotates and echoes one record after the other (identifier.cc:267-277).
     auto echo_variants = [&](size_t upto) {
-        if (!p->echo) return;
+        const bool all = upto >= relevant.size();
+        if (!p->echo) { vcf.flush_notes(all ? SIZE_MAX : relevant[upto - 1] + 1); return; }
         std::string s;
         s.reserve(std::min(upto, relevant.size()) * 72);
         for (size_t w = 0; w < upto && w < relevant.size(); ++w) {
             const size_t i = relevant[w];
+            if (vcf.notes_printed < vcf.notes.size() && vcf.notes[vcf.notes_printed].first <= i) {
+                fwrite(s.data(), 1, s.size(), stderr); s.clear();
+                vcf.flush_notes(i + 1);
+            }
             const uint32_t start = vcf.recs[i].pos0, end = start + 1;
             const uint32_t rs = p->window ? (uint32_t)(start - p->window) : H.ces[i], re = p->window ? (uint32_t)(end + p->window) : H.cee[i];
             s += "Variant "; s += vcf.recs[i].chrom; s += '\t'; put_u(s, start); s += '\t'; put_u(s, end); s += '\t';
@@ -955,10 +963,17 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
             s += "\t\t\nVariant region is "; s += vcf.recs[i].chrom; s += ':'; put_u(s, rs); s += '-'; put_u(s, re); s += "\n\n";
         }
         fwrite(s.data(), 1, s.size(), stderr);
+        if (all) vcf.flush_notes(SIZE_MAX);
+    };
+    // the record the reference's process ends in, once everything in front of it is echoed (its variants have had their windows read by then)
+    auto died_reading_the_vcf = [&]() -> int {
+        if (vcf.fatal.empty()) return RGX_OK;
+        return fail(err, errlen, vcf.fatal_aborts ? RGX_ERR_ABORT : RGX_ERR_EXIT, "%s\n", vcf.fatal.c_str());
     };
     JMap uj;
     if (p->bed_path) {
         echo_variants(relevant.size());
+        if (int rc_died = died_reading_the_vcf()) return rc_died;
         // ---- associate: junctions from a BED12 (associator.cc:206-276) ----
         BedJunctions B;
         { std::string e = B.load(p->bed_path); if (!e.empty()) return fail(err, errlen, RGX_ERR_FORMAT, "%s", e.c_str()); }
@@ -1070,6 +1085,7 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
             for (size_t t = 0; t < nt; ++t) if (bad[t] != SIZE_MAX) { echo_variants(bad[t] + 1); return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion); }
         }
         echo_variants(relevant.size());
+        if (int rc_died = died_reading_the_vcf()) return rc_died;
         S.n_windows = w_tid.size();
         auto jlap = [&](const char *what) { if (jtrace) { const double t = now_ms(); fprintf(stderr, "[rgx trace] join: %-22s +%8.3f ms\n", what, t - jt);
             jt = t; } };
@@ -1174,7 +1190,7 @@ extern "C" int rgx_variants_annotate(rgx_ctx *c, const rgx_identify_params *p, r
     S.ms_gtf = now_ms() - t0;
     VariantOpts vo{p->intronic_min, p->exonic_min, p->all_intronic, p->all_exonic, p->skip_single};
     t_vcf.join();
-    if (!vcf_err.empty()) return fail(err, errlen, RGX_ERR_OPEN, "%s", vcf_err.c_str());
+    if (!vcf_err.empty()) return fail(err, errlen, V.vcf.death == 2 ? RGX_ERR_ABORT : V.vcf.death == 1 ? RGX_ERR_EXIT : RGX_ERR_OPEN, "%s", vcf_err.c_str());
     rc = variant_scan_stage(c, g, vo, V, &S.exon_visits_variants, err, errlen);
     if (rc != RGX_OK) return rc;
     S.n_variants = V.vcf.recs.size(); S.n_relevant = V.relevant.size();

@@ -37,21 +37,6 @@ static bool slurp(const std::string &path, std::string &out) {
     return ok;
 }
 
-// lineFileUtilities.h:24-33 Tokenize (std::getline: consecutive delimiters give empty fields, no trailing empty field)
-static void tokenize(const char *s, size_t len, char delim, std::vector<std::pair<const char *, size_t>> &out) {
-    out.clear();
-    if (!len) return;
-    size_t i = 0;
-    for (;;) {
-        size_t j = i;
-        while (j < len && s[j] != delim) ++j;
-        out.push_back({s + i, j - i});
-        if (j >= len) break;
-        i = j + 1;
-        if (i >= len) break;
-    }
-}
-
 // gtf_parser.cc:89-104 parse_attribute + utils/common.h:85-92 unquote
 static std::string gtf_attr(const char *attrs, size_t alen, const char *key) {
     const size_t klen = strlen(key);
@@ -403,7 +388,15 @@ std::string GtfModel::load(const std::string &path) {
 
 // gzip / bgzip input (hts_open accepts both, hts.c:204-260): host_io's gunzip_all, i.e. the product's own decoder compiled for the host.
 // A stream that starts with the BCF magic is a BCF file (bcf_hdr_read vcf.c:788-818, bcf_read1_core :899-926).
-std::string VcfText::load(const std::string &path) {
+// bcf_hdr_append x 4 (variants_annotator.cc:136-151)
+static void declare_annotation_keys(VcfDictionary &h) {
+    h.declare("##INFO=<ID=genes,Number=1,Type=String,Description=\"The Variant falls in the splice region of these genes\">");
+    h.declare("##INFO=<ID=transcripts,Number=1,Type=String,Description=\"The Variant falls in the splice region of these transcripts\">");
+    h.declare("##INFO=<ID=distances,Number=1,Type=String,Description=\"Vector of Min(Distance from start/end of exon in the transcript.)\">");
+    h.declare("##INFO=<ID=annotations,Number=1,Type=String,Description=\"Does the variant fall in exonic/intronic splicing related space in the transcript.\">");
+}
+
+std::string VcfText::load(const std::string &path, bool annotating) {
     if (!slurp(path, text)) return "Unable to open file.\n\n";
     if (text.size() >= 2 && (uint8_t)text[0] == 0x1f && (uint8_t)text[1] == 0x8b) {
         std::string plain;
@@ -417,7 +410,7 @@ std::string VcfText::load(const std::string &path) {
         uint32_t l_text; memcpy(&l_text, text.data() + 5, 4);
         if (text.size() - 9 < l_text) return "Unable to read header.\n\n";
         hdr.ingest(std::string(text.data() + 9, strnlen(text.data() + 9, l_text)));
-        if (!hdr.failure().empty()) return hdr.failure() + "\n";
+        if (!hdr.failure().empty()) { death = hdr.failure_aborts() ? 2 : 1; return hdr.failure() + "\n"; }
         size_t o = 9 + (size_t)l_text;
         while (text.size() - o >= 32) {
             uint32_t x[4]; memcpy(x, text.data() + o, 16);
@@ -446,13 +439,13 @@ std::string VcfText::load(const std::string &path) {
         for (size_t i = 0; i < n_lines_; ++i) {
             const char *l; size_t n; line(i, l, n);
             if (!n) continue;
-            if (l[0] != '#') break;
+            if (l[0] != '#') { fputs("[E::vcf_hdr_read] no sample line\n", stderr); return "Unable to read header.\n\n"; }      // vcf.c:1249-1256
             htxt.append(l, n); htxt += '\n';
             if (n < 2 || l[1] != '#') { closed = true; first_rec_line = i + 1; break; }
         }
-        if (!closed) return "Unable to read header.\n\n";
+        (void)closed;                                      // (a file that ends inside its "##" lines is a header without samples and no record, vcf.c:1247-1287)
         hdr.ingest(htxt);
-        if (!hdr.failure().empty()) return hdr.failure() + "\n";
+        if (!hdr.failure().empty()) { death = hdr.failure_aborts() ? 2 : 1; return hdr.failure() + "\n"; }
         // a tabix index next to the file: the sequence names it lists that the header does not declare join the header as ##contig lines
         // (vcf_hdr_read, vcf.c:1289-1309) -- they are written out with it, and a record on such a contig draws no warning.  An index that
         // cannot be read is no index (tbx_index_load returns NULL).
@@ -495,37 +488,38 @@ std::string VcfText::load(const std::string &path) {
             }
         }
     }
-    // CHROM and POS of every record line, by several threads over ranges of lines (file order kept: the ranges are concatenated in order).
-    // vcf_parse refuses a record whose sample columns do not match the header (vcf.c:1551-1556, 1760-1766): the read loop ends there.
-    const size_t n_samples = hdr.n_samples();
+    // CHROM and POS of every record line, by several threads over ranges of lines (file order kept: the ranges are concatenated in order).  Every line
+    // is also read the way vcf_parse reads its NAMES (read_text_record, names_only): what it says on stderr is kept with the record's index, and the
+    // read loop ends at the first record it refuses (sample columns that do not match the header, vcf.c:1551-1556, 1760-1766) -- or dies in
+    // (vcf.c:1612-1613, 1638-1639).  A thread has its own copy of the header: a name the header does not declare draws its line once per FILE upstream
+    // (the name joins the header there), so a later range's line for a name an earlier range has met is dropped when the ranges are put together.
     const size_t T = n_lines_ < (1u << 16) ? 1 : usable_threads(16);
-    std::vector<std::vector<Rec>> part(T);
-    std::vector<size_t> part_stop(T, SIZE_MAX), part_first_id(T, SIZE_MAX);       // (first record of the range that has an ID column)
+    struct Range { std::vector<Rec> recs; std::vector<std::pair<size_t, std::string>> notes; bool stopped = false; size_t first_id = SIZE_MAX; std::string fatal; bool aborts = false; };
+    std::vector<Range> part(T);
     auto scan = [&](size_t t) {
-        std::vector<Rec> &out = part[t];
+        Range &R = part[t];
+        std::vector<Rec> &out = R.recs;
         const size_t a = std::max(first_rec_line, n_lines_ * t / T), b = n_lines_ * (t + 1) / T;
         if (b > a) out.reserve(b - a);
+        VcfDictionary h = hdr;
+        if (annotating) declare_annotation_keys(h);
+        std::vector<std::string> said;
+        h.notes_to(&said);
+        VcfRecord probe;
         for (size_t i = a; i < b; ++i) {
             const char *l; size_t n; line(i, l, n);
+            const ReadResult got = read_text_record(h, l, n, probe, /*names_only=*/true);
+            for (std::string &m : said) R.notes.emplace_back(out.size(), std::move(m));
+            said.clear();
+            if (got != ReadResult::kOk) { R.stopped = true; if (got == ReadResult::kFatal) { R.fatal = h.failure(); R.aborts = h.failure_aborts(); } break; }
             // Every line behind the header is a record upstream (vcf_read, vcf.c:1958-1964: hts_getline + vcf_parse, no look at what the line
             // is): a blank line, a '#' line or any text without a tab is CHROM = the whole line with everything else left as bcf_clear1
             // left it (POS 1, no ID / REF / ALT / QUAL / FILTER / INFO)
             const char *t1 = (const char *)memchr(l, '\t', n);
             if (!t1) { out.push_back({i, std::string(l, n), 0u}); continue; }
             const char *t2 = (const char *)memchr(t1 + 1, '\t', (size_t)(l + n - t1 - 1));
-            if (n_samples && t2) {
-                // columns 9.. : FORMAT and the samples
-                const char *c = t2; int col = 2;
-                while (c && col < 8) { c = (const char *)memchr(c + 1, '\t', (size_t)(l + n - c - 1)); ++col; }
-                if (c) {                                           // c = the tab in front of FORMAT
-                    const char *f_end = (const char *)memchr(c + 1, '\t', (size_t)(l + n - c - 1));
-                    size_t have = 0;
-                    if (f_end) { have = 1; for (const char *q = f_end + 1; q < l + n; ++q) if (*q == '\t') ++have; if (l[n - 1] == '\t') --have; }
-                    if (have < n_samples) { part_stop[t] = i; break; }
-                }
-            }
             std::string ps(t1 + 1, t2 ? (size_t)(t2 - t1 - 1) : (size_t)(l + n - t1 - 1));
-            if (t2 && part_first_id[t] == SIZE_MAX) part_first_id[t] = out.size();
+            if (t2 && R.first_id == SIZE_MAX) R.first_id = out.size();
             out.push_back({i, std::string(l, (size_t)(t1 - l)), (uint32_t)atoi(ps.c_str()) - 1u});
         }
     };
@@ -536,14 +530,24 @@ std::string VcfText::load(const std::string &path) {
         for (auto &th : pool) th.join();
     }
     first_with_id = SIZE_MAX;
-    if (T == 1) { first_with_id = part_first_id[0]; recs.swap(part[0]); }
-    else {
-        size_t total = 0; for (auto &v : part) total += v.size();
+    {
+        size_t total = 0; for (auto &R : part) total += R.recs.size();
         recs.reserve(total);
+        std::set<std::string> warned;                                      // the "[W::" lines earlier ranges have drawn
         for (size_t t = 0; t < T; ++t) {
-            if (first_with_id == SIZE_MAX && part_first_id[t] != SIZE_MAX) first_with_id = recs.size() + part_first_id[t];
-            for (auto &r : part[t]) recs.push_back(std::move(r));
-            if (part_stop[t] != SIZE_MAX) break;
+            Range &R = part[t];
+            const size_t base = recs.size();
+            if (first_with_id == SIZE_MAX && R.first_id != SIZE_MAX) first_with_id = base + R.first_id;
+            std::vector<const std::string *> fresh;
+            for (auto &m : R.notes) {
+                const bool once = m.second.compare(0, 4, "[W::") == 0;
+                if (once && T > 1 && warned.count(m.second)) continue;
+                if (once && T > 1) fresh.push_back(&m.second);
+                notes.emplace_back(base + m.first, m.second);
+            }
+            for (const std::string *m : fresh) warned.insert(*m);
+            if (T == 1) recs.swap(R.recs); else for (auto &r : R.recs) recs.push_back(std::move(r));
+            if (R.stopped) { fatal = R.fatal; fatal_aborts = R.aborts; break; }
         }
     }
     return "";
@@ -555,12 +559,9 @@ ReadResult VcfText::typed(size_t i, VcfDictionary &h, VcfRecord &r) const {
     return read_text_record(h, l, n, r);
 }
 
-std::string write_annotated_vcf_records(FILE *fv, const VcfText &vcf, const std::vector<size_t> &todo, const std::function<VcfAnnot(size_t)> &annot) {
+std::string write_annotated_vcf_records(FILE *fv, const VcfText &vcf, const std::vector<size_t> &todo, const std::function<VcfAnnot(size_t)> &annot, bool print_notes) {
     VcfDictionary hdr = vcf.hdr;
-    hdr.declare("##INFO=<ID=genes,Number=1,Type=String,Description=\"The Variant falls in the splice region of these genes\">");
-    hdr.declare("##INFO=<ID=transcripts,Number=1,Type=String,Description=\"The Variant falls in the splice region of these transcripts\">");
-    hdr.declare("##INFO=<ID=distances,Number=1,Type=String,Description=\"Vector of Min(Distance from start/end of exon in the transcript.)\">");
-    hdr.declare("##INFO=<ID=annotations,Number=1,Type=String,Description=\"Does the variant fall in exonic/intronic splicing related space in the transcript.\">");
+    declare_annotation_keys(hdr);
     { std::string h; hdr.render(h); fwrite(h.data(), 1, h.size(), fv); }
     // records are independent: ranges of them are re-serialised by several threads, each with its own copy of the dictionary (a name the
     // header does not declare joins the copy; what is printed is the name), and written in order
@@ -568,11 +569,13 @@ std::string write_annotated_vcf_records(FILE *fv, const VcfText &vcf, const std:
     std::vector<std::string> outs(T), fatal(T);
     auto work = [&](size_t t) {
         VcfDictionary h = hdr;
+        h.silence();                                                       // (what reading a record says is in vcf.notes already)
         VcfRecord rec;
         std::string &o = outs[t];
         static const std::string kNA = "NA";
         for (size_t k = todo.size() * t / T; k < todo.size() * (t + 1) / T; ++k) {
             const size_t ri = todo[k];
+            if (print_notes && T == 1) vcf.flush_notes(ri + 1);
             const ReadResult got = vcf.typed(ri, h, rec);
             if (got == ReadResult::kFatal) { fatal[t] = h.failure(); return; }
             if (got != ReadResult::kOk) continue;
@@ -591,11 +594,13 @@ std::string write_annotated_vcf_records(FILE *fv, const VcfText &vcf, const std:
         work(0);
         for (auto &th : pool) th.join();
     }
+    if (print_notes && T > 1) vcf.flush_notes(SIZE_MAX);
     for (size_t t = 0; t < T; ++t) {
         fwrite(outs[t].data(), 1, outs[t].size(), fv);
         if (!fatal[t].empty()) return fatal[t];
     }
-    return "";
+    if (print_notes) vcf.flush_notes(SIZE_MAX);
+    return vcf.fatal;                                                      // (the record behind the last one: load() has met it)
 }
 
 void VcfText::line(size_t i, const char *&p, size_t &len) const {

@@ -50,7 +50,21 @@ struct VcfText {
     size_t first_with_id = (size_t)-1; // first record that carries an ID column: bcf_unpack gives the reader's record its ID buffer there, and a
                                        // later record WITHOUT the column prints that buffer, emptied, where an earlier one prints "." (vcf.c:2012-2018, :2075)
     VcfDictionary hdr;                 // the header as the reference's reader holds it (vcf_rewrite.h)
-    std::string load(const std::string &path);
+    // What the reference's parser says on stderr about the records it reads, each line with the index of the record that draws it (recs.size() = the
+    // record the read loop ends at): names the header does not declare (once per name, vcf.c:1829-1838, 1877-1887, 1908-1919, 1561-1571), sample columns
+    // that do not fit.  load() finds them -- it looks at every record's names -- and the caller prints them where the reference would (flush_notes).
+    std::vector<std::pair<size_t, std::string>> notes;
+    mutable size_t notes_printed = 0;
+    // the first `upto` records' lines that are not out yet (one thread at a time)
+    void flush_notes(size_t upto) const { for (; notes_printed < notes.size() && notes[notes_printed].first < upto; ++notes_printed) fputs(notes[notes_printed].second.c_str(), stderr); }
+    // the record behind the last one ends the PROCESS upstream (exit(1) in the middle of vcf_parse, or abort()): its message, without the '\n'
+    std::string fatal;
+    bool fatal_aborts = false;
+    // load()'s message is what htslib printed before it ended the process itself: 1 = with exit(1), 2 = with abort() (0: the tool's own error path)
+    int death = 0;
+    // annotating = the four INFO lines of the annotated VCF are declared before the records are read (variants_annotator.cc:130-154; `identify`
+    // without -v does not do that, identifier.cc:263-264): a record that carries one of those keys draws no line then
+    std::string load(const std::string &path, bool annotating = true);
     size_t n_lines() const { return line_off.empty() ? 0 : line_off.size() - 1; }
     void line(size_t i, const char *&p, size_t &len) const;
     // record i as typed values (h = a private copy of hdr: names the header does not declare join it)
@@ -61,7 +75,8 @@ struct VcfText {
 // INFO values annot(i) supplies (all nullptr = "NA") -- variants_annotator.cc:130-154, 521-533 through htslib's typed round trip.
 // Returns "" or the message upstream stops with.
 struct VcfAnnot { const std::string *genes, *transcripts, *distances, *annotations; };
-std::string write_annotated_vcf_records(FILE *fv, const VcfText &vcf, const std::vector<size_t> &todo, const std::function<VcfAnnot(size_t)> &annot);
+// print_notes: vcf.notes go to stderr from here, a record's lines in front of what writing it says (the caller prints none of them itself).
+std::string write_annotated_vcf_records(FILE *fv, const VcfText &vcf, const std::vector<size_t> &todo, const std::function<VcfAnnot(size_t)> &annot, bool print_notes = true);
 
 // faidx.c:288-413 (uncompressed FASTA + .fai, the index is built in memory when the file is missing)
 struct Fasta {

@@ -1,6 +1,7 @@
 // vcf_rewrite.cpp -- see vcf_rewrite.h.  Written from the rules of DESIGN.md section 7.1 (H* header, R* record, S* samples, P* printing); the
 // rule a piece of code implements is named next to it.  Host code only.
 #include "vcf_rewrite.h"
+#include <atomic>
 
 #include <cctype>
 #include <climits>
@@ -56,11 +57,11 @@ uint32_t real_bits(double d) { const float f = (float)d; uint32_t u; memcpy(&u, 
 //   depth     the '>' behind a value is counted AGAIN when it follows directly, so after a bare last value the depth is -1, after a quoted one 0;
 //             attributes go on while the depth is not 0 and the line has not ended, one separator byte (whatever it is) skipped in front of each
 //   tail      blanks are skipped; the next line starts one byte further on
-bool VcfDictionary::scan_line(const std::string &s, size_t from, Entry &e, size_t &next) {
+int VcfDictionary::scan_line(const std::string &s, size_t from, Entry &e, size_t &next) {
     const size_t end = s.size();
     auto at = [&](size_t i) -> unsigned char { return i < end ? (unsigned char)s[i] : 0; };
     e = Entry();
-    if (at(from) != '#' || at(from + 1) != '#') { next = from; return false; }
+    if (at(from) != '#' || at(from + 1) != '#') { next = from; return 0; }
     enum State { kTag, kPlain, kGap, kName, kQuoted, kBare, kBehindValue, kTail, kBroken } st = kTag;
     size_t i = from + 2, mark = i;
     int depth = 1;
@@ -70,15 +71,15 @@ bool VcfDictionary::scan_line(const std::string &s, size_t from, Entry &e, size_
         switch (st) {
         case kTag:
             if (c == '=') {
-                if (i == mark) { next = i + 1; return false; }
+                if (i == mark) { next = i + 1; return 0; }
                 e.tag.assign(s, mark, i - mark);
                 ++i;
                 if (at(i) == '<') { e.angle = true; st = kGap; } else { mark = i; st = kPlain; }
-            } else if (!c) { next = i + 1; return false; }
+            } else if (!c) { next = i + 1; return 0; }
             else ++i;
             break;
         case kPlain:
-            if (!c || c == '\n') { e.plain.assign(s, mark, i - mark); next = i + 1; return true; }
+            if (!c || c == '\n') { e.plain.assign(s, mark, i - mark); next = i + 1; return 1; }
             ++i;
             break;
         case kGap:                                                  // on '<' or on the byte between two attributes
@@ -117,12 +118,11 @@ bool VcfDictionary::scan_line(const std::string &s, size_t from, Entry &e, size_
         case kTail:
             while (at(i) == ' ') ++i;
             next = i + 1;
-            return true;
+            return 1;
         case kBroken:
             while (at(i) && at(i) != '\n') ++i;
-            fprintf(stderr, "Could not parse the header line: \"%.*s\"\n", (int)(i - from), s.c_str() + from);
-            next = i + 1;
-            return false;
+            next = i + 1;                                                  // (the caller says so: unscannable())
+            return -1;
         }
     }
 }
@@ -131,7 +131,8 @@ bool VcfDictionary::scan_line(const std::string &s, size_t from, Entry &e, size_
 bool VcfDictionary::claim(std::vector<std::string> &names, int &number, const std::string &name) {
     if (number < 0) number = (int)names.size();
     else if ((size_t)number < names.size() && !names[(size_t)number].empty()) {
-        failure_ = "Conflicting IDX=" + std::to_string(number) + " lines in the header dictionary, the new tag is " + name;
+        // exit(1), vcf.c:349-353 (the message carries __FILE__ upstream: the build's path; the file's name here)
+        fail("[vcf.c:351 bcf_hdr_set_idx] Conflicting IDX=" + std::to_string(number) + " lines in the header dictionary, the new tag is " + name);
         return false;
     }
     if ((size_t)number >= names.size()) names.resize((size_t)number + 1);
@@ -154,7 +155,10 @@ bool VcfDictionary::admit_contig(const Entry &e) {
     const std::string *id = attr_text(e.attrs, "ID", true);
     if (!id || contig_number_.count(*id)) return false;
     int number = -1;
-    if (const std::string *idx = attr_text(e.attrs, "IDX", true)) if (!whole_int(*idx, number)) return false;
+    if (const std::string *idx = attr_text(e.attrs, "IDX", true)) if (!whole_int(*idx, number)) {
+        note("[vcf.c:398 bcf_hdr_register_hrec] Error parsing the IDX tag, skipping.\n");
+        return false;
+    }
     if (!claim(contig_names_, number, *id)) return false;
     contig_number_[*id] = number;
     return true;
@@ -164,12 +168,23 @@ bool VcfDictionary::admit_contig(const Entry &e) {
 bool VcfDictionary::admit_id(const Entry &e, Role role) {
     const std::string *id = nullptr;
     int number = -1, kind = kUndeclared;
-    for (const Attr &a : e.attrs) {
+    bool counted_per_genotype = false;
+    for (const Attr &a : e.attrs) {                                          // (in the line's order: what is said about it comes out in that order, vcf.c:421-461)
         if (a.name == "ID") id = &a.text;
-        else if (a.name == "IDX") { if (!whole_int(a.text, number)) return false; }
-        else if (a.name == "Type") kind = a.text == "Integer" ? kInteger : a.text == "Float" ? kReal : a.text == "Flag" ? kFlag : kText;
+        else if (a.name == "IDX") {
+            if (!whole_int(a.text, number)) { note("[vcf.c:431 bcf_hdr_register_hrec] Error parsing the IDX tag, skipping.\n"); return false; }
+        } else if (a.name == "Type") {
+            if (a.text == "Integer") kind = kInteger;
+            else if (a.text == "Float") kind = kReal;
+            else if (a.text == "Flag") kind = kFlag;
+            else {
+                kind = kText;
+                if (a.text != "String" && a.text != "Character") note("[E::bcf_hdr_register_hrec] The type \"" + a.text + "\" is not supported, assuming \"String\"\n");
+            }
+        } else if (a.name == "Number") counted_per_genotype = a.text == "G";
     }
     if (!id) return false;
+    if (role == kFormat && *id == "PL" && !(ids_.count(*id) && ids_[*id].has[kFormat])) pl_is_per_genotype_ = counted_per_genotype;
     auto known = ids_.find(*id);
     if (known != ids_.end()) {
         if (known->second.has[role]) return false;
@@ -198,9 +213,16 @@ void VcfDictionary::admit(Entry &&e) {
     if (keep) entries_.push_back(std::move(e));
 }
 
+// vcf.c:309
+void VcfDictionary::unscannable(const std::string &s, size_t from, size_t next) {
+    note("Could not parse the header line: \"" + s.substr(from, next - 1 - from) + "\"\n");
+}
+
 bool VcfDictionary::declare(const std::string &line) {
     Entry e; size_t next;
-    if (!scan_line(line, 0, e, next)) return false;
+    const int scanned = scan_line(line, 0, e, next);
+    if (scanned < 0) unscannable(line, 0, next);
+    if (scanned <= 0) return false;
     admit(std::move(e));
     return true;
 }
@@ -214,8 +236,9 @@ void VcfDictionary::read_column_line(const std::string &s, size_t from) {
     cut(Span{s.data() + from, stop - from}, [](char c) { return c == '\t'; }, cols);
     for (size_t k = 9; k < cols.size(); ++k) {
         std::string name = cols[k].str();
-        if (name.empty()) { failure_ = "Empty sample name: trailing spaces/tabs in the header line?"; return; }
-        for (auto &have : samples_) if (have == name) { failure_ = "Duplicated sample name '" + name + "'"; return; }
+        // both end in abort() (vcf.c:64-69, 79-83)
+        if (name.empty()) { fail("[E::bcf_hdr_add_sample] Empty sample name: trailing spaces/tabs in the header line?", true); return; }
+        for (auto &have : samples_) if (have == name) { fail("[E::bcf_hdr_add_sample] Duplicated sample name '" + name + "'", true); return; }
         samples_.push_back(std::move(name));
     }
 }
@@ -223,13 +246,27 @@ void VcfDictionary::read_column_line(const std::string &s, size_t from) {
 // H1, H8
 void VcfDictionary::ingest(const std::string &text) {
     Entry e; size_t next;
-    const bool first_scans = scan_line(text, 0, e, next);
+    const int first_scan = scan_line(text, 0, e, next);
+    const bool first_scans = first_scan > 0;
+    if (first_scan < 0) unscannable(text, 0, next);
     if (!first_scans || strcasecmp(e.tag.c_str(), "fileformat")) fprintf(stderr, "[W::bcf_hdr_parse] The first line should be ##fileformat; is the VCF/BCF header broken?\n");
     if (first_scans) admit(std::move(e));
     declare("##FILTER=<ID=PASS,Description=\"All filters passed\">");          // id number 0, line 2 of what is printed
     size_t at = 0;                                                             // (the first line is met again here, as a repeat)
-    while (at < text.size() && scan_line(text, at, e, next)) { admit(std::move(e)); at = next; }
+    while (failure_.empty() && at < text.size()) {
+        const int scanned = scan_line(text, at, e, next);
+        if (scanned < 0) unscannable(text, at, next);
+        if (scanned <= 0) break;
+        admit(std::move(e)); at = next;
+    }
+    if (!failure_.empty()) return;
     read_column_line(text, at);
+    if (!failure_.empty()) return;
+    // bcf_hdr_check_sanity (vcf.c:564-586): once per process.  (Its GL half looks the name up among the SAMPLES -- vcf.c:577 passes the wrong
+    // dictionary -- and so never fires for a FORMAT id; it is left out.)
+    static std::atomic<bool> pl_warned{false};
+    const Id *pl = find_id("PL");
+    if (pl && pl->has[kFormat] && !pl_is_per_genotype_ && !pl_warned.exchange(true)) note("[W::bcf_hdr_check_sanity] PL should be declared as Number=G\n");
 }
 
 // P1
@@ -251,10 +288,16 @@ void VcfDictionary::render(std::string &out) const {
     out += '\n';
 }
 
+void VcfDictionary::note(const std::string &line) {
+    if (quiet_) return;
+    if (sink_) sink_->push_back(line);
+    else fputs(line.c_str(), stderr);
+}
+
 int VcfDictionary::contig_for(const std::string &name) {
     auto it = contig_number_.find(name);
     if (it == contig_number_.end()) {
-        fprintf(stderr, "[W::vcf_parse] contig '%s' is not defined in the header. (Quick workaround: index the file with tabix.)\n", name.c_str());
+        note("[W::vcf_parse] contig '" + name + "' is not defined in the header. (Quick workaround: index the file with tabix.)\n");
         declare("##contig=<ID=" + name + ">");
         it = contig_number_.find(name);
     }
@@ -265,11 +308,10 @@ VcfDictionary::Id VcfDictionary::id_for(const std::string &name, Role role) {
     const Id *have = find_id(name);
     if (have && (role == kFilter || have->has[role])) return *have;            // R6: a FILTER name may be an id of any role
     if (role == kFilter) {
-        fprintf(stderr, "[W::vcf_parse] FILTER '%s' is not defined in the header\n", name.c_str());
+        note("[W::vcf_parse] FILTER '" + name + "' is not defined in the header\n");
         declare("##FILTER=<ID=" + name + ",Description=\"Dummy\">");
     } else {
-        fprintf(stderr, "[W::%s] %s '%s' is not defined in the header, assuming Type=String\n", role == kInfo ? "vcf_parse" : "_vcf_parse_format",
-                role == kInfo ? "INFO" : "FORMAT", name.c_str());
+        note(std::string(role == kInfo ? "[W::vcf_parse] INFO '" : "[W::_vcf_parse_format] FORMAT '") + name + "' is not defined in the header, assuming Type=String\n");
         declare(std::string(role == kInfo ? "##INFO=<ID=" : "##FORMAT=<ID=") + name + ",Number=1,Type=String,Description=\"Dummy\">");
     }
     have = find_id(name);
@@ -358,7 +400,7 @@ class Tape {
   public:
     size_t add_block(size_t bytes) { const size_t at = (mem_.size() + 7) & ~(size_t)7; mem_.resize(at + bytes, '\0'); return at; }
     void byte(size_t at, char c) { if (at < mem_.size()) mem_[at] = c; }
-    void word(size_t at, uint32_t w) { if (at + 4 <= mem_.size()) memcpy(&mem_[at], &w, 4); }
+    void word(size_t at, uint32_t w) { if (at < mem_.size()) memcpy(&mem_[at], &w, std::min<size_t>(4, mem_.size() - at)); }   // (a number that straddles the end leaves its first bytes)
     const char *at(size_t o) const { return mem_.data() + o; }
   private:
     std::string mem_;
@@ -431,10 +473,17 @@ void write_absent(Tape &tape, const Column &col, size_t sample) {
     for (size_t k = 1; k < col.slot / 4; ++k) tape.word(at + 4 * k, rest);
 }
 
-ReadResult read_samples(VcfDictionary &dict, Span format, Span samples_region, bool have_region, VcfRecord &rec) {
+// "CHROM:POS" the way the reference's messages name a record
+std::string place_of(const VcfDictionary &dict, const VcfRecord &rec) { return dict.contig_name(rec.contig) + ":" + std::to_string((long long)rec.pos0 + 1); }
+
+// The messages below carry __FILE__ and __LINE__ upstream (vcf.c:1553, 1764): the path is the build's, so only the file's name is repeated here.
+ReadResult read_samples(VcfDictionary &dict, Span format, Span samples_region, bool have_region, VcfRecord &rec, bool names_only) {
     const size_t want = dict.n_samples();
     if (!want) return ReadResult::kOk;                                               // S1: a header without samples: the columns are not looked at
-    if (!have_region) { fprintf(stderr, "[vcf_parse] Error: FORMAT column with no sample columns\n"); return ReadResult::kRefused; }
+    if (!have_region) {
+        dict.note("[vcf.c:1553 _vcf_parse_format] Error: FORMAT column with no sample columns starting at " + place_of(dict, rec) + "\n");
+        return ReadResult::kRefused;
+    }
     // S1: the keys
     std::vector<Span> names;
     cut(format.until_nul(), [](char c) { return c == ':'; }, names);
@@ -456,7 +505,7 @@ ReadResult read_samples(VcfDictionary &dict, Span format, Span samples_region, b
     // S3: widths
     for (size_t s = 0; s < have; ++s) {
         cut(all[s], [](char c) { return c == ':'; }, pieces);
-        if (pieces.size() > cols.size()) { dict.fail("Incorrect number of FORMAT fields"); return ReadResult::kFatal; }
+        if (pieces.size() > cols.size()) { dict.fail("Incorrect number of FORMAT fields at " + place_of(dict, rec)); return ReadResult::kFatal; }   // exit(1), vcf.c:1612
         for (size_t j = 0; j < pieces.size(); ++j) {
             Column &c = cols[j];
             long commas1 = 1, alleles = 1;
@@ -471,11 +520,22 @@ ReadResult read_samples(VcfDictionary &dict, Span format, Span samples_region, b
     for (size_t j = 0; j < cols.size(); ++j) {
         Column &c = cols[j];
         if (declared[j] != VcfDictionary::kInteger && declared[j] != VcfDictionary::kReal && declared[j] != VcfDictionary::kText) {
-            dict.fail("the format type is currently not supported"); return ReadResult::kFatal;
+            // (abort(), vcf.c:1638-1639; the number is the declaration's type code: a Flag is 0)
+            // (a declaration without a Type reads as 15 there)
+            dict.fail("[E::_vcf_parse_format] the format type " + std::to_string(declared[j] < 0 ? 15 : declared[j]) + " currently not supported", true);
+            return ReadResult::kFatal;
         }
+        if (names_only) continue;
         c.slot = c.shape == Column::kText ? (size_t)c.chars : 4 * (size_t)(c.shape == Column::kGenotype ? c.alleles : c.commas1 ? c.commas1 : 1);
         c.origin = tape.add_block(c.slot * have);
     }
+    const auto counted = [&]() {
+        if (have == want) return ReadResult::kOk;
+        dict.note("[vcf.c:1764 _vcf_parse_format] Number of columns at " + place_of(dict, rec) + " does not match the number of samples (" + std::to_string(have) + " vs " +
+                  std::to_string(want) + ").\n");
+        return ReadResult::kRefused;
+    };
+    if (names_only) return counted();
     // S5-S7: the values, sample by sample, key by key
     for (size_t s = 0; s < have; ++s) {
         if (all[s].n == 0) continue;                                                  // S7: an empty column writes nothing: its slots stay zero bytes
@@ -502,11 +562,7 @@ ReadResult read_samples(VcfDictionary &dict, Span format, Span samples_region, b
         }
         rec.fields.push_back(std::move(f));
     }
-    if (have != want) {
-        fprintf(stderr, "[vcf_parse] Number of columns does not match the number of samples (%d vs %d).\n", (int)have, (int)want);
-        return ReadResult::kRefused;
-    }
-    return ReadResult::kOk;
+    return counted();
 }
 
 }  // namespace
@@ -514,7 +570,7 @@ ReadResult read_samples(VcfDictionary &dict, Span format, Span samples_region, b
 // =================================================================================================================================================
 // a text line -> record (R1-R11)
 // =================================================================================================================================================
-ReadResult read_text_record(VcfDictionary &dict, const char *line, size_t len, VcfRecord &rec) {
+ReadResult read_text_record(VcfDictionary &dict, const char *line, size_t len, VcfRecord &rec, bool names_only) {
     rec = VcfRecord();
     std::vector<Span> col;
     cut(Span{line, len}, [](char c) { return c == '\t'; }, col);
@@ -526,13 +582,13 @@ ReadResult read_text_record(VcfDictionary &dict, const char *line, size_t len, V
         rec.past_pos = true;
         if (!col[2].until_nul().is(".")) rec.id = col[2].str();                       // (kept whole: printing stops at a NUL byte, P2)
     }
-    if (col.size() > 3) rec.alleles.push_back(col[3].str());                          // R4
-    if (col.size() > 4 && !col[4].until_nul().is(".")) {                              // R4: ALT is cut at commas -- and at NUL bytes
+    if (col.size() > 3 && !names_only) rec.alleles.push_back(col[3].str());           // R4
+    if (col.size() > 4 && !names_only && !col[4].until_nul().is(".")) {                              // R4: ALT is cut at commas -- and at NUL bytes
         std::vector<Span> alts;
         cut(col[4], [](char c) { return c == ',' || c == 0; }, alts);
         for (Span a : alts) rec.alleles.push_back(a.str());
     }
-    if (col.size() > 5) {                                                             // R5
+    if (col.size() > 5 && !names_only) {                                              // R5
         const std::string q = col[5].until_nul().str();
         if (q != ".") rec.qual = real_bits(atof(q.c_str()));
     }
@@ -551,6 +607,7 @@ ReadResult read_text_record(VcfDictionary &dict, const char *line, size_t len, V
             const Span key{it.p, eq ? (size_t)(eq - it.p) : it.n};
             if (!key.n) continue;                                                     // ";;", "=x"
             const VcfDictionary::Id id = dict.id_for(key.str(), VcfDictionary::kInfo);
+            if (names_only) continue;
             VcfRecord::Tagged t; t.key = id.number;
             if (eq) {                                                                 // R7: without '=' there is no value, whatever the type
                 const Span val{eq + 1, it.n - key.n - 1};
@@ -565,7 +622,7 @@ ReadResult read_text_record(VcfDictionary &dict, const char *line, size_t len, V
     if (col.size() > 8) {                                                             // R11
         const bool have_region = col.size() > 9;
         const Span region = have_region ? Span{col[9].p, (size_t)(line + len - col[9].p)} : Span{};
-        return read_samples(dict, col[8], region, have_region, rec);
+        return read_samples(dict, col[8], region, have_region, rec, names_only);
     }
     return ReadResult::kOk;
 }
@@ -729,7 +786,7 @@ void print_genotype(std::string &out, const VcfValue &v, size_t from, int count)
 bool write_text_record(const VcfDictionary &dict, const VcfRecord &rec, std::string &out) {
     const long pos = (int32_t)((uint32_t)rec.pos0 + 1u);
     if ((int)dict.n_samples() != rec.n_samples) {                                     // P7
-        fprintf(stderr, "[bcf_write] Broken VCF record, the number of columns at %s:%d does not match the number of samples (%d vs %d).\n",
+        fprintf(stderr, "[vcf.c:1207 bcf_write] Broken VCF record, the number of columns at %s:%d does not match the number of samples (%d vs %d).\n",
                 dict.contig_name(rec.contig).c_str(), (int)pos, rec.n_samples, (int)dict.n_samples());
         return false;
     }

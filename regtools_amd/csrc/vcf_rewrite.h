@@ -32,7 +32,13 @@ class VcfDictionary {
     bool declare(const std::string &line);
     void render(std::string &out) const;
     const std::string &failure() const { return failure_; }
-    void fail(const std::string &why) { failure_ = why; }
+    bool failure_aborts() const { return failure_aborts_; }              // the reference ends in abort() there, not in exit(1)
+    void fail(const std::string &why, bool aborts = false) { failure_ = why; failure_aborts_ = aborts; }
+    // What the reference's parser writes to stderr about a record (a name the header does not declare, sample columns that do not fit) goes to
+    // stderr here too -- or into `sink`, one line per entry, for a caller that prints it where the reference would; quiet = nowhere.
+    void notes_to(std::vector<std::string> *sink) { sink_ = sink; quiet_ = false; }
+    void silence() { sink_ = nullptr; quiet_ = true; }
+    void note(const std::string &line);
 
     size_t n_samples() const { return samples_.size(); }
     bool knows_contig(const std::string &name) const { return contig_number_.count(name) != 0; }
@@ -54,7 +60,8 @@ class VcfDictionary {
         std::vector<Attr> attrs;
         Class cls = kGeneric;
     };
-    static bool scan_line(const std::string &s, size_t from, Entry &e, size_t &next);
+    static int scan_line(const std::string &s, size_t from, Entry &e, size_t &next);      // 1: scanned, 0: not a "##" line, -1: one that does not scan
+    void unscannable(const std::string &s, size_t from, size_t next);
     void admit(Entry &&e);
     bool admit_contig(const Entry &e);
     bool admit_id(const Entry &e, Role role);
@@ -72,6 +79,10 @@ class VcfDictionary {
     std::vector<std::string> contig_names_;
     std::vector<std::string> samples_;
     std::string failure_;
+    bool failure_aborts_ = false;
+    bool pl_is_per_genotype_ = false;                             // the FORMAT declaration of PL says Number=G
+    std::vector<std::string> *sink_ = nullptr;
+    bool quiet_ = false;
 };
 
 // ---- one record ------------------------------------------------------------------------------------------------------------------------------
@@ -103,8 +114,9 @@ struct VcfRecord {
 
 enum class ReadResult { kOk, kRefused /* the reference's reader stops at this record */, kFatal /* dict.failure() says why */ };
 
-// one text line without its '\n'
-ReadResult read_text_record(VcfDictionary &dict, const char *line, size_t len, VcfRecord &rec);
+// one text line without its '\n'.  names_only: what the reference's parser would SAY about the line and whether it reads it (the names the line uses, the
+// shape of its sample columns) without converting a value -- rec is not usable afterwards.
+ReadResult read_text_record(VcfDictionary &dict, const char *line, size_t len, VcfRecord &rec, bool names_only = false);
 // p = the record's first byte (its two length words), avail = bytes readable.  Returns the record's size, 0 when it is cut short or damaged.
 size_t read_bcf_record(const uint8_t *p, size_t avail, VcfRecord &rec);
 // R12: the INFO entry `key` becomes the text `value` where it stands, or is appended.  false = the header declares no such INFO id.

@@ -150,17 +150,19 @@ extern "C" long emu_scan_members(const uint8_t *bam, size_t n, int threads, uint
 // the annotated-VCF writer (cse_host.cpp write_annotated_vcf_records over vcf_rewrite.cpp) with "NA" for every record: what
 // `variants annotate` writes when no transcript is near any variant.  Returns 0, 1 = load error (message in err), 2 = writer error.
 #include "../../regtools_amd/csrc/cse_host.h"
+// returns 0, or how the reference's process ends: 1 = through the tool's own error path (message, status 1); 4 / 5 = htslib ends it while the header is read,
+// with exit(1) / abort(); 2 / 3 = the same at a record (what was written in front of it is in the file)
 extern "C" int emu_vcf_rewrite(const char *in_path, const char *out_path, char *err, size_t errlen) {
     rgx::VcfText vcf;
     std::string e = vcf.load(in_path);
-    if (!e.empty()) { snprintf(err, errlen, "%s", e.c_str()); return 1; }
+    if (!e.empty()) { snprintf(err, errlen, "%s", e.c_str()); return vcf.death == 2 ? 5 : vcf.death == 1 ? 4 : 1; }
     FILE *f = fopen(out_path, "w");
     if (!f) return 2;
     std::vector<size_t> todo(vcf.recs.size());
     for (size_t i = 0; i < todo.size(); ++i) todo[i] = i;
     e = rgx::write_annotated_vcf_records(f, vcf, todo, [](size_t) { return rgx::VcfAnnot{nullptr, nullptr, nullptr, nullptr}; });
     fclose(f);
-    if (!e.empty()) { snprintf(err, errlen, "%s", e.c_str()); return 2; }
+    if (!e.empty()) { snprintf(err, errlen, "%s", e.c_str()); return vcf.fatal_aborts ? 3 : 2; }
     return 0;
 }
 

@@ -76,6 +76,49 @@ def valid_cases(td):
             ["cis-splice-effects", "associate", "-w", "500", "-o", o("ca2.tsv"), VCF, BED, FA, GTF]]
 
 
+def vcf_note_cases(td):
+    """The test VCF with records that make htslib talk or end the process (vcf.c: undeclared names once per name, sample columns that do not fit,
+    exit(1) on a sample with too many fields, abort() on a Flag in FORMAT), through the tool: (argument list, expected status)."""
+    lines = open(VCF).read().split("\n")
+    first = next(k for k, l in enumerate(lines) if l and not l.startswith("#"))
+    head, recs = lines[:first], [l for l in lines[first:] if l]
+
+    def variant(name, edit, extra_header=()):
+        r = [l.split("\t") for l in recs]
+        edit(r)
+        path = os.path.join(td, name + ".vcf")
+        open(path, "w").write("\n".join(head[:-1] + list(extra_header) + head[-1:] + ["\t".join(x) for x in r]) + "\n")
+        return path
+
+    def names(r):                              # undeclared names on records of both kinds (splice relevant or not), a repeat, the four annotation keys
+        r[0][7] += ";NEW1=5"; r[0][6] = "lowq"; r[2][7] += ";NEW1=6;NEW2"; r[4][7] = "genes=G;" + r[4][7]; r[7][0] = "23"; r[9][8] += ":ZZ"; r[9][9] += ":1"; r[9][10] += ":2"
+        r[12][7] += ";NEW3=x"; r[12][6] = "lowq;q10"
+
+    def short(r): names(r); r[10] = r[10][:10]                      # one sample column short: the read loop ends there
+    def many(r): names(r); r[10][9] += ":7:8"                       # more fields than FORMAT has keys: exit(1) inside htslib
+    def many_early(r): r[0][9] += ":7:8"
+    def flag(r): names(r); r[10][8] += ":FL"; r[10][9] += ":1"; r[10][10] += ":1"     # a Flag among the FORMAT keys: abort() inside htslib
+
+    o = lambda n: os.path.join(td, n)
+    fl = ['##FORMAT=<ID=FL,Number=0,Type=Flag,Description="a flag">']
+    v_names, v_short, v_many, v_early, v_flag = (variant("names", names), variant("short", short), variant("many", many), variant("many_early", many_early),
+                                                 variant("flag", flag, fl))
+    ident = ["cis-splice-effects", "identify", "-s", "XS"]
+    return [(["variants", "annotate", "-o", o("n1.vcf"), v_names, GTF], 0), (["variants", "annotate", "-o", o("n2.vcf"), v_short, GTF], 0),
+            (["variants", "annotate", "-o", o("n3.vcf"), v_many, GTF], 1), (["variants", "annotate", "-o", o("n4.vcf"), v_flag, GTF], -6),
+            (ident + ["-o", o("i1.tsv"), "-v", o("i1.vcf"), v_names, BAM, FA, GTF], 0), (ident + ["-o", o("i2.tsv"), v_names, BAM, FA, GTF], 0),
+            (ident + ["-o", o("i3.tsv"), "-v", o("i3.vcf"), v_short, BAM, FA, GTF], 0), (ident + ["-o", o("i4.tsv"), "-v", o("i4.vcf"), v_many, BAM, FA, GTF], 1),
+            (ident + ["-o", o("i5.tsv"), v_flag, BAM, FA, GTF], -6), (ident + ["-o", o("i6.tsv"), v_early, BAM, FA, GTF], 1),
+            (["cis-splice-effects", "associate", "-o", o("a1.tsv"), "-v", o("a1.vcf"), v_names, BED, FA, GTF], 0),
+            (["cis-splice-effects", "associate", "-o", o("a2.tsv"), v_many, BED, FA, GTF], 1)]
+
+
+def normalise_streams(b, td):
+    """paths of this checkout and of the temporary directory; htslib's __FILE__ in front of "vcf.c:<line>" (the build's path upstream, nothing here)"""
+    import re
+    return re.sub(rb"\[[^\] ]*/(vcf\.c:\d+ )", rb"[\1", b.replace(ROOT.encode(), b"@ROOT@").replace(td.encode(), b"@TMP@"))
+
+
 def case_id(argv):
     return " ".join(os.path.basename(a) for a in argv) or "(none)"
 
@@ -145,3 +188,22 @@ def test_stderr_of_runs_that_go_all_the_way(built, tmp_path):
         assert r.returncode == want["rc"] == 0, (argv, r.returncode, r.stderr[-300:])
         assert fix(r.stdout) == want["stdout"].encode("latin-1"), argv
         assert fix(r.stderr) == want["stderr"].encode("latin-1"), (argv, fix(r.stderr)[-400:])
+
+
+@pytest.mark.gpu
+def test_what_htslib_says_about_a_vcf_and_where_it_ends_the_process(built, tmp_path):
+    """htslib talks while the reference reads a VCF -- a line for every name the header does not declare, once per name, between the "Variant" blocks of
+    `cis-splice-effects`; a line for the record whose sample columns do not fit, where reading stops -- and on two kinds of record it ends the process
+    itself, past regtools' handlers: exit(1) behind "Incorrect number of FORMAT fields at ...", abort() behind "the format type 0 currently not supported".
+    Streams and status are the reference's (tests/golden/cli/cli_vcf_notes_streams.json), and so are the files of the runs that complete."""
+    gold = json.load(open(os.path.join(GOLD, "cli", "cli_vcf_notes_streams.json")))
+    td = str(tmp_path)
+    for argv, status in vcf_note_cases(td):
+        want = gold[case_id(argv)]
+        r = subprocess.run([EXE] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == want["rc"] == status, (argv, r.returncode, r.stderr[-300:])
+        assert normalise_streams(r.stdout, td) == want["stdout"].encode("latin-1"), argv
+        assert normalise_streams(r.stderr, td) == want["stderr"].encode("latin-1"), (argv, normalise_streams(r.stderr, td)[-600:])
+        if status == 0:
+            for path, text in want["files"].items():
+                assert open(os.path.join(td, path), "rb").read() == text.encode("latin-1"), (argv, path)

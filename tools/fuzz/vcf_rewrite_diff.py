@@ -81,9 +81,9 @@ with tempfile.TemporaryDirectory() as td:
             continue                                                   # the reference hung or died of a signal: nothing to compare with
         if (rc_new != 0) != (rc_o != 0) or (rc_new == 0 and out_new != out_o):
             bad += 1
-            if bad <= 5:
-                keep = os.path.join(tempfile.gettempdir(), "vcf_diff_%s_%d_%d.vcf" % (mode, seed, k))
-                open(keep, "wb").write(data)
+            if bad <= 40:                                              # (the first five inputs are kept, the first forty differences shown)
+                keep = os.path.join(tempfile.gettempdir(), "vcf_diff_%s_%d_%d.vcf" % (mode, seed, k)) if bad <= 5 or os.environ.get("KEEP_ALL") else None
+                if keep: open(keep, "wb").write(data)
                 print("DIFF case", k, "rc", rc_new, rc_o, "kept", keep)
                 a, b = out_new.split(b"\n"), out_o.split(b"\n")
                 for i in range(max(len(a), len(b))):
