@@ -10,6 +10,7 @@ extern "C" int rgx_extract_device(rgx_ctx *ctx, const void *d_bam, size_t bam_le
 extern "C" int rgx_extract_mem(rgx_ctx *ctx, const void *bam, size_t bam_len, const void *bai, size_t bai_len, const rgx_extract_params *p,
                                rgx_junction_table **out, char *err, size_t errlen) {
     if (!ctx || !bam || !out) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
+    fputs(bam_open_notes((const uint8_t *)bam, bam_len, nullptr, nullptr).c_str(), stderr);         // (a file without its EOF member: bam_hdr_read says so)
     return run_pipeline(ctx, nullptr, (const uint8_t *)bam, bam_len, (const uint8_t *)bai, bai_len, p, out, err, errlen);
 }
 
@@ -31,9 +32,11 @@ extern "C" void rgx_host_free(void *p) { if (p) (void)hipHostFree(p); }
 extern "C" int rgx_extract(rgx_ctx *ctx, const char *bam_path, const rgx_extract_params *p, rgx_junction_table **out, char *err, size_t errlen) {
     if (!ctx || !bam_path || !out) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
     FileBytes bam; std::vector<uint8_t> bai;
-    if (!bam.open(bam_path)) return fail(err, errlen, RGX_ERR_OPEN, "%s", kMsgOpen);
+    // (hts_open_format's line in front of regtools' own, hts.c:408-411)
+    if (!bam.open(bam_path)) return fail(err, errlen, RGX_ERR_OPEN, "[E::hts_open_format] fail to open file '%s'\n%s", bam_path, kMsgOpen);
     std::string idx;
     int r = find_index(bam_path, idx);
+    fputs(bam_open_notes(bam.data(), bam.size(), r == 0 ? bam_path : nullptr, r == 0 ? idx.c_str() : nullptr).c_str(), stderr);
     if (r != 0 || !read_index(idx, bai)) return fail(err, errlen, RGX_ERR_INDEX, "%s", kMsgIndex);
     return run_pipeline(ctx, nullptr, bam.data(), bam.size(), bai.data(), bai.size(), p, out, err, errlen);
 }

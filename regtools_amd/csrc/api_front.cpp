@@ -348,7 +348,8 @@ int EventsRun::stage_members() {
         if (!head) { head_copy.resize(head_len); HIP_TRY(hipMemcpy(head_copy.data(), d_bam, head_len, hipMemcpyDeviceToHost)); head = head_copy.data(); }
         BamHeader hh;
         int32_t tid = -1, beg = 0, end = 0;
-        if (host_bam_header(head, head_len, hh) && parse_region(hh, p->region, tid, beg, end) && tid < bi.n_ref && end >= beg &&
+        // (the one parse of a call that talks: what sam_itr_querys -> hts_parse_decimal says about the region's numbers, once per query)
+        if (host_bam_header(head, head_len, hh) && parse_region(hh, p->region, tid, beg, end, /*say=*/p->n_shards <= 1 || p->shard == 0) && tid < bi.n_ref && end >= beg &&
             region_chunks(bai, bai_len, tid, beg, end, chunks)) {
             chunked = true;
             if (p->n_shards > 1) {

@@ -890,6 +890,9 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
 
     // ---- identify: the extraction, ONCE for all windows (the reference re-opens the BAM per variant: identifier.cc:288-290) ----
     FileBytes bam; std::vector<uint8_t> bai;
+    // what htslib says when the BAM and its index are opened (no EOF member, an index older than the file): upstream opens both once per splice-relevant
+    // variant, behind the variant's echo (identifier.cc:288-289)
+    std::string bam_notes;
     Prep P;
     int rc_bam = RGX_OK;
     char err_bam[512]; err_bam[0] = 0;
@@ -900,7 +903,10 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
         ep.fasta_path = (p->override_motif || p->strandness == 3) ? p->fasta_path : nullptr;   // ref_to_pass (identifier.cc:282-287)
         std::string idx;
         if (!bam.open(p->bam_path)) rc_bam = fail(err_bam, sizeof err_bam, RGX_ERR_OPEN, "%s", kMsgOpen);
-        else if (find_index(p->bam_path, idx) != 0 || !read_index(idx, bai)) rc_bam = fail(err_bam, sizeof err_bam, RGX_ERR_INDEX, "%s", kMsgIndex);
+        else if (find_index(p->bam_path, idx) != 0) { bam_notes = bam_open_notes(bam.data(), bam.size(), nullptr, nullptr);
+            rc_bam = fail(err_bam, sizeof err_bam, RGX_ERR_INDEX, "%s", kMsgIndex); }
+        else if (bam_notes = bam_open_notes(bam.data(), bam.size(), p->bam_path, idx.c_str()), !read_index(idx, bai)) rc_bam = fail(err_bam, sizeof err_bam,
+            RGX_ERR_INDEX, "%s", kMsgIndex);
         else if (shards && shards->size() > 1) rc_bam = prepare_events_sharded(*shards, bam.data(), bam.size(), bai.data(), bai.size(), &ep, P, err_bam,
             sizeof err_bam);
         else rc_bam = prepare_events(c, nullptr, bam.data(), bam.size(), bai.data(), bai.size(), &ep, true, P, err_bam, sizeof err_bam);
@@ -947,7 +953,11 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
     // "Variant" lines: upstream reads, annotates and echoes one record after the other (identifier.cc:267-277).
     auto echo_variants = [&](size_t upto) {
         const bool all = upto >= relevant.size();
-        if (!p->echo) { vcf.flush_notes(all ? SIZE_MAX : relevant[upto - 1] + 1); return; }
+        if (!p->echo) {                                                    // (a library caller: the records' lines, and the BAM's once)
+            vcf.flush_notes(all ? SIZE_MAX : relevant[upto - 1] + 1);
+            if (upto && !relevant.empty()) fputs(bam_notes.c_str(), stderr);
+            return;
+        }
         std::string s;
         s.reserve(std::min(upto, relevant.size()) * 72);
         for (size_t w = 0; w < upto && w < relevant.size(); ++w) {
@@ -961,6 +971,7 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
             s += "Variant "; s += vcf.recs[i].chrom; s += '\t'; put_u(s, start); s += '\t'; put_u(s, end); s += '\t';
             if (H.last[i] == 0xffffffffu) s += "-1"; else put_u(s, H.last[i]);
             s += "\t\t\nVariant region is "; s += vcf.recs[i].chrom; s += ':'; put_u(s, rs); s += '-'; put_u(s, re); s += "\n\n";
+            s += bam_notes;
         }
         fwrite(s.data(), 1, s.size(), stderr);
         if (all) vcf.flush_notes(SIZE_MAX);

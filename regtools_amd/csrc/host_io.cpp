@@ -368,6 +368,21 @@ static bool idx_name(const std::string &fn, const char *ext, std::string &out) {
 
 bool find_tbi(const std::string &path, std::string &out) { return idx_name(path, ".tbi", out); }       // hts_idx_getfn, as for the BAM indexes
 
+// What htslib says when a BAM and its index are opened (stderr, default verbosity): the file does not end in the empty BGZF member
+// (bam_hdr_read -> bgzf_check_EOF, sam.c:122-127, bgzf.c:835-846); the index is older than the file (hts_idx_load2, hts.c:2046-2054: whole seconds).
+std::string bam_open_notes(const uint8_t *bam, size_t len, const char *bam_path, const char *index_path) {
+    static const uint8_t kEof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    std::string s;
+    if (bam) {
+        if (len < 28) s += "[W::bam_hdr_read] bgzf_check_EOF: Invalid argument\n";            // (perror: the seek to 28 bytes before the end fails)
+        else if (memcmp(bam + len - 28, kEof, 28)) s += "[W::bam_hdr_read] EOF marker is absent. The input is probably truncated.\n";
+    }
+    struct stat sb, si;
+    if (bam_path && index_path && !stat(bam_path, &sb) && !stat(index_path, &si) && si.st_mtime < sb.st_mtime)
+        s += std::string("Warning: The index file is older than the data file: ") + index_path + "\n";
+    return s;
+}
+
 int find_index(const std::string &bam_path, std::string &out) {      // hts_idx_load: <fn>.csi, <stem>.csi, <fn>.bai, <stem>.bai (hts.c:2031-2042)
     if (idx_name(bam_path, ".csi", out)) return 0;
     if (idx_name(bam_path, ".bai", out)) return 0;
@@ -561,8 +576,9 @@ int parse_bam_header(const uint8_t *d, uint64_t have, BamHeader &h, uint64_t &ne
     return 0;
 }
 
-static long long parse_decimal(const char *str, const char **end) {
-    long long n = 0; int decimals = 0, e = 0; char sign = '+', esign = '+';
+// (say: the two lines hts_parse_decimal writes to stderr at htslib's default verbosity, hts.c:1865-1872)
+static long long parse_decimal(const char *str, const char **end, bool say) {
+    long long n = 0; int decimals = 0, e = 0, lost = 0; char sign = '+', esign = '+';
     while (isspace((unsigned char)*str)) str++;
     const char *s = str;
     if (*s == '+' || *s == '-') sign = *s++;
@@ -580,8 +596,10 @@ static long long parse_decimal(const char *str, const char **end) {
     }
     e -= decimals;
     while (e > 0) { n *= 10; e--; }
-    while (e < 0) { n /= 10; e++; }
+    while (e < 0) { lost += (int)(n % 10); n /= 10; e++; }
+    if (say && lost > 0) fprintf(stderr, "[W::hts_parse_decimal] discarding fractional part of %.*s\n", (int)(s - str), str);
     if (end) *end = s;
+    else if (say && *s) fprintf(stderr, "[W::hts_parse_decimal] ignoring unknown characters after %.*s[%s]\n", (int)(s - str), str, s);
     return sign == '+' ? n : -n;
 }
 
@@ -591,16 +609,16 @@ static int name2id(const BamHeader &h, const std::string &name) {
     return id;
 }
 
-bool parse_region(const BamHeader &h, const char *reg, int32_t &tid, int32_t &beg, int32_t &end) {
+bool parse_region(const BamHeader &h, const char *reg, int32_t &tid, int32_t &beg, int32_t &end, bool say) {
     const char *colon = strrchr(reg, ':');
     bool parsed = false;
     if (!colon) { beg = 0; end = INT_MAX; parsed = true; colon = reg + strlen(reg); }
     else {
         const char *hy;
-        beg = (int32_t)(parse_decimal(colon + 1, &hy) - 1);
+        beg = (int32_t)(parse_decimal(colon + 1, &hy, say) - 1);
         if (beg < 0) beg = 0;
         if (*hy == '\0') { end = INT_MAX; parsed = true; }
-        else if (*hy == '-') { end = (int32_t)parse_decimal(hy + 1, nullptr); parsed = true; }
+        else if (*hy == '-') { end = (int32_t)parse_decimal(hy + 1, nullptr, say); parsed = true; }
         if (parsed && beg >= end) parsed = false;
     }
     if (parsed) tid = name2id(h, std::string(reg, (size_t)(colon - reg)));

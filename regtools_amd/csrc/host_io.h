@@ -103,6 +103,8 @@ int parse_bam_header(const uint8_t *d, uint64_t have, BamHeader &h, uint64_t &ne
 
 // hts.c:1834-1922 hts_parse_decimal / hts_parse_reg / hts_itr_querys (+ sam.c:262-277 bam_name2id, last duplicate wins).
 // returns false when the reference's iterator would be NULL.
-bool parse_region(const BamHeader &h, const char *reg, int32_t &tid, int32_t &beg, int32_t &end);
+// say: hts_parse_decimal's two warnings go to stderr (one call per query upstream: the caller that stands for it passes true)
+bool parse_region(const BamHeader &h, const char *reg, int32_t &tid, int32_t &beg, int32_t &end, bool say = false);
+std::string bam_open_notes(const uint8_t *bam, size_t len, const char *bam_path, const char *index_path);
 
 }  // namespace rgx

@@ -395,9 +395,11 @@ extern "C" int rgx_extract_multi(const int *devices, int n_devices, const char *
                                  char *err, size_t errlen) {
     if (!bam_path || !out) return failm(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
     FileBytes bam; std::vector<uint8_t> bai;
-    if (!bam.open(bam_path)) return failm(err, errlen, RGX_ERR_OPEN, "Unable to open BAM/SAM file.\n\n");
+    if (!bam.open(bam_path)) return failm(err, errlen, RGX_ERR_OPEN, "[E::hts_open_format] fail to open file '%s'\nUnable to open BAM/SAM file.\n\n", bam_path);
     std::string idx;
-    if (find_index(bam_path, idx) != 0 || !read_index(idx, bai)) return failm(err, errlen, RGX_ERR_INDEX,
+    const bool have_index = find_index(bam_path, idx) == 0;
+    fputs(bam_open_notes(bam.data(), bam.size(), have_index ? bam_path : nullptr, have_index ? idx.c_str() : nullptr).c_str(), stderr);
+    if (!have_index || !read_index(idx, bai)) return failm(err, errlen, RGX_ERR_INDEX,
         "Unable to open BAM/SAM index. Make sure alignments are indexed\n\n");
     return rgx_extract_multi_mem(devices, n_devices, bam.data(), bam.size(), bai.data(), bai.size(), p, out, err, errlen);
 }

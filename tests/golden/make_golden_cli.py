@@ -47,10 +47,10 @@ print("%d complete runs recorded" % len(va))
 # round 6: what htslib says about a VCF and where it ends the process (tests/test_cli_contract.py vcf_note_cases)
 vn = {}
 with tempfile.TemporaryDirectory() as td:
-    for argv, status in t.vcf_note_cases(td):
+    for argv, status in t.vcf_note_cases(td) + t.bam_note_cases(td):
         r = subprocess.run([t.REF] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         assert r.returncode == status, (argv, r.returncode, r.stderr[-300:])
-        outs = [a for a in argv if a.startswith(td) and os.path.basename(a)[0] in "nia" and os.path.basename(a)[1].isdigit()]
+        outs = [a for a in argv if a.startswith(td) and os.path.basename(a)[0] in "niab" and os.path.basename(a)[1].isdigit()]
         vn[t.case_id(argv)] = {"rc": r.returncode, "stdout": t.normalise_streams(r.stdout, td).decode("latin-1"), "stderr": t.normalise_streams(r.stderr, td).decode("latin-1"),
                                "files": {os.path.basename(a): open(a, "rb").read().decode("latin-1") for a in outs} if status == 0 else {}}
 json.dump(vn, open(os.path.join(HERE, "cli", "cli_vcf_notes_streams.json"), "w"), indent=1, sort_keys=True)

@@ -113,6 +113,26 @@ def vcf_note_cases(td):
             (["cis-splice-effects", "associate", "-o", o("a2.tsv"), v_many, BED, FA, GTF], 1)]
 
 
+def bam_note_cases(td):
+    """what htslib says when a BAM and its index are opened and a region string is read (sam.c:122-127 no EOF member; hts.c:2046-2054 an index older than its
+    file; hts.c:1865-1872 the numbers of -r; hts.c:408-411 a file that is not there): (argument list, expected status)"""
+    import shutil
+    o = lambda n: os.path.join(td, n)
+    old, cut = o("old_index.bam"), o("no_eof.bam")
+    shutil.copy(BAM, old); shutil.copy(BAM + ".bai", old + ".bai")
+    os.utime(old + ".bai", (1500000000, 1500000000))
+    data = open(BAM, "rb").read()
+    assert data[-28:-16] == bytes.fromhex("1f8b08040000000000ff0600")
+    open(cut, "wb").write(data[:-28]); shutil.copy(BAM + ".bai", cut + ".bai")
+    os.utime(cut, (1500000000, 1500000000))                                    # (the copy's index is not the older one)
+    je = ["junctions", "extract", "-s", "XS"]
+    ident = ["cis-splice-effects", "identify", "-s", "XS"]
+    return [(je + ["-o", o("b1.bed"), cut], 0), (je + ["-o", o("b2.bed"), old], 0), (je + ["-o", o("b3.bed"), "-r", "22:1-100000.5", BAM], 0),
+            (je + ["-o", o("b4.bed"), "-r", "22:1-100000x", BAM], 0), (je + ["-o", o("b5.bed"), "-r", "22:1.55e1-1e5", BAM], 0),
+            (je + ["-o", o("b6.bed"), "-r", "22:1,000-200,000", BAM], 0), (je + ["-o", o("b7.bed"), o("not_there.bam")], 1),
+            (ident + ["-o", o("b8.tsv"), VCF, cut, FA, GTF], 0), (ident + ["-o", o("b9.tsv"), "-v", o("b9.vcf"), VCF, old, FA, GTF], 0)]
+
+
 def normalise_streams(b, td):
     """paths of this checkout and of the temporary directory; htslib's __FILE__ in front of "vcf.c:<line>" (the build's path upstream, nothing here)"""
     import re
@@ -195,10 +215,12 @@ def test_what_htslib_says_about_a_vcf_and_where_it_ends_the_process(built, tmp_p
     """htslib talks while the reference reads a VCF -- a line for every name the header does not declare, once per name, between the "Variant" blocks of
     `cis-splice-effects`; a line for the record whose sample columns do not fit, where reading stops -- and on two kinds of record it ends the process
     itself, past regtools' handlers: exit(1) behind "Incorrect number of FORMAT fields at ...", abort() behind "the format type 0 currently not supported".
+    The same for a BAM: no EOF member, an index older than its file (both said again for every splice-relevant variant of `identify`, which opens the BAM per
+    variant upstream), numbers in -r that lose digits or drag letters along, a file that is not there.
     Streams and status are the reference's (tests/golden/cli/cli_vcf_notes_streams.json), and so are the files of the runs that complete."""
     gold = json.load(open(os.path.join(GOLD, "cli", "cli_vcf_notes_streams.json")))
     td = str(tmp_path)
-    for argv, status in vcf_note_cases(td):
+    for argv, status in vcf_note_cases(td) + bam_note_cases(td):
         want = gold[case_id(argv)]
         r = subprocess.run([EXE] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         assert r.returncode == want["rc"] == status, (argv, r.returncode, r.stderr[-300:])
