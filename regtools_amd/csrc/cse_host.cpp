@@ -451,7 +451,13 @@ std::string VcfText::load(const std::string &path, bool annotating) {
         // cannot be read is no index (tbx_index_load returns NULL).
         std::string tbi_path;
         std::vector<uint8_t> raw;
-        if (find_tbi(path, tbi_path) && read_file(tbi_path, raw)) {
+        const bool have_tbi = find_tbi(path, tbi_path);
+        if (have_tbi) {                                            // hts_idx_load2 (hts.c:2046-2054), as for a BAM's index
+            struct stat sm, si;
+            if (!stat(path.c_str(), &sm) && !stat(tbi_path.c_str(), &si) && si.st_mtime < sm.st_mtime)
+                fprintf(stderr, "Warning: The index file is older than the data file: %s\n", tbi_path.c_str());
+        }
+        if (have_tbi && read_file(tbi_path, raw)) {
             std::string idx;
             const uint8_t *d = raw.data(); size_t n = raw.size();
             if (n >= 2 && d[0] == 0x1f && d[1] == 0x8b) { if (gunzip_all(d, n, idx).empty()) { d = (const uint8_t *)idx.data(); n = idx.size(); } else n = 0; }

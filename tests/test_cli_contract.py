@@ -125,9 +125,14 @@ def bam_note_cases(td):
     assert data[-28:-16] == bytes.fromhex("1f8b08040000000000ff0600")
     open(cut, "wb").write(data[:-28]); shutil.copy(BAM + ".bai", cut + ".bai")
     os.utime(cut, (1500000000, 1500000000))                                    # (the copy's index is not the older one)
+    import vcf_cases                                                           # a VCF with a tabix index next to it, the index the older file
+    with_tbi = o("with_tbi.vcf")
+    open(with_tbi, "wb").write(vcf_cases.build(td)["tbi_with_bins"])
+    for suffix, blob in vcf_cases.companions()["tbi_with_bins"].items(): open(with_tbi[:-4] + suffix, "wb").write(blob)
+    for suffix in vcf_cases.companions()["tbi_with_bins"]: os.utime(with_tbi[:-4] + suffix, (1500000000, 1500000000))
     je = ["junctions", "extract", "-s", "XS"]
     ident = ["cis-splice-effects", "identify", "-s", "XS"]
-    return [(je + ["-o", o("b1.bed"), cut], 0), (je + ["-o", o("b2.bed"), old], 0), (je + ["-o", o("b3.bed"), "-r", "22:1-100000.5", BAM], 0),
+    return [(["variants", "annotate", "-o", o("b0.vcf"), with_tbi, GTF], 0), (je + ["-o", o("b1.bed"), cut], 0), (je + ["-o", o("b2.bed"), old], 0), (je + ["-o", o("b3.bed"), "-r", "22:1-100000.5", BAM], 0),
             (je + ["-o", o("b4.bed"), "-r", "22:1-100000x", BAM], 0), (je + ["-o", o("b5.bed"), "-r", "22:1.55e1-1e5", BAM], 0),
             (je + ["-o", o("b6.bed"), "-r", "22:1,000-200,000", BAM], 0), (je + ["-o", o("b7.bed"), o("not_there.bam")], 1),
             (ident + ["-o", o("b8.tsv"), VCF, cut, FA, GTF], 0), (ident + ["-o", o("b9.tsv"), "-v", o("b9.vcf"), VCF, old, FA, GTF], 0)]
