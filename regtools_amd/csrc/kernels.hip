@@ -861,7 +861,9 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
             h.l_qseq = (int32_t)x[5]; h.mtid = (int32_t)x[6];
             h.aux_off = (int64_t)h.l_qname + 4 * (int64_t)h.n_cigar + (((int64_t)h.l_qseq + 1) >> 1) + h.l_qseq;
         }
-        if (cfg.insane_out && !rec_sane(h)) cfg.insane_out[0] = 1;   // (the framing only looked at block_size: the call starts over with the full walk)
+        // (the framing only looked at block_size: the call starts over with the full walk.  Until then the record is inert: its CIGAR count and its
+        //  aux offset are not to be believed -- a negative l_seq puts the aux walk in front of the arena, 65,535 operations run past its end)
+        if (cfg.insane_out && !rec_sane(h)) { cfg.insane_out[0] = 1; h.n_cigar = 0; }
         // body (CIGAR, aux) from the LDS window when the whole record is inside it, else straight from the arena
         const uint64_t rec_end = o + 4 + (uint64_t)(uint32_t)h.block_len;
         const bool in_win = STAGED && rec_end <= w1;
@@ -948,7 +950,7 @@ __global__ __launch_bounds__(64) void k_decode_sparse(const uint8_t *__restrict_
             for (uint32_t k = 0; k < cnt; ++k) {
                 RecHead h;
                 rec_head(arena + o, h);
-                if (cfg.insane_out && !rec_sane(h)) cfg.insane_out[0] = 1;
+                if (cfg.insane_out && !rec_sane(h)) { cfg.insane_out[0] = 1; h.n_cigar = 0; }       // (inert until the full walk, as in k_decode_seg)
                 const uint8_t *g_data = arena + o + 36;
                 auto cigar_at = [&](uint32_t q) -> uint32_t { return ld32(g_data + h.l_qname + 4 * (size_t)q); };
                 const uint32_t i = base + k;

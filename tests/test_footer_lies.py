@@ -199,3 +199,63 @@ def test_shards_of_a_damaged_file_merge_to_the_single_pass(gpu_ctx, tmp_path):
             assert merged.bed12() == single, (name, G)
             n += 1
     assert n >= 15
+
+
+# ---- a record whose block_size keeps the chain whole and whose other head fields cannot be believed (round 6: a GPU memory fault found by
+#      tools/fuzz/gpu_corrupt_bam.py).  The framing follows block_size only; the decode pass meets the record, tells the host (which starts over with
+#      the framing that makes bam_read1's full test, sam.c:421-423) -- and until then must not follow the record's own numbers: a negative l_seq puts
+#      the aux walk of `-s XS` far in front of the arena, an n_cigar of 65,535 runs 256 KiB past a small arena's end ----------------------------------
+def unbelievable_heads(tmp_path):
+    import struct
+    import bamio
+    out = []
+    base = str(tmp_path / "heads_base.bam")
+    from regtools_amd import synth
+    synth.write(base, 150, shape="long", seed=5)
+    raw = bytearray(bamio.inflate_all(base))
+    (l_text,) = struct.unpack_from("<i", raw, 4)
+    (n_ref,) = struct.unpack_from("<i", raw, 8 + l_text)
+    o = 12 + l_text
+    for _ in range(n_ref):
+        (ln,) = struct.unpack_from("<i", raw, o); o += 8 + ln
+    recs = []
+    while o + 36 <= len(raw):
+        (bs,) = struct.unpack_from("<i", raw, o)
+        recs.append(o); o += 4 + bs
+    spliced = [r for r in recs if struct.unpack_from("<H", raw, r + 16)[0] > 1]
+    bai = open(base + ".bai", "rb").read()
+    for name, at, field, value in (("negative_l_seq", spliced[len(spliced) // 2], 20, -0x40000000), ("l_seq_most_negative", spliced[-1], 20, -0x80000000),
+                                   ("n_cigar_65535_in_the_last_record", recs[-1], 16, None), ("l_read_name_0", spliced[3], 12, None)):
+        b = bytearray(raw)
+        if field == 20: struct.pack_into("<i", b, at + 20, value)
+        elif field == 16: struct.pack_into("<H", b, at + 16, 65535)
+        else: b[at + 12] = 0
+        p = str(tmp_path / (name + ".bam"))
+        blob = b"".join(bamio.bgzf_member(bytes(b[k:k + 0xff00])) for k in range(0, len(b), 0xff00)) + bamio.EOF_MARKER
+        open(p, "wb").write(blob); open(p + ".bai", "wb").write(bai)
+        out.append((name, p))
+    return out
+
+
+def test_oracle_equals_reference_on_unbelievable_heads(tmp_path):
+    if not os.path.exists(REF):
+        pytest.skip("the reference binary lives in the dev container")
+    for name, p in unbelievable_heads(tmp_path):
+        r = subprocess.run([REF, "junctions", "extract", "-s", "XS", "-o", str(tmp_path / "r.bed"), p], capture_output=True, timeout=60)
+        rc, out, _ = run_oracle(["-s", "XS", p])
+        assert r.returncode in (0, 1) and (r.returncode != 0) == (rc != 0), name
+        if rc == 0:
+            assert open(tmp_path / "r.bed", "rb").read() == out, name
+
+
+@pytest.mark.gpu
+def test_product_does_not_follow_unbelievable_heads(gpu_ctx, tmp_path):
+    from test_gpu_parity import gpu_extract
+    rows = 0
+    for name, p in unbelievable_heads(tmp_path):
+        for args in (["-s", "XS"], ["-s", "RF", "-a", "3"]):
+            rc, out, _ = gpu_extract(gpu_ctx, p, args)
+            orc, exp, _ = run_oracle(args + [p])
+            assert rc == orc and out == exp, (name, args)
+            rows += out.count(b"\n")
+    assert rows > 100
