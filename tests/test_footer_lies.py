@@ -224,6 +224,11 @@ def unbelievable_heads(tmp_path):
         recs.append(o); o += 4 + bs
     spliced = [r for r in recs if struct.unpack_from("<H", raw, r + 16)[0] > 1]
     bai = open(base + ".bai", "rb").read()
+    # (the index names the first record's place: the header's member stays as it is, the records behind it are packed again)
+    whole = open(base, "rb").read()
+    first = next(iter(bamio.bgzf_members(whole)))
+    head_bytes, head_len = whole[:struct.unpack_from("<H", whole, 16)[0] + 1], first[2]
+    assert head_len <= recs[0]
     for name, at, field, value in (("negative_l_seq", spliced[len(spliced) // 2], 20, -0x40000000), ("l_seq_most_negative", spliced[-1], 20, -0x80000000),
                                    ("n_cigar_65535_in_the_last_record", recs[-1], 16, None), ("l_read_name_0", spliced[3], 12, None)):
         b = bytearray(raw)
@@ -231,7 +236,8 @@ def unbelievable_heads(tmp_path):
         elif field == 16: struct.pack_into("<H", b, at + 16, 65535)
         else: b[at + 12] = 0
         p = str(tmp_path / (name + ".bam"))
-        blob = b"".join(bamio.bgzf_member(bytes(b[k:k + 0xff00])) for k in range(0, len(b), 0xff00)) + bamio.EOF_MARKER
+        assert bytes(b[:head_len]) == bytes(raw[:head_len])
+        blob = head_bytes + b"".join(bamio.bgzf_member(bytes(b[k:k + 0xff00])) for k in range(head_len, len(b), 0xff00)) + bamio.EOF_MARKER
         open(p, "wb").write(blob); open(p + ".bai", "wb").write(bai)
         out.append((name, p))
     return out
