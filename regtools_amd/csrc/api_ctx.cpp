@@ -95,7 +95,13 @@ hipError_t ensure_upload_streams(rgx_ctx *c) {
 //  several contexts of one device would each hold a second arena at the same time)
 void rgx_ctx_no_arena_trials(rgx_ctx *c) { if (c) c->arena_calibrated_bytes = UINT64_MAX; }
 // pipeline.cpp: the contexts of one pipeline take the host link in turns
-void *rgx_link_turn_create() { return new LinkTurn; }
+void *rgx_link_turn_create() {
+    LinkTurn *l = new LinkTurn;
+    // (what the environment held when HIP started is what the runtime uses; a value set later is only a wrong guess about it, and either way is correct)
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    l->chip_in_turns = !(q && atoi(q) >= 16);
+    return l;
+}
 void rgx_link_turn_destroy(void *l) { delete (LinkTurn *)l; }
 void rgx_ctx_set_link(rgx_ctx *c, void *l) { if (c) c->link = (LinkTurn *)l; }
 

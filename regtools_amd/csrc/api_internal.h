@@ -211,10 +211,14 @@ inline const OverlapKnobs &overlap_knobs() {
 //   chip -- the DEFLATE launch: a call's launch is enqueued when the launch before it has finished.  One launch is 2,647 of the chip's 3,072 wave slots and all
 //           of its LDS; two at once leave the first file's framing / decode / sort kernels nowhere to run until the second file's waves drain (measured: both
 //           files of a pair end together, 43 ms for the two).  One after the other, a file's tail runs in the slots its successor's launch leaves free.
+//           That is what happens on the runtime's default FOUR hardware queues, which the eight streams of two contexts share pairwise (a kernel behind
+//           another stream's launch in the same queue waits for it).  With a hardware queue per stream (GPU_MAX_HW_QUEUES >= 16 when HIP starts) the
+//           launches go out at once and the files' kernels interleave: 20.2-21.5 ms per file against 20.8-23.0 in turns and 22.1-22.8 on four queues
+//           (profiles/r06_pipeline_hw_queues_ab.txt) -- chip_in_turns = false (rgx_pipeline_create).
 struct Turn {
     std::mutex mu; std::condition_variable cv; uint64_t next = 0, serving = 0;
 };
-struct LinkTurn { Turn wire, chip; };
+struct LinkTurn { Turn wire, chip; bool chip_in_turns = true; };
 // one context's hold on a turn: taken by the call's host thread, given back from a host function on the stream when the copy / the launch is over
 // (or by the end of the call, whichever comes first).  Lives in the context: a stream may still owe the give when a failed call has returned.
 struct TurnHold {

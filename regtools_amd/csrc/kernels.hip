@@ -354,16 +354,12 @@ void launch_wait_done(const uint32_t *done, uint32_t expected, uint32_t *timed_o
 }
 
 // one lane per member like k_inflate; no lane leaves before the wave is done (the lanes without a member serve the others' copies)
-template <bool PROBE, bool PIECE = false, int WIN = 0 /* bit reader: 0 = 8 bytes a refill, 1 = 16-byte window */,
-          int OCC = 3 /* waves per SIMD: 3 = twelve per CU, a whole 50 M-read file in one round; 2 = eight per CU (lab, REGTOOLS_AMD_INFLATE_OCC=2) */>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_inflate_coop(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
+template <bool PROBE, bool PIECE = false, int WIN = 0 /* bit reader: 0 = 8 bytes a refill, 1 = 16-byte window */>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_inflate_coop(const uint8_t *__restrict__ comp, const Member *__restrict__ members,
                                                 uint32_t n_members, uint8_t *arena, uint64_t upos_bias, uint32_t *len_scratch,
                                                 uint32_t *status, uint32_t ignore_below, uint32_t index_bias, uint8_t *bad, uint32_t pairs,
                                                 const uint32_t *__restrict__ perm, const uint32_t *veto, InflateGate gate) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    // (two waves per SIMD: the register file decides how many waves a SIMD holds -- a wave that owns v200 leaves room for one more of its kind
-    //  and ~90 registers per SIMD for the kernels of another file's tail)
-    if constexpr (OCC == 2) asm volatile("" ::: "v200");
     // (stage entry point only: k_members_check found the list's layout unfit for 32-bit offsets -- nothing may be written)
     if (veto && *veto) return;
     const uint32_t lane = threadIdx.x;
@@ -530,8 +526,6 @@ static void inflate_attrs() {
     set((const void *)k_inflate_coop<false, false, 1>, kInflateLdsBytes);
     set((const void *)k_inflate_coop<false, true, 1>, kInflateLdsBytes);
     set((const void *)k_inflate_coop<true>, kInflateLdsBytes);
-    set((const void *)k_inflate_coop<false, true, 1, 2>, kInflateLdsBytes);
-    set((const void *)k_inflate_coop<false, false, 1, 2>, kInflateLdsBytes);
     set((const void *)k_inflate_wave, (uint32_t)sizeof(WaveShared));
     set((const void *)k_inflate_ring<false>, kRingLdsBytes);
     set((const void *)k_inflate_ring<true>, kRingLdsBytes);
@@ -579,11 +573,9 @@ void launch_inflate(const uint8_t *comp, const Member *members, uint32_t n_membe
             (void)hipMemsetAsync(veto, 0, 4, stream);
             hipLaunchKernelGGL(k_members_check, dim3((n_members + 255) / 256), dim3(256), 0, stream, members, n_members, status, veto);
         }
-#define RGX_COOP(PIECE_, WIN_, OCC_) hipLaunchKernelGGL((k_inflate_coop<false, PIECE_, WIN_, OCC_>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad, two, perm, veto, gate)
-        static const bool occ2 = [] { const char *e = getenv("REGTOOLS_AMD_INFLATE_OCC"); return e && e[0] == '2'; }();      // (lab)
-        if (occ2 && win) { if (piece) RGX_COOP(true, 1, 2); else RGX_COOP(false, 1, 2); }
-        else if (piece) { if (win) RGX_COOP(true, 1, 3); else RGX_COOP(true, 0, 3); }
-        else { if (win) RGX_COOP(false, 1, 3); else RGX_COOP(false, 0, 3); }
+#define RGX_COOP(PIECE_, WIN_) hipLaunchKernelGGL((k_inflate_coop<false, PIECE_, WIN_>), dim3(blocks), dim3(64), kInflateLdsBytes, stream, comp, members, n_members, arena, upos_bias, len_scratch, status, ignore_below, index_bias, bad, two, perm, veto, gate)
+        if (piece) { if (win) RGX_COOP(true, 1); else RGX_COOP(true, 0); }
+        else { if (win) RGX_COOP(false, 1); else RGX_COOP(false, 0); }
 #undef RGX_COOP
         break;
     }

@@ -37,9 +37,11 @@ def _sequential(ctx, f):
     return ("ok", je.bed12(False), je.stats["n_records"])
 
 
-@pytest.mark.parametrize("depth", [1, 2])
+@pytest.mark.parametrize("depth", [1, 2, 3])
 def test_interleaved_files_equal_sequential_calls(gpu_ctx, tmp_path, depth):
     import regtools_amd
+    if depth > 2 and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 4 * depth:
+        pytest.skip("three files in flight want a hardware queue per stream (run by test_launches_at_once_with_a_hardware_queue_per_stream)")
     files = _files(tmp_path)
     want = [_sequential(gpu_ctx, f) for f in files]
     assert [w[0] for w, f in zip(want, files) if f["kind"] == "junk"] == ["error"]
@@ -95,3 +97,15 @@ def test_more_than_two_files_in_flight_need_more_hardware_queues(gpu_ctx):
         with pytest.raises(regtools_amd.RegtoolsError) as e:
             regtools_amd.Pipeline(0, 3)
         assert "GPU_MAX_HW_QUEUES" in str(e.value)
+
+
+def test_launches_at_once_with_a_hardware_queue_per_stream():
+    """GPU_MAX_HW_QUEUES >= 16 when HIP starts: the pipeline's DEFLATE launches no longer take the chip in turns (api_internal.h LinkTurn::chip_in_turns) and
+    three files may be in flight.  The runtime reads the variable once, so the same tests run again in a process of their own."""
+    import sys
+    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 16:
+        pytest.skip("this process already runs that way")
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "interleaved_files_equal_sequential_calls or more_than_two_files"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], r.stdout[-3000:]

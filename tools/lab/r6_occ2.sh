@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU-box script (round 6): k_inflate_coop at two waves per SIMD (REGTOOLS_AMD_INFLATE_OCC=2: eight waves per CU, registers and LDS left on every CU
+# (needs tools/lab/r6_occ2.patch and the REGTOOLS_AMD_CHIP_TURN switch of commit "lab: REGTOOLS_AMD_CHIP_TURN=0" applied: neither ships)
 # for another file's tail) against three, with and without the chip turn, bench payload and realistic.   ->  gpurun_out/r6/occ2/
 cd "$(dirname "$0")/../.."
 O=gpurun_out/r6/occ2; mkdir -p $O

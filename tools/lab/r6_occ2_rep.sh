@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU-box script (round 6): the pipeline's forms, three interleaved repetitions on one box (24 files per line).   ->  gpurun_out/r6/occ2_rep/
+# (needs tools/lab/r6_occ2.patch and the REGTOOLS_AMD_CHIP_TURN switch of commit "lab: REGTOOLS_AMD_CHIP_TURN=0" applied: neither ships)
 cd "$(dirname "$0")/../.."
 O=gpurun_out/r6/occ2_rep; mkdir -p $O
 for rep in 1 2 3; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU-box script (round 6): the realistic payload with files in flight -- chip turn on / off, 2 and 3 in flight on 16 hardware queues, then the timeline
+# (needs tools/lab/r6_occ2.patch and the REGTOOLS_AMD_CHIP_TURN switch of commit "lab: REGTOOLS_AMD_CHIP_TURN=0" applied: neither ships)
 # of both forms.   tools/lab/r6_realistic_sustained.sh  ->  gpurun_out/r6/realistic_sustained/
 cd "$(dirname "$0")/../.."
 O=gpurun_out/r6/realistic_sustained; mkdir -p $O
