@@ -99,7 +99,7 @@ void *rgx_link_turn_create() {
     LinkTurn *l = new LinkTurn;
     // (what the environment held when HIP started is what the runtime uses; a value set later is only a wrong guess about it, and either way is correct)
     const char *q = getenv("GPU_MAX_HW_QUEUES");
-    l->chip_in_turns = !(q && atoi(q) >= 16);
+    l->chip.width = q && atoi(q) >= 16 ? 2 : 1;
     return l;
 }
 void rgx_link_turn_destroy(void *l) { delete (LinkTurn *)l; }

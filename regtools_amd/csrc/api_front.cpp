@@ -498,7 +498,7 @@ int EventsRun::stage_range_and_inflate() {
     //  verdict, first makes the pipeline's stream wait for it)
     c->launch_timed = false;
     auto timed_launch = [&](hipStream_t q, bool piece, InflateGate gate) {      // the call's whole-range launch, with its own pair of events on its own stream
-        if (c->link && c->link->chip_in_turns) { c->chip_hold.take(&c->link->chip); mark("the chip's DEFLATE turn is ours"); }
+        if (c->link) { c->chip_hold.take(&c->link->chip); mark("the chip's DEFLATE turn is ours"); }
         (void)hipEventRecord(c->ev_launch[0], q);
         launch_inflate(d_bam, d_members + m_lo, n_range, b_arena.as<uint8_t>(), upos_lo, b_lens.as<uint32_t>(), d_sc, q, ignore_below, 0, piece, 0, d_bad,
             pairs, false, gate);

@@ -214,11 +214,13 @@ inline const OverlapKnobs &overlap_knobs() {
 //           That is what happens on the runtime's default FOUR hardware queues, which the eight streams of two contexts share pairwise (a kernel behind
 //           another stream's launch in the same queue waits for it).  With a hardware queue per stream (GPU_MAX_HW_QUEUES >= 16 when HIP starts) the
 //           launches go out at once and the files' kernels interleave: 20.2-21.5 ms per file against 20.8-23.0 in turns and 22.1-22.8 on four queues
-//           (profiles/r06_pipeline_hw_queues_ab.txt) -- chip_in_turns = false (rgx_pipeline_create).
+//           (profiles/r06_pipeline_hw_queues_ab.txt) -- the chip turn is then TWO wide (rgx_link_turn_create).  Not wider: three launches at once on sixteen
+//           queues took 92-93 ms per file (the third file's waves sit in the slots the second file's late waves need, waiting for an upload that has not begun).
 struct Turn {
     std::mutex mu; std::condition_variable cv; uint64_t next = 0, serving = 0;
+    uint64_t width = 1;                                // how many may hold it at once, admitted in the order they asked
 };
-struct LinkTurn { Turn wire, chip; bool chip_in_turns = true; };
+struct LinkTurn { Turn wire, chip; };
 // one context's hold on a turn: taken by the call's host thread, given back from a host function on the stream when the copy / the launch is over
 // (or by the end of the call, whichever comes first).  Lives in the context: a stream may still owe the give when a failed call has returned.
 struct TurnHold {
@@ -227,7 +229,7 @@ struct TurnHold {
         if (!x || held.load()) return;
         std::unique_lock<std::mutex> lk(x->mu);
         const uint64_t mine = x->next++;
-        x->cv.wait(lk, [&] { return x->serving == mine; });
+        x->cv.wait(lk, [&] { return mine < x->serving + x->width; });
         t = x; held.store(true);
     }
     void give() { if (held.exchange(false)) { { std::lock_guard<std::mutex> lk(t->mu); ++t->serving; } t->cv.notify_all(); } }
