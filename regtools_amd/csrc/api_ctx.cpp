@@ -95,11 +95,13 @@ hipError_t ensure_upload_streams(rgx_ctx *c) {
 //  several contexts of one device would each hold a second arena at the same time)
 void rgx_ctx_no_arena_trials(rgx_ctx *c) { if (c) c->arena_calibrated_bytes = UINT64_MAX; }
 // pipeline.cpp: the contexts of one pipeline take the host link in turns
-void *rgx_link_turn_create() {
+void *rgx_link_turn_create(int depth) {
     LinkTurn *l = new LinkTurn;
     // (what the environment held when HIP started is what the runtime uses; a value set later is only a wrong guess about it, and either way is correct)
     const char *q = getenv("GPU_MAX_HW_QUEUES");
-    l->chip.width = q && atoi(q) >= 16 ? 2 : 1;
+    // (eight queues per file in flight: three files on sixteen queues with two launches at once took 90-93 ms per file -- some of their twelve-odd streams
+    //  share a queue again; in turns they take 20.4-22.2, and on thirty-two queues 19.1-19.5 at once)
+    l->chip.width = q && atoi(q) >= 8 * std::max(2, depth) ? 2 : 1;
     return l;
 }
 void rgx_link_turn_destroy(void *l) { delete (LinkTurn *)l; }

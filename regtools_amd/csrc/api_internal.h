@@ -214,8 +214,8 @@ inline const OverlapKnobs &overlap_knobs() {
 //           That is what happens on the runtime's default FOUR hardware queues, which the eight streams of two contexts share pairwise (a kernel behind
 //           another stream's launch in the same queue waits for it).  With a hardware queue per stream (GPU_MAX_HW_QUEUES >= 16 when HIP starts) the
 //           launches go out at once and the files' kernels interleave: 20.2-21.5 ms per file against 20.8-23.0 in turns and 22.1-22.8 on four queues
-//           (profiles/r06_pipeline_hw_queues_ab.txt) -- the chip turn is then TWO wide (rgx_link_turn_create).  Not wider: three launches at once on sixteen
-//           queues took 92-93 ms per file (the third file's waves sit in the slots the second file's late waves need, waiting for an upload that has not begun).
+//           (profiles/r06_pipeline_hw_queues_ab.txt) -- the chip turn is then TWO wide (rgx_link_turn_create: eight queues per file in flight; three files
+//           on sixteen queues with two launches at once took 90-93 ms per file, on thirty-two 19.1-19.5).
 struct Turn {
     std::mutex mu; std::condition_variable cv; uint64_t next = 0, serving = 0;
     uint64_t width = 1;                                // how many may hold it at once, admitted in the order they asked

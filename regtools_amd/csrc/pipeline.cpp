@@ -21,7 +21,7 @@
 #include "../../include/regtools_amd.h"
 
 // api_ctx.cpp: the contexts of a pipeline take the host link in turns (a call's upload starts when the call before it has its file on the device)
-void *rgx_link_turn_create();
+void *rgx_link_turn_create(int depth);
 void rgx_link_turn_destroy(void *l);
 void rgx_ctx_set_link(rgx_ctx *c, void *l);
 
@@ -102,7 +102,7 @@ extern "C" int rgx_pipeline_create(int device, int depth, rgx_pipeline **out, ch
         const int rc = rgx_ctx_create(device, &pl->lanes[(size_t)k].ctx, err, errlen);
         if (rc != RGX_OK) { for (Lane &ln : pl->lanes) if (ln.ctx) rgx_ctx_destroy(ln.ctx); return rc; }
     }
-    if (depth > 1) { pl->link = rgx_link_turn_create(); for (Lane &ln : pl->lanes) rgx_ctx_set_link(ln.ctx, pl->link); }
+    if (depth > 1) { pl->link = rgx_link_turn_create(depth); for (Lane &ln : pl->lanes) rgx_ctx_set_link(ln.ctx, pl->link); }
     for (size_t k = 0; k < pl->lanes.size(); ++k) pl->lanes[k].th = std::thread(lane_loop, pl.get(), k);
     *out = pl.release();
     return RGX_OK;
