@@ -26,8 +26,10 @@ sys.path.insert(0, ROOT)
 # A hardware queue per stream for the pass with two files in flight (two contexts x four streams; the HIP runtime reads this once, when it starts -- hence
 # here, in front of the first import of torch): on the default four queues the streams of the two files share queues pairwise and a kernel behind another
 # stream's launch waits for it -- 22.1-22.8 ms per file against 20.2-21.5 on sixteen (profiles/r06_pipeline_hw_queues_ab.txt).  The timed step (`value`) does
-# not move with it (24.7-25.6 ms on either).  An environment that sets the variable is left alone.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# not move with it (24.7-25.6 ms on either).  Thirty-two rather than sixteen: a rank of an N > 1 job has torch's and RCCL's streams beside the pipeline's ten, and streams that
+# share a queue again are what made three files in flight on sixteen queues take 90 ms per file (two in flight: 19.7-20.1 ms on thirty-two, 19.8-20.3 on sixteen).
+# An environment that sets the variable is left alone.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # the whole-file launch of the DEFLATE kernel the pipeline runs above 2048 members (kernels.hip launch_inflate; REGTOOLS_AMD_INFLATE overrides)
