@@ -2,6 +2,7 @@
 """Files back to back on one device: one call after the other on one context against rgx_pipeline with 1, 2, 3 files in flight (csrc/pipeline.cpp).
    python tools/sustained_ab.py [--reads N] [--files F] [--realistic]"""
 import argparse, json, os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")     # (as bench.py: a hardware queue per stream, read by the HIP runtime when it starts; DESIGN.md 4.5)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
