@@ -314,6 +314,10 @@ struct Prep {
     uint32_t framing_sweeps = 0;
     bool stream_ended = false;     // the record stream stopped for a reason that ends iteration upstream (not: it reached this shard's upper cut)
     double t_begin = 0;
+    // identify -s XS: the reads with an N operation whose strand tag lies behind an aux field of unknown type -- bam_aux_get abort()s on them (sam.c:1233-1252)
+    // in the first window that reads one (ExtractCfg::odd_count; empty on every file that is not damaged)
+    struct OddAux { int32_t tid, pos, end; };
+    std::vector<OddAux> odd_aux;
 };
 
 int prepare_events(rgx_ctx *c, const uint8_t *d_bam_in, const uint8_t *h_bam, size_t bam_len, const uint8_t *bai, size_t bai_len,

@@ -141,6 +141,9 @@ int EventsRun::stage_bounds_and_chains() {
     cfg.n_ref = n_ref; cfg.strandness = p->strandness; cfg.tag0 = (uint8_t)p->strand_tag[0]; cfg.tag1 = (uint8_t)p->strand_tag[1];
     // (`junctions extract` only: identify's per-window extractions upstream meet such a read only inside a window -- DESIGN 8)
     if (p->strandness == 0 && !want_read_span) { cfg.abort_out = d_sc + 96; HIP_TRY(hipMemsetAsync(d_sc + 96, 0xff, 4, st)); }
+    // (identify: the same reads counted and marked; which of them a window reads is known when the windows are, cse_api.cpp)
+    if (p->strandness == 0 && want_read_span) { cfg.odd_count = d_sc + 97; HIP_TRY(hipMemsetAsync(d_sc + 97, 0, 4, st)); }
+    P.odd_aux.clear();
     cfg.min_anchor = p->min_anchor; cfg.min_intron = p->min_intron; cfg.max_intron = p->max_intron;
     cfg.region_tid = -2; cfg.long_threshold = 16;
     if (!whole) {
@@ -425,6 +428,7 @@ int EventsRun::stage_decode() {
             if (cfg.stop_out) HIP_TRY(hipMemcpyAsync(h_sc + 80, d_sc + 80, 8, hipMemcpyDeviceToHost, st));
             if (cfg.insane_out) HIP_TRY(hipMemcpyAsync(h_sc + 82, d_sc + 82, 4, hipMemcpyDeviceToHost, st));
             if (cfg.abort_out) HIP_TRY(hipMemcpyAsync(h_sc + 96, d_sc + 96, 4, hipMemcpyDeviceToHost, st));
+            if (cfg.odd_count) HIP_TRY(hipMemcpyAsync(h_sc + 97, d_sc + 97, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (cfg.insane_out && h_sc[82]) {
                 // a record the reference's reader would not have accepted (sam.c:421-423) lies on the chain the block_size walk followed:
@@ -458,6 +462,20 @@ int EventsRun::stage_decode() {
             } else n_events = (uint32_t)tot;
         }
         n_iterated = h_sc[8];
+        if (cfg.odd_count && h_sc[97]) {
+            // damaged files only: the marked rows' (tid, pos, end) come to the host; what was counted (a second decode pass counts again) bounds the list
+            const uint32_t cap = h_sc[97];
+            DevBuf &b_odd = c->buf("odd_aux");
+            HIP_TRY(b_odd.ensure((size_t)cap * 12 + 16));
+            HIP_TRY(hipMemsetAsync(d_sc + 97, 0, 4, st));
+            launch_collect_odd_aux(arena, soa, n_rec, cap, d_sc + 97, b_odd.as<int32_t>(), st);
+            HIP_TRY(hipMemcpyAsync(h_sc + 97, d_sc + 97, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const uint32_t n_odd = std::min(h_sc[97], cap);
+            std::vector<int32_t> rows((size_t)n_odd * 3);
+            if (n_odd) { HIP_TRY(hipMemcpyAsync(rows.data(), b_odd.p, (size_t)n_odd * 12, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); }
+            for (uint32_t k = 0; k < n_odd; ++k) P.odd_aux.push_back(Prep::OddAux{rows[3 * (size_t)k], rows[3 * (size_t)k + 1], rows[3 * (size_t)k + 2]});
+        }
         // this shard read the record that ends the iteration (hts.c:1946-1950)
         if (geom.chunks && p->n_shards > 1 && h_sc[80] != 0xffffffffu) P.stream_ended = true;
         if (n_long) launch_long_fill(n_seg, seg_base, seg_cnt[cur], seg_long_base, cfg, soa, long_list, st);

@@ -39,7 +39,8 @@ void die_as_upstream_on_empty_gtf_line(const char *err, bool caught = false) {
 // library reports them (RGX_ERR_EXIT / RGX_ERR_ABORT with what htslib printed) and the tool goes the same way.
 void die_where_upstreams_library_does(int rc, const char *err) {
     if (rc != RGX_ERR_EXIT && rc != RGX_ERR_ABORT) return;
-    std::cerr.flush(); fputs(err, stderr); fflush(nullptr);
+    // (what htslib printed; the library's own words -- a read whose aux fields bam_aux_get abort()s on, sam.c:1233-1252 -- are not upstream's: nothing is printed there)
+    std::cerr.flush(); if (strncmp(err, "regtools_amd:", 13)) fputs(err, stderr); fflush(nullptr);
     if (rc == RGX_ERR_ABORT) abort();
     exit(1);
 }

@@ -836,6 +836,7 @@ static int prepare_events_sharded(const std::vector<rgx_ctx *> &cs, const uint8_
     P = Prep();
     P.hdr = parts[0].hdr; P.ev = all; P.n_events = (uint32_t)N; P.n_iterated = iterated; P.n_rec = (uint32_t)std::min<uint64_t>(rec, 0xffffffffull);
     P.stream_ended = used < n || parts[(size_t)used - 1].stream_ended;
+    for (int g = 0; g < used; ++g) P.odd_aux.insert(P.odd_aux.end(), parts[(size_t)g].odd_aux.begin(), parts[(size_t)g].odd_aux.end());
     return RGX_OK;
 }
 
@@ -1092,8 +1093,20 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
                     w_tid[w] = tid; w_beg[w] = beg; w_end[w] = en;
                 }
             });
+            size_t w_bad = SIZE_MAX;
+            for (size_t t = 0; t < nt && w_bad == SIZE_MAX; ++t) w_bad = bad[t];           // (a thread stops at its first: the first thread's is the file's first)
+            // -s XS: a read with an N operation whose strand tag lies behind an aux field of unknown type ends the process in the first window that READS it
+            // (tid, pos < end, bam_endpos > beg: hts.c:1946-1957) -- bam_aux_get abort()s, sam.c:1233-1252, nothing printed -- behind that variant's echo
+            if (!P.odd_aux.empty())
+                for (size_t w = 0; w < std::min(W, w_bad); ++w)
+                    for (const Prep::OddAux &o : P.odd_aux)
+                        if (o.tid == w_tid[w] && o.pos < w_end[w] && o.end > w_beg[w]) {
+                            echo_variants(w + 1);
+                            return fail(err, errlen, RGX_ERR_ABORT, "regtools_amd: a read at %s:%d has an auxiliary field of unknown type in front of its strand tag: the reference "
+                                "abort()s in this variant's window\n", vcf.recs[relevant[w]].chrom.c_str(), o.pos + 1);
+                        }
             // aborts the run
-            for (size_t t = 0; t < nt; ++t) if (bad[t] != SIZE_MAX) { echo_variants(bad[t] + 1); return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion); }
+            if (w_bad != SIZE_MAX) { echo_variants(w_bad + 1); return fail(err, errlen, RGX_ERR_REGION, "%s", kMsgRegion); }
         }
         echo_variants(relevant.size());
         if (int rc_died = died_reading_the_vcf()) return rc_died;

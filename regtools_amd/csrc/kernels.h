@@ -166,7 +166,12 @@ struct ExtractCfg {
     // -s XS: the smallest index of an iterated read with an N operation whose strand tag lies behind an aux field of unknown type (preset ~0; null =
     // off): the reference's bam_aux_get abort()s on it (sam.c:1233-1252) when the read's first junction asks for its strand (junctions_extractor.cc:283-286)
     uint32_t *abort_out;
+    // `identify -s XS` (one extraction for every window): such reads are COUNTED here (null = off) and marked in bit 7 of their row's strand byte; upstream
+    // abort()s in the first window -- in the order of the variants -- that reads one of them (launch_collect_odd_aux, cse_api.cpp)
+    uint32_t *odd_count;
 };
+// the reads the decode kernels marked (ExtractCfg::odd_count): out[3 k ..] = tid, pos, bam_endpos of the k-th found (any order); *count = how many (may exceed cap)
+void launch_collect_odd_aux(const uint8_t *arena, ReadSoA soa, uint32_t n_rec, uint32_t cap, uint32_t *count, int32_t *out, hipStream_t stream);
 
 // one wave per framing segment, segment bytes staged through LDS (replaces launch_seg_fill + launch_decode on the hot path)
 // seg_iter[s] = records of segment s that pass the region filter; seg_long[s] = its reads for the wave-per-read kernel

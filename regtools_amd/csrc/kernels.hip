@@ -896,6 +896,7 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
         if (in_region) last_in = i + 1;
         uint32_t nev = 0;
         char strand = '?';
+        uint8_t odd = 0;                                     // bit 7 of the row's strand byte: k_collect_odd_aux (identify)
         if (in_region && h.n_cigar > 1 && h.tid >= 0 && h.tid < cfg.n_ref) {
             bool has_n = false;
             for (uint32_t q = 0; q < h.n_cigar; ++q) {
@@ -903,7 +904,7 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
                 if (cig_is_N(c)) { const uint32_t len = c >> 4; nev += !(len < cfg.min_intron || len > cfg.max_intron); has_n = true; }
             }
             // (the tag is asked for by every junction the walk reaches, also one junction_qc then drops: any N operation, cc:415 / :447 / :467 / :490)
-            if (nev || (has_n && cfg.abort_out && cfg.strandness == 0)) {
+            if (nev || (has_n && (cfg.abort_out || cfg.odd_count) && cfg.strandness == 0)) {
                 if (cfg.strandness == 0) {
                     const int64_t l_data = (int64_t)h.block_len - 32;
                     bool unknown = false;
@@ -911,11 +912,12 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
                     if (in_win) { const uint8_t *body = s_buf + ro + 36; strand = strand_from_tag(body + h.aux_off, body + l_data, cfg.tag0, cfg.tag1, &unknown); }
                     else strand = strand_from_tag(g_data + h.aux_off, g_data + l_data, cfg.tag0, cfg.tag1, &unknown);
                     if (unknown && cfg.abort_out) atomicMin(cfg.abort_out, i);
+                    if (unknown && cfg.odd_count) { atomicAdd(cfg.odd_count, 1u); odd = 0x80; }
                 } else strand = strand_from_flag(h.flag, cfg.strandness);
                 if (nev) n_long += h.n_cigar > cfg.long_threshold ? 1u : 0u;
             }
         }
-        soa.strand[i] = (uint8_t)strand;
+        soa.strand[i] = (uint8_t)strand | odd;
         soa.n_ev[i] = nev;
     }
     // per-segment totals instead of global atomics: one hot address serialises at ~90 atomics/us
@@ -979,23 +981,25 @@ __global__ __launch_bounds__(64) void k_decode_sparse(const uint8_t *__restrict_
                 if (in_region) last_in = i + 1;
                 uint32_t nev = 0;
                 char strand = '?';
+                uint8_t odd = 0;
                 if (in_region && h.n_cigar > 1 && h.tid >= 0 && h.tid < cfg.n_ref) {
                     bool has_n = false;
                     for (uint32_t q = 0; q < h.n_cigar; ++q) {
                         const uint32_t c = cigar_at(q);
                         if (cig_is_N(c)) { const uint32_t len = c >> 4; nev += !(len < cfg.min_intron || len > cfg.max_intron); has_n = true; }
                     }
-                    if (nev || (has_n && cfg.abort_out && cfg.strandness == 0)) {
+                    if (nev || (has_n && (cfg.abort_out || cfg.odd_count) && cfg.strandness == 0)) {
                         if (cfg.strandness == 0) {
                             const int64_t l_data = (int64_t)h.block_len - 32;
                             bool unknown = false;
                             strand = strand_from_tag(g_data + h.aux_off, g_data + l_data, cfg.tag0, cfg.tag1, &unknown);
                             if (unknown && cfg.abort_out) atomicMin(cfg.abort_out, i);
+                            if (unknown && cfg.odd_count) { atomicAdd(cfg.odd_count, 1u); odd = 0x80; }
                         } else strand = strand_from_flag(h.flag, cfg.strandness);
                         if (nev) n_long += h.n_cigar > cfg.long_threshold ? 1u : 0u;
                     }
                 }
-                soa.strand[i] = (uint8_t)strand;
+                soa.strand[i] = (uint8_t)strand | odd;
                 soa.n_ev[i] = nev;
                 o += 4 + (uint64_t)(uint32_t)h.block_len;
             }
@@ -1051,6 +1055,18 @@ void launch_decode_seg(const uint8_t *arena, SegGeom g, uint32_t n_seg, const ui
         if (wave_form && g.seg_bytes == kSegBytes) hipLaunchKernelGGL(k_decode_seg<false>, dim3(n), dim3(64), 0, stream, arena, g, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, seg_cp, s_begin);
         else hipLaunchKernelGGL(k_decode_sparse, dim3((n + 63) / 64), dim3(64), 0, stream, arena, n_seg, seg_start, seg_base, seg_cnt, cfg, soa, seg_iter, seg_long, s_begin);
     }
+}
+// identify -s XS: the reads whose strand tag lies behind an aux field of unknown type (marked by the decode kernels), with the span the iterator tests
+__global__ void k_collect_odd_aux(const uint8_t *__restrict__ arena, ReadSoA soa, uint32_t n_rec, uint32_t cap, uint32_t *count, int32_t *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec || !(soa.strand[i] & 0x80u)) return;
+    const uint32_t fnc = soa.flag_nc[i];
+    const int32_t pos = soa.pos[i];
+    const uint32_t k = atomicAdd(count, 1u);
+    if (k < cap) { out[3 * (size_t)k] = soa.tid[i]; out[3 * (size_t)k + 1] = pos; out[3 * (size_t)k + 2] = rec_endpos(arena + soa.cig_off[i], fnc & 0xffffu, fnc >> 16, pos); }
+}
+void launch_collect_odd_aux(const uint8_t *arena, ReadSoA soa, uint32_t n_rec, uint32_t cap, uint32_t *count, int32_t *out, hipStream_t stream) {
+    if (n_rec) hipLaunchKernelGGL(k_collect_odd_aux, dim3((n_rec + 255) / 256), dim3(256), 0, stream, arena, soa, n_rec, cap, count, out);
 }
 void launch_long_fill(uint32_t n_seg, const uint32_t *seg_base, const uint32_t *seg_cnt, const uint32_t *seg_long_base, ExtractCfg cfg, ReadSoA soa,
                       uint32_t *long_list, hipStream_t stream) {
