@@ -29,9 +29,9 @@ extern "C" {
 #define RGX_ERR_FORMAT     6  /* malformed BGZF/BAM beyond what the reference tolerates silently */
 #define RGX_ERR_ARG        7
 #define RGX_ERR_FASTA      8  /* "Unable to extract FASTA sequence for position ...\n\n" junctions_extractor.cc:553 */
-#define RGX_ERR_ABORT      9  /* the reference abort()s on this input (`junctions extract -s XS`: an aux field of unknown type in front of the strand tag of a
-                               * spliced read, sam.c:1233-1252 skip_aux; a VCF record whose FORMAT names a Flag, vcf.c:1638-1639); the tool then prints err
-                               * and calls abort() itself, a library caller gets this code */
+#define RGX_ERR_ABORT      9  /* the reference abort()s on this input (`junctions extract -s XS`, and `identify -s XS` in the first variant's window that reads it: an
+                               * aux field of unknown type in front of the strand tag of a spliced read, sam.c:1233-1252 skip_aux; a VCF record whose FORMAT
+                               * names a Flag, vcf.c:1638-1639); the tool then prints what htslib printed and calls abort() itself, a library caller gets this code */
 #define RGX_ERR_EXIT      10  /* the reference's LIBRARY ends the process with exit(1) on this input, past the tool's own error handling (a VCF sample with more
                                * fields than FORMAT has keys, vcf.c:1610-1614): err is all it prints; the tool prints it and exits with 1 */
 
