@@ -698,7 +698,8 @@ size_t orc_umap_order(const char *const *keys, size_t n, size_t *order, int *cou
 
 /* junctions_extractor.cc:362-374 set_junction_barcode: bam_aux_get("CB") (sam.c:1254-1266) then bam_aux2Z (sam.c:1309-1315).
  * returns 1 with [*s,*s+*len) = the value, 0 = tag absent ("?"), -1 = tag present but not Z/H (the reference constructs a
- * std::string from NULL there and dies; reported as an error) */
+ * std::string from NULL there and dies; reported as an error), -2 = a field of a type skip_aux does not know stands in front of the tag (or
+ * anywhere, when there is no such tag): bam_aux_get abort()s (sam.c:1233-1252) -- for every read with more than one CIGAR operation, whatever -s says */
 static int barcode_from_tag(const uint8_t *aux, const uint8_t *end, const uint8_t **val, size_t *len) {
     const uint8_t *s = aux;
     while (s + 3 <= end) {
@@ -725,7 +726,7 @@ static int barcode_from_tag(const uint8_t *aux, const uint8_t *end, const uint8_
                 s += (size_t)sz * n;
                 break;
             }
-            default: return 0;
+            default: return -2;
         }
     }
     return 0;
@@ -965,6 +966,7 @@ int orc_extract(const orc_params *p, orc_table **out, char *err, size_t errlen) 
         if (p->barcodes) {
             const uint8_t *v = NULL; size_t vl = 0;
             int r = barcode_from_tag(data + aux_off, data + l_data, &v, &vl);
+            if (r == -2) { rc = fail(err, errlen, "abort()\n"); break; }       /* set_junction_barcode, junctions_extractor.cc:393-395: before the CIGAR is looked at */
             if (r < 0) { rc = fail(err, errlen, "regtools_amd oracle: the CB tag is not a string\n\n"); break; }
             if (r) { ec.bc = (const char *)v; ec.bc_len = vl; } else { ec.bc = "?"; ec.bc_len = 1; }
         }

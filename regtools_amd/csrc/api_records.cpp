@@ -140,7 +140,8 @@ int EventsRun::stage_bounds_and_chains() {
     memset(&cfg, 0, sizeof cfg);
     cfg.n_ref = n_ref; cfg.strandness = p->strandness; cfg.tag0 = (uint8_t)p->strand_tag[0]; cfg.tag1 = (uint8_t)p->strand_tag[1];
     // (`junctions extract` only: identify's per-window extractions upstream meet such a read only inside a window -- DESIGN 8)
-    if (p->strandness == 0 && !want_read_span) { cfg.abort_out = d_sc + 96; HIP_TRY(hipMemsetAsync(d_sc + 96, 0xff, 4, st)); }
+    if ((p->strandness == 0 || p->barcodes) && !want_read_span) { cfg.abort_out = d_sc + 96; HIP_TRY(hipMemsetAsync(d_sc + 96, 0xff, 4, st)); }
+    if (p->barcodes && !want_read_span) { cfg.bc0 = (uint8_t)p->barcode_tag[0]; cfg.bc1 = (uint8_t)p->barcode_tag[1]; }
     // (identify: the same reads counted and marked; which of them a window reads is known when the windows are, cse_api.cpp)
     if (p->strandness == 0 && want_read_span) { cfg.odd_count = d_sc + 97; HIP_TRY(hipMemsetAsync(d_sc + 97, 0, 4, st)); }
     P.odd_aux.clear();
@@ -447,7 +448,7 @@ int EventsRun::stage_decode() {
         }
         // an iterated read (in front of the record that ends the iteration) whose strand tag upstream cannot get at
         if (cfg.abort_out && h_sc[96] != 0xffffffffu && h_sc[96] < (cfg.stop_out ? cfg.stop_index : 0xffffffffu))
-            return fail(err, errlen, RGX_ERR_ABORT, "regtools_amd: record %u has an auxiliary field of unknown type in front of its strand tag: the reference abort()s here\n", h_sc[96]);
+            return fail(err, errlen, RGX_ERR_ABORT, "regtools_amd: record %u has an auxiliary field of unknown type in front of its strand or barcode tag: the reference abort()s here\n", h_sc[96]);
         n_events = h_sc[4]; n_long = h_sc[5];
         if (emit_parts_ok && s_from) {
             uint64_t tot = 0;

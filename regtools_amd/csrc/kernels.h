@@ -166,6 +166,8 @@ struct ExtractCfg {
     // -s XS: the smallest index of an iterated read with an N operation whose strand tag lies behind an aux field of unknown type (preset ~0; null =
     // off): the reference's bam_aux_get abort()s on it (sam.c:1233-1252) when the read's first junction asks for its strand (junctions_extractor.cc:283-286)
     uint32_t *abort_out;
+    uint8_t  bc0, bc1;             // -b: the barcode tag (0 = no -b).  set_junction_barcode asks for it on every read with more than one CIGAR operation, before the
+                                   // CIGAR is looked at (junctions_extractor.cc:393-395): a field of unknown type in front of it (or anywhere, without it) is abort_out's too
     // `identify -s XS` (one extraction for every window): such reads are COUNTED here (null = off) and marked in bit 7 of their row's strand byte; upstream
     // abort()s in the first window -- in the order of the variants -- that reads one of them (launch_collect_odd_aux, cse_api.cpp)
     uint32_t *odd_count;

@@ -898,6 +898,13 @@ __global__ __launch_bounds__(64) void k_decode_seg(const uint8_t *__restrict__ a
         char strand = '?';
         uint8_t odd = 0;                                     // bit 7 of the row's strand byte: k_collect_odd_aux (identify)
         if (in_region && h.n_cigar > 1 && h.tid >= 0 && h.tid < cfg.n_ref) {
+            if (cfg.bc0 && cfg.abort_out) {                   // -b: the barcode tag is asked for first (the walk is strand_from_tag's; what it finds is the barcode kernels' business)
+                const int64_t l_data = (int64_t)h.block_len - 32;
+                bool unknown = false;
+                if (in_win) { const uint8_t *body = s_buf + ro + 36; (void)strand_from_tag(body + h.aux_off, body + l_data, cfg.bc0, cfg.bc1, &unknown); }
+                else (void)strand_from_tag(g_data + h.aux_off, g_data + l_data, cfg.bc0, cfg.bc1, &unknown);
+                if (unknown) atomicMin(cfg.abort_out, i);
+            }
             bool has_n = false;
             for (uint32_t q = 0; q < h.n_cigar; ++q) {
                 const uint32_t c = cigar_at(q);
@@ -983,6 +990,11 @@ __global__ __launch_bounds__(64) void k_decode_sparse(const uint8_t *__restrict_
                 char strand = '?';
                 uint8_t odd = 0;
                 if (in_region && h.n_cigar > 1 && h.tid >= 0 && h.tid < cfg.n_ref) {
+                    if (cfg.bc0 && cfg.abort_out) {
+                        bool unknown = false;
+                        (void)strand_from_tag(g_data + h.aux_off, g_data + ((int64_t)h.block_len - 32), cfg.bc0, cfg.bc1, &unknown);
+                        if (unknown) atomicMin(cfg.abort_out, i);
+                    }
                     bool has_n = false;
                     for (uint32_t q = 0; q < h.n_cigar; ++q) {
                         const uint32_t c = cigar_at(q);
