@@ -56,7 +56,8 @@ with tempfile.TemporaryDirectory() as td:
                 b[coff:coff + bl] = newm
         path = os.path.join(td, "case.bam")
         open(path, "wb").write(bytes(b)); open(path + ".bai", "wb").write(bai)
-        args = rng.choice([["-s", "XS"], ["-s", "RF", "-a", "3"], ["-s", "XS", "-r", rng.choice(["chr1", "1", "chr2:1-90000000", "10:1000-200000"])]])
+        args = rng.choice([["-s", "XS"], ["-s", "RF", "-a", "3"], ["-s", "XS", "-r", rng.choice(["chr1", "1", "chr2:1-90000000", "10:1000-200000"])]]
+                          + ([["-s", "RF", "-b", os.path.join(td, "bc.txt")]] if os.environ.get("FUZZ_BARCODES") else []))   # (-b: set_junction_barcode's walk over damaged aux fields)
         orc = subprocess.run([ORACLE, "extract"] + args + [path], capture_output=True)
         if CPU and kind == "bgzf_extra":
             continue
