@@ -23,6 +23,7 @@ int EventsRun::run() {
     { const int rc = stage_decode(); if (rc != kGoOn) return rc; }
     const int rc_emit = stage_emit();
     if (rc_emit == RGX_OK) { const int rc = calibrate_arena(); if (rc != RGX_OK) return rc; }
+    P.d_file = rc_emit == RGX_OK && p->n_shards <= 1 && (!p->region || !strcmp(p->region, ".")) ? d_bam : nullptr;      // (every byte of the file went up)
     return rc_emit;
 }
 

@@ -375,6 +375,74 @@ static int window_join(rgx_ctx *c, const Prep &P, const std::vector<int32_t> &w_
     return RGX_OK;
 }
 
+// `identify` on a file whose record stream ENDED somewhere (a member that does not inflate, an unreadable record): upstream reads every variant's window through
+// the index on its own (identifier.cc:288-290) -- also the windows BEHIND the damage, which one pass over the file never reaches.  Here, for such a file only: one
+// region extraction per window from the file's bytes in HBM (what `junctions extract -r` makes of a damaged file: the iterator's chunks are seeks of their own), the
+// windows' events put together as window_join's pairs are, the same group-by behind them.  *w_abort (SIZE_MAX = none): the first window that reads a read bam_aux_get
+// abort()s on (Prep::odd_aux); the windows behind it are not read.
+static int window_join_by_seeks(rgx_ctx *c, const uint8_t *d_file, size_t bam_len, const uint8_t *bai, size_t bai_len, const rgx_extract_params &ep0,
+                                const std::vector<std::string> &w_region, uint32_t ilen_bits, HostRows &R, uint64_t &n_pairs, size_t &w_abort, char *err, size_t errlen) {
+    R = HostRows(); n_pairs = 0; w_abort = SIZE_MAX;
+    const size_t W = w_region.size();
+    hipStream_t st = c->stream;
+    std::vector<uint32_t> h_col[6];                               // window (batch-local), start, ilen_cls, ts, te; [5] unused
+    std::vector<uint8_t> h_strand;
+    size_t w0 = 0;
+    auto flush = [&](size_t w1) -> int {
+        const size_t total = h_col[0].size(), nw = w1 - w0;
+        if (total && nw) {
+            if (total >= (1ull << 31)) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: %zu junction-supporting reads in one batch of windows; more than the join handles\n", total);
+            DevBuf &bp = c->buf("cse_pairs");
+            HIP_TRY(bp.ensure(total * 4 * 7 + total + 256));
+            uint32_t *q = bp.as<uint32_t>() + 2 * total;          // (window_join's layout: the pair lists' place stays empty)
+            EventSoA pe; memset(&pe, 0, sizeof pe);
+            pe.tid = q; q += total; pe.start = q; q += total; pe.ilen_cls = q; q += total; pe.ts = q; q += total; pe.te = q; q += total; pe.strand = (uint8_t *)q;
+            uint32_t *dst[5] = {pe.tid, pe.start, pe.ilen_cls, pe.ts, pe.te};
+            for (int k = 0; k < 5; ++k) HIP_TRY(hipMemcpyAsync(dst[k], h_col[k].data(), total * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(pe.strand, h_strand.data(), total, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            std::vector<uint32_t> ident(nw);
+            for (size_t i = 0; i < nw; ++i) ident[i] = (uint32_t)i;
+            HostRows B;
+            const int rc = reduce_events(c, pe, (uint32_t)total, std::max<uint32_t>(1, bitlen((uint32_t)nw - 1)), ilen_bits, ident.data(), (uint32_t)nw, B, err, errlen, false,
+                nullptr, nullptr, /*allow_preagg=*/false);
+            if (rc != RGX_OK) return rc;
+            for (uint32_t &g : B.group) g += (uint32_t)w0;
+            auto app = [](std::vector<uint32_t> &d, const std::vector<uint32_t> &s2) { d.insert(d.end(), s2.begin(), s2.end()); };
+            app(R.group, B.group); app(R.start, B.start); app(R.end, B.end); app(R.ts, B.ts); app(R.te, B.te); app(R.count, B.count);
+            app(R.name_rank, B.name_rank); app(R.first_seen, B.first_seen); app(R.last_seen, B.last_seen);
+            R.strand.insert(R.strand.end(), B.strand.begin(), B.strand.end());
+            R.n += B.n;
+            n_pairs += total;
+        }
+        for (auto &v : h_col) v.clear();
+        h_strand.clear();
+        w0 = w1;
+        return RGX_OK;
+    };
+    for (size_t w = 0; w < W; ++w) {
+        rgx_extract_params q = ep0;
+        q.region = w_region[w].c_str(); q.shard = 0; q.n_shards = 1;
+        Prep Pw;
+        const int rc = prepare_events(c, d_file, nullptr, bam_len, bai, bai_len, &q, true, Pw, err, errlen);
+        if (rc != RGX_OK) return rc;
+        if (!Pw.odd_aux.empty()) { w_abort = w; break; }
+        const size_t n = Pw.n_events;
+        if (n) {
+            const size_t at = h_col[0].size();
+            for (int k = 0; k < 5; ++k) h_col[k].resize(at + n);
+            h_strand.resize(at + n);
+            const uint32_t *src[5] = {nullptr, Pw.ev.start, Pw.ev.ilen_cls, Pw.ev.ts, Pw.ev.te};
+            for (int k = 1; k < 5; ++k) HIP_TRY(hipMemcpyAsync(h_col[k].data() + at, src[k], n * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_strand.data() + at, Pw.ev.strand, n, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            std::fill(h_col[0].begin() + (ptrdiff_t)at, h_col[0].end(), (uint32_t)(w - w0));
+        }
+        if (h_col[0].size() >= (1u << 22)) { const int rc2 = flush(w + 1); if (rc2 != RGX_OK) return rc2; }
+    }
+    return flush(w_abort == SIZE_MAX ? W : w_abort);
+}
+
 extern "C" int rgx_window_join(rgx_ctx *c, const char *bam_path, const rgx_extract_params *p, uint64_t n_windows, const char *const *chrom, const int32_t *beg,
                                const int32_t *end, rgx_window_rows **out, char *err, size_t errlen) {
     if (!c || !bam_path || !p || !out || (n_windows && (!chrom || !beg || !end))) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: bad arguments\n");
@@ -897,8 +965,8 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
     Prep P;
     int rc_bam = RGX_OK;
     char err_bam[512]; err_bam[0] = 0;
+    rgx_extract_params ep; rgx_extract_params_default(&ep);
     if (!p->bed_path) {
-        rgx_extract_params ep; rgx_extract_params_default(&ep);
         ep.region = "."; ep.strandness = p->strandness; ep.strand_tag[0] = p->strand_tag[0]; ep.strand_tag[1] = p->strand_tag[1];
         ep.min_anchor = p->min_anchor; ep.min_intron = p->min_anchor /* ctor quirk junctions_extractor.h:200 */; ep.max_intron = p->max_intron;
         ep.fasta_path = (p->override_motif || p->strandness == 3) ? p->fasta_path : nullptr;   // ref_to_pass (identifier.cc:282-287)
@@ -1072,12 +1140,17 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
         const bool jtrace = getenv("REGTOOLS_AMD_TRACE") != nullptr;
         double jt = now_ms();
         std::vector<int32_t> w_tid, w_beg, w_end;
+        // a file whose record stream ended (damage): every window is read through the index on its own, as upstream reads it (window_join_by_seeks)
+        const bool by_seeks = P.stream_ended && !relevant.empty();
+        std::vector<std::string> w_region;
+        HostRows R;
         BaiInfo bi; (void)parse_bai(bai.data(), bai.size(), bi, false);
         {
             // (every window's region string goes through the region parser, as upstream; ranges of them on several threads, the first one that
             //  does not parse -- in file order -- aborts the run)
             const size_t W = relevant.size();
             w_tid.resize(W); w_beg.resize(W); w_end.resize(W);
+            if (by_seeks) w_region.resize(W);
             WorkerPool own(tl_pool || W < 4096 ? 1 : usable_threads(16));
             WorkerPool &pool = tl_pool && W >= 4096 ? *tl_pool : own;
             const size_t nt = pool.threads();
@@ -1091,13 +1164,32 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
                     int32_t tid, beg, en;
                     if (!parse_region(P.hdr, region.c_str(), tid, beg, en) || tid >= bi.n_ref || en < beg) { bad[t] = w; return; }
                     w_tid[w] = tid; w_beg[w] = beg; w_end[w] = en;
+                    if (by_seeks) w_region[w] = region;
                 }
             });
             size_t w_bad = SIZE_MAX;
             for (size_t t = 0; t < nt && w_bad == SIZE_MAX; ++t) w_bad = bad[t];           // (a thread stops at its first: the first thread's is the file's first)
             // -s XS: a read with an N operation whose strand tag lies behind an aux field of unknown type ends the process in the first window that READS it
             // (tid, pos < end, bam_endpos > beg: hts.c:1946-1957) -- bam_aux_get abort()s, sam.c:1233-1252, nothing printed -- behind that variant's echo
-            if (!P.odd_aux.empty())
+            if (by_seeks) {
+                const uint8_t *d_file = P.d_file;
+                Prep P0;                                                    // (a sharded extraction left no whole copy of the file in HBM: once more, unsharded)
+                if (!d_file) {
+                    const int rc0 = prepare_events(c, nullptr, bam.data(), bam.size(), bai.data(), bai.size(), &ep, true, P0, err, errlen);
+                    if (rc0 != RGX_OK) { echo_variants(1); return rc0; }
+                    d_file = P0.d_file;
+                }
+                w_region.resize(std::min(W, w_bad));
+                size_t w_abort = SIZE_MAX;
+                const int rcj = window_join_by_seeks(c, d_file, bam.size(), bai.data(), bai.size(), ep, w_region, std::min<uint32_t>(32, bitlen(p->max_intron) + 2), R, S.n_pairs,
+                    w_abort, err, errlen);
+                if (rcj != RGX_OK) { echo_variants(1); return rcj; }
+                if (w_abort != SIZE_MAX) {
+                    echo_variants(w_abort + 1);
+                    return fail(err, errlen, RGX_ERR_ABORT, "regtools_amd: a read in the window of the variant at %s:%u has an auxiliary field of unknown type in front of its strand "
+                        "tag: the reference abort()s there\n", vcf.recs[relevant[w_abort]].chrom.c_str(), vcf.recs[relevant[w_abort]].pos0 + 1);
+                }
+            } else if (!P.odd_aux.empty())
                 for (size_t w = 0; w < std::min(W, w_bad); ++w)
                     for (const Prep::OddAux &o : P.odd_aux)
                         if (o.tid == w_tid[w] && o.pos < w_end[w] && o.end > w_beg[w]) {
@@ -1114,8 +1206,7 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
         auto jlap = [&](const char *what) { if (jtrace) { const double t = now_ms(); fprintf(stderr, "[rgx trace] join: %-22s +%8.3f ms\n", what, t - jt);
             jt = t; } };
         jlap("window regions");
-        HostRows R;
-        rc = window_join(c, P, w_tid, w_beg, w_end, std::min<uint32_t>(32, bitlen(p->max_intron) + 2), R, S.n_pairs, err, errlen);
+        if (!by_seeks) rc = window_join(c, P, w_tid, w_beg, w_end, std::min<uint32_t>(32, bitlen(p->max_intron) + 2), R, S.n_pairs, err, errlen);
         if (rc != RGX_OK) return rc;
         S.n_window_rows = R.n;
         jlap("window_join");
