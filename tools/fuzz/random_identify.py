@@ -18,6 +18,19 @@ with tempfile.TemporaryDirectory() as td:
     for case in range(n_cases):
         seed = rng.randrange(1000, 100000)
         q = cse_synth.build(os.path.join(td, "s%d" % case), seed=seed, n_genes=rng.choice([3, 8, 20]), reads_per_junction=rng.choice([1, 4, 9]))
+        if os.environ.get("FUZZ_DAMAGE"):
+            # the record stream ends somewhere: a member that does not inflate, or the file cut short (upstream reads every window through the index on its own)
+            import bamio
+            raw = bytearray(open(q["bam"], "rb").read())
+            mem = list(bamio.bgzf_members(bytes(raw)))
+            if rng.random() < 0.7 and len(mem) > 3:
+                for _ in range(rng.choice([1, 1, 2])):
+                    coff, payload, _isz = mem[rng.randrange(1, len(mem) - 1)]
+                    for j in range(rng.randrange(0, max(1, len(payload) - 24)), min(len(payload), rng.randrange(8, 64) + 40)):
+                        raw[coff + 18 + j] ^= rng.randrange(1, 256)
+            else:
+                raw = raw[: rng.randrange(len(raw) // 4, len(raw))]
+            open(q["bam"], "wb").write(bytes(raw))
         args = ["-s", rng.choice(["XS", "RF", "FR", "intron-motif"])]
         for flag, vals in (("-w", [1, 100, 5000, 200000]), ("-e", [0, 1, 3, 10]), ("-i", [0, 2, 50]), ("-a", [1, 8, 20]), ("-M", [500, 500000])):
             if rng.random() < 0.3: args += [flag, str(rng.choice(vals))]
