@@ -350,7 +350,8 @@ int EventsRun::stage_members() {
         BamHeader hh;
         int32_t tid = -1, beg = 0, end = 0;
         // (the one parse of a call that talks: what sam_itr_querys -> hts_parse_decimal says about the region's numbers, once per query)
-        if (host_bam_header(head, head_len, hh) && parse_region(hh, p->region, tid, beg, end, /*say=*/p->n_shards <= 1 || p->shard == 0) && tid < bi.n_ref && end >= beg &&
+        if (host_bam_header(head, head_len, hh) && parse_region(hh, p->region, tid, beg, end,
+            /*say=*/p->n_shards <= 1 || p->shard == 0) && tid < bi.n_ref && end >= beg &&
             region_chunks(bai, bai_len, tid, beg, end, chunks)) {
             chunked = true;
             if (p->n_shards > 1) {

@@ -318,7 +318,8 @@ struct Prep {
     // in the first window that reads one (ExtractCfg::odd_count; empty on every file that is not damaged)
     struct OddAux { int32_t tid, pos, end; };
     std::vector<OddAux> odd_aux;
-    // the file's bytes in HBM as this call left them (the context's "bam" block, or the caller's device buffer): whole only for an unsharded call.  identify on a
+    // the file's bytes in HBM as this call left them (the context's "bam" block, or the caller's device buffer): whole only for an unsharded call.  identify
+    // on a
     // damaged file reads every window through the index on its own from here (cse_api.cpp window_join_by_seeks)
     const uint8_t *d_file = nullptr;
 };

@@ -448,7 +448,9 @@ int EventsRun::stage_decode() {
         }
         // an iterated read (in front of the record that ends the iteration) whose strand tag upstream cannot get at
         if (cfg.abort_out && h_sc[96] != 0xffffffffu && h_sc[96] < (cfg.stop_out ? cfg.stop_index : 0xffffffffu))
-            return fail(err, errlen, RGX_ERR_ABORT, "regtools_amd: record %u has an auxiliary field of unknown type in front of its strand or barcode tag: the reference abort()s here\n", h_sc[96]);
+            return fail(err, errlen, RGX_ERR_ABORT,
+                "regtools_amd: record %u has an auxiliary field of unknown type in front of its strand or barcode tag: the reference abort()s here\n",
+                h_sc[96]);
         n_events = h_sc[4]; n_long = h_sc[5];
         if (emit_parts_ok && s_from) {
             uint64_t tot = 0;

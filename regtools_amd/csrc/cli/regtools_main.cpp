@@ -27,7 +27,8 @@ namespace {
 // An empty line in a GTF: upstream's loader calls line.at(0) on it outside any try block (gtf_parser.cc:230), the std::out_of_range is nobody's to catch,
 // the process prints libstdc++'s terminate message and aborts (status 134).  The library reports the line as an error; the tool then does what upstream
 // does -- the same call, uncaught (the handlers around it take std::runtime_error only) -- so the message and the status are the reference's.
-// (`cis-splice-effects identify / associate` catch std::exception around everything, cis_splice_effects_main.cc:35-51, :55-71 (std::logic_error): there the same exception's
+// (`cis-splice-effects identify / associate` catch std::exception around everything, cis_splice_effects_main.cc:35-51, :55-71 (std::logic_error): there the
+// same exception's
 // what() is the message and the status is 1 -- caught = true)
 void die_as_upstream_on_empty_gtf_line(const char *err, bool caught = false) {
     if (strcmp(err, "basic_string::at")) return;
@@ -39,7 +40,8 @@ void die_as_upstream_on_empty_gtf_line(const char *err, bool caught = false) {
 // library reports them (RGX_ERR_EXIT / RGX_ERR_ABORT with what htslib printed) and the tool goes the same way.
 void die_where_upstreams_library_does(int rc, const char *err) {
     if (rc != RGX_ERR_EXIT && rc != RGX_ERR_ABORT) return;
-    // (what htslib printed; the library's own words -- a read whose aux fields bam_aux_get abort()s on, sam.c:1233-1252 -- are not upstream's: nothing is printed there)
+    // (what htslib printed; the library's own words -- a read whose aux fields bam_aux_get abort()s on, sam.c:1233-1252 -- are not upstream's: nothing is
+    // printed there)
     std::cerr.flush(); if (strncmp(err, "regtools_amd:", 13)) fputs(err, stderr); fflush(nullptr);
     if (rc == RGX_ERR_ABORT) abort();
     exit(1);
@@ -118,7 +120,8 @@ int junctions_extract(int argc, char **argv) {
         // all-gather of the shards' rows, merge on the first); the output does not depend on the list
         std::vector<int> devices;
         if (const char *d = getenv("REGTOOLS_AMD_DEVICES")) {
-            for (const char *q = d; *q;) { char *e; long v = strtol(q, &e, 10); if (e == q) break; devices.push_back((int)v); q = *e == ',' ? e + 1 : e; if (*e && *e != ',') break; }
+            for (const char *q = d; *q;) { char *e; long v = strtol(q, &e, 10); if (e == q) break; devices.push_back((int)v); q = *e == ',' ? e + 1 : e;
+                if (*e && *e != ',') break; }
         }
         if (devices.size() == 1) o.device = devices[0];
         if (devices.size() <= 1 && rgx_ctx_create(o.device, &ctx, err, sizeof err) != RGX_OK) throw std::runtime_error(err);
@@ -219,7 +222,8 @@ int junctions_annotate(int argc, char **argv) {
         rgx_ctx *ctx = open_ctx();
         char err[512] = {0};
         uint64_t n = 0;
-        int rc = rgx_junctions_annotate_opts(ctx, bed.c_str(), ref.c_str(), gtf.c_str(), out == "NA" ? nullptr : out.c_str(), (skip_single ? 0 : RGX_ANNOTATE_SINGLE_EXON) | RGX_ANNOTATE_ECHO, &n, err, sizeof err);
+        int rc = rgx_junctions_annotate_opts(ctx, bed.c_str(), ref.c_str(), gtf.c_str(), out == "NA" ? nullptr : out.c_str(), (skip_single ? 0 :
+            RGX_ANNOTATE_SINGLE_EXON) | RGX_ANNOTATE_ECHO, &n, err, sizeof err);
         rgx_ctx_destroy(ctx);
         if (rc != RGX_OK) { die_as_upstream_on_empty_gtf_line(err); throw std::runtime_error(err); }
         std::cerr << "\nAnnotated " << n << " lines.\n";
@@ -261,7 +265,8 @@ void window_options(std::ostream &out) {
 }
 
 void identify_usage(std::ostream &out, bool associate = false) {
-    out << "Usage:\t\tregtools cis-splice-effects " << (associate ? "associate [options] variants.vcf junctions.bed" : "identify [options] variants.vcf alignments.bam") << " ref.fa annotations.gtf\n"
+    out << "Usage:\t\tregtools cis-splice-effects " << (associate ? "associate [options] variants.vcf junctions.bed" :
+        "identify [options] variants.vcf alignments.bam") << " ref.fa annotations.gtf\n"
         << "Options:\n"
         << "\t\t-o STR\tOutput file containing the aberrant splice junctions with annotations. [STDOUT]\n"
         << "\t\t-v STR\tOutput file containing variants annotated as splice relevant (VCF format).\n"
@@ -318,12 +323,15 @@ int cse_identify(int argc, char **argv, bool associate = false) {
         }
         std::string vcf = "NA", bam = "NA", ref = "NA", gtf = "NA";
         if (argc - optind >= 4) { vcf = argv[optind++]; bam = argv[optind++]; ref = argv[optind++]; gtf = argv[optind++]; }
-        if (optind < argc || vcf == "NA" || bam == "NA" || ref == "NA" || gtf == "NA") { identify_usage(std::cerr, associate); throw std::runtime_error("Error parsing inputs!(2)\n\n"); }
+        if (optind < argc || vcf == "NA" || bam == "NA" || ref == "NA" || gtf == "NA") { identify_usage(std::cerr, associate);
+            throw std::runtime_error("Error parsing inputs!(2)\n\n"); }
         if (associate) p.strandness = 0;
         if (p.strandness == -1) { identify_usage(std::cerr); throw std::runtime_error("Please supply strand specificity with '-s' option!\n\n"); }
-        if (!file_exists(vcf) || !file_exists(bam) || !file_exists(ref) || !file_exists(gtf)) throw std::runtime_error("Please make sure input files exist.\n\n");
+        if (!file_exists(vcf) || !file_exists(bam) || !file_exists(ref) ||
+            !file_exists(gtf)) throw std::runtime_error("Please make sure input files exist.\n\n");
         // the echo of parse_options (identifier.cc:203-218, associator.cc:156-171), then what identify() / associate() write while they work (p.echo)
-        std::cerr << "Variant file: " << vcf << (associate ? "\nJunctions BED file: " : "\nAlignment file: ") << bam << "\nReference fasta file: " << ref << "\nAnnotation file: " << gtf << "\n";
+        std::cerr << "Variant file: " << vcf << (associate ? "\nJunctions BED file: " :
+            "\nAlignment file: ") << bam << "\nReference fasta file: " << ref << "\nAnnotation file: " << gtf << "\n";
         if (p.window != 0) std::cerr << "Window size: " << p.window << "\n";
         if (out_tsv != "NA") std::cerr << "Output file: " << out_tsv << "\n";
         if (out_bed != "NA") std::cerr << "Output junctions BED file: " << out_bed << "\n";
@@ -332,7 +340,8 @@ int cse_identify(int argc, char **argv, bool associate = false) {
         p.echo = 1;
         if (associate) p.bed_path = bam.c_str();
         p.vcf_path = vcf.c_str(); p.bam_path = bam.c_str(); p.fasta_path = ref.c_str(); p.gtf_path = gtf.c_str();
-        p.out_tsv = out_tsv == "NA" ? nullptr : out_tsv.c_str(); p.out_vcf = out_vcf == "NA" ? nullptr : out_vcf.c_str(); p.out_bed = out_bed == "NA" ? nullptr : out_bed.c_str();
+        p.out_tsv = out_tsv == "NA" ? nullptr : out_tsv.c_str(); p.out_vcf = out_vcf == "NA" ? nullptr : out_vcf.c_str(); p.out_bed = out_bed == "NA" ?
+            nullptr : out_bed.c_str();
         p.strand_tag[0] = tag.size() > 0 ? tag[0] : 0; p.strand_tag[1] = tag.size() > 1 ? tag[1] : 0;
         char err[512] = {0};
         rgx_ctx *ctx = nullptr;
@@ -340,14 +349,16 @@ int cse_identify(int argc, char **argv, bool associate = false) {
         // REGTOOLS_AMD_DEVICES=0,1,...: identify's extraction is sharded over these GPUs (rgx_identify_multi); the outputs do not depend on the list
         std::vector<int> devices;
         if (const char *d = getenv("REGTOOLS_AMD_DEVICES")) {
-            for (const char *q = d; *q;) { char *e; long v = strtol(q, &e, 10); if (e == q) break; devices.push_back((int)v); q = *e == ',' ? e + 1 : e; if (*e && *e != ',') break; }
+            for (const char *q = d; *q;) { char *e; long v = strtol(q, &e, 10); if (e == q) break; devices.push_back((int)v); q = *e == ',' ? e + 1 : e;
+                if (*e && *e != ',') break; }
         }
         if (devices.size() == 1) dev = devices[0];
         const bool multi = !associate && devices.size() > 1;
         if (!multi && rgx_ctx_create(dev, &ctx, err, sizeof err) != RGX_OK) throw std::runtime_error(err);
         rgx_identify_stats st;
         int rc = associate ? rgx_associate(ctx, &p, &st, err, sizeof err)
-                           : multi ? rgx_identify_multi(devices.data(), (int)devices.size(), &p, &st, err, sizeof err) : rgx_identify(ctx, &p, &st, err, sizeof err);
+                           : multi ? rgx_identify_multi(devices.data(), (int)devices.size(), &p, &st, err, sizeof err) : rgx_identify(ctx, &p, &st, err,
+                               sizeof err);
         if (ctx) rgx_ctx_destroy(ctx);
         die_where_upstreams_library_does(rc, err);
         if (rc != RGX_OK) { die_as_upstream_on_empty_gtf_line(err, /*caught=*/true); throw std::runtime_error(err); }
@@ -360,7 +371,8 @@ int cse_identify(int argc, char **argv, bool associate = false) {
             fclose(b);
         }
         if (getenv("REGTOOLS_AMD_STATS"))
-            fprintf(stderr, "[regtools_amd] variants=%llu relevant=%llu windows=%llu pairs=%llu junctions=%llu total=%.3fms (gtf %.3f variants %.3f extract %.3f join %.3f annotate %.3f output %.3f)\n",
+            fprintf(stderr,
+                "[regtools_amd] variants=%llu relevant=%llu windows=%llu pairs=%llu junctions=%llu total=%.3fms (gtf %.3f variants %.3f extract %.3f join %.3f annotate %.3f output %.3f)\n",
                     (unsigned long long)st.n_variants, (unsigned long long)st.n_relevant, (unsigned long long)st.n_windows, (unsigned long long)st.n_pairs,
                     (unsigned long long)st.n_junctions, st.ms_total, st.ms_gtf, st.ms_variants, st.ms_extract, st.ms_join, st.ms_annotate, st.ms_output);
     } catch (const HelpRequested &h) {
@@ -457,7 +469,8 @@ int cse_main(int argc, char **argv) {
 // regtools.cc:36-74: the banner and the top-level usage are the reference's bytes (pinned against the reference's own main() in tests/test_cli_contract.py);
 // the library's own version string is rgx_version() (REGTOOLS_AMD_TRACE prints it)
 int main(int argc, char **argv) {
-    setenv("REGTOOLS_AMD_ONE_SHOT", "1", 0);                   // this process makes one library call: the context does without streams of its own (api.cpp ensure_upload_streams)
+    // this process makes one library call: the context does without streams of its own (api.cpp ensure_upload_streams)
+    setenv("REGTOOLS_AMD_ONE_SHOT", "1", 0);
     std::cerr << "\nProgram:\tregtools\nVersion:\t1.0.0" << std::endl;
     if (getenv("REGTOOLS_AMD_TRACE")) std::cerr << "[rgx trace] " << rgx_version() << std::endl;
     if (argc > 1) {
@@ -465,7 +478,8 @@ int main(int argc, char **argv) {
         if (sub == "junctions") return junctions_main(argc - 1, argv + 1);
         if (sub == "cis-splice-effects") return cse_main(argc - 1, argv + 1);
         if (sub == "variants") return variants_main(argc - 1, argv + 1);
-        if (sub == "cis-ase") {                                // listed by the usage text below, as upstream's; not part of this build (out of scope)
+        // listed by the usage text below, as upstream's; not part of this build (out of scope)
+        if (sub == "cis-ase") {
             std::cerr << "regtools-amd: the cis-ase commands are not part of the MI355X build; use the reference binary for them\n";
             return 1;
         }

@@ -1,7 +1,8 @@
 // cse_api.cpp -- `cis-splice-effects identify / associate`, `variants annotate`, `junctions annotate` behind the C ABI.
 #include "api_internal.h"
 
-// `cis-splice-effects identify` on the device (rgx_ctx, DevBuf, prepare_events / reduce_events: api_internal.h).  Host code here parses text and assembles strings; every interval computation is a kernel.
+// `cis-splice-effects identify` on the device (rgx_ctx, DevBuf, prepare_events / reduce_events: api_internal.h).  Host code here parses text and assembles
+// strings; every interval computation is a kernel.
 #include <set>
 #include <tuple>
 
@@ -375,13 +376,18 @@ static int window_join(rgx_ctx *c, const Prep &P, const std::vector<int32_t> &w_
     return RGX_OK;
 }
 
-// `identify` on a file whose record stream ENDED somewhere (a member that does not inflate, an unreadable record): upstream reads every variant's window through
-// the index on its own (identifier.cc:288-290) -- also the windows BEHIND the damage, which one pass over the file never reaches.  Here, for such a file only: one
-// region extraction per window from the file's bytes in HBM (what `junctions extract -r` makes of a damaged file: the iterator's chunks are seeks of their own), the
-// windows' events put together as window_join's pairs are, the same group-by behind them.  *w_abort (SIZE_MAX = none): the first window that reads a read bam_aux_get
+// `identify` on a file whose record stream ENDED somewhere (a member that does not inflate, an unreadable record): upstream reads every variant's window
+// through
+// the index on its own (identifier.cc:288-290) -- also the windows BEHIND the damage, which one pass over the file never reaches.  Here, for such a file only:
+// one
+// region extraction per window from the file's bytes in HBM (what `junctions extract -r` makes of a damaged file: the iterator's chunks are seeks of their
+// own), the
+// windows' events put together as window_join's pairs are, the same group-by behind them.  *w_abort (SIZE_MAX = none): the first window that reads a read
+// bam_aux_get
 // abort()s on (Prep::odd_aux); the windows behind it are not read.
 static int window_join_by_seeks(rgx_ctx *c, const uint8_t *d_file, size_t bam_len, const uint8_t *bai, size_t bai_len, const rgx_extract_params &ep0,
-                                const std::vector<std::string> &w_region, uint32_t ilen_bits, HostRows &R, uint64_t &n_pairs, size_t &w_abort, char *err, size_t errlen) {
+                                const std::vector<std::string> &w_region, uint32_t ilen_bits, HostRows &R, uint64_t &n_pairs, size_t &w_abort, char *err,
+                                    size_t errlen) {
     R = HostRows(); n_pairs = 0; w_abort = SIZE_MAX;
     const size_t W = w_region.size();
     hipStream_t st = c->stream;
@@ -391,12 +397,14 @@ static int window_join_by_seeks(rgx_ctx *c, const uint8_t *d_file, size_t bam_le
     auto flush = [&](size_t w1) -> int {
         const size_t total = h_col[0].size(), nw = w1 - w0;
         if (total && nw) {
-            if (total >= (1ull << 31)) return fail(err, errlen, RGX_ERR_ARG, "regtools_amd: %zu junction-supporting reads in one batch of windows; more than the join handles\n", total);
+            if (total >= (1ull << 31)) return fail(err, errlen, RGX_ERR_ARG,
+                "regtools_amd: %zu junction-supporting reads in one batch of windows; more than the join handles\n", total);
             DevBuf &bp = c->buf("cse_pairs");
             HIP_TRY(bp.ensure(total * 4 * 7 + total + 256));
             uint32_t *q = bp.as<uint32_t>() + 2 * total;          // (window_join's layout: the pair lists' place stays empty)
             EventSoA pe; memset(&pe, 0, sizeof pe);
-            pe.tid = q; q += total; pe.start = q; q += total; pe.ilen_cls = q; q += total; pe.ts = q; q += total; pe.te = q; q += total; pe.strand = (uint8_t *)q;
+            pe.tid = q; q += total; pe.start = q; q += total; pe.ilen_cls = q; q += total; pe.ts = q; q += total; pe.te = q; q += total;
+                pe.strand = (uint8_t *)q;
             uint32_t *dst[5] = {pe.tid, pe.start, pe.ilen_cls, pe.ts, pe.te};
             for (int k = 0; k < 5; ++k) HIP_TRY(hipMemcpyAsync(dst[k], h_col[k].data(), total * 4, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(pe.strand, h_strand.data(), total, hipMemcpyHostToDevice, st));
@@ -404,7 +412,8 @@ static int window_join_by_seeks(rgx_ctx *c, const uint8_t *d_file, size_t bam_le
             std::vector<uint32_t> ident(nw);
             for (size_t i = 0; i < nw; ++i) ident[i] = (uint32_t)i;
             HostRows B;
-            const int rc = reduce_events(c, pe, (uint32_t)total, std::max<uint32_t>(1, bitlen((uint32_t)nw - 1)), ilen_bits, ident.data(), (uint32_t)nw, B, err, errlen, false,
+            const int rc = reduce_events(c, pe, (uint32_t)total, std::max<uint32_t>(1, bitlen((uint32_t)nw - 1)), ilen_bits, ident.data(), (uint32_t)nw, B,
+                err, errlen, false,
                 nullptr, nullptr, /*allow_preagg=*/false);
             if (rc != RGX_OK) return rc;
             for (uint32_t &g : B.group) g += (uint32_t)w0;
@@ -820,7 +829,8 @@ static int write_junction_outputs(rgx_ctx *c, const rgx_gtf *g, const char *fast
     if (writer.joinable()) { writer.join(); mem_ok = !mem_bad.load(); }
     else {
         for (const Chunk &ck : chunks) if (!ck.ok) mem_ok = false;
-        if (mem_ok) for (Chunk &ck : chunks) { if (!ck.tsv.empty()) fwrite(ck.tsv.data(), 1, ck.tsv.size(), fo); if (fj && !ck.bed.empty()) fwrite(ck.bed.data(), 1, ck.bed.size(), fj); }
+        if (mem_ok) for (Chunk &ck : chunks) { if (!ck.tsv.empty()) fwrite(ck.tsv.data(), 1, ck.tsv.size(), fo); if (fj &&
+            !ck.bed.empty()) fwrite(ck.bed.data(), 1, ck.bed.size(), fj); }
     }
     if (!mem_ok) { if (fo != stdout) fclose(fo); if (fj) fclose(fj); return fail(err, errlen, RGX_ERR_OPEN, "regtools_amd: no memory for the output rows\n"); }
     if (first_bad != SIZE_MAX) { if (fo != stdout) fclose(fo); if (fj) fclose(fj); return fail(err, errlen, RGX_ERR_FASTA, "%s", bad_msg); }
@@ -987,7 +997,8 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
     struct PoolScope { WorkerPool *prev; PoolScope(WorkerPool *p) : prev(tl_pool) { tl_pool = p; } ~PoolScope() { tl_pool = prev; } } pool_scope{&stage_pool};
     t_gtf.join();
     if (!gtf_err.empty()) return fail(err, errlen, RGX_ERR_FORMAT, "%s", gtf_err.c_str());
-    if (p->echo) fputs("exonic_min_distance_ is 3\n", stderr);      // (the annotator's constructor prints the member before it assigns it: always the default, variants_annotator.h:141-152)
+    // (the annotator's constructor prints the member before it assigns it: always the default, variants_annotator.h:141-152)
+    if (p->echo) fputs("exonic_min_distance_ is 3\n", stderr);
     int rc = gtf_upload(c, g, err, errlen, /*pooled=*/true);
     if (rc != RGX_OK) return rc;
     lap(S.ms_gtf);                                              // (what of the GTF was still to do when the extraction was done)
@@ -1132,7 +1143,8 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
         S.n_junctions = uj.size();
         lap(S.ms_join);
     } else {
-        if (!relevant.empty() && rc_bam != RGX_OK) { echo_variants(1); return fail(err, errlen, rc_bam, "%s", err_bam); }      // (upstream opens the BAM for the first such variant)
+        // (upstream opens the BAM for the first such variant)
+        if (!relevant.empty() && rc_bam != RGX_OK) { echo_variants(1); return fail(err, errlen, rc_bam, "%s", err_bam); }
         if (relevant.empty()) P = Prep();                       // (no variant asks for the BAM: upstream never opens it)
         S.n_records = P.n_iterated; S.n_events = P.n_events;
 
@@ -1168,12 +1180,14 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
                 }
             });
             size_t w_bad = SIZE_MAX;
-            for (size_t t = 0; t < nt && w_bad == SIZE_MAX; ++t) w_bad = bad[t];           // (a thread stops at its first: the first thread's is the file's first)
+            // (a thread stops at its first: the first thread's is the file's first)
+            for (size_t t = 0; t < nt && w_bad == SIZE_MAX; ++t) w_bad = bad[t];
             // -s XS: a read with an N operation whose strand tag lies behind an aux field of unknown type ends the process in the first window that READS it
             // (tid, pos < end, bam_endpos > beg: hts.c:1946-1957) -- bam_aux_get abort()s, sam.c:1233-1252, nothing printed -- behind that variant's echo
             if (by_seeks) {
                 const uint8_t *d_file = P.d_file;
-                Prep P0;                                                    // (a sharded extraction left no whole copy of the file in HBM: once more, unsharded)
+                // (a sharded extraction left no whole copy of the file in HBM: once more, unsharded)
+                Prep P0;
                 if (!d_file) {
                     const int rc0 = prepare_events(c, nullptr, bam.data(), bam.size(), bai.data(), bai.size(), &ep, true, P0, err, errlen);
                     if (rc0 != RGX_OK) { echo_variants(1); return rc0; }
@@ -1181,12 +1195,14 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
                 }
                 w_region.resize(std::min(W, w_bad));
                 size_t w_abort = SIZE_MAX;
-                const int rcj = window_join_by_seeks(c, d_file, bam.size(), bai.data(), bai.size(), ep, w_region, std::min<uint32_t>(32, bitlen(p->max_intron) + 2), R, S.n_pairs,
+                const int rcj = window_join_by_seeks(c, d_file, bam.size(), bai.data(), bai.size(), ep, w_region, std::min<uint32_t>(32,
+                    bitlen(p->max_intron) + 2), R, S.n_pairs,
                     w_abort, err, errlen);
                 if (rcj != RGX_OK) { echo_variants(1); return rcj; }
                 if (w_abort != SIZE_MAX) {
                     echo_variants(w_abort + 1);
-                    return fail(err, errlen, RGX_ERR_ABORT, "regtools_amd: a read in the window of the variant at %s:%u has an auxiliary field of unknown type in front of its strand "
+                    return fail(err, errlen, RGX_ERR_ABORT,
+                        "regtools_amd: a read in the window of the variant at %s:%u has an auxiliary field of unknown type in front of its strand "
                         "tag: the reference abort()s there\n", vcf.recs[relevant[w_abort]].chrom.c_str(), vcf.recs[relevant[w_abort]].pos0 + 1);
                 }
             } else if (!P.odd_aux.empty())
@@ -1194,7 +1210,8 @@ static int identify_run(rgx_ctx *c, const std::vector<rgx_ctx *> *shards, const 
                     for (const Prep::OddAux &o : P.odd_aux)
                         if (o.tid == w_tid[w] && o.pos < w_end[w] && o.end > w_beg[w]) {
                             echo_variants(w + 1);
-                            return fail(err, errlen, RGX_ERR_ABORT, "regtools_amd: a read at %s:%d has an auxiliary field of unknown type in front of its strand tag: the reference "
+                            return fail(err, errlen, RGX_ERR_ABORT,
+                                "regtools_amd: a read at %s:%d has an auxiliary field of unknown type in front of its strand tag: the reference "
                                 "abort()s in this variant's window\n", vcf.recs[relevant[w]].chrom.c_str(), o.pos + 1);
                         }
             // aborts the run
@@ -1351,11 +1368,13 @@ extern "C" int rgx_junctions_annotate_opts(rgx_ctx *c, const char *bed_path, con
         std::string site;
         std::string said;
         if (!have_fa) { rc = fail(err, errlen, RGX_ERR_FASTA, "Unable to extract FASTA sequence for position %s:%u-%u\n\n", B.chrom[i].c_str(),
-            B.start[i] + 1, B.start[i] + 2); if (echo) { append_positions(said, B.chrom[i], B.start[i], B.end[i], false); fputs(said.c_str(), stderr); } break; }
+            B.start[i] + 1, B.start[i] + 2); if (echo) { append_positions(said, B.chrom[i], B.start[i], B.end[i], false); fputs(said.c_str(), stderr);
+                } break; }
         rc = splice_site(*fap, B.chrom[i], B.start[i], B.end[i], B.strand[i], site, err, errlen);
         if (echo) {
             std::string tmp;
-            append_positions(said, B.chrom[i], B.start[i], B.end[i], rc == RGX_OK || fap->fetch(B.chrom[i], (int64_t)B.start[i] + 1, (int64_t)B.start[i] + 2, tmp));
+            append_positions(said, B.chrom[i], B.start[i], B.end[i], rc == RGX_OK || fap->fetch(B.chrom[i], (int64_t)B.start[i] + 1, (int64_t)B.start[i] + 2,
+                tmp));
             fputs(said.c_str(), stderr);
         }
         if (rc != RGX_OK) break;
