@@ -280,7 +280,9 @@ class _BorrowedContext(object):
 class Pipeline(object):
     """rgx_pipeline: several files in flight on one device (depth contexts, file k on context k mod depth).  submit() returns a ticket at once,
     wait(ticket) a JunctionsExtractor holding that file's table -- the same table a sequential identify_junctions_from_BAM gives.  The caller
-    keeps the input buffers alive until wait() returns (bytes objects are pinned to the ticket here)."""
+    keeps the input buffers alive until wait() returns (bytes objects are pinned to the ticket here).
+    GPU_MAX_HW_QUEUES in the environment BEFORE the process's first HIP call (importing torch counts): 16 or more (eight per file in flight) lets the files'
+    DEFLATE launches go out at once, ~7 % per file; depth > 2 needs 4 x depth."""
 
     def __init__(self, device=0, depth=2):
         self._lib = _ffi.lib()
