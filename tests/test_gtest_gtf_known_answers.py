@@ -6,6 +6,10 @@ loader (GtfModel::load, csrc/cse_host.cpp: on the host through tests/hostemu, on
   SortExonTranscriptPsTest (:122-199)                    exons 10100, 9900, 9700 of a '+' transcript come out ascending
   SortExonTranscriptNsTest (:202-279)                    exons 9900, 9700, 10100 of a '-' transcript come out descending
 
+The sort tests' transcripts are also annotated against: tests/golden/gtest_gtf/ holds the gtest's lines as two GTFs, BED12 rows around their introns and what the REAL
+reference's `junctions annotate` makes of them (make_golden_gtest_gtf.py) -- which junction is known and which exon skipped depends on the exons' order -- for the
+oracle here and the product on the GPU box.
+
 The vectors are the gtest's data (its line text, coordinates, expected values), not its code."""
 import ctypes as C
 import os
@@ -13,6 +17,9 @@ import os
 import pytest
 
 from conftest import ROOT
+
+GOLD = os.path.join(ROOT, "tests", "golden", "gtest_gtf")
+ANNOTATE = [(n, f) for n in ("ps", "ns") for f in ([], ["-S"])]
 
 # the attribute column of test_gtf_parser.cc:45-52 with the fields the three sort tests vary
 def column(ccds, exon_id, exon_number):
@@ -98,3 +105,30 @@ def test_product_loads_the_gtest_lines(gpu_ctx, tmp_path):
         assert b.value == 37359
         assert L.rgx_gtf_transcript_bin(g, b"ENSTfake", C.byref(b)) != 0                                       # (:108-111: nothing is known of it)
         L.rgx_gtf_free(g)
+
+
+def test_the_committed_gtfs_are_the_gtest_lines():
+    assert open(os.path.join(GOLD, "ps.gtf")).read() == SORT_PS and open(os.path.join(GOLD, "ns.gtf")).read() == SORT_NS
+
+
+@pytest.mark.parametrize("name,flag", ANNOTATE, ids=["%s%s" % (n, "_S" if f else "") for n, f in ANNOTATE])
+def test_oracle_annotates_against_the_sorted_exons_as_the_reference(name, flag, tmp_path, oracle_cli):
+    import subprocess
+    out = str(tmp_path / "o.out")
+    r = subprocess.run([oracle_cli, "junctions-annotate"] + flag + ["-o", out, os.path.join(GOLD, name + ".bed"), os.path.join(GOLD, "genome.fa"), os.path.join(GOLD, name + ".gtf")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    got = open(out, "rb").read()
+    assert got == open(os.path.join(GOLD, "%s%s.out" % (name, "_S" if flag else "")), "rb").read()
+    assert {row.split(b"\t")[10] for row in got.split(b"\n")[1:-1]} == {b"A", b"D", b"DA", b"NDA", b"N"}     # (every anchor class is among the rows)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,flag", ANNOTATE, ids=["%s%s" % (n, "_S" if f else "") for n, f in ANNOTATE])
+def test_product_annotates_against_the_sorted_exons_as_the_reference(gpu_ctx, name, flag, tmp_path):
+    import regtools_amd
+    out = str(tmp_path / "p.out")
+    ja = regtools_amd.JunctionsAnnotator(ctx=gpu_ctx)
+    ja.parse_options(flag + ["-o", out, os.path.join(GOLD, name + ".bed"), os.path.join(GOLD, "genome.fa"), os.path.join(GOLD, name + ".gtf")])
+    ja.annotate()
+    assert open(out, "rb").read() == open(os.path.join(GOLD, "%s%s.out" % (name, "_S" if flag else "")), "rb").read()
