@@ -1,0 +1,56 @@
+"""`cis-splice-effects identify` / `associate` on the REFERENCE'S OWN data files under every option combination its integration tests run them with
+(tests/integration-test/test_cis_splice_effects_identify.py:100-348, test_cis_splice_effects_associate.py:80-200 -- upstream asserts only the exit status there;
+its two golden triplets cover `-s XS` and `-s RF` with nothing else set).  tests/golden/cse_ref_opts/ holds the three output files of the real reference for each
+(make_golden_cse_ref_opts.py): the oracle must print them here, the product on the GPU box."""
+import json
+import os
+import subprocess
+
+import pytest
+
+import cases
+
+OPTS = os.path.join(cases.GOLD, "cse_ref_opts")
+CSE_REF = os.path.join(cases.GOLD, "cse_ref")
+BED = os.path.join(cases.GOLD, "annot_ref", "junctions_extract.bed")
+MANIFEST = json.load(open(os.path.join(OPTS, "manifest.json")))
+QUARTET = [os.path.join(CSE_REF, x) for x in ("test1.vcf", "test_hcc1395.2.bam", "test_chr22.fa", "test_ensemble_chr22.2.gtf")]
+
+
+def inputs(case):
+    return QUARTET if case["cmd"] == "identify" else [QUARTET[0], BED, QUARTET[2], QUARTET[3]]
+
+
+def same_files(pre, case):
+    for ext in ("tsv", "vcf", "bed"):
+        assert open("%s.%s" % (pre, ext), "rb").read() == open(os.path.join(OPTS, "%s.%s" % (case["name"], ext)), "rb").read(), (case["name"], ext)
+
+
+def test_every_upstream_combination_is_among_the_cases():
+    # test_cis_splice_effects_identify.py: -e 6 -i 6 -S, -E, -I, -E -i 6, -e 6 -I, -a 30, -m 8039 -M 8039, -w 5 (each with -s XS)
+    have = {tuple(c["args"]) for c in MANIFEST if c["cmd"] == "identify"}
+    for opts in (["-e", "6", "-i", "6", "-S"], ["-E"], ["-I"], ["-E", "-i", "6"], ["-e", "6", "-I"], ["-a", "30"], ["-m", "8039", "-M", "8039"], ["-w", "5"]):
+        assert tuple(opts + ["-s", "XS"]) in have, opts
+    # the option runs do not all print the same thing (the switches reach the outputs on this data)
+    assert len({open(os.path.join(OPTS, c["name"] + ".vcf"), "rb").read() for c in MANIFEST}) >= 5
+    assert len({open(os.path.join(OPTS, c["name"] + ".tsv"), "rb").read() for c in MANIFEST}) >= 3
+
+
+@pytest.mark.parametrize("case", MANIFEST, ids=[c["name"] for c in MANIFEST])
+def test_oracle_prints_what_the_reference_prints(case, tmp_path, oracle_cli):
+    pre = str(tmp_path / case["name"])
+    r = subprocess.run([oracle_cli, case["cmd"]] + case["args"] + ["-o", pre + ".tsv", "-v", pre + ".vcf", "-j", pre + ".bed"] + inputs(case), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == case["rc"], r.stderr
+    same_files(pre, case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", MANIFEST, ids=[c["name"] for c in MANIFEST])
+def test_product_prints_what_the_reference_prints(gpu_ctx, case, tmp_path):
+    import regtools_amd
+    pre = str(tmp_path / case["name"])
+    obj = (regtools_amd.CisSpliceEffectsIdentifier if case["cmd"] == "identify" else regtools_amd.CisSpliceEffectsAssociator)(ctx=gpu_ctx)
+    obj.parse_options(case["args"] + ["-o", pre + ".tsv", "-v", pre + ".vcf", "-j", pre + ".bed"] + inputs(case))
+    getattr(obj, case["cmd"])()
+    assert case["rc"] == 0
+    same_files(pre, case)
