@@ -1,7 +1,11 @@
 """`cis-splice-effects identify` / `associate` on the REFERENCE'S OWN data files under every option combination its integration tests run them with
 (tests/integration-test/test_cis_splice_effects_identify.py:100-348, test_cis_splice_effects_associate.py:80-200 -- upstream asserts only the exit status there;
 its two golden triplets cover `-s XS` and `-s RF` with nothing else set).  tests/golden/cse_ref_opts/ holds the three output files of the real reference for each
-(make_golden_cse_ref_opts.py): the oracle must print them here, the product on the GPU box."""
+(make_golden_cse_ref_opts.py): the oracle must print them here, the product on the GPU box.
+
+The same for `junctions extract` on the two BAMs of real aligner output the reference's tests hold, under options its six goldens do not reach (FR, intron-motif with the
+chr22 genome -- which ends the run with status 1 on the BAM of contig 1 --, another strand tag, anchor and intron bounds at their edges, regions of every form):
+tests/golden/extract_ref_opts/ (make_golden_extract_ref_opts.py), 50 runs of the real reference."""
 import json
 import os
 import subprocess
@@ -14,6 +18,8 @@ OPTS = os.path.join(cases.GOLD, "cse_ref_opts")
 CSE_REF = os.path.join(cases.GOLD, "cse_ref")
 BED = os.path.join(cases.GOLD, "annot_ref", "junctions_extract.bed")
 MANIFEST = json.load(open(os.path.join(OPTS, "manifest.json")))
+EXTRACT = os.path.join(cases.GOLD, "extract_ref_opts")
+EXTRACT_MANIFEST = json.load(open(os.path.join(EXTRACT, "manifest.json")))
 QUARTET = [os.path.join(CSE_REF, x) for x in ("test1.vcf", "test_hcc1395.2.bam", "test_chr22.fa", "test_ensemble_chr22.2.gtf")]
 
 
@@ -54,3 +60,35 @@ def test_product_prints_what_the_reference_prints(gpu_ctx, case, tmp_path):
     getattr(obj, case["cmd"])()
     assert case["rc"] == 0
     same_files(pre, case)
+
+
+def extract_argv(case):
+    return case["args"] + [os.path.join(cases.GOLD, case["bam"])] + ([os.path.join(cases.GOLD, case["fasta"])] if case["fasta"] else [])
+
+
+def test_the_extract_runs_are_not_all_alike():
+    assert len({open(os.path.join(EXTRACT, c["name"] + ".out"), "rb").read() for c in EXTRACT_MANIFEST}) >= 15
+    assert sorted({c["rc"] for c in EXTRACT_MANIFEST}) == [0, 1]
+
+
+@pytest.mark.parametrize("case", EXTRACT_MANIFEST, ids=[c["name"] for c in EXTRACT_MANIFEST])
+def test_oracle_extracts_what_the_reference_extracts(case):
+    from conftest import run_oracle
+    rc, out, _ = run_oracle(extract_argv(case))
+    assert rc == case["rc"]
+    assert out == open(os.path.join(EXTRACT, case["name"] + ".out"), "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", EXTRACT_MANIFEST, ids=[c["name"] for c in EXTRACT_MANIFEST])
+def test_product_extracts_what_the_reference_extracts(gpu_ctx, case):
+    import regtools_amd
+    je = regtools_amd.JunctionsExtractor(ctx=gpu_ctx)
+    try:
+        je.parse_options(extract_argv(case))
+        je.identify_junctions_from_BAM()
+        rc, out = 0, je.bed12()
+    except regtools_amd.RegtoolsError as e:
+        rc, out = (0 if e.code == 0 else 1), b""
+    assert rc == case["rc"]
+    assert out == open(os.path.join(EXTRACT, case["name"] + ".out"), "rb").read()
