@@ -101,8 +101,9 @@ struct DevBuf {
     void *p = nullptr; size_t cap = 0;
     // asked for by the owner (the arena): memory created in pieces of this size and mapped side by side, see map_pieces (0: one hipMalloc block)
     size_t piece = 0;
-    size_t mapped = 0;              // bytes of the reserved address range the pieces are mapped into (0: a hipMalloc block)
+    size_t mapped = 0;              // bytes of the reserved address range the pieces are mapped into, which may be longer than they are (0: a hipMalloc block)
     std::vector<size_t> piece_len;  // the mappings inside that range, in address order (each is unmapped on its own)
+    int range_dev = -1;             // the device the range's pieces were created on
     // The arena's form (round 5).  The DEFLATE launch writes 169,000 streams 64 KB apart at once, and what it costs depends on the memory under
     // them: 13.9-15.9 ms
     // into one hipMalloc block of 11 GB, 12.3-12.6 ms into the same bytes created as pieces of 1 GiB (hipMemCreate) and mapped side by side into one reserved
@@ -110,7 +111,27 @@ struct DevBuf {
     // whatever the order of the pieces (profiles/r05_inflate_arena_pieces.txt: forty pieces, 110 subsets, 12.30-12.37 ms).  Pieces of 2 MiB: 16.0 ms; 32 MiB:
     // 12.8-13.7;
     // 256 MiB: 12.4-13.7.  A runtime that refuses any of the calls leaves the buffer to hipMalloc.
-    static void unmap_range(void *base, const std::vector<size_t> &lens, size_t reserved) {
+    // Reserved address ranges are KEPT for the next arena, never handed back (round 6, fifth session): hipMemAddressFree of a range whose pieces had all
+    // been unmapped -- behind a hipDeviceSynchronize -- died of a null pointer inside the runtime (SIGSEGV at address 0x68 in libamdhip64, ROCm 7.0.2) once
+    // in ~150 calls when ranges were reserved, mapped, unmapped and freed in quick succession (the arena placement trials:
+    // tests/test_gpu_parity.py::test_arena_placement_trials_leave_the_results_alone failed 3-5 % of its runs; backtraces in
+    // profiles/r06_s5_addressfree_segv.txt).  A range holds no memory once its pieces are unmapped, only addresses; map_pieces takes the smallest kept
+    // range of its device that is large enough before it reserves a new one.
+    struct KeptRange { void *base; size_t len; int dev; };
+    struct KeptRanges { std::mutex mu; std::vector<KeptRange> v; };
+    // (never destroyed: contexts are released by static destructors too)
+    static KeptRanges &kept_ranges() { static KeptRanges *k = new KeptRanges(); return *k; }
+    static void *take_range(int dev, size_t total, size_t *reserved) {           // (a range goes back to the device whose pieces it held)
+        KeptRanges &k = kept_ranges();
+        std::lock_guard<std::mutex> lock(k.mu);
+        size_t best = SIZE_MAX;
+        for (size_t i = 0; i < k.v.size(); ++i) if (k.v[i].dev == dev && k.v[i].len >= total && (best == SIZE_MAX || k.v[i].len < k.v[best].len)) best = i;
+        if (best == SIZE_MAX) return nullptr;
+        void *base = k.v[best].base; *reserved = k.v[best].len;
+        k.v.erase(k.v.begin() + (long)best);
+        return base;
+    }
+    static void unmap_range(void *base, const std::vector<size_t> &lens, size_t reserved, int dev) {
         static const bool trace = getenv("REGTOOLS_AMD_TRACE") != nullptr;
         size_t at = 0;
         // (one mapping at a time: the form HIP's own tests use; a refusal would leak the piece silently)
@@ -120,9 +141,9 @@ struct DevBuf {
             if (e != hipSuccess) (void)hipGetLastError();
             at += n;
         }
-        const hipError_t e = hipMemAddressFree(base, reserved);
-        if (e != hipSuccess) { if (trace) fprintf(stderr, "[rgx trace] hipMemAddressFree of %zu bytes: %s\n", reserved, hipGetErrorString(e));
-            (void)hipGetLastError(); }
+        KeptRanges &k = kept_ranges();
+        std::lock_guard<std::mutex> lock(k.mu);
+        k.v.push_back(KeptRange{base, reserved, dev});
     }
     hipError_t map_pieces(size_t bytes, void **out) {
         int dev = 0;
@@ -133,8 +154,9 @@ struct DevBuf {
         if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) { (void)hipGetLastError();
             gran = (size_t)2 << 20; }
         const size_t total = (bytes + gran - 1) / gran * gran, each = std::max(gran, piece / gran * gran);
-        void *base = nullptr;
-        if ((e = hipMemAddressReserve(&base, total, 0, nullptr, 0)) != hipSuccess) return e;
+        size_t reserved = total;
+        void *base = take_range(dev, total, &reserved);
+        if (!base) { reserved = total; if ((e = hipMemAddressReserve(&base, total, 0, nullptr, 0)) != hipSuccess) return e; }
         std::vector<size_t> lens;
         size_t done = 0;
         while (done < total) {
@@ -151,8 +173,8 @@ struct DevBuf {
             hipMemAccessDesc ad = {}; ad.location.type = hipMemLocationTypeDevice; ad.location.id = dev; ad.flags = hipMemAccessFlagsProtReadWrite;
             e = hipMemSetAccess(base, total, &ad, 1);
         }
-        if (e != hipSuccess) { unmap_range(base, lens, total); return e; }
-        *out = base; mapped = total; piece_len.swap(lens);
+        if (e != hipSuccess) { unmap_range(base, lens, reserved, dev); return e; }
+        *out = base; mapped = reserved; range_dev = dev; piece_len.swap(lens);
         return hipSuccess;
     }
     hipError_t ensure(size_t bytes) {
@@ -180,7 +202,7 @@ struct DevBuf {
     }
     void release() {
         if (p && mapped) { (void)hipDeviceSynchronize();    /* (what hipFree does by itself: nothing in flight may still touch the range) */
-                           unmap_range((uint8_t *)p - kFront, piece_len, mapped); }
+                           unmap_range((uint8_t *)p - kFront, piece_len, mapped, range_dev); }
         else if (p) (void)hipFree((uint8_t *)p - kFront);
         p = nullptr; cap = 0; mapped = 0; piece_len.clear();
     }

@@ -41,6 +41,16 @@ def main():
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         cases.append(dict(name=n, cmd="associate", args=opts, rc=r.returncode, rows=open(files["tsv"]).read().count("\n") - 1))
         print(cases[-1])
+    # `junctions annotate` (upstream: one golden, test_junctions_annotate.py:34-42): both junction files and both annotations the reference's tests hold, with and without -S
+    annot = os.path.join(HERE, "annot_ref")
+    for bk, b in (("hccj", os.path.join(annot, "test_hcc1395_junctions.bed")), ("jex", bed)):
+        for gk, g in (("gtf1", os.path.join(annot, "test_ensemble_chr22.gtf")), ("gtf2", quartet[3])):
+            for opts in ([], ["-S"]):
+                n = "ja_%s_%s%s" % (bk, gk, "_S" if opts else "")
+                out = os.path.join(OUT, n + ".tsv")
+                r = subprocess.run([REF, "junctions", "annotate"] + opts + ["-o", out, b, quartet[2], g], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                cases.append(dict(name=n, cmd="junctions-annotate", args=opts, bed=os.path.relpath(b, HERE), gtf=os.path.relpath(g, HERE), rc=r.returncode, rows=open(out).read().count("\n") - 1))
+                print(cases[-1])
     json.dump(cases, open(os.path.join(OUT, "manifest.json"), "w"), indent=1)
     print(len(cases), "cases")
 

@@ -659,7 +659,7 @@ def test_arena_placement_trials_leave_the_results_alone(gpu_ctx):
         env.pop("REGTOOLS_AMD_ARENA", None)
         if knob: env["REGTOOLS_AMD_ARENA"] = knob
         r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
-        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert r.returncode == 0, r.stderr.decode()[-8000:]
         trials = json.loads([l for l in r.stderr.decode().splitlines() if l.startswith("TRIALS ")][-1][7:])
         if knob:
             # the call's arena + one to five challengers (the first that wins ends the trials: never two challengers' memory at once), once per context
